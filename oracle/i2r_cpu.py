@@ -1,0 +1,331 @@
+"""CPU ORACLE of the I2R-Net inference forward -- TEST INFRASTRUCTURE, NOT THE PRODUCT.
+
+A from-scratch restatement, in plain fp32 torch CPU ops over a bare state-dict, of the algorithm the
+reference runs in lib/models (file:line cited per function).  It exists only to check the HIP path:
+only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg import it; the product path
+(i2r_amd.engine) never does and fails loudly without the HIP library.
+
+Parity status: the reference has no tests / golden vectors for this path, and its
+arithmetic lives in PyTorch itself (nn.Conv2d, nn.BatchNorm2d, nn.MultiheadAttention, nn.LayerNorm,
+F.interpolate; torch unpinned in the reference's requirements.txt, README says 1.10).  This oracle is
+therefore pinned by *outputs of the reference itself run here*: oracle/make_golden.py imports the
+reference (oracle/ref_shim.py) on CPU with torch 2.10, loads the key-addressed synthetic weights,
+and commits inputs-by-seed + expected heatmaps/stage checksums under tests/golden/; tests/test_oracle.py
+checks this file against those vectors (<=2e-5 max-abs) on every run, with or without /root/reference.
+
+Layout notes: everything is NCHW / [B, L, d] batch-first; attention is written out as
+softmax(q k^T + mask) v -- the published algorithm of torch.nn.functional.multi_head_attention_forward
+(q scaled by head_dim**-0.5 after the bias add; boolean key_padding_mask -> -inf before softmax).
+"""
+import math
+
+import torch
+import torch.nn.functional as F
+
+BN_EPS = 1e-5
+
+
+# --------------------------------------------------------------------------------------------------
+# primitives
+# --------------------------------------------------------------------------------------------------
+def _bn(sd, p, x, eps=BN_EPS):
+    """nn.BatchNorm2d in eval mode (running statistics)."""
+    return F.batch_norm(x, sd[p + ".running_mean"], sd[p + ".running_var"], sd[p + ".weight"], sd[p + ".bias"],
+                        False, 0.0, eps)
+
+
+def _conv(sd, p, x, stride=1, pad=None, groups=1):
+    w = sd[p + ".weight"]
+    if pad is None:
+        pad = w.shape[-1] // 2
+    return F.conv2d(x, w, sd.get(p + ".bias"), stride=stride, padding=pad, groups=groups)
+
+
+def _maxpool(x):
+    """nn.MaxPool2d(kernel_size=3, stride=2, padding=1)  (interformer.py:162, position_embedding.py:9)."""
+    return F.max_pool2d(x, 3, 2, 1)
+
+
+def _deconv_bn_relu(sd, p_deconv, p_bn, x):
+    """ConvTranspose2d(k=4, s=2, p=1, output_padding=0, bias=False) + BN + ReLU (interformer.py:84-122)."""
+    y = F.conv_transpose2d(x, sd[p_deconv + ".weight"], sd.get(p_deconv + ".bias"), stride=2, padding=1)
+    return F.relu(_bn(sd, p_bn, y))
+
+
+# --------------------------------------------------------------------------------------------------
+# HRNet-W48-S backbone (interformer_pureMulti.py:37-107, 246-410, 543-633, 675-704; same code in
+# transpose_h.py:621-647)
+# --------------------------------------------------------------------------------------------------
+def _basic_block(sd, p, x):
+    """interformer_pureMulti.py:50-66"""
+    o = F.relu(_bn(sd, p + ".bn1", _conv(sd, p + ".conv1", x)))
+    o = _bn(sd, p + ".bn2", _conv(sd, p + ".conv2", o))
+    return F.relu(o + x)
+
+
+def _bottleneck(sd, p, x):
+    """interformer_pureMulti.py:87-107"""
+    o = F.relu(_bn(sd, p + ".bn1", _conv(sd, p + ".conv1", x)))
+    o = F.relu(_bn(sd, p + ".bn2", _conv(sd, p + ".conv2", o)))
+    o = _bn(sd, p + ".bn3", _conv(sd, p + ".conv3", o))
+    res = x
+    if (p + ".downsample.0.weight") in sd:
+        res = _bn(sd, p + ".downsample.1", _conv(sd, p + ".downsample.0", x))
+    return F.relu(o + res)
+
+
+def _hr_module(sd, p, xs, num_blocks, n_out):
+    """HighResolutionModule.forward, interformer_pureMulti.py:392-410 (+ fuse layers :332-387)."""
+    nb = len(xs)
+    xs = list(xs)
+    for i in range(nb):
+        for b in range(num_blocks[i]):
+            xs[i] = _basic_block(sd, "%s.branches.%d.%d" % (p, i, b), xs[i])
+    if nb == 1:
+        return xs
+    out = []
+    for i in range(n_out):
+        y = None
+        for j in range(nb):
+            if j == i:
+                t = xs[j]
+            elif j > i:  # 1x1 conv + BN + nearest upsample 2^(j-i)
+                q = "%s.fuse_layers.%d.%d" % (p, i, j)
+                t = _bn(sd, q + ".1", _conv(sd, q + ".0", xs[j]))
+                t = F.interpolate(t, scale_factor=2 ** (j - i), mode="nearest")
+            else:  # chain of 3x3 stride-2 convs; ReLU on all hops but the last
+                t = xs[j]
+                for k in range(i - j):
+                    q = "%s.fuse_layers.%d.%d.%d" % (p, i, j, k)
+                    t = _bn(sd, q + ".1", _conv(sd, q + ".0", t, stride=2))
+                    if k != i - j - 1:
+                        t = F.relu(t)
+            y = t if y is None else y + t
+        out.append(F.relu(y))
+    return out
+
+
+def hrnet_w48_stages(sd, p, x, extra, collect=None):
+    """stem + layer1 + stage2 + stage3 -> list of branch maps (deal_by_backbone, :675-699)."""
+    x = F.relu(_bn(sd, p + "bn1", _conv(sd, p + "conv1", x, stride=2)))
+    x = F.relu(_bn(sd, p + "bn2", _conv(sd, p + "conv2", x, stride=2)))
+    if collect is not None:
+        collect["stem"] = x
+    for b in range(4):
+        x = _bottleneck(sd, "%slayer1.%d" % (p, b), x)
+    if collect is not None:
+        collect["layer1"] = x
+    s2, s3 = extra["STAGE2"], extra["STAGE3"]
+    # transition1 (:543-582): branch0 3x3 256->48, branch1 3x3 s2 256->96 (inside a Sequential)
+    xs = [F.relu(_bn(sd, p + "transition1.0.1", _conv(sd, p + "transition1.0.0", x))),
+          F.relu(_bn(sd, p + "transition1.1.0.1", _conv(sd, p + "transition1.1.0.0", x, stride=2)))]
+    for m in range(s2["NUM_MODULES"]):
+        xs = _hr_module(sd, "%sstage2.%d" % (p, m), xs, s2["NUM_BLOCKS"], len(xs))
+    if collect is not None:
+        collect["stage2"] = xs
+    # transition2: new branch from the LAST branch of the previous stage (:694-698)
+    t = F.relu(_bn(sd, p + "transition2.2.0.1", _conv(sd, p + "transition2.2.0.0", xs[-1], stride=2)))
+    xs = [xs[0], xs[1], t]
+    for m in range(s3["NUM_MODULES"]):
+        xs = _hr_module(sd, "%sstage3.%d" % (p, m), xs, s3["NUM_BLOCKS"], len(xs))
+        if collect is not None:
+            collect["stage3.%d" % m] = xs
+    return xs
+
+
+# --------------------------------------------------------------------------------------------------
+# DETR-style post-norm encoder layer (interformer_pureMulti.py:192-213, attention.py:61-82,
+# transpose_h.py:189-210); nn.MultiheadAttention with one head (or n_head heads)
+# --------------------------------------------------------------------------------------------------
+def encoder_layer(sd, p, src, pos, key_mask, n_head=1):
+    """src [B, L, d]; pos [B or 1, L, d] or None; key_mask bool [B, L] (True = padded key) or None."""
+    B, L, d = src.shape
+    hd = d // n_head
+    w, b = sd[p + ".self_attn.in_proj_weight"], sd[p + ".self_attn.in_proj_bias"]
+    qk_in = src if pos is None else src + pos
+    q = F.linear(qk_in, w[:d], b[:d]) * (hd ** -0.5)
+    k = F.linear(qk_in, w[d:2 * d], b[d:2 * d])
+    v = F.linear(src, w[2 * d:], b[2 * d:])
+    q = q.view(B, L, n_head, hd).transpose(1, 2)
+    k = k.view(B, L, n_head, hd).transpose(1, 2)
+    v = v.view(B, L, n_head, hd).transpose(1, 2)
+    s = q @ k.transpose(-1, -2)  # [B, h, L, L]
+    if key_mask is not None:
+        s = s.masked_fill(key_mask[:, None, None, :], float("-inf"))
+    a = torch.softmax(s, dim=-1) @ v
+    a = a.transpose(1, 2).reshape(B, L, d)
+    a = F.linear(a, sd[p + ".self_attn.out_proj.weight"], sd[p + ".self_attn.out_proj.bias"])
+    src = F.layer_norm(src + a, (d,), sd[p + ".norm1.weight"], sd[p + ".norm1.bias"], 1e-5)
+    f = F.linear(F.relu(F.linear(src, sd[p + ".linear1.weight"], sd[p + ".linear1.bias"])),
+                 sd[p + ".linear2.weight"], sd[p + ".linear2.bias"])
+    return F.layer_norm(src + f, (d,), sd[p + ".norm2.weight"], sd[p + ".norm2.bias"], 1e-5)
+
+
+def _pad_persons(t, length):
+    """[S, ...] -> [B, N, ...] zero-padded (padding_tensor, interformer_pureMulti.py:721-742)."""
+    N = max(length)
+    out = t.new_zeros((len(length), N) + tuple(t.shape[1:]))
+    o = 0
+    for b, n in enumerate(length):
+        out[b, :n] = t[o:o + n]
+        o += n
+    return out
+
+
+def _unpad_persons(t, length):
+    """[B, N, ...] -> [S, ...] (get_valid_output, lib/utils/utils.py:24-37)."""
+    return torch.cat([t[b, :n] for b, n in enumerate(length)], dim=0)
+
+
+def inter_human_encoder(sd, p, n_layers, feat, pos, length, n_head=1, collect=None):
+    """feat [S, d, h, w] (+ pos [S, d, h, w] or None) -> [S, d, h, w].
+
+    Reference: pad persons per image to N=max(length), tokens ordered (n, y, x), key_padding_mask on the
+    padded persons, pos re-added in every layer (attention.py:131-172 / interformer_pureMulti.py:744-772).
+    """
+    S, d, h, w = feat.shape
+    B, N = len(length), max(length)
+    x = _pad_persons(feat, length)  # [B,N,d,h,w]
+    tok = x.permute(0, 1, 3, 4, 2).reshape(B, N * h * w, d)
+    ptok = None
+    if pos is not None:
+        ptok = _pad_persons(pos, length).permute(0, 1, 3, 4, 2).reshape(B, N * h * w, d)
+    mask = torch.zeros(B, N, h * w, dtype=torch.bool)
+    for b, n in enumerate(length):
+        mask[b, n:] = True
+    mask = mask.view(B, N * h * w)
+    for l in range(n_layers):
+        tok = encoder_layer(sd, "%s.layers.%d" % (p, l), tok, ptok, mask, n_head)
+        if collect is not None:
+            collect["%s.layers.%d" % (p, l)] = _unpad_persons(tok.view(B, N, h * w, d), length)
+    out = tok.view(B, N, h, w, d).permute(0, 1, 4, 2, 3)
+    return _unpad_persons(out, length)
+
+
+def multi_position_embedding(sd, p, pos_mask, trans_w):
+    """PositionEmbeddingImage mode 'conv' (position_embedding.py:99-109): [S,1,H,W] -> [S,d,h,w].
+
+    The reference also runs this on the zero masks of padded persons; those tokens are masked keys /
+    discarded queries, so evaluating only the S real persons is output-equivalent.
+    """
+    x = F.relu(_bn(sd, p + ".bn1", _conv(sd, p + ".conv1", pos_mask, stride=2)))
+    x = F.relu(_bn(sd, p + ".bn2", _conv(sd, p + ".conv2", x, stride=2)))
+    for _ in range(int(math.log(x.shape[-1] // trans_w, 2))):
+        x = _maxpool(x)
+    return x
+
+
+# --------------------------------------------------------------------------------------------------
+# vanilla I2R-Net (interformer_pureMulti.TransPoseH.forward, :752-778)
+# --------------------------------------------------------------------------------------------------
+def forward_vanilla(sd, cfg, x, pos_mask, length, collect=None):
+    M = cfg["MODEL"]
+    ys = hrnet_w48_stages(sd, "", x, M["EXTRA"], collect)
+    f = F.conv2d(ys[-1], sd["reduce.weight"])  # lowest-resolution branch (:702)
+    if collect is not None:
+        collect["reduce"] = f
+    pos = None
+    if M["USE_MULTI_POS"]:
+        pos = multi_position_embedding(sd, "position_embedding", pos_mask, M["TRANS_SIZE"][-1])
+        if collect is not None:
+            collect["pos"] = pos
+    f = inter_human_encoder(sd, "global_encoder", M["ENCODER_LAYERS"], f, pos, length, M["N_HEAD"], collect)
+    if collect is not None:
+        collect["encoder"] = f
+    f = _deconv_bn_relu(sd, "deconv_layers.0", "deconv_layers.1", f)  # the SAME layer twice (:774-775)
+    f = _deconv_bn_relu(sd, "deconv_layers.0", "deconv_layers.1", f)
+    if collect is not None:
+        collect["deconv"] = f
+    return F.conv2d(f, sd["final_layer.weight"], sd["final_layer.bias"])
+
+
+# --------------------------------------------------------------------------------------------------
+# TransPose-H intra-human stage (transpose_h.TransPoseH.forward, :649-655; sine PE :502-527)
+# --------------------------------------------------------------------------------------------------
+def sine_position_embedding(h, w, d_model, temperature=10000.0, scale=2 * math.pi):
+    """transpose_h.py:502-527 -> [h*w, d_model] (the reference keeps it as [h*w, 1, d])."""
+    area = torch.ones(1, h, w)
+    y_embed = area.cumsum(1, dtype=torch.float32)
+    x_embed = area.cumsum(2, dtype=torch.float32)
+    half = d_model // 2
+    eps = 1e-6
+    y_embed = y_embed / (y_embed[:, -1:, :] + eps) * scale
+    x_embed = x_embed / (x_embed[:, :, -1:] + eps) * scale
+    dim_t = torch.arange(half, dtype=torch.float32)
+    dim_t = temperature ** (2 * torch.div(dim_t, 2, rounding_mode="floor") / half)
+    pos_x = x_embed[:, :, :, None] / dim_t
+    pos_y = y_embed[:, :, :, None] / dim_t
+    pos_x = torch.stack((pos_x[:, :, :, 0::2].sin(), pos_x[:, :, :, 1::2].cos()), dim=4).flatten(3)
+    pos_y = torch.stack((pos_y[:, :, :, 0::2].sin(), pos_y[:, :, :, 1::2].cos()), dim=4).flatten(3)
+    pos = torch.cat((pos_y, pos_x), dim=3)  # [1,h,w,d]
+    return pos.reshape(h * w, d_model)
+
+
+def forward_transpose_h(sd, p, cfg, x, collect=None):
+    """-> (features [S,d,H/4,W/4], heatmaps [S,J,H/4,W/4])"""
+    M = cfg["MODEL"]
+    ys = hrnet_w48_stages(sd, p, x, M["EXTRA"], collect)
+    f = F.conv2d(ys[M["HRNET_RES_LAYER"]], sd[p + "reduce.weight"])
+    S, d, h, w = f.shape
+    tok = f.flatten(2).transpose(1, 2)  # [S, hw, d]
+    pos = sd[p + "pos_embedding"].reshape(1, h * w, d)  # a (non-trainable) parameter -> read from weights
+    for l in range(M["ENCODER_LAYERS"]):
+        tok = encoder_layer(sd, "%sglobal_encoder.layers.%d" % (p, l), tok, pos, None, M["N_HEAD"])
+        if collect is not None:
+            collect["single.layers.%d" % l] = tok
+    f = tok.transpose(1, 2).reshape(S, d, h, w)
+    return f, F.conv2d(f, sd[p + "final_layer.weight"], sd[p + "final_layer.bias"])
+
+
+# --------------------------------------------------------------------------------------------------
+# 2-stage I2R-Net (interformer.InterFormer.forward, :282-323)
+# --------------------------------------------------------------------------------------------------
+def forward_two_stage(sd, cfg, x, pos_mask, length, collect=None):
+    M = cfg["MODEL"]
+    if M["SINGLEFORMER"] == "transpose_h":
+        feat, single = forward_transpose_h(sd, "singleformer.", cfg, x, collect)
+    elif M["SINGLEFORMER"] == "hrformer":
+        from i2r_cpu_hrformer import forward_hrformer
+        feat, single = forward_hrformer(sd, "singleformer.", cfg, x, collect)
+    else:
+        raise NotImplementedError("SINGLEFORMER=%r" % (M["SINGLEFORMER"],))
+    if collect is not None:
+        collect["single_feat"] = feat
+    f = feat
+    for _ in range(int(math.log(f.shape[-1] // M["TRANS_SIZE"][-1], 2))):  # max_pool, :260-264,:290
+        f = _maxpool(f)
+    pos = None
+    if M["USE_MULTI_POS"]:
+        assert M["MULTI_POS_EMBEDDING"] == "conv", "only the 'conv' multi-position mode is restated"
+        pos = multi_position_embedding(sd, "multi_position_embedding", pos_mask, M["TRANS_SIZE"][-1])
+    f = inter_human_encoder(sd, "multi_global_encoder", M["ENCODER_MULTI_LAYERS"], f, pos, length,
+                            M["N_HEAD"], collect)
+    if collect is not None:
+        collect["encoder"] = f
+    up = M["UPSAMPLE_TYPE"]
+    if up == "deconv":  # interformer.DeConv :67-127 -- log2(HEATMAP_W // TRANS_SIZE[1]) distinct layers
+        n = int(math.log(M["HEATMAP_SIZE"][0] // M["TRANS_SIZE"][1], 2))
+        for i in range(n):
+            f = _deconv_bn_relu(sd, "upsample_layer.deconv_layers.%d.0" % i,
+                                "upsample_layer.deconv_layers.%d.1" % i, f)
+    elif up == "multiplex":
+        f = _deconv_bn_relu(sd, "deconv_layers.0", "deconv_layers.1", f)
+        f = _deconv_bn_relu(sd, "deconv_layers.0", "deconv_layers.1", f)
+    else:
+        raise NotImplementedError("UPSAMPLE_TYPE=%r" % up)
+    f = feat + f  # residual (:315)
+    multi = F.conv2d(f, sd["final_layer.weight"], sd["final_layer.bias"])
+    if M["INTER_SUPERVISION"] and not M["SINGLEFORMER_FIX"]:
+        return {"single": single, "multi": multi}
+    return multi
+
+
+def forward(sd, cfg, x, pos_mask, length, collect=None):
+    """Dispatch on MODEL.NAME like tools/test.py:87 does."""
+    name = cfg["MODEL"]["NAME"]
+    with torch.no_grad():
+        if name == "interformer_pureMulti":
+            return forward_vanilla(sd, cfg, x, pos_mask, length, collect)
+        if name == "interformer":
+            return forward_two_stage(sd, cfg, x, pos_mask, length, collect)
+    raise NotImplementedError("MODEL.NAME=%r" % name)
