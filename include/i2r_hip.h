@@ -1,0 +1,193 @@
+/*
+ * i2r_hip.h -- C-ABI of the MI355X-native I2R-Net inference hot path (libi2r_hip.so, gfx950 only).
+ *
+ * The reference (leijue222/Intra-and-Inter-Human-Relation-Network-for-MPEE) has NO FFI on this path: its
+ * boundary is the Python module contract  models.<MODEL.NAME>.get_pose_net(cfg, is_train) ->
+ * nn.Module,  called as  model(input, pos_mask, length)  (lib/core/function.py:135, tools/test.py:87).
+ * Every arithmetic op behind that call is issued by torch.nn modules.  This header declares the
+ * entry points a maintainer binds instead (ctypes stub in INTEGRATION.md); each one names the
+ * reference construct it replaces.
+ *
+ * Conventions
+ *  - plain pointers + sizes only; all pointers are DEVICE pointers owned by the caller (inputs, outputs,
+ *    packed weights, workspace); the library allocates nothing and keeps no global state.
+ *  - `stream` is a hipStream_t passed as void* (NULL = default stream); calls are asynchronous and
+ *    re-entrant per stream.
+ *  - return 0 on success, negative I2R_E_* otherwise; i2r_last_error() gives a thread-local message.
+ *  - activations are fp32 NHWC ("pixel-major, channel-minor") with an explicit channel stride; the
+ *    boundary tensors keep the reference's NCHW fp32 layout (i2r_stem_conv reads NCHW, i2r_head writes NCHW).
+ */
+#ifndef I2R_HIP_H
+#define I2R_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define I2R_ABI_VERSION 1
+
+#define I2R_OK 0
+#define I2R_E_ARG (-1)      /* bad argument (shape / alignment / unsupported combination) */
+#define I2R_E_LAUNCH (-2)   /* HIP launch failure */
+#define I2R_E_NODEV (-3)    /* no gfx950 device */
+
+#define I2R_MAX_TAPS 9
+
+/* ------------------------------------------------------------------------------------------------
+ * i2r_conv_desc -- one fused  conv (implicit GEMM on fp32 MFMA) [+ folded BN bias] [+ residual(s)]
+ * [+ ReLU] [+ nearest-upsample scatter]  launch.
+ * Replaces: nn.Conv2d + nn.BatchNorm2d(eval) + nn.ReLU / residual add / nn.Upsample(nearest) /
+ * the sum of HighResolutionModule.forward (reference lib/models/interformer_pureMulti.py:50-66,
+ * 87-107, 332-410), nn.ConvTranspose2d(k4,s2,p1) split into its 4 output-parity 2x2 convs
+ * (interformer_pureMulti.py:648-673, interformer.py:84-122), and nn.Linear on token matrices
+ * (a 1x1 conv over [T,1,1,C]).
+ *
+ *   acc[p, co] = sum_{t < ntaps} sum_{ci < cin}  IN[n, oy*stride + iy0 + dy[t], ox*stride + ix0 + dx[t], ci]
+ *                                               * W[t][ci][co]              (IN = in (+ in2 if given))
+ *   v = acc + bias[co];  v += res1[dst, co] (if res1);  v += res2[dst, co] (if res2);  relu (if relu);
+ *   v += res_post[dst, co] (if res_post: residual added AFTER the ReLU, interformer.py:315)
+ *   dst pixels: (oy*out_step + out_off_y + ry, ox*out_step + out_off_x + rx) for ry,rx < rep
+ *
+ * Packed weight layout ("k4"): float w[ntaps][cin/4][cout_pad][4]  (cin % 16 == 0, cout_pad % 16 == 0,
+ * zero-filled beyond cout); bias[cout_pad].
+ * ------------------------------------------------------------------------------------------------ */
+typedef struct i2r_conv_desc {
+    const float* in;     /* [n_img, in_h, in_w, in_cs] */
+    const float* in2;    /* optional second input added element-wise while staging (same geometry) */
+    const float* w;      /* packed k4 weights */
+    const float* bias;   /* [cout_pad] */
+    const float* res1;   /* optional, laid out like out */
+    const float* res2;   /* optional, laid out like out */
+    const float* res_post; /* optional, laid out like out, added after the ReLU */
+    float* out;          /* [n_img, out_h, out_w, out_cs] */
+    int32_t n_img;
+    int32_t in_h, in_w, in_cs;     /* in_cs = channel stride (floats) per input pixel */
+    int32_t cin;                   /* multiple of 16, <= in_cs */
+    int32_t conv_h, conv_w;        /* logical conv output grid (oy, ox ranges) */
+    int32_t out_h, out_w, out_cs;  /* destination tensor geometry */
+    int32_t cout, cout_pad;        /* real / padded output channels */
+    int32_t stride;                /* 1 or 2 */
+    int32_t iy0, ix0;              /* input coordinate of tap offset (0,0) for output (0,0): -pad */
+    int32_t ntaps;
+    int32_t dy[I2R_MAX_TAPS], dx[I2R_MAX_TAPS];
+    int32_t out_step, out_off_y, out_off_x, rep;
+    int32_t relu;
+    int32_t tile_h, tile_w;        /* output tile per workgroup (0 = let the library choose) */
+    int32_t ck;                    /* input channels staged in LDS per pass (0 = choose) */
+    int32_t wn;                    /* waves along cout in the 4-wave workgroup: 1, 2 or 4 (0 = choose) */
+    int32_t mt;                    /* 16-pixel fragments per wave, 1..4 (0 = derive from the tile) */
+} i2r_conv_desc;
+
+int i2r_conv(const i2r_conv_desc* d, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * i2r_stem_conv -- first 3x3 stride-2 pad-1 conv of a tower (cin = 1..4) + folded BN + ReLU, reading the
+ * boundary NCHW fp32 tensor and writing NHWC.
+ * Replaces: conv1+bn1+relu (interformer_pureMulti.py:677-679) and PositionEmbeddingImage conv1+bn1+relu
+ * (position_embedding.py:99-101).   w: float[9][cin][cout], bias[cout]; cout % 16 == 0.
+ * ------------------------------------------------------------------------------------------------ */
+int i2r_stem_conv(const float* in_nchw, const float* w, const float* bias, float* out_nhwc, int32_t n_img,
+                  int32_t cin, int32_t in_h, int32_t in_w, int32_t cout, int32_t out_cs, void* stream);
+
+/* i2r_maxpool3x3s2 -- nn.MaxPool2d(kernel_size=3, stride=2, padding=1) on NHWC
+ * (interformer.py:162,260-264; position_embedding.py:9,106-109).  c % 4 == 0. */
+int i2r_maxpool3x3s2(const float* in, float* out, int32_t n_img, int32_t in_h, int32_t in_w, int32_t c,
+                     int32_t in_cs, int32_t out_cs, void* stream);
+
+/* i2r_head -- final 1x1 conv (with bias) NHWC -> boundary NCHW heatmaps
+ * (final_layer, interformer_pureMulti.py:486-492,776; interformer.py:176-182,317).
+ * w: float[cout][cin] (the nn.Conv2d weight as is), bias[cout]. out: [n_img, cout, h, w]. */
+int i2r_head(const float* in, const float* w, const float* bias, float* out_nchw, int32_t n_img, int32_t h,
+             int32_t w_, int32_t cin, int32_t in_cs, int32_t cout, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * i2r_encoder_desc -- one DETR-style post-norm encoder layer over variable-length token groups
+ * (persons of one image attend to each other; no padding, no mask tensor).
+ * Replaces: TransformerEncoderLayer.forward_post (interformer_pureMulti.py:192-213; attention.py:61-82;
+ * transpose_h.py:189-210) incl. nn.MultiheadAttention (1 head), both LayerNorms and the FFN, plus the
+ * pad / key_padding_mask / get_valid_output dance (interformer_pureMulti.py:706-750, utils.py:24-37).
+ *
+ *   q = ((src+pos) Wq^T + bq) * d^-0.5 ; k = (src+pos) Wk^T + bk ; v = src Wv^T + bv
+ *   a = softmax_over_group(q k^T) v ;  x = LN1(src + a Wo^T + bo) ;  out = LN2(x + W2 relu(W1 x + b1) + b2)
+ *
+ * Token matrix layout: [n_tok, cs] fp32 (cs = padded d, multiple of 16).  Group g owns the contiguous
+ * token rows [grp_off[g], grp_off[g+1]).  `pos` has per-token rows when pos_stride_tok = cs, or is a
+ * table indexed by (token % pos_period) when pos_period > 0 (TransPose-H sine table).
+ * Weights are the reference's own row-major [out][in] matrices, zero-padded to cs / dff_pad.
+ * i2r_encoder_kv fills the K,V rows; i2r_encoder_layer consumes them.
+ * ------------------------------------------------------------------------------------------------ */
+typedef struct i2r_encoder_desc {
+    const float* src;      /* [n_tok, cs] */
+    const float* pos;      /* optional */
+    float* kbuf;           /* [n_tok, cs] workspace */
+    float* vbuf;           /* [cs, n_tok_pad] workspace, FEATURE-major; n_tok_pad = roundup(n_tok, 64) + 64 */
+    float* out;            /* [n_tok, cs] (may not alias src) */
+    const int32_t* grp_off;/* device int32 [n_grp + 1] */
+    const float* w_in;     /* [3*cs, cs]  (q rows, k rows, v rows; padded) */
+    const float* b_in;     /* [3*cs] */
+    const float* w_out;    /* [cs, cs] */
+    const float* b_out;    /* [cs] */
+    const float* ln1_w; const float* ln1_b;  /* [cs] */
+    const float* w1;       /* [dff_pad, cs] */
+    const float* b1;       /* [dff_pad] */
+    const float* w2;       /* [cs, dff_pad] */
+    const float* b2;       /* [cs] */
+    const float* ln2_w; const float* ln2_b;  /* [cs] */
+    int32_t n_tok, n_grp;
+    int32_t d;             /* real model dim (LayerNorm width, softmax scale d^-0.5) */
+    int32_t cs;            /* padded dim: 96 or 80 */
+    int32_t dff_pad;       /* padded feed-forward dim: 192 */
+    int32_t pos_period;    /* 0: pos row = token; >0: pos row = token % pos_period */
+    int32_t n_qtiles32;    /* sum over groups of ceil(group_len / 32): the query-tile count (host knows lengths) */
+    float ln_eps;
+} i2r_encoder_desc;
+
+int i2r_encoder_kv(const i2r_encoder_desc* d, void* stream);
+int i2r_encoder_layer(const i2r_encoder_desc* d, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Program runner: replay a pre-built list of launches from one C call (no per-op host overhead, and
+ * capturable into a hipGraph by the caller).  Streams: ops carry a lane id 0..3; lane 0 is `stream`,
+ * other lanes are forked/joined with events by I2R_OP_FORK / I2R_OP_JOIN.
+ * ------------------------------------------------------------------------------------------------ */
+enum {
+    I2R_OP_CONV = 1, I2R_OP_STEM = 2, I2R_OP_MAXPOOL = 3, I2R_OP_HEAD = 4,
+    I2R_OP_ENC_KV = 5, I2R_OP_ENC_LAYER = 6, I2R_OP_FORK = 7, I2R_OP_JOIN = 8
+};
+
+typedef struct i2r_stem_args {
+    const float* in; const float* w; const float* bias; float* out;
+    int32_t n_img, cin, in_h, in_w, cout, out_cs;
+} i2r_stem_args;
+
+typedef struct i2r_pool_args {
+    const float* in; float* out;
+    int32_t n_img, in_h, in_w, c, in_cs, out_cs;
+} i2r_pool_args;
+
+typedef struct i2r_head_args {
+    const float* in; const float* w; const float* bias; float* out;
+    int32_t n_img, h, w_, cin, in_cs, cout;
+} i2r_head_args;
+
+typedef struct i2r_op {
+    int32_t kind;
+    int32_t lane;          /* stream lane 0..3 (FORK/JOIN: bitmask of lanes to fork to / join from) */
+    const void* args;      /* host pointer to the matching *_desc / *_args struct */
+} i2r_op;
+
+/* streams: array of 4 hipStream_t (lane 0 = the caller's stream); events: array of >= 8 hipEvent_t
+ * created by the caller with hipEventDisableTiming.  Both may be NULL when every op uses lane 0. */
+int i2r_run_program(const i2r_op* ops, int32_t n_ops, void* const* streams, void* const* events);
+
+int i2r_abi_version(void);
+const char* i2r_last_error(void);
+/* device sanity: returns 0 when device `dev` is gfx950, fills cu_count / lds_bytes if non-NULL */
+int i2r_device_check(int32_t dev, int32_t* cu_count, int32_t* lds_bytes);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* I2R_HIP_H */

@@ -1,0 +1,115 @@
+"""ctypes binding of the C-ABI library libi2r_hip.so (declared in include/i2r_hip.h).
+
+This is the ONLY way the product path reaches arithmetic: there is no CPU / eager fallback.  If the
+shared library is missing, or the visible GPU is not gfx950, ``lib()`` raises -- loudly.
+
+Build: ``python -m i2r_amd.build`` / ``__graft_entry__.build()`` (hipcc --offload-arch=gfx950, in-tree .so).
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libi2r_hip.so")
+
+MAX_TAPS = 9
+OP_CONV, OP_STEM, OP_MAXPOOL, OP_HEAD, OP_ENC_KV, OP_ENC_LAYER, OP_FORK, OP_JOIN = 1, 2, 3, 4, 5, 6, 7, 8
+
+_fp = C.c_void_p  # device pointers travel as integers
+_i32 = C.c_int32
+
+
+class ConvDesc(C.Structure):
+    _fields_ = [
+        ("in_", _fp), ("in2", _fp), ("w", _fp), ("bias", _fp), ("res1", _fp), ("res2", _fp), ("res_post", _fp), ("out", _fp),
+        ("n_img", _i32), ("in_h", _i32), ("in_w", _i32), ("in_cs", _i32), ("cin", _i32),
+        ("conv_h", _i32), ("conv_w", _i32), ("out_h", _i32), ("out_w", _i32), ("out_cs", _i32),
+        ("cout", _i32), ("cout_pad", _i32), ("stride", _i32), ("iy0", _i32), ("ix0", _i32), ("ntaps", _i32),
+        ("dy", _i32 * MAX_TAPS), ("dx", _i32 * MAX_TAPS),
+        ("out_step", _i32), ("out_off_y", _i32), ("out_off_x", _i32), ("rep", _i32), ("relu", _i32),
+        ("tile_h", _i32), ("tile_w", _i32), ("ck", _i32), ("wn", _i32), ("mt", _i32),
+    ]
+
+
+class EncoderDesc(C.Structure):
+    _fields_ = [
+        ("src", _fp), ("pos", _fp), ("kbuf", _fp), ("vbuf", _fp), ("out", _fp), ("grp_off", _fp),
+        ("w_in", _fp), ("b_in", _fp), ("w_out", _fp), ("b_out", _fp), ("ln1_w", _fp), ("ln1_b", _fp),
+        ("w1", _fp), ("b1", _fp), ("w2", _fp), ("b2", _fp), ("ln2_w", _fp), ("ln2_b", _fp),
+        ("n_tok", _i32), ("n_grp", _i32), ("d", _i32), ("cs", _i32), ("dff_pad", _i32), ("pos_period", _i32),
+        ("n_qtiles32", _i32), ("ln_eps", C.c_float),
+    ]
+
+
+class StemArgs(C.Structure):
+    _fields_ = [("in_", _fp), ("w", _fp), ("bias", _fp), ("out", _fp),
+                ("n_img", _i32), ("cin", _i32), ("in_h", _i32), ("in_w", _i32), ("cout", _i32), ("out_cs", _i32)]
+
+
+class PoolArgs(C.Structure):
+    _fields_ = [("in_", _fp), ("out", _fp),
+                ("n_img", _i32), ("in_h", _i32), ("in_w", _i32), ("c", _i32), ("in_cs", _i32), ("out_cs", _i32)]
+
+
+class HeadArgs(C.Structure):
+    _fields_ = [("in_", _fp), ("w", _fp), ("bias", _fp), ("out", _fp),
+                ("n_img", _i32), ("h", _i32), ("w_", _i32), ("cin", _i32), ("in_cs", _i32), ("cout", _i32)]
+
+
+class Op(C.Structure):
+    _fields_ = [("kind", _i32), ("lane", _i32), ("args", C.c_void_p)]
+
+
+# every symbol include/i2r_hip.h declares (tests/test_cabi.py checks the built library exports them all)
+EXPORTS = ("i2r_conv", "i2r_stem_conv", "i2r_maxpool3x3s2", "i2r_head", "i2r_encoder_kv", "i2r_encoder_layer",
+           "i2r_run_program", "i2r_abi_version", "i2r_last_error", "i2r_device_check")
+
+_LIB = None
+
+
+class I2RError(RuntimeError):
+    pass
+
+
+def load_library(path=LIB_PATH):
+    """dlopen the library and set prototypes. No GPU needed (used by the CPU-side ABI test)."""
+    if not os.path.exists(path):
+        raise I2RError(
+            "HIP extension %s is missing -- build it with `python -c 'import __graft_entry__ as g; g.build()'`. "
+            "There is no CPU fallback for the product path." % path)
+    L = C.CDLL(path)
+    L.i2r_conv.argtypes = [C.POINTER(ConvDesc), C.c_void_p]
+    L.i2r_stem_conv.argtypes = [_fp, _fp, _fp, _fp, _i32, _i32, _i32, _i32, _i32, _i32, C.c_void_p]
+    L.i2r_maxpool3x3s2.argtypes = [_fp, _fp, _i32, _i32, _i32, _i32, _i32, _i32, C.c_void_p]
+    L.i2r_head.argtypes = [_fp, _fp, _fp, _fp, _i32, _i32, _i32, _i32, _i32, _i32, C.c_void_p]
+    L.i2r_encoder_kv.argtypes = [C.POINTER(EncoderDesc), C.c_void_p]
+    L.i2r_encoder_layer.argtypes = [C.POINTER(EncoderDesc), C.c_void_p]
+    L.i2r_run_program.argtypes = [C.POINTER(Op), _i32, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p)]
+    L.i2r_device_check.argtypes = [_i32, C.POINTER(_i32), C.POINTER(_i32)]
+    L.i2r_last_error.restype = C.c_char_p
+    for name in EXPORTS:
+        if name != "i2r_last_error":
+            getattr(L, name).restype = C.c_int
+    return L
+
+
+def lib():
+    """The loaded library, verified against the ABI version (and cached)."""
+    global _LIB
+    if _LIB is None:
+        L = load_library()
+        if L.i2r_abi_version() != 1:
+            raise I2RError("libi2r_hip.so ABI version %d != 1 -- rebuild" % L.i2r_abi_version())
+        _LIB = L
+    return _LIB
+
+
+def check(rc, what=""):
+    if rc != 0:
+        msg = lib().i2r_last_error()
+        raise I2RError("%s failed (rc=%d): %s" % (what or "i2r call", rc, msg.decode() if msg else "?"))
+
+
+def require_gfx950(device_index=0):
+    cu, lds = _i32(0), _i32(0)
+    check(lib().i2r_device_check(device_index, C.byref(cu), C.byref(lds)), "i2r_device_check")
+    return cu.value, lds.value

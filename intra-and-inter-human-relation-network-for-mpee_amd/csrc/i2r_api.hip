@@ -1,0 +1,90 @@
+// C-ABI plumbing: error string, device check, and the program runner that replays a list of launches.
+#include <stdarg.h>
+#include <string.h>
+
+#include "i2r_common.h"
+
+static thread_local char g_err[512] = "";
+
+void i2r_set_error(const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+}
+
+extern "C" const char* i2r_last_error(void) { return g_err; }
+extern "C" int i2r_abi_version(void) { return I2R_ABI_VERSION; }
+
+extern "C" int i2r_device_check(int32_t dev, int32_t* cu_count, int32_t* lds_bytes) {
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, dev) != hipSuccess) {
+        i2r_set_error("i2r_device_check: no HIP device %d", dev);
+        return I2R_E_NODEV;
+    }
+    if (cu_count) *cu_count = prop.multiProcessorCount;
+    if (lds_bytes) *lds_bytes = (int32_t)prop.sharedMemPerBlock;
+    if (strncmp(prop.gcnArchName, "gfx950", 6) != 0) {
+        i2r_set_error("i2r_device_check: device %d is %s, this library is built for gfx950 only", dev, prop.gcnArchName);
+        return I2R_E_NODEV;
+    }
+    return I2R_OK;
+}
+
+extern "C" int i2r_run_program(const i2r_op* ops, int32_t n_ops, void* const* streams, void* const* events) {
+    I2R_CHECK_ARG(ops && n_ops >= 0, "i2r_run_program: null program");
+    int next_event = 0;
+    for (int i = 0; i < n_ops; ++i) {
+        const i2r_op& op = ops[i];
+        int rc = I2R_OK;
+        if (op.kind == I2R_OP_FORK || op.kind == I2R_OP_JOIN) {
+            I2R_CHECK_ARG(streams && events, "i2r_run_program: fork/join needs streams and events");
+            if (op.kind == I2R_OP_FORK) {  // lanes in the mask wait for everything issued on lane 0 so far
+                hipEvent_t ev = (hipEvent_t)events[next_event++ & 7];
+                if (hipEventRecord(ev, (hipStream_t)streams[0]) != hipSuccess) rc = I2R_E_LAUNCH;
+                for (int l = 1; l < 4 && rc == I2R_OK; ++l)
+                    if (op.lane & (1 << l))
+                        if (hipStreamWaitEvent((hipStream_t)streams[l], ev, 0) != hipSuccess) rc = I2R_E_LAUNCH;
+            } else {  // lane 0 waits for the lanes in the mask
+                for (int l = 1; l < 4 && rc == I2R_OK; ++l)
+                    if (op.lane & (1 << l)) {
+                        hipEvent_t ev = (hipEvent_t)events[next_event++ & 7];
+                        if (hipEventRecord(ev, (hipStream_t)streams[l]) != hipSuccess ||
+                            hipStreamWaitEvent((hipStream_t)streams[0], ev, 0) != hipSuccess)
+                            rc = I2R_E_LAUNCH;
+                    }
+            }
+            if (rc != I2R_OK) {
+                i2r_set_error("i2r_run_program: event fork/join failed at op %d", i);
+                return rc;
+            }
+            continue;
+        }
+        I2R_CHECK_ARG(op.lane >= 0 && op.lane < 4 && op.args, "i2r_run_program: op %d bad lane/args", i);
+        void* st = streams ? streams[op.lane] : nullptr;
+        I2R_CHECK_ARG(streams || op.lane == 0, "i2r_run_program: op %d uses lane %d without streams", i, op.lane);
+        switch (op.kind) {
+            case I2R_OP_CONV: rc = i2r_conv((const i2r_conv_desc*)op.args, st); break;
+            case I2R_OP_STEM: {
+                const i2r_stem_args* a = (const i2r_stem_args*)op.args;
+                rc = i2r_stem_conv(a->in, a->w, a->bias, a->out, a->n_img, a->cin, a->in_h, a->in_w, a->cout, a->out_cs, st);
+                break;
+            }
+            case I2R_OP_MAXPOOL: {
+                const i2r_pool_args* a = (const i2r_pool_args*)op.args;
+                rc = i2r_maxpool3x3s2(a->in, a->out, a->n_img, a->in_h, a->in_w, a->c, a->in_cs, a->out_cs, st);
+                break;
+            }
+            case I2R_OP_HEAD: {
+                const i2r_head_args* a = (const i2r_head_args*)op.args;
+                rc = i2r_head(a->in, a->w, a->bias, a->out, a->n_img, a->h, a->w_, a->cin, a->in_cs, a->cout, st);
+                break;
+            }
+            case I2R_OP_ENC_KV: rc = i2r_encoder_kv((const i2r_encoder_desc*)op.args, st); break;
+            case I2R_OP_ENC_LAYER: rc = i2r_encoder_layer((const i2r_encoder_desc*)op.args, st); break;
+            default: i2r_set_error("i2r_run_program: op %d unknown kind %d", i, op.kind); return I2R_E_ARG;
+        }
+        if (rc != I2R_OK) return rc;
+    }
+    return I2R_OK;
+}

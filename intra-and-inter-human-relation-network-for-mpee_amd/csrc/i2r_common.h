@@ -1,0 +1,34 @@
+// Shared helpers for the gfx950 kernels of libi2r_hip.so (internal; the public boundary is include/i2r_hip.h).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+
+#include "i2r_hip.h"
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+// D = A(16x4) * B(4x16) + C on the fp32 matrix pipe (v_mfma_f32_16x16x4_f32, 32 cycles/SIMD, exact fp32).
+// lane l supplies A[i = l&15][k = l>>4] and B[k = l>>4][j = l&15]; D: col j = l&15, rows 4*(l>>4)+r.
+__device__ __forceinline__ f32x4 mfma16(float a, float b, f32x4 c) {
+    return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
+}
+
+void i2r_set_error(const char* fmt, ...);
+
+#define I2R_CHECK_ARG(cond, ...)            \
+    do {                                    \
+        if (!(cond)) {                      \
+            i2r_set_error(__VA_ARGS__);     \
+            return I2R_E_ARG;               \
+        }                                   \
+    } while (0)
+
+#define I2R_CHECK_LAUNCH(what)                                              \
+    do {                                                                    \
+        hipError_t e__ = hipGetLastError();                                 \
+        if (e__ != hipSuccess) {                                            \
+            i2r_set_error("%s: %s", what, hipGetErrorString(e__));          \
+            return I2R_E_LAUNCH;                                            \
+        }                                                                   \
+    } while (0)

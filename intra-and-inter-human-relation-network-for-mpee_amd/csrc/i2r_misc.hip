@@ -1,0 +1,162 @@
+// Boundary / glue kernels: NCHW stem conv, NHWC max-pool, NHWC -> NCHW heatmap head.  All HBM-bound
+// element-wise-class work (a few % of the forward); written for coalesced 16-byte accesses.
+#include "i2r_common.h"
+
+namespace {
+
+// 3x3 stride-2 pad-1 conv with tiny cin (3 = RGB crop, 1 = person box mask) + folded BN + ReLU.
+// thread = one output pixel x 16 output channels; the cout/16 threads of a pixel are adjacent lanes, so a
+// pixel's cout floats are written as one contiguous run (NHWC).  w: [9][CIN][cout].
+template <int CIN>
+__global__ __launch_bounds__(256) void stem_conv_k(const float* __restrict__ in, const float* __restrict__ w,
+                                                   const float* __restrict__ bias, float* __restrict__ out, int n_img,
+                                                   int in_h, int in_w, int out_h, int out_w, int cout, int out_cs) {
+    const int groups = cout >> 4;
+    const long long gid = (long long)blockIdx.x * 256 + threadIdx.x;
+    const int cg = (int)(gid % groups);
+    const long long pix = gid / groups;
+    if (pix >= (long long)n_img * out_h * out_w) return;
+    const int ox = (int)(pix % out_w);
+    const int oy = (int)((pix / out_w) % out_h);
+    const int img = (int)(pix / ((long long)out_w * out_h));
+
+    float acc[16];
+#pragma unroll
+    for (int j = 0; j < 16; ++j) acc[j] = bias[cg * 16 + j];
+#pragma unroll
+    for (int ky = 0; ky < 3; ++ky) {
+        const int iy = oy * 2 - 1 + ky;
+#pragma unroll
+        for (int kx = 0; kx < 3; ++kx) {
+            const int ix = ox * 2 - 1 + kx;
+            const bool ok = iy >= 0 && iy < in_h && ix >= 0 && ix < in_w;
+#pragma unroll
+            for (int ci = 0; ci < CIN; ++ci) {
+                const float x = ok ? in[((size_t)(img * CIN + ci) * in_h + iy) * in_w + ix] : 0.f;
+                const f32x4* wr = reinterpret_cast<const f32x4*>(w + ((ky * 3 + kx) * CIN + ci) * cout + cg * 16);
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const f32x4 wv = wr[q];
+                    acc[q * 4 + 0] = fmaf(x, wv[0], acc[q * 4 + 0]);
+                    acc[q * 4 + 1] = fmaf(x, wv[1], acc[q * 4 + 1]);
+                    acc[q * 4 + 2] = fmaf(x, wv[2], acc[q * 4 + 2]);
+                    acc[q * 4 + 3] = fmaf(x, wv[3], acc[q * 4 + 3]);
+                }
+            }
+        }
+    }
+    f32x4* o = reinterpret_cast<f32x4*>(out + (size_t)pix * out_cs + cg * 16);
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+        o[q] = (f32x4){fmaxf(acc[q * 4], 0.f), fmaxf(acc[q * 4 + 1], 0.f), fmaxf(acc[q * 4 + 2], 0.f),
+                       fmaxf(acc[q * 4 + 3], 0.f)};
+}
+
+// nn.MaxPool2d(3, 2, 1) on NHWC; thread = one output pixel x 4 channels (padding behaves as -inf)
+__global__ __launch_bounds__(256) void maxpool_k(const float* __restrict__ in, float* __restrict__ out, int n_img,
+                                                 int in_h, int in_w, int out_h, int out_w, int c4, int in_cs,
+                                                 int out_cs) {
+    const long long gid = (long long)blockIdx.x * 256 + threadIdx.x;
+    const int cg = (int)(gid % c4);
+    const long long pix = gid / c4;
+    if (pix >= (long long)n_img * out_h * out_w) return;
+    const int ox = (int)(pix % out_w);
+    const int oy = (int)((pix / out_w) % out_h);
+    const int img = (int)(pix / ((long long)out_w * out_h));
+    const float ninf = -__builtin_inff();
+    f32x4 m = (f32x4){ninf, ninf, ninf, ninf};
+#pragma unroll
+    for (int ky = 0; ky < 3; ++ky) {
+        const int iy = oy * 2 - 1 + ky;
+        if (iy < 0 || iy >= in_h) continue;
+#pragma unroll
+        for (int kx = 0; kx < 3; ++kx) {
+            const int ix = ox * 2 - 1 + kx;
+            if (ix < 0 || ix >= in_w) continue;
+            const f32x4 v = *reinterpret_cast<const f32x4*>(in + ((size_t)(img * in_h + iy) * in_w + ix) * in_cs + cg * 4);
+            m[0] = fmaxf(m[0], v[0]); m[1] = fmaxf(m[1], v[1]); m[2] = fmaxf(m[2], v[2]); m[3] = fmaxf(m[3], v[3]);
+        }
+    }
+    *reinterpret_cast<f32x4*>(out + (size_t)pix * out_cs + cg * 4) = m;
+}
+
+// final 1x1 conv with bias: NHWC features -> NCHW heatmaps. thread = one pixel, all joints (JP = padded
+// joint count held in registers); weights are wave-uniform -> scalar loads.  w: [cout][cin].
+template <int JP>
+__global__ __launch_bounds__(256) void head_k(const float* __restrict__ in, const float* __restrict__ w,
+                                              const float* __restrict__ bias, float* __restrict__ out, int n_img, int hw,
+                                              int cin, int in_cs, int cout) {
+    const long long pix = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (pix >= (long long)n_img * hw) return;
+    float acc[JP];
+#pragma unroll
+    for (int j = 0; j < JP; ++j) acc[j] = j < cout ? bias[j] : 0.f;
+    const f32x4* x = reinterpret_cast<const f32x4*>(in + (size_t)pix * in_cs);
+    for (int c = 0; c < cin; c += 4) {
+        const f32x4 v = x[c >> 2];
+#pragma unroll
+        for (int j = 0; j < JP; ++j) {
+            if (j < cout) {
+                const float* wr = w + j * cin + c;
+                acc[j] = fmaf(v[0], wr[0], acc[j]);
+                acc[j] = fmaf(v[1], wr[1], acc[j]);
+                acc[j] = fmaf(v[2], wr[2], acc[j]);
+                acc[j] = fmaf(v[3], wr[3], acc[j]);
+            }
+        }
+    }
+    const int img = (int)(pix / hw);
+    const int p = (int)(pix - (long long)img * hw);
+#pragma unroll
+    for (int j = 0; j < JP; ++j)
+        if (j < cout) out[((size_t)img * cout + j) * hw + p] = acc[j];
+}
+
+}  // namespace
+
+extern "C" int i2r_stem_conv(const float* in_nchw, const float* w, const float* bias, float* out_nhwc, int32_t n_img,
+                             int32_t cin, int32_t in_h, int32_t in_w, int32_t cout, int32_t out_cs, void* stream) {
+    I2R_CHECK_ARG(in_nchw && w && bias && out_nhwc, "i2r_stem_conv: null pointer");
+    I2R_CHECK_ARG(cout > 0 && cout % 16 == 0 && out_cs >= cout && out_cs % 4 == 0, "i2r_stem_conv: cout=%d out_cs=%d", cout, out_cs);
+    I2R_CHECK_ARG(cin == 1 || cin == 3, "i2r_stem_conv: cin=%d (1 or 3)", cin);
+    const int out_h = (in_h - 1) / 2 + 1, out_w = (in_w - 1) / 2 + 1;
+    const long long nthr = (long long)n_img * out_h * out_w * (cout / 16);
+    const unsigned nblk = (unsigned)((nthr + 255) / 256);
+    if (cin == 3)
+        hipLaunchKernelGGL(stem_conv_k<3>, dim3(nblk), dim3(256), 0, (hipStream_t)stream, in_nchw, w, bias, out_nhwc, n_img,
+                           in_h, in_w, out_h, out_w, cout, out_cs);
+    else
+        hipLaunchKernelGGL(stem_conv_k<1>, dim3(nblk), dim3(256), 0, (hipStream_t)stream, in_nchw, w, bias, out_nhwc, n_img,
+                           in_h, in_w, out_h, out_w, cout, out_cs);
+    I2R_CHECK_LAUNCH("i2r_stem_conv");
+    return I2R_OK;
+}
+
+extern "C" int i2r_maxpool3x3s2(const float* in, float* out, int32_t n_img, int32_t in_h, int32_t in_w, int32_t c,
+                                int32_t in_cs, int32_t out_cs, void* stream) {
+    I2R_CHECK_ARG(in && out && in != out, "i2r_maxpool3x3s2: bad pointers");
+    I2R_CHECK_ARG(c > 0 && c % 4 == 0 && in_cs % 4 == 0 && out_cs % 4 == 0 && c <= in_cs && c <= out_cs,
+                  "i2r_maxpool3x3s2: c=%d in_cs=%d out_cs=%d", c, in_cs, out_cs);
+    const int out_h = (in_h - 1) / 2 + 1, out_w = (in_w - 1) / 2 + 1;
+    const long long nthr = (long long)n_img * out_h * out_w * (c / 4);
+    hipLaunchKernelGGL(maxpool_k, dim3((unsigned)((nthr + 255) / 256)), dim3(256), 0, (hipStream_t)stream, in, out, n_img,
+                       in_h, in_w, out_h, out_w, c / 4, in_cs, out_cs);
+    I2R_CHECK_LAUNCH("i2r_maxpool3x3s2");
+    return I2R_OK;
+}
+
+extern "C" int i2r_head(const float* in, const float* w, const float* bias, float* out_nchw, int32_t n_img, int32_t h,
+                        int32_t w_, int32_t cin, int32_t in_cs, int32_t cout, void* stream) {
+    I2R_CHECK_ARG(in && w && bias && out_nchw, "i2r_head: null pointer");
+    I2R_CHECK_ARG(cin % 4 == 0 && in_cs % 4 == 0 && cin <= in_cs && cout >= 1 && cout <= 32, "i2r_head: cin=%d cout=%d", cin, cout);
+    const long long npix = (long long)n_img * h * w_;
+    const unsigned nblk = (unsigned)((npix + 255) / 256);
+    if (cout <= 16)
+        hipLaunchKernelGGL(head_k<16>, dim3(nblk), dim3(256), 0, (hipStream_t)stream, in, w, bias, out_nchw, n_img, h * w_, cin,
+                           in_cs, cout);
+    else
+        hipLaunchKernelGGL(head_k<32>, dim3(nblk), dim3(256), 0, (hipStream_t)stream, in, w, bias, out_nchw, n_img, h * w_, cin,
+                           in_cs, cout);
+    I2R_CHECK_LAUNCH("i2r_head");
+    return I2R_OK;
+}

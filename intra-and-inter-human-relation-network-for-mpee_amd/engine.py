@@ -1,0 +1,626 @@
+"""Execution engine of the hot path: packs reference-layout weights for the HIP kernels and replays a
+pre-built launch program through the C-ABI (cabi.py).  No arithmetic happens in Python/torch here: torch
+only owns device memory and streams.
+
+Weight packing (done once per load_state_dict / device move):
+  * every conv + eval-mode BatchNorm pair is folded:  w' = w * gamma/sqrt(var+eps),  b' = beta - mean*gamma/sqrt(var+eps)
+    (reference applies nn.Conv2d then nn.BatchNorm2d, e.g. interformer_pureMulti.py:53-60); folding is done in
+    float64 and rounded once to fp32.
+  * conv weights go to the "k4" layout  [tap][cin/4][cout_pad][4]  consumed by i2r_conv (include/i2r_hip.h).
+  * ConvTranspose2d(k4,s2,p1) is split into its four output-parity 2x2 convolutions.
+  * encoder matrices stay in the reference's row-major [out][in] form, zero-padded to multiples of 16.
+
+A Program is the static list of launches for one (S, H, W, length) signature: all intermediate NHWC buffers
+are pre-allocated (arena with reuse), so a forward is ONE call into i2r_run_program.
+"""
+import ctypes as C
+import math
+
+import torch
+
+from . import cabi
+
+
+def _r16(c):
+    return (c + 15) // 16 * 16
+
+
+# ------------------------------------------------------------------------------------------------
+# packing
+# ------------------------------------------------------------------------------------------------
+def fold_bn(w, bn, conv_bias=None, eps=1e-5):
+    """w [Cout, ...] fp32 CPU; bn = (gamma, beta, mean, var) or None -> (w', b') float64."""
+    w = w.double()
+    cout = w.shape[0]
+    b = conv_bias.double() if conv_bias is not None else torch.zeros(cout, dtype=torch.float64)
+    if bn is not None:
+        gamma, beta, mean, var = [t.double() for t in bn]
+        scale = gamma / torch.sqrt(var + eps)
+        w = w * scale.view(-1, *([1] * (w.dim() - 1)))
+        b = (b - mean) * scale + beta
+    return w, b
+
+
+def pack_k4(w_taps, cin_pad, cout_pad):
+    """w_taps [ntaps, cin, cout] -> fp32 [ntaps, cin_pad/4, cout_pad, 4] (zero padded)."""
+    nt, cin, cout = w_taps.shape
+    full = torch.zeros(nt, cin_pad, cout_pad, dtype=torch.float64)
+    full[:, :cin, :cout] = w_taps
+    return full.view(nt, cin_pad // 4, 4, cout_pad).permute(0, 1, 3, 2).contiguous().float()
+
+
+class PackedConv:
+    __slots__ = ("w", "bias", "cin", "cin_pad", "cout", "cout_pad", "taps", "iy0", "ix0", "stride", "ksize")
+
+    def __init__(self, w, bias, cin, cout, taps, iy0, ix0, stride, ksize):
+        self.w, self.bias = w, bias
+        self.cin, self.cin_pad = cin, w.shape[1] * 4
+        self.cout, self.cout_pad = cout, w.shape[2]
+        self.taps, self.iy0, self.ix0, self.stride, self.ksize = taps, iy0, ix0, stride, ksize
+
+
+class Packer:
+    def __init__(self, sd, device):
+        self.sd = {k: v.detach().to("cpu") for k, v in sd.items()}
+        self.device = device
+
+    def _bn(self, key):
+        if key is None:
+            return None
+        s = self.sd
+        return (s[key + ".weight"], s[key + ".bias"], s[key + ".running_mean"], s[key + ".running_var"])
+
+    def _dev(self, t):
+        return t.contiguous().to(self.device)
+
+    def conv(self, conv_key, bn_key=None, stride=1, eps=1e-5):
+        w = self.sd[conv_key + ".weight"]
+        cout, cin, kh, kw = w.shape
+        assert kh == kw and kh in (1, 3)
+        wf, bf = fold_bn(w, self._bn(bn_key), self.sd.get(conv_key + ".bias"), eps)
+        taps = [(dy, dx) for dy in range(kh) for dx in range(kw)]
+        w_taps = wf.permute(2, 3, 1, 0).reshape(kh * kw, cin, cout)
+        cout_pad = _r16(cout)
+        bias = torch.zeros(cout_pad, dtype=torch.float64)
+        bias[:cout] = bf
+        pad = kh // 2
+        return PackedConv(self._dev(pack_k4(w_taps, _r16(cin), cout_pad)), self._dev(bias.float()), cin, cout, taps,
+                          -pad, -pad, stride, kh)
+
+    def linear_as_conv(self, w, b):
+        """[out, in] matrix + bias -> 1x1 PackedConv."""
+        cout, cin = w.shape
+        cout_pad = _r16(cout)
+        bias = torch.zeros(cout_pad, dtype=torch.float64)
+        bias[:cout] = b.double()
+        return PackedConv(self._dev(pack_k4(w.double().t().reshape(1, cin, cout), _r16(cin), cout_pad)),
+                          self._dev(bias.float()), cin, cout, [(0, 0)], 0, 0, 1, 1)
+
+    def deconv(self, deconv_key, bn_key, eps=1e-5):
+        """ConvTranspose2d(k=4, s=2, p=1) [Cin, Cout, 4, 4] (+BN) -> {(py,px): PackedConv with 2x2 taps}.
+
+        out[2q+py] gathers in[q+iy0+dy]:  py=0: iy0=-1, ky = 3-2dy ;  py=1: iy0=0, ky = 2-2dy  (oy = 2*iy - 1 + ky).
+        """
+        w = self.sd[deconv_key + ".weight"]
+        cin, cout, kh, kw = w.shape
+        assert kh == 4 and kw == 4
+        wf, bf = fold_bn(w.permute(1, 0, 2, 3), self._bn(bn_key), self.sd.get(deconv_key + ".bias"), eps)  # [Cout,Cin,4,4]
+        cout_pad = _r16(cout)
+        bias = torch.zeros(cout_pad, dtype=torch.float64)
+        bias[:cout] = bf
+        bias = self._dev(bias.float())
+        out = {}
+        for py in (0, 1):
+            for px in (0, 1):
+                taps, mats = [], []
+                for dy in (0, 1):
+                    for dx in (0, 1):
+                        ky = 3 - 2 * dy if py == 0 else 2 - 2 * dy
+                        kx = 3 - 2 * dx if px == 0 else 2 - 2 * dx
+                        taps.append((dy, dx))
+                        mats.append(wf[:, :, ky, kx].t())  # [Cin, Cout]
+                w_taps = torch.stack(mats, 0)
+                out[(py, px)] = PackedConv(self._dev(pack_k4(w_taps, _r16(cin), cout_pad)), bias, cin, cout, taps,
+                                           -1 if py == 0 else 0, -1 if px == 0 else 0, 1, 2)
+        return out
+
+    def stem(self, conv_key, bn_key, eps=1e-5):
+        w = self.sd[conv_key + ".weight"]  # [cout, cin, 3, 3]
+        cout, cin = w.shape[:2]
+        wf, bf = fold_bn(w, self._bn(bn_key), None, eps)
+        return dict(w=self._dev(wf.permute(2, 3, 1, 0).reshape(9, cin, cout).float()), bias=self._dev(bf.float()),
+                    cin=cin, cout=cout)
+
+    def head(self, key):
+        w = self.sd[key + ".weight"]
+        cout, cin, kh, kw = w.shape
+        assert kh == 1 and kw == 1, "FINAL_CONV_KERNEL=3 heads are not used by the shipped configs"
+        cin_pad = _r16(cin)
+        wp = torch.zeros(cout, cin_pad)
+        wp[:, :cin] = w.view(cout, cin)
+        return dict(w=self._dev(wp), bias=self._dev(self.sd[key + ".bias"].float()), cin=cin_pad, cout=cout)
+
+    def encoder_layer(self, p, d, dff):
+        cs, fs = _r16(d), _r16(dff)
+        s = self.sd
+
+        def padm(m, r, c):
+            o = torch.zeros(r, c)
+            o[:m.shape[0], :m.shape[1]] = m
+            return o
+
+        def padv(v, n):
+            o = torch.zeros(n)
+            o[:v.shape[0]] = v
+            return o
+
+        wi, bi = s[p + ".self_attn.in_proj_weight"], s[p + ".self_attn.in_proj_bias"]
+        w_in = torch.cat([padm(wi[i * d:(i + 1) * d], cs, cs) for i in range(3)], 0)
+        b_in = torch.cat([padv(bi[i * d:(i + 1) * d], cs) for i in range(3)], 0)
+        t = dict(
+            w_in=w_in, b_in=b_in,
+            w_out=padm(s[p + ".self_attn.out_proj.weight"], cs, cs), b_out=padv(s[p + ".self_attn.out_proj.bias"], cs),
+            ln1_w=padv(s[p + ".norm1.weight"], cs), ln1_b=padv(s[p + ".norm1.bias"], cs),
+            w1=padm(s[p + ".linear1.weight"], fs, cs), b1=padv(s[p + ".linear1.bias"], fs),
+            w2=padm(s[p + ".linear2.weight"], cs, fs), b2=padv(s[p + ".linear2.bias"], cs),
+            ln2_w=padv(s[p + ".norm2.weight"], cs), ln2_b=padv(s[p + ".norm2.bias"], cs))
+        t = {k: self._dev(v.float()) for k, v in t.items()}
+        t.update(d=d, cs=cs, dff_pad=fs)
+        return t
+
+    def table(self, key, rows, d):
+        """[rows, 1, d] parameter (TransPose-H pos_embedding) -> [rows, cs] device table."""
+        v = self.sd[key].reshape(rows, d)
+        o = torch.zeros(rows, _r16(d))
+        o[:, :d] = v
+        return self._dev(o)
+
+
+# ------------------------------------------------------------------------------------------------
+# program
+# ------------------------------------------------------------------------------------------------
+class Act:
+    """NHWC fp32 activation buffer [n, h, w, cs] holding c real channels."""
+    __slots__ = ("t", "n", "h", "w", "c", "cs")
+
+    def __init__(self, t, n, h, w, c, cs):
+        self.t, self.n, self.h, self.w, self.c, self.cs = t, n, h, w, c, cs
+
+    @property
+    def ptr(self):
+        return self.t.data_ptr()
+
+
+def choose_tile(conv_h, conv_w, wm, stride, max_d, n_img, n_cblk):
+    """(tile_h, tile_w, mt) for a workgroup of wm M-waves: maximise useful-lane fraction, then occupancy."""
+    best = None
+    cands_w = sorted({w for w in (conv_w, 48, 32, 24, 16, 12, 8, 6, 4) if w <= conv_w and w <= 48})
+    for mt in (1, 2, 3, 4):
+        cap = wm * mt * 16
+        for tw in cands_w:
+            th = min(conv_h, cap // tw)
+            if th < 1:
+                continue
+            ph, pw = (th - 1) * stride + max_d + 1, (tw - 1) * stride + max_d + 1
+            if ph * pw > 1280:
+                continue
+            tiles = -(-conv_h // th) * -(-conv_w // tw)
+            eff = conv_h * conv_w / float(tiles * cap)
+            halo = (th * stride) * (tw * stride) / float(ph * pw)
+            blocks = tiles * n_img * n_cblk
+            fill = min(1.0, blocks / 512.0)
+            score = eff * (0.85 + 0.15 * halo) * (0.6 + 0.4 * fill) * (1.0 + 0.03 * mt)
+            if best is None or score > best[0]:
+                best = (score, th, tw, mt)
+    assert best is not None, "no tile for %dx%d" % (conv_h, conv_w)
+    return best[1], best[2], best[3]
+
+
+def conv_split(cout_pad):
+    nfrag = cout_pad // 16
+    nt = next(c for c in (3, 4, 5, 2, 1) if nfrag % c == 0)  # same rule as csrc/i2r_conv.hip
+    nb = nfrag // nt
+    wn = 4 if nb % 4 == 0 else 2 if nb % 2 == 0 else 1
+    return nt, wn
+
+
+class Program:
+    def __init__(self, device):
+        self.device = device
+        self.ops = []        # (kind, lane, struct)
+        self.keep = []       # everything the structs point to
+        self.pool = {}       # numel -> [tensor]
+        self.nbytes = 0
+        self._c_ops = None
+
+    # ---- buffers ----
+    def alloc(self, n, h, w, c):
+        cs = _r16(c)
+        numel = n * h * w * cs
+        lst = self.pool.get(numel)
+        if lst:
+            t = lst.pop()
+        else:
+            t = torch.empty(numel, dtype=torch.float32, device=self.device)
+            self.nbytes += numel * 4
+            self.keep.append(t)
+        return Act(t, n, h, w, c, cs)
+
+    def release(self, *acts):
+        for a in acts:
+            self.pool.setdefault(a.t.numel(), []).append(a.t)
+
+    # ---- ops ----
+    def stem(self, st, n, h, w, in_ptr=0, lane=0):
+        out = self.alloc(n, (h - 1) // 2 + 1, (w - 1) // 2 + 1, st["cout"])
+        a = cabi.StemArgs(in_ptr, st["w"].data_ptr(), st["bias"].data_ptr(), out.ptr, n, st["cin"], h, w, st["cout"], out.cs)
+        self.ops.append((cabi.OP_STEM, lane, a))
+        return out, a
+
+    def conv(self, x, pc, relu=False, res1=None, res2=None, res_post=None, in2=None, up=1, out=None, out_step=1,
+             out_off=(0, 0), out_hw=None, lane=0):
+        assert x.cs >= pc.cin_pad and x.c == pc.cin, "conv input channels %d/%d vs weight %d" % (x.c, x.cs, pc.cin)
+        k = pc.ksize
+        if pc.stride == 1:
+            conv_h, conv_w = x.h, x.w  # 'same' geometry for 1x1 / 3x3 pad 1 / deconv parity 2x2
+        else:
+            conv_h, conv_w = (x.h - 1) // 2 + 1, (x.w - 1) // 2 + 1
+        if up > 1:
+            out_step = up
+        if out is None:
+            oh, ow = out_hw if out_hw else (conv_h * out_step, conv_w * out_step)
+            out = self.alloc(x.n, oh, ow, pc.cout)
+        assert out.cs >= pc.cout_pad or out.cs >= pc.cout
+        d = cabi.ConvDesc()
+        d.in_, d.in2, d.w, d.bias = x.ptr, (in2.ptr if in2 is not None else None), pc.w.data_ptr(), pc.bias.data_ptr()
+        d.res1 = res1.ptr if res1 is not None else None
+        d.res2 = res2.ptr if res2 is not None else None
+        d.res_post = res_post.ptr if res_post is not None else None
+        d.out = out.ptr
+        d.n_img, d.in_h, d.in_w, d.in_cs, d.cin = x.n, x.h, x.w, x.cs, pc.cin_pad
+        d.conv_h, d.conv_w, d.out_h, d.out_w, d.out_cs = conv_h, conv_w, out.h, out.w, out.cs
+        d.cout, d.cout_pad, d.stride, d.iy0, d.ix0 = pc.cout, pc.cout_pad, pc.stride, pc.iy0, pc.ix0
+        d.ntaps = len(pc.taps)
+        for i, (dy, dx) in enumerate(pc.taps):
+            d.dy[i], d.dx[i] = dy, dx
+        d.out_step, d.out_off_y, d.out_off_x, d.rep, d.relu = out_step, out_off[0], out_off[1], up, int(relu)
+        nt, wn = conv_split(pc.cout_pad)
+        n_cblk = (pc.cout_pad // 16) // (nt * wn)
+        max_d = max(max(t) for t in pc.taps)
+        th, tw, mt = choose_tile(conv_h, conv_w, 4 // wn, pc.stride, max_d, x.n, n_cblk)
+        d.tile_h, d.tile_w, d.mt, d.wn, d.ck = th, tw, mt, wn, 0
+        self.ops.append((cabi.OP_CONV, lane, d))
+        return out
+
+    def deconv(self, x, pcs, relu=True, res_post=None, lane=0):
+        """ConvTranspose(k4,s2,p1)+BN(+ReLU)(+post-ReLU residual) as four parity convs writing the interleaved 2x output."""
+        out = self.alloc(x.n, 2 * x.h, 2 * x.w, pcs[(0, 0)].cout)
+        for (py, px), pc in pcs.items():
+            self.conv(x, pc, relu=relu, res_post=res_post, out=out, out_step=2, out_off=(py, px), lane=lane)
+        return out
+
+    def maxpool(self, x, lane=0):
+        out = self.alloc(x.n, (x.h - 1) // 2 + 1, (x.w - 1) // 2 + 1, x.c)
+        a = cabi.PoolArgs(x.ptr, out.ptr, x.n, x.h, x.w, x.cs, x.cs, out.cs)  # pool all cs channels (pads stay 0)
+        self.ops.append((cabi.OP_MAXPOOL, lane, a))
+        return out
+
+    def head(self, x, hd, out_ptr=0, lane=0):
+        a = cabi.HeadArgs(x.ptr, hd["w"].data_ptr(), hd["bias"].data_ptr(), out_ptr, x.n, x.h, x.w, hd["cin"], x.cs, hd["cout"])
+        self.ops.append((cabi.OP_HEAD, lane, a))
+        return a
+
+    def encoder(self, x, layers, grp_off_host, pos=None, pos_period=0, lane=0):
+        """x: Act viewed as tokens [n*h*w, cs]; grp_off_host: python list of token offsets per group."""
+        n_tok = x.n * x.h * x.w
+        cs = x.cs
+        n_pad = (n_tok + 63) // 64 * 64 + 64
+        kbuf = torch.empty(n_tok * cs, dtype=torch.float32, device=self.device)
+        vbuf = torch.zeros(cs * n_pad, dtype=torch.float32, device=self.device)
+        goff = torch.tensor(grp_off_host, dtype=torch.int32, device=self.device)
+        self.keep += [kbuf, vbuf, goff]
+        assert all(o % 4 == 0 for o in grp_off_host), "token group offsets must be multiples of 4"
+        nq = sum(-(-(grp_off_host[i + 1] - grp_off_host[i]) // 32) for i in range(len(grp_off_host) - 1))
+        cur = x
+        for L in layers:
+            assert L["cs"] == cs
+            out = self.alloc(x.n, x.h, x.w, x.c)
+            d = cabi.EncoderDesc()
+            d.src, d.pos = cur.ptr, (pos if pos else None)
+            d.kbuf, d.vbuf, d.out, d.grp_off = kbuf.data_ptr(), vbuf.data_ptr(), out.ptr, goff.data_ptr()
+            for name in ("w_in", "b_in", "w_out", "b_out", "ln1_w", "ln1_b", "w1", "b1", "w2", "b2", "ln2_w", "ln2_b"):
+                setattr(d, name, L[name].data_ptr())
+            d.n_tok, d.n_grp, d.d, d.cs, d.dff_pad = n_tok, len(grp_off_host) - 1, L["d"], cs, L["dff_pad"]
+            d.pos_period, d.n_qtiles32, d.ln_eps = pos_period, nq, 1e-5
+            self.ops.append((cabi.OP_ENC_KV, lane, d))
+            self.ops.append((cabi.OP_ENC_LAYER, lane, d))
+            if cur is not x:
+                self.release(cur)
+            cur = out
+        return cur
+
+    def fork(self, mask):
+        self.ops.append((cabi.OP_FORK, mask, None))
+
+    def join(self, mask):
+        self.ops.append((cabi.OP_JOIN, mask, None))
+
+    # ---- run ----
+    def finalize(self):
+        arr = (cabi.Op * len(self.ops))()
+        for i, (kind, lane, st) in enumerate(self.ops):
+            arr[i].kind, arr[i].lane = kind, lane
+            arr[i].args = C.cast(C.pointer(st), C.c_void_p) if st is not None else None
+        self._c_ops = arr
+        self.uses_lanes = any(lane != 0 or kind in (cabi.OP_FORK, cabi.OP_JOIN) for kind, lane, _ in self.ops)
+
+    def run(self, streams=None, events=None):
+        L = cabi.lib()
+        if streams is None:
+            cur = torch.cuda.current_stream(self.device).cuda_stream
+            streams = (C.c_void_p * 4)(cur, cur, cur, cur)
+        cabi.check(L.i2r_run_program(self._c_ops, len(self.ops), streams, events), "i2r_run_program")
+
+
+# ------------------------------------------------------------------------------------------------
+# network assembly
+# ------------------------------------------------------------------------------------------------
+class HRNetW48:
+    """Packed HRNet-W48-S tower (reference interformer_pureMulti.py:675-699) + its program emitter."""
+
+    def __init__(self, pk, p, extra):
+        self.extra = extra
+        s2, s3 = extra["STAGE2"], extra["STAGE3"]
+        self.stem1 = pk.stem(p + "conv1", p + "bn1")
+        self.conv2 = pk.conv(p + "conv2", p + "bn2", stride=2)
+        self.layer1 = []
+        for b in range(4):
+            q = "%slayer1.%d" % (p, b)
+            blk = dict(c1=pk.conv(q + ".conv1", q + ".bn1"), c2=pk.conv(q + ".conv2", q + ".bn2"),
+                       c3=pk.conv(q + ".conv3", q + ".bn3"))
+            if (q + ".downsample.0.weight") in pk.sd:
+                blk["ds"] = pk.conv(q + ".downsample.0", q + ".downsample.1")
+            self.layer1.append(blk)
+        self.t1 = [pk.conv(p + "transition1.0.0", p + "transition1.0.1"),
+                   pk.conv(p + "transition1.1.0.0", p + "transition1.1.0.1", stride=2)]
+        self.stage2 = [self._module(pk, "%sstage2.%d" % (p, m), s2) for m in range(s2["NUM_MODULES"])]
+        self.t2 = pk.conv(p + "transition2.2.0.0", p + "transition2.2.0.1", stride=2)
+        self.stage3 = [self._module(pk, "%sstage3.%d" % (p, m), s3) for m in range(s3["NUM_MODULES"])]
+
+    @staticmethod
+    def _module(pk, q, st):
+        nb = st["NUM_BRANCHES"]
+        mod = dict(nb=nb, blocks=[], fuse={})
+        for i in range(nb):
+            mod["blocks"].append([(pk.conv("%s.branches.%d.%d.conv1" % (q, i, b), "%s.branches.%d.%d.bn1" % (q, i, b)),
+                                   pk.conv("%s.branches.%d.%d.conv2" % (q, i, b), "%s.branches.%d.%d.bn2" % (q, i, b)))
+                                  for b in range(st["NUM_BLOCKS"][i])])
+        for i in range(nb):
+            for j in range(nb):
+                if j > i:
+                    mod["fuse"][(i, j)] = pk.conv("%s.fuse_layers.%d.%d.0" % (q, i, j), "%s.fuse_layers.%d.%d.1" % (q, i, j))
+                elif j < i:
+                    mod["fuse"][(i, j)] = [pk.conv("%s.fuse_layers.%d.%d.%d.0" % (q, i, j, k),
+                                                   "%s.fuse_layers.%d.%d.%d.1" % (q, i, j, k), stride=2)
+                                           for k in range(i - j)]
+        return mod
+
+    @staticmethod
+    def _emit_module(P, mod, xs):
+        nb = mod["nb"]
+        xs = list(xs)
+        for i in range(nb):
+            for (c1, c2) in mod["blocks"][i]:
+                t = P.conv(xs[i], c1, relu=True)
+                y = P.conv(t, c2, relu=True, res1=xs[i])
+                P.release(t, xs[i])
+                xs[i] = y
+        outs = []
+        for i in range(nb):
+            # y = ((t_0 + t_1) + ...) in the reference's order (interformer_pureMulti.py:401-408). Identity terms are
+            # folded into a neighbouring conv's residual inputs; the running sum is accumulated in place in `y`.
+            acc, y, j = None, None, 0
+            while j < nb:
+                if j == i:
+                    assert acc is None
+                    acc = xs[i]
+                    j += 1
+                    continue
+                if j > i:
+                    chain, up = [mod["fuse"][(i, j)]], 2 ** (j - i)
+                else:
+                    chain, up = mod["fuse"][(i, j)], 1
+                cur = xs[j]
+                for pc in chain[:-1]:
+                    nxt = P.conv(cur, pc, relu=True)
+                    if cur is not xs[j]:
+                        P.release(cur)
+                    cur = nxt
+                res = [acc] if acc is not None else []
+                if j + 1 == i:
+                    res.append(xs[i])
+                jn = j + 2 if j + 1 == i else j + 1
+                if y is None:
+                    y = P.alloc(xs[i].n, xs[i].h, xs[i].w, xs[i].c)
+                P.conv(cur, chain[-1], relu=(jn >= nb), res1=res[0] if res else None,
+                       res2=res[1] if len(res) > 1 else None, up=up, out=y)
+                if cur is not xs[j]:
+                    P.release(cur)
+                acc, j = y, jn
+            outs.append(y)
+        P.release(*xs)
+        return outs
+
+    def emit(self, P, n, h, w):
+        """-> (list of branch Acts, stem StemArgs to patch the input pointer into)."""
+        a, stem_args = P.stem(self.stem1, n, h, w)
+        b = P.conv(a, self.conv2, relu=True)
+        P.release(a)
+        x = b
+        for blk in self.layer1:
+            t1 = P.conv(x, blk["c1"], relu=True)
+            t2 = P.conv(t1, blk["c2"], relu=True)
+            res = P.conv(x, blk["ds"]) if "ds" in blk else x
+            y = P.conv(t2, blk["c3"], relu=True, res1=res)
+            P.release(t1, t2, x)
+            if res is not x:
+                P.release(res)
+            x = y
+        xs = [P.conv(x, self.t1[0], relu=True), P.conv(x, self.t1[1], relu=True)]
+        P.release(x)
+        for mod in self.stage2:
+            xs = self._emit_module(P, mod, xs)
+        t = P.conv(xs[-1], self.t2, relu=True)
+        xs = [xs[0], xs[1], t]
+        for mod in self.stage3:
+            xs = self._emit_module(P, mod, xs)
+        return xs, stem_args
+
+
+class Engine:
+    """Packed model + program cache for one device. Built by models/_base.I2RModule."""
+
+    def __init__(self, cfg, state_dict, device):
+        cabi.lib()  # fail loudly here when the HIP library is absent
+        self.cfg = cfg
+        self.device = torch.device(device)
+        assert self.device.type == "cuda", "the product path runs on the GPU only (device=%s)" % (device,)
+        cabi.require_gfx950(self.device.index or 0)
+        self.programs = {}
+        M = cfg["MODEL"]
+        self.name = M["NAME"]
+        pk = Packer(state_dict, self.device)
+        d, dff = M["DIM_MODEL"], M["DIM_FEEDFORWARD"]
+        assert M["N_HEAD"] == 1, "the shipped configs use single-head attention (N_HEAD=1)"
+        assert not M["NORMALIZE_BEFORE"], "NORMALIZE_BEFORE is false in every shipped config (post-norm only)"
+        if self.name == "interformer_pureMulti":
+            self.tower = HRNetW48(pk, "", M["EXTRA"])
+            self.reduce = pk.conv("reduce")
+            self.use_pos = bool(M["USE_MULTI_POS"])
+            if self.use_pos:
+                assert M["MULTI_POS_EMBEDDING"] == "conv", "only MULTI_POS_EMBEDDING 'conv' is wired"
+                self.pe_stem = pk.stem("position_embedding.conv1", "position_embedding.bn1")
+                self.pe_conv2 = pk.conv("position_embedding.conv2", "position_embedding.bn2", stride=2)
+            self.layers = [pk.encoder_layer("global_encoder.layers.%d" % l, d, dff) for l in range(M["ENCODER_LAYERS"])]
+            self.deconvs = [pk.deconv("deconv_layers.0", "deconv_layers.1")] * 2  # the same layer twice (:774-775)
+            self.head = pk.head("final_layer")
+        elif self.name == "interformer":
+            sf = M["SINGLEFORMER"]
+            assert sf == "transpose_h", "SINGLEFORMER=%r is not wired into the HIP engine yet" % (sf,)
+            p = "singleformer."
+            self.tower = HRNetW48(pk, p, M["EXTRA"])
+            self.res_layer = M["HRNET_RES_LAYER"]
+            self.reduce = pk.conv(p + "reduce")
+            w, h = M["IMAGE_SIZE"]
+            self.single_tokens = (h // 2 ** self.res_layer // 4) * (w // 2 ** self.res_layer // 4)
+            self.single_pos = pk.table(p + "pos_embedding", self.single_tokens, d) if M["POS_EMBEDDING"] != "none" else None
+            self.single_layers = [pk.encoder_layer("%sglobal_encoder.layers.%d" % (p, l), d, dff)
+                                  for l in range(M["ENCODER_LAYERS"])]
+            self.single_head = pk.head(p + "final_layer")
+            self.use_pos = bool(M["USE_MULTI_POS"])
+            if self.use_pos:
+                assert M["MULTI_POS_EMBEDDING"] == "conv", "only MULTI_POS_EMBEDDING 'conv' is wired"
+                self.pe_stem = pk.stem("multi_position_embedding.conv1", "multi_position_embedding.bn1")
+                self.pe_conv2 = pk.conv("multi_position_embedding.conv2", "multi_position_embedding.bn2", stride=2)
+            self.layers = [pk.encoder_layer("multi_global_encoder.layers.%d" % l, d, dff)
+                           for l in range(M["ENCODER_MULTI_LAYERS"])]
+            up = M["UPSAMPLE_TYPE"]
+            if up == "deconv":
+                n = int(math.log(M["HEATMAP_SIZE"][0] // M["TRANS_SIZE"][1], 2))
+                self.deconvs = [pk.deconv("upsample_layer.deconv_layers.%d.0" % i, "upsample_layer.deconv_layers.%d.1" % i)
+                                for i in range(n)]
+            elif up == "multiplex":
+                self.deconvs = [pk.deconv("deconv_layers.0", "deconv_layers.1")] * 2
+            else:
+                raise NotImplementedError("UPSAMPLE_TYPE=%r" % up)
+            self.head = pk.head("final_layer")
+            self.return_dict = bool(M["INTER_SUPERVISION"]) and not M["SINGLEFORMER_FIX"]
+        else:
+            raise NotImplementedError("MODEL.NAME=%r" % self.name)
+
+    # ---- program construction ----
+    def _pos_branch(self, P, n, h, w, trans_w):
+        a, pe_args = P.stem(self.pe_stem, n, h, w)
+        b = P.conv(a, self.pe_conv2, relu=True)
+        P.release(a)
+        for _ in range(int(math.log(b.w // trans_w, 2))):
+            c = P.maxpool(b)
+            P.release(b)
+            b = c
+        return b, pe_args
+
+    def _build(self, S, H, W, length):
+        M = self.cfg["MODEL"]
+        P = Program(self.device)
+        patch = {}
+        xs, patch["x"] = self.tower.emit(P, S, H, W)
+        if self.name == "interformer_pureMulti":
+            f = P.conv(xs[-1], self.reduce)
+            P.release(*xs)
+            single_feat = None
+        else:
+            f = P.conv(xs[self.res_layer], self.reduce)
+            P.release(*xs)
+            tok = f.h * f.w
+            assert tok == self.single_tokens, "input size does not match MODEL.IMAGE_SIZE (pos_embedding rows)"
+            g = P.encoder(f, self.single_layers, [i * tok for i in range(S + 1)],
+                          pos=self.single_pos.data_ptr() if self.single_pos is not None else 0, pos_period=tok)
+            P.release(f)
+            single_feat = g
+            if self.return_dict:
+                patch["single"] = P.head(g, self.single_head)
+            f = g
+            for _ in range(int(math.log(f.w // M["TRANS_SIZE"][-1], 2))):
+                c = P.maxpool(f)
+                if f is not single_feat:
+                    P.release(f)
+                f = c
+        pos_ptr = 0
+        if self.use_pos:
+            pos, patch["pos_mask"] = self._pos_branch(P, S, H, W, M["TRANS_SIZE"][-1])
+            assert (pos.h, pos.w, pos.cs) == (f.h, f.w, f.cs)
+            pos_ptr = pos.ptr
+        tok = f.h * f.w
+        offs = [0]
+        for n in length:
+            offs.append(offs[-1] + n * tok)
+        e = P.encoder(f, self.layers, offs, pos=pos_ptr)
+        for i, dc in enumerate(self.deconvs):
+            last = i == len(self.deconvs) - 1
+            # 2-stage models add the first-stage features AFTER the deconv's ReLU (x = single_res + x, interformer.py:315)
+            u = P.deconv(e, dc, relu=True, res_post=single_feat if (last and single_feat is not None) else None)
+            P.release(e)
+            e = u
+        patch["multi"] = P.head(e, self.head)
+        P.finalize()
+        return P, patch
+
+    def forward(self, x, pos_mask, length):
+        M = self.cfg["MODEL"]
+        assert x.dim() == 4 and x.shape[1] == 3 and x.dtype == torch.float32
+        S, _, H, W = x.shape
+        assert S == sum(length), "sum(length)=%d != number of crops %d" % (sum(length), S)
+        assert all(n >= 1 for n in length), "every image needs at least one person"
+        x = x.to(self.device).contiguous()
+        key = (S, H, W, tuple(length))
+        if key not in self.programs:
+            self.programs[key] = self._build(S, H, W, list(length))
+        P, patch = self.programs[key]
+        J = M["NUM_JOINTS"]
+        patch["x"].in_ = x.data_ptr()
+        keep = [x]
+        if "pos_mask" in patch:
+            pm = pos_mask.to(self.device, torch.float32).contiguous()
+            assert pm.shape == (S, 1, H, W)
+            patch["pos_mask"].in_ = pm.data_ptr()
+            keep.append(pm)
+        out = torch.empty(S, J, H // 4, W // 4, dtype=torch.float32, device=self.device)
+        patch["multi"].out = out.data_ptr()
+        single = None
+        if "single" in patch:
+            single = torch.empty_like(out)
+            patch["single"].out = single.data_ptr()
+        P.run()
+        if self.name == "interformer" and self.return_dict:
+            return {"single": single, "multi": out}
+        return out

@@ -1,0 +1,96 @@
+"""nn.Module shell shared by the model factories: a parameter tree with the reference's state-dict keys
+whose forward() runs the HIP engine.  The module owns the parameters (load_state_dict / .cuda() / DataParallel
+work as for the reference, tools/test.py:87-118); packed device copies are rebuilt lazily after any change."""
+import math
+
+import torch
+import torch.nn as nn
+
+from .. import arch, synth
+
+
+def sine_position_embedding(h, w, d_model, temperature=10000.0, scale=2 * math.pi):
+    """Fixed 2-D sine table [h*w, 1, d] the reference constructors store as a frozen parameter
+    (interformer_pureMulti.py:516-541, transpose_h.py:502-527): cumsum coordinates normalised to (0, 2pi],
+    frequencies temperature^(2*floor(i/2)/(d/2)), sin on even / cos on odd feature slots, y half then x half."""
+    half = d_model // 2
+    ys = torch.arange(1, h + 1, dtype=torch.float32) / (h + 1e-6) * scale
+    xs = torch.arange(1, w + 1, dtype=torch.float32) / (w + 1e-6) * scale
+    i = torch.arange(half, dtype=torch.float32)
+    dim_t = temperature ** (2 * torch.div(i, 2, rounding_mode="floor") / half)
+
+    def enc(v):  # [n] -> [n, half]
+        a = v[:, None] / dim_t
+        return torch.stack((a[:, 0::2].sin(), a[:, 1::2].cos()), dim=2).flatten(1)
+
+    py = enc(ys)[:, None, :].expand(h, w, half)
+    px = enc(xs)[None, :, :].expand(h, w, half)
+    return torch.cat((py, px), dim=2).reshape(h * w, 1, d_model).contiguous()
+
+
+class I2RModule(nn.Module):
+    def __init__(self, cfg, spec=None):
+        super().__init__()
+        self.cfg = cfg
+        self._engine = None
+        self._engine_key = None
+        spec = arch.param_spec(cfg) if spec is None else spec
+        for key, shape, dtype in spec:
+            parts = key.split(".")
+            mod = self
+            for p in parts[:-1]:
+                if p not in mod._modules:
+                    mod.add_module(p, nn.Module())
+                mod = mod._modules[p]
+            leaf = parts[-1]
+            val = torch.from_numpy(synth.make_tensor(key, shape, dtype, seed=1234))
+            if leaf in ("running_mean", "running_var", "num_batches_tracked"):
+                mod.register_buffer(leaf, val)
+            else:
+                mod.register_parameter(leaf, nn.Parameter(val, requires_grad=False))
+        self._init_sine_tables()
+
+    def _init_sine_tables(self):
+        M = self.cfg["MODEL"]
+        if M["POS_EMBEDDING"] != "sine":
+            return
+        w, h = M["IMAGE_SIZE"]
+        for name, p in self.named_parameters():
+            if name.endswith("pos_embedding"):
+                r = M["HRNET_RES_LAYER"] if name.startswith("singleformer.") else 0
+                hh, ww = h // 2 ** r // 4, w // 2 ** r // 4
+                if p.shape[0] == hh * ww:
+                    p.data.copy_(sine_position_embedding(hh, ww, p.shape[2]))
+
+    # ---- engine lifecycle ----
+    def _invalidate(self):
+        self._engine = None
+
+    def load_state_dict(self, state_dict, strict=True, **kw):
+        out = super().load_state_dict(state_dict, strict=strict, **kw)
+        self._invalidate()
+        return out
+
+    def _apply(self, fn, *a, **kw):
+        out = super()._apply(fn, *a, **kw)
+        self._invalidate()
+        return out
+
+    def engine(self):
+        dev = next(self.parameters()).device
+        if dev.type != "cuda":
+            raise RuntimeError(
+                "i2r_amd models run on an MI355X through the HIP extension only; move the module to the GPU "
+                "(model.cuda()) -- there is no CPU execution path in the product (the CPU oracle lives in oracle/).")
+        if self._engine is None or self._engine_key != dev:
+            from ..engine import Engine
+            self._engine = Engine(self.cfg, self.state_dict(), dev)
+            self._engine_key = dev
+        return self._engine
+
+    def forward(self, x, pos_mask, length):
+        """model(input, pos_mask, length) -- reference lib/core/function.py:135."""
+        if torch.is_tensor(length):
+            length = length.tolist()
+        with torch.no_grad():
+            return self.engine().forward(x, pos_mask, [int(n) for n in length])

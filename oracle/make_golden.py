@@ -1,0 +1,101 @@
+"""Generate the golden vectors under tests/golden/ by running THE REFERENCE ITSELF (imported from
+/root/reference through oracle/ref_shim.py) on CPU.  Run in the build container only:
+
+    python oracle/make_golden.py
+
+Per workload config it writes
+  <tag>_keys.json   state-dict key -> [shape, dtype] manifest of the reference module (drop-in contract)
+  <tag>.npz         expected outputs of the reference for the seeded synthetic inputs/weights
+                    (inputs and weights are NOT stored: i2r_amd.synth regenerates them bit-identically),
+                    input/weight checksums, and per-stage probes (mean, abs-mean, 32 sampled values)
+Every case is also cross-checked against the CPU restatement (oracle/i2r_cpu.py) before it is written.
+"""
+import json
+import os
+import sys
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+sys.path.insert(0, ROOT)
+sys.path.insert(0, HERE)
+
+import i2r_amd  # noqa: E402,F401
+from i2r_amd import config, synth  # noqa: E402
+import i2r_cpu  # noqa: E402
+import ref_shim  # noqa: E402
+
+OUT = os.path.join(ROOT, "tests", "golden")
+
+CASES = [
+    # tag, config name, length, (H, W), store full output?
+    ("w48_l31", "w48_pure_en6", [3, 1], (256, 192), True),
+    ("w48_l44", "w48_pure_en6", [4, 4], (256, 192), False),      # BASELINE config 1 (checksums + samples)
+    ("w48_l1", "w48_pure_en6", [1], (256, 192), False),
+    ("w48_l213", "w48_pure_en6", [2, 1, 3], (256, 192), False),
+    ("tph_l21", "tph_192_p6_b4", [2, 1], (256, 192), True),
+]
+
+
+def probe(t, key):
+    t = t.detach().float().reshape(-1)
+    idx = (synth.uniform01(99, "probe." + key, 32) * t.numel()).astype(np.int64)
+    return np.concatenate([[t.mean().item(), t.abs().mean().item()], t[torch.from_numpy(idx)].numpy()]).astype(np.float64)
+
+
+def flatten_collect(collect):
+    out = {}
+    for k, v in collect.items():
+        if isinstance(v, (list, tuple)):
+            for i, t in enumerate(v):
+                out["%s.%d" % (k, i)] = t
+        else:
+            out[k] = v
+    return out
+
+
+def main():
+    torch.set_num_threads(8)
+    os.makedirs(OUT, exist_ok=True)
+    nets = {}
+    for tag, cname, length, (H, W), full in CASES:
+        cfg = config.load_config(cname)
+        if cname not in nets:
+            net = ref_shim.build_reference_model(cfg)
+            spec = synth.spec_of(net)
+            sd = synth.make_state_dict(spec)
+            net.load_state_dict(sd, strict=True)
+            nets[cname] = (net, sd)
+            with open(os.path.join(OUT, cname + "_keys.json"), "w") as f:
+                json.dump({k: [list(s), d] for k, s, d in spec}, f, indent=0, sort_keys=True)
+        net, sd = nets[cname]
+        x, m, length = synth.make_inputs(length, H, W)
+        with torch.no_grad():
+            y = net(x, m, length)
+        collect = {}
+        z = i2r_cpu.forward(sd, cfg, x, m, length, collect)
+        outs = y if isinstance(y, dict) else {"multi": y}
+        zs = z if isinstance(z, dict) else {"multi": z}
+        data = {}
+        for k in outs:
+            err = (outs[k] - zs[k]).abs().max().item()
+            print("%-10s %-7s ref-vs-restatement max-abs %.2e  (|y| mean %.3f)" % (tag, k, err, outs[k].abs().mean().item()))
+            assert err < 2e-5
+            data["probe_out_" + k] = probe(outs[k], tag + k)
+            if full:
+                data["out_" + k] = outs[k].numpy()
+        for k, t in flatten_collect(collect).items():
+            data["stage_" + k] = probe(t, tag + k)
+        data["length"] = np.asarray(length, dtype=np.int64)
+        data["hw"] = np.asarray([H, W], dtype=np.int64)
+        data["x_checksum"] = np.asarray([x.double().sum().item(), x.double().abs().sum().item()])
+        data["mask_checksum"] = np.asarray([m.double().sum().item()])
+        data["w_checksum"] = np.asarray([sum(v.double().abs().sum().item() for v in sd.values() if v.dtype == torch.float32)])
+        np.savez_compressed(os.path.join(OUT, tag + ".npz"), **data)
+    print("golden vectors written to", OUT)
+
+
+if __name__ == "__main__":
+    main()

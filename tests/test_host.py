@@ -1,0 +1,135 @@
+"""CPU: host-side logic -- config surface, parameter inventory, synthetic generator, model factories, C-ABI exports."""
+import ctypes
+import glob
+import os
+import re
+import subprocess
+
+import numpy as np
+import pytest
+import torch
+
+from _golden import CASES, keys_manifest
+from i2r_amd import arch, cabi, config, models, synth
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_config_defaults_merge_and_freeze(tmp_path):
+    cfg = config.load_config("w48_pure_en6")
+    assert cfg.MODEL.NAME == "interformer_pureMulti" and cfg["MODEL"]["EXTRA"]["STAGE3"]["NUM_CHANNELS"] == [48, 96, 192]
+    assert cfg.MODEL.EXTRA.DECONV_WITH_BIAS is False and cfg.GPUS == (0,) and cfg.TEST.FLIP_TEST is True
+    assert cfg.MODEL.ENCODER_MULTI_LAYERS == 4  # default kept (reference default.py:61)
+    with pytest.raises(AttributeError):
+        cfg.MODEL.NAME = "x"
+    c2 = config.load_config("w48_pure_en6", ["MODEL.NUM_JOINTS", "17", "TEST.FLIP_TEST", "False"], freeze=False)
+    assert c2.MODEL.NUM_JOINTS == 17 and c2.TEST.FLIP_TEST is False
+    with pytest.raises(KeyError):
+        config.load_config("w48_pure_en6", ["MODEL.NOPE", "1"])
+    with pytest.raises(ValueError):
+        config.load_config("w48_pure_en6", ["MODEL.NUM_JOINTS", "'a'"])
+    p = tmp_path / "c.yaml"
+    p.write_text("MODEL:\n  NAME: interformer\n  EXTRA:\n    ANY: {NEW: 1}\nGPUS: (0,1)\n")
+    c3 = config.load_config(str(p))
+    assert c3.MODEL.EXTRA.ANY.NEW == 1 and c3.GPUS == (0, 1)
+
+
+@pytest.mark.skipif(not os.path.isdir("/root/reference/experiments"), reason="reference tree only in the build container")
+def test_reference_yaml_files_load_unchanged():
+    files = glob.glob("/root/reference/experiments/*/*.yaml")
+    assert len(files) == 10
+    for f in files:
+        cfg = config.load_config(f)
+        assert cfg.MODEL.NAME in ("interformer", "interformer_pureMulti", "interformer_2stage")
+    a = config.load_config("/root/reference/experiments/crowdpose/interformer_crowdpose_w48_pure_en6.yaml")
+    b = config.load_config("w48_pure_en6")
+    for k in b.MODEL:
+        if k != "EXTRA":
+            assert a.MODEL[k] == b.MODEL[k] or k in ("PRETRAINED", "INIT_WEIGHTS"), k
+
+
+@pytest.mark.parametrize("cname", sorted(set(CASES.values())))
+def test_parameter_inventory_equals_reference_manifest(cname):
+    man = keys_manifest(cname)
+    mine = {k: (tuple(s), d) for k, s, d in arch.param_spec(config.load_config(cname))}
+    assert set(mine) == set(man)
+    assert all(mine[k] == man[k] for k in man)
+
+
+def test_model_factory_contract():
+    cfg = config.load_config("w48_pure_en6")
+    net = eval("models." + cfg.MODEL.NAME + ".get_pose_net")(cfg, is_train=False)  # tools/test.py:87
+    man = keys_manifest("w48_pure_en6")
+    sd = net.state_dict()
+    assert set(sd) == set(man) and all(tuple(sd[k].shape) == man[k][0] for k in man)
+    assert not net.training
+    spec = [(k, s, d) for k, (s, d) in man.items()]
+    missing = net.load_state_dict(synth.make_state_dict(spec), strict=True)  # ddp_test.py:113 uses strict=True
+    assert not missing.missing_keys and not missing.unexpected_keys
+    partial = {k: v for k, v in synth.make_state_dict(spec).items() if not k.startswith("deconv_layers")}
+    net.load_state_dict(partial, strict=False)  # tools/test.py:96
+    # no silent CPU path: the product refuses to run without the GPU extension
+    with pytest.raises(RuntimeError, match="HIP extension|MI355X"):
+        net(torch.zeros(1, 3, 256, 192), torch.zeros(1, 1, 256, 192), [1])
+    with pytest.raises(NotImplementedError):
+        models.interformer_pureMulti.get_pose_net(cfg, is_train=True)
+    two = models.interformer.get_pose_net(config.load_config("tph_192_p6_b4"), is_train=False)
+    assert any(k.startswith("singleformer.global_encoder.layers.3.") for k in two.state_dict())
+
+
+def test_synth_is_key_addressed_and_deterministic():
+    a = synth.make_tensor("stage3.0.branches.1.2.conv1.weight", (96, 96, 3, 3), "float32")
+    b = synth.make_tensor("stage3.0.branches.1.2.conv1.weight", (96, 96, 3, 3), "float32")
+    c = synth.make_tensor("stage3.0.branches.1.2.conv2.weight", (96, 96, 3, 3), "float32")
+    assert np.array_equal(a, b) and not np.array_equal(a, c)
+    assert abs(float(a.std()) - (2.0 / (96 * 9)) ** 0.5) < 2e-3
+    v = synth.make_tensor("bn1.running_var", (64,), "float32")
+    assert v.min() > 0.5
+    assert synth.make_tensor("bn1.num_batches_tracked", (), "int64").dtype == np.int64
+    # known-answer values of the counter-based generator (guards against numpy / platform drift)
+    u = synth.uniform01(0, "kat", 4)
+    assert u.dtype == np.float64 and np.all((u >= 0) & (u < 1))
+    np.testing.assert_array_equal(u, synth.uniform01(0, "kat", 8)[:4])
+    x, m, length = synth.make_inputs([2, 1], 64, 48, as_torch=False)
+    assert x.shape == (3, 3, 64, 48) and m.shape == (3, 1, 64, 48) and set(np.unique(m)) <= {0.0, 1.0}
+    assert abs(x.std() - 1.0) < 0.02 and m.sum() > 0
+
+
+def test_cabi_library_exports_every_declared_symbol():
+    """include/i2r_hip.h <-> libi2r_hip.so <-> cabi.EXPORTS agree (no compute call: no GPU here)."""
+    header = open(os.path.join(ROOT, "include", "i2r_hip.h")).read()
+    declared = set(re.findall(r"^(?:int|const char\*)\s+(i2r_\w+)\s*\(", header, flags=re.M))
+    assert declared == set(cabi.EXPORTS), declared ^ set(cabi.EXPORTS)
+    if not os.path.exists(cabi.LIB_PATH):
+        import __graft_entry__
+        __graft_entry__.build()
+    L = cabi.load_library()
+    for name in cabi.EXPORTS:
+        assert hasattr(L, name)
+    assert L.i2r_abi_version() == 1
+    # struct sizes must match the C side: a descriptor with a null pointer is rejected with I2R_E_ARG, not a crash
+    d = cabi.ConvDesc()
+    assert L.i2r_conv(ctypes.byref(d), None) == -1
+    assert b"null pointer" in L.i2r_last_error()
+    e = cabi.EncoderDesc()
+    assert L.i2r_encoder_layer(ctypes.byref(e), None) == -1
+    assert L.i2r_run_program(None, 0, None, None) == -1
+
+
+def test_struct_layouts_match_header():
+    """sizeof() of every ctypes mirror equals the C struct size (checked with a tiny gcc program)."""
+    src = r'''
+#include <stdio.h>
+#include "i2r_hip.h"
+int main(void){ printf("%zu %zu %zu %zu %zu %zu\n", sizeof(i2r_conv_desc), sizeof(i2r_encoder_desc), sizeof(i2r_stem_args),
+ sizeof(i2r_pool_args), sizeof(i2r_head_args), sizeof(i2r_op)); return 0; }
+'''
+    import tempfile
+    with tempfile.TemporaryDirectory() as td:
+        c = os.path.join(td, "s.c")
+        open(c, "w").write(src)
+        exe = os.path.join(td, "s")
+        subprocess.check_call(["gcc", "-I", os.path.join(ROOT, "include"), c, "-o", exe])
+        sizes = [int(v) for v in subprocess.check_output([exe]).split()]
+    mine = [ctypes.sizeof(t) for t in (cabi.ConvDesc, cabi.EncoderDesc, cabi.StemArgs, cabi.PoolArgs, cabi.HeadArgs, cabi.Op)]
+    assert sizes == mine

@@ -1,0 +1,210 @@
+"""-m gpu: each HIP entry point of include/i2r_hip.h against the plain fp32 torch CPU op it replaces."""
+import pytest
+import torch
+import torch.nn.functional as F
+
+import i2r_cpu
+from _gpu_util import from_act, run, to_act
+from i2r_amd import engine, synth
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def _rand(shape, key, scale=1.0):
+    return torch.from_numpy(synth._sym(7, key, tuple(shape), scale))
+
+
+def _conv_case(cin, cout, k, stride, n, h, w, relu, nres, up=1, bn=True, tag=""):
+    sd = {"c.weight": _rand((cout, cin, k, k), "w" + tag, (6.0 / (cin * k * k)) ** 0.5)}
+    if bn:
+        sd.update({"b.weight": _rand((cout,), "g" + tag, 0.5) + 1.0, "b.bias": _rand((cout,), "b" + tag, 0.3),
+                   "b.running_mean": _rand((cout,), "m" + tag, 0.3), "b.running_var": _rand((cout,), "v" + tag, 0.4) + 1.0})
+    x = _rand((n, cin, h, w), "x" + tag)
+    ref = F.conv2d(x, sd["c.weight"], None, stride=stride, padding=k // 2)
+    if bn:
+        ref = F.batch_norm(ref, sd["b.running_mean"], sd["b.running_var"], sd["b.weight"], sd["b.bias"], False, 0.0, 1e-5)
+    if up > 1:
+        ref = F.interpolate(ref, scale_factor=up, mode="nearest")
+    res = [_rand(tuple(ref.shape), "r%d%s" % (i, tag)) for i in range(nres)]
+    for r in res:
+        ref = ref + r
+    if relu:
+        ref = F.relu(ref)
+    P = engine.Program(torch.device(DEV))
+    pk = engine.Packer(sd, torch.device(DEV))
+    pc = pk.conv("c", "b" if bn else None, stride=stride)
+    xa = to_act(P, x)
+    ra = [to_act(P, r) for r in res]
+    out = P.conv(xa, pc, relu=relu, res1=ra[0] if nres > 0 else None, res2=ra[1] if nres > 1 else None, up=up)
+    run(P)
+    got = from_act(out)
+    assert got.shape == ref.shape
+    err = (got - ref).abs().max().item()
+    assert err < 2e-4, "conv %s max-abs %.3e" % (tag, err)
+    # padded output channels must stay exactly as allocated-zero or finite garbage-free: check finite
+    assert torch.isfinite(out.t).all()
+
+
+@pytest.mark.parametrize("cin,cout,k,stride,n,h,w,relu,nres,up", [
+    (48, 48, 3, 1, 2, 64, 48, True, 1, 1),      # BasicBlock conv2 + residual, high-res branch
+    (96, 96, 3, 1, 3, 32, 24, True, 0, 1),      # BasicBlock conv1
+    (192, 192, 3, 1, 2, 16, 12, True, 1, 1),    # low-res branch (cout 192 -> 4 cout waves)
+    (64, 64, 3, 2, 2, 128, 96, True, 0, 1),     # stem conv2 (stride 2)
+    (256, 96, 3, 2, 1, 64, 48, True, 0, 1),     # transition1.1 (cin chunked through LDS)
+    (256, 48, 3, 1, 1, 64, 48, True, 0, 1),     # transition1.0
+    (64, 256, 1, 1, 2, 64, 48, False, 0, 1),    # bottleneck downsample
+    (256, 64, 1, 1, 2, 64, 48, True, 0, 1),     # bottleneck conv1
+    (64, 256, 1, 1, 1, 64, 48, True, 1, 1),     # bottleneck conv3 + residual
+    (96, 48, 1, 1, 2, 32, 24, False, 1, 2),     # fuse 1x1 + nearest x2 accumulate
+    (192, 48, 1, 1, 2, 16, 12, True, 1, 4),     # fuse 1x1 + nearest x4 accumulate + relu
+    (192, 96, 1, 1, 2, 16, 12, True, 2, 2),     # two residual inputs
+    (48, 96, 3, 2, 2, 64, 48, False, 1, 1),     # fuse down path
+    (96, 192, 3, 2, 2, 32, 24, True, 2, 1),     # fuse down path, last branch
+    (192, 96, 1, 1, 3, 16, 12, False, 0, 1),    # reduce (no BN handled below)
+    (48, 48, 3, 1, 1, 13, 9, True, 1, 1),       # ragged spatial size (partial tiles)
+    (64, 96, 3, 2, 2, 33, 21, True, 0, 1),      # odd input, stride 2
+    (80, 80, 3, 1, 1, 16, 12, False, 0, 1),     # 5-fragment cout (HRFormer-style padded 78 -> 80 uses this path)
+])
+def test_conv_matches_torch(cin, cout, k, stride, n, h, w, relu, nres, up):
+    _conv_case(cin, cout, k, stride, n, h, w, relu, nres, up, tag="%d_%d_%d_%d_%d_%d" % (cin, cout, k, stride, h, up))
+
+
+def test_conv_without_bn_and_channel_padding():
+    _conv_case(192, 96, 1, 1, 2, 16, 12, False, 0, bn=False, tag="nobn")
+    # cin 78 (padded to 80 in the activation), cout 78
+    sd = {"c.weight": _rand((78, 78, 3, 3), "w78", 0.05)}
+    x = _rand((2, 78, 16, 12), "x78")
+    ref = F.conv2d(x, sd["c.weight"], padding=1)
+    P = engine.Program(torch.device(DEV))
+    pc = engine.Packer(sd, torch.device(DEV)).conv("c")
+    out = P.conv(to_act(P, x), pc)
+    run(P)
+    assert (from_act(out) - ref).abs().max().item() < 2e-4
+
+
+def test_deconv_matches_conv_transpose():
+    sd = {"d.weight": _rand((96, 96, 4, 4), "dw", 0.08), "b.weight": _rand((96,), "dg", 0.5) + 1.0,
+          "b.bias": _rand((96,), "db", 0.3), "b.running_mean": _rand((96,), "dm", 0.3),
+          "b.running_var": _rand((96,), "dv", 0.4) + 1.0}
+    x = _rand((3, 96, 16, 12), "dx")
+    post = _rand((3, 96, 32, 24), "dpost")
+    ref = F.conv_transpose2d(x, sd["d.weight"], None, stride=2, padding=1)
+    ref = F.relu(F.batch_norm(ref, sd["b.running_mean"], sd["b.running_var"], sd["b.weight"], sd["b.bias"], False, 0.0, 1e-5))
+    P = engine.Program(torch.device(DEV))
+    pcs = engine.Packer(sd, torch.device(DEV)).deconv("d", "b")
+    xa = to_act(P, x)
+    out = P.deconv(xa, pcs, relu=True)
+    out2 = P.deconv(xa, pcs, relu=True, res_post=to_act(P, post))
+    run(P)
+    assert (from_act(out) - ref).abs().max().item() < 2e-4
+    assert (from_act(out2) - (ref + post)).abs().max().item() < 2e-4
+
+
+@pytest.mark.parametrize("cin,cout", [(3, 64), (1, 64)])
+def test_stem_conv(cin, cout):
+    sd = {"c.weight": _rand((cout, cin, 3, 3), "sw%d" % cin, 0.4), "b.weight": _rand((cout,), "sg", 0.5) + 1.0,
+          "b.bias": _rand((cout,), "sb", 0.3), "b.running_mean": _rand((cout,), "sm", 0.3),
+          "b.running_var": _rand((cout,), "sv", 0.4) + 1.0}
+    x = _rand((2, cin, 64, 48), "sx%d" % cin)
+    ref = F.relu(F.batch_norm(F.conv2d(x, sd["c.weight"], None, 2, 1), sd["b.running_mean"], sd["b.running_var"],
+                              sd["b.weight"], sd["b.bias"], False, 0.0, 1e-5))
+    P = engine.Program(torch.device(DEV))
+    st = engine.Packer(sd, torch.device(DEV)).stem("c", "b")
+    xd = x.to(DEV)
+    out, args = P.stem(st, 2, 64, 48, in_ptr=xd.data_ptr())
+    run(P)
+    assert (from_act(out) - ref).abs().max().item() < 1e-4
+
+
+def test_maxpool_and_head():
+    x = _rand((2, 96, 64, 48), "px")
+    P = engine.Program(torch.device(DEV))
+    xa = to_act(P, x)
+    p1 = P.maxpool(xa)
+    p2 = P.maxpool(p1)
+    sd = {"f.weight": _rand((14, 96, 1, 1), "hw", 0.2), "f.bias": _rand((14,), "hb", 0.2)}
+    hd = engine.Packer(sd, torch.device(DEV)).head("f")
+    out = torch.empty(2, 14, 64, 48, device=DEV)
+    P.head(xa, hd, out_ptr=out.data_ptr())
+    run(P)
+    assert torch.equal(from_act(p2), F.max_pool2d(F.max_pool2d(x, 3, 2, 1), 3, 2, 1))
+    assert (out.cpu() - F.conv2d(x, sd["f.weight"], sd["f.bias"])).abs().max().item() < 1e-4
+    # odd spatial size, 17 joints
+    x2 = _rand((1, 80, 9, 7), "px2")
+    x2[:, 78:] = 0
+    P = engine.Program(torch.device(DEV))
+    a2 = to_act(P, x2[:, :78])
+    q = P.maxpool(a2)
+    sd = {"f.weight": _rand((17, 78, 1, 1), "hw2", 0.2), "f.bias": _rand((17,), "hb2", 0.2)}
+    hd = engine.Packer(sd, torch.device(DEV)).head("f")
+    out = torch.empty(1, 17, 9, 7, device=DEV)
+    P.head(a2, hd, out_ptr=out.data_ptr())
+    run(P)
+    assert torch.equal(from_act(q), F.max_pool2d(x2[:, :78], 3, 2, 1))
+    assert (out.cpu() - F.conv2d(x2[:, :78], sd["f.weight"], sd["f.bias"])).abs().max().item() < 1e-4
+
+
+def _encoder_sd(d, dff, tag):
+    sd = {}
+    p = "L"
+    sd[p + ".self_attn.in_proj_weight"] = _rand((3 * d, d), "ipw" + tag, 2.5 * (3.0 / d) ** 0.5)
+    sd[p + ".self_attn.in_proj_bias"] = _rand((3 * d,), "ipb" + tag, 0.1)
+    sd[p + ".self_attn.out_proj.weight"] = _rand((d, d), "opw" + tag, (3.0 / d) ** 0.5)
+    sd[p + ".self_attn.out_proj.bias"] = _rand((d,), "opb" + tag, 0.1)
+    sd[p + ".linear1.weight"] = _rand((dff, d), "l1w" + tag, (3.0 / d) ** 0.5)
+    sd[p + ".linear1.bias"] = _rand((dff,), "l1b" + tag, 0.1)
+    sd[p + ".linear2.weight"] = _rand((d, dff), "l2w" + tag, (3.0 / dff) ** 0.5)
+    sd[p + ".linear2.bias"] = _rand((d,), "l2b" + tag, 0.1)
+    for n in ("norm1", "norm2"):
+        sd[p + ".%s.weight" % n] = _rand((d,), n + "w" + tag, 0.3) + 1.0
+        sd[p + ".%s.bias" % n] = _rand((d,), n + "b" + tag, 0.2)
+    return sd
+
+
+@pytest.mark.parametrize("d,length,hw,use_pos", [
+    (96, [3, 1, 2], (16, 12), True),    # vanilla inter-human: persons of an image share keys
+    (96, [1], (16, 12), False),
+    (78, [2, 3], (16, 12), False),      # HRFormer inter-human width (padded to 80)
+    (96, [2, 1], (6, 6), True),         # 36 tokens per person: partial query / key tiles
+    (96, [5], (24, 18), True),          # 2160 keys in one group
+])
+def test_encoder_layer_matches_oracle(d, length, hw, use_pos):
+    h, w = hw
+    S = sum(length)
+    sd = _encoder_sd(d, 192, "%d_%d" % (d, S))
+    feat = _rand((S, d, h, w), "ef%d%d" % (d, S))
+    pos = _rand((S, d, h, w), "ep%d%d" % (d, S), 0.5) if use_pos else None
+    sd2 = {k.replace("L.", "E.layers.0."): v for k, v in sd.items()}
+    ref = i2r_cpu.inter_human_encoder(sd2, "E", 1, feat, pos, length)
+    P = engine.Program(torch.device(DEV))
+    L = engine.Packer(sd, torch.device(DEV)).encoder_layer("L", d, 192)
+    fa = to_act(P, feat)
+    pa = to_act(P, pos) if use_pos else None
+    offs = [0]
+    for n in length:
+        offs.append(offs[-1] + n * h * w)
+    out = P.encoder(fa, [L], offs, pos=pa.ptr if pa is not None else 0)
+    run(P)
+    got = from_act(out)
+    err = (got - ref).abs().max().item()
+    assert err < 2e-4, "encoder d=%d max-abs %.3e" % (d, err)
+    if d == 78:
+        assert out.t.view(-1, out.cs)[:, 78:].abs().max().item() == 0.0
+
+
+def test_encoder_sine_table_period():
+    """TransPose-H style: one group per crop, pos rows = token % period."""
+    d, S, h, w = 96, 3, 16, 12
+    sd = _encoder_sd(d, 192, "tp")
+    feat = _rand((S, d, h, w), "tpf")
+    table = _rand((h * w, d), "tpt", 0.5)
+    sd2 = {k.replace("L.", "E.layers.0."): v for k, v in sd.items()}
+    tok = feat.flatten(2).transpose(1, 2)
+    ref = i2r_cpu.encoder_layer(sd2, "E.layers.0", tok, table[None], None).transpose(1, 2).reshape(S, d, h, w)
+    P = engine.Program(torch.device(DEV))
+    L = engine.Packer(sd, torch.device(DEV)).encoder_layer("L", d, 192)
+    tdev = table.to(DEV)
+    out = P.encoder(to_act(P, feat), [L], [i * h * w for i in range(S + 1)], pos=tdev.data_ptr(), pos_period=h * w)
+    run(P)
+    assert (from_act(out) - ref).abs().max().item() < 2e-4
