@@ -32,7 +32,7 @@ struct ConvK {
     int n_img, in_h, in_w, in_cs, cin;
     int conv_h, conv_w, out_h, out_w, out_cs, cout, cout_pad;
     int stride, iy0, ix0, ntaps;
-    int tapoff[I2R_MAX_TAPS];  // dy*PW + dx in patch pixels
+    int tap_kh, tap_kw;  // taps form a dense kh x kw grid, row-major: tap t sits at patch offset (t / kw, t % kw)
     int out_step, out_off_y, out_off_x, rep, relu;
     int tile_h, tile_w, tiles_y, tiles_x, n_cblk;
     int ph, pw, plane;  // patch dims (pixels) and plane stride (float4 slots, multiple of 16)
@@ -60,19 +60,25 @@ __global__ __launch_bounds__(256) void conv_igemm_f32(const ConvK p) {
     const int py0 = oy0 * p.stride + p.iy0, px0 = ox0 * p.stride + p.ix0;
     const int phw = p.ph * p.pw;
 
-    // patch pixel -> global float offset of channel 0 (or -1 outside the image); channel independent
+    // patch pixel -> global float offset of channel 0 (clamped to 0 outside the image, with a validity bit);
+    // channel independent, so computed once
     int goff[kMaxPP];
+    bool gval[kMaxPP];
 #pragma unroll
     for (int j = 0; j < kMaxPP; ++j) {
         const int pp = tid + j * 256;
-        goff[j] = -1;
+        goff[j] = 0;
+        gval[j] = false;
         if (pp < phw) {
             const int py = pp / p.pw, px = pp - py * p.pw;
             const int iy = py0 + py, ix = px0 + px;
-            if (iy >= 0 && iy < p.in_h && ix >= 0 && ix < p.in_w)
+            if (iy >= 0 && iy < p.in_h && ix >= 0 && ix < p.in_w) {
                 goff[j] = ((img * p.in_h + iy) * p.in_w + ix) * p.in_cs;
+                gval[j] = true;
+            }
         }
     }
+    const int npp = (phw + 255) >> 8;  // patch pixels per thread actually in use (wave-uniform)
 
     // A-fragment patch-pixel base of this lane's pixel in each M fragment
     const int tile_px = p.tile_h * p.tile_w;
@@ -100,54 +106,77 @@ __global__ __launch_bounds__(256) void conv_igemm_f32(const ConvK p) {
         const int ckc = min(p.ck, p.cin - c0);
         const int ncg = ckc >> 2;
         if (c0 != 0) __syncthreads();
-        // ---- stage the patch: lds[cg][pp] = in[pixel(pp)][c0 + 4cg .. +3] ----
-        for (int cg = 0; cg < ncg; ++cg) {
+        // ---- stage the patch: lds[cg][pp] = in[pixel(pp)][c0 + 4cg .. +3]; 4 channel groups per trip so the
+        //      global loads of a trip are all in flight before the first LDS store waits for them ----
+        for (int cg0 = 0; cg0 < ncg; cg0 += 4) {
+            f32x4 v[4][kMaxPP];
 #pragma unroll
-            for (int j = 0; j < kMaxPP; ++j) {
-                const int pp = tid + j * 256;
-                if (pp < phw) {
-                    f32x4 v = (f32x4){0.f, 0.f, 0.f, 0.f};
-                    if (goff[j] >= 0) {
-                        v = *reinterpret_cast<const f32x4*>(p.in + goff[j] + c0 + cg * 4);
-                        if (p.in2) v += *reinterpret_cast<const f32x4*>(p.in2 + goff[j] + c0 + cg * 4);
-                    }
-                    lds[cg * p.plane + pp] = v;
-                }
+            for (int u = 0; u < 4; ++u)
+#pragma unroll
+                for (int j = 0; j < kMaxPP; ++j)
+                    if (j < npp) v[u][j] = *reinterpret_cast<const f32x4*>(p.in + goff[j] + c0 + (cg0 + u) * 4);
+            if (p.in2) {
+#pragma unroll
+                for (int u = 0; u < 4; ++u)
+#pragma unroll
+                    for (int j = 0; j < kMaxPP; ++j)
+                        if (j < npp) v[u][j] += *reinterpret_cast<const f32x4*>(p.in2 + goff[j] + c0 + (cg0 + u) * 4);
             }
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+#pragma unroll
+                for (int j = 0; j < kMaxPP; ++j) {
+                    const int pp = tid + j * 256;
+                    if (j < npp && pp < phw)
+                        lds[(cg0 + u) * p.plane + pp] = gval[j] ? v[u][j] : (f32x4){0.f, 0.f, 0.f, 0.f};
+                }
         }
         __syncthreads();
 
-        // ---- K loop over (tap, 16-channel step); B fragments prefetched one step ahead ----
+        // ---- K loop over (tap, 16-channel step), software-pipelined one step ahead with two named register
+        //      sets (no register copies, so the compiler's vmcnt/lgkmcnt waits land at the first use) ----
         const int ncs = ckc >> 4;
         const int nit = p.ntaps * ncs;
-        const int cg_lane0 = (c0 >> 2) + g;
-        f32x4 bcur[NT], bnxt[NT];
+        const f32x4* const wp0 = wq + (size_t)((c0 >> 2) + g) * p.cout_pad;  // step (tap 0, cs 0) of this chunk
+        const f32x4* wp = wp0;
+        const size_t inc_cs = (size_t)4 * p.cout_pad;
+        const size_t inc_tap = (size_t)(cin4 - (ncs - 1) * 4) * p.cout_pad;
+        int cs_n = 0, tx_n = 0, ty_n = 0;  // position of the next step to fetch
+        auto fetch = [&](f32x4(&a)[MT], f32x4(&b)[NT]) {
 #pragma unroll
-        for (int nt = 0; nt < NT; ++nt) bcur[nt] = wq[(size_t)(0 * cin4 + cg_lane0) * p.cout_pad + nt * 16];
-        int tap = 0, cs = 0;
-        for (int it = 0; it < nit; ++it) {
-            int ntap = tap, ncs_ = cs + 1;
-            if (ncs_ == ncs) { ncs_ = 0; ntap = tap + 1; }
-            if (it + 1 < nit) {
-#pragma unroll
-                for (int nt = 0; nt < NT; ++nt)
-                    bnxt[nt] = wq[(size_t)(ntap * cin4 + cg_lane0 + ncs_ * 4) * p.cout_pad + nt * 16];
-            }
-            const int abase = (cs * 4 + g) * p.plane + p.tapoff[tap];
-            f32x4 a[MT];
+            for (int nt = 0; nt < NT; ++nt) b[nt] = wp[nt * 16];
+            const int abase = (cs_n * 4 + g) * p.plane + ty_n * p.pw + tx_n;
 #pragma unroll
             for (int mt = 0; mt < MT; ++mt) a[mt] = lds[abase + ppix[mt]];
+            if (++cs_n == ncs) {
+                cs_n = 0;
+                wp += inc_tap;
+                if (++tx_n == p.tap_kw) {
+                    tx_n = 0;
+                    if (++ty_n == p.tap_kh) { ty_n = 0; wp = wp0; }  // wrap: the look-ahead past the last step stays in bounds
+                }
+            } else {
+                wp += inc_cs;
+            }
+        };
+        auto fma_step = [&](const f32x4(&a)[MT], const f32x4(&b)[NT]) {
 #pragma unroll
             for (int s = 0; s < 4; ++s)
 #pragma unroll
                 for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
-                    for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = mfma16(a[mt][s], bcur[nt][s], acc[mt][nt]);
-#pragma unroll
-            for (int nt = 0; nt < NT; ++nt) bcur[nt] = bnxt[nt];
-            tap = ntap;
-            cs = ncs_;
+                    for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = mfma16(a[mt][s], b[nt][s], acc[mt][nt]);
+        };
+        f32x4 a0[MT], a1[MT], b0[NT], b1[NT];
+        fetch(a0, b0);
+        int it = 0;
+        for (; it + 2 <= nit; it += 2) {
+            fetch(a1, b1);
+            fma_step(a0, b0);
+            fetch(a0, b0);  // unconditional (wraps after the last step) so both halves keep counted waits
+            fma_step(a1, b1);
         }
+        if (it < nit) fma_step(a0, b0);
     }
 
     // ---- epilogue: D layout col = l&15 -> cout, rows 4g+r -> pixels ----
@@ -288,8 +317,11 @@ extern "C" int i2r_conv(const i2r_conv_desc* d, void* stream) {
     k.pw = (tw - 1) * d->stride + max_dx + 1;
     I2R_CHECK_ARG(k.ph * k.pw <= kMaxPP * 256, "i2r_conv: patch %dx%d too large", k.ph, k.pw);
     k.plane = cdiv(k.ph * k.pw, 16) * 16;
-    for (int t = 0; t < d->ntaps; ++t) k.tapoff[t] = d->dy[t] * k.pw + d->dx[t];
-    for (int t = d->ntaps; t < I2R_MAX_TAPS; ++t) k.tapoff[t] = 0;
+    k.tap_kw = max_dx + 1;
+    k.tap_kh = max_dy + 1;
+    for (int t = 0; t < d->ntaps; ++t)
+        I2R_CHECK_ARG(d->dy[t] == t / k.tap_kw && d->dx[t] == t % k.tap_kw && d->ntaps == (max_dy + 1) * (max_dx + 1),
+                      "i2r_conv: taps must form a dense row-major kh x kw grid");
     int ck = d->ck;
     if (ck == 0) {
         const int budget = 72 * 1024;  // two workgroups per CU

@@ -191,8 +191,12 @@ class Act:
         return self.t.data_ptr()
 
 
+_MT_EFF = {1: 0.62, 2: 0.9, 3: 1.0, 4: 1.0}  # measured on MI355X (tools/sweep_conv.py): B-fragment reuse per wave
+
+
 def choose_tile(conv_h, conv_w, wm, stride, max_d, n_img, n_cblk):
-    """(tile_h, tile_w, mt) for a workgroup of wm M-waves: maximise useful-lane fraction, then occupancy."""
+    """(tile_h, tile_w, mt) for a workgroup of wm M-waves.  Cost model fitted to tools/sweep_conv.py on MI355X:
+    time ~ rounds of 256 workgroups x padded pixels per workgroup / per-wave efficiency(mt), plus a halo-staging term."""
     best = None
     cands_w = sorted({w for w in (conv_w, 48, 32, 24, 16, 12, 8, 6, 4) if w <= conv_w and w <= 48})
     for mt in (1, 2, 3, 4):
@@ -205,13 +209,12 @@ def choose_tile(conv_h, conv_w, wm, stride, max_d, n_img, n_cblk):
             if ph * pw > 1280:
                 continue
             tiles = -(-conv_h // th) * -(-conv_w // tw)
-            eff = conv_h * conv_w / float(tiles * cap)
-            halo = (th * stride) * (tw * stride) / float(ph * pw)
             blocks = tiles * n_img * n_cblk
-            fill = min(1.0, blocks / 512.0)
-            score = eff * (0.85 + 0.15 * halo) * (0.6 + 0.4 * fill) * (1.0 + 0.03 * mt)
-            if best is None or score > best[0]:
-                best = (score, th, tw, mt)
+            rounds = -(-blocks // 256)
+            halo = ph * pw / float(th * stride * tw * stride)
+            cost = rounds * (cap / _MT_EFF[mt]) * (1.0 + 0.08 * (halo - 1.0))
+            if best is None or cost < best[0] - 1e-9:
+                best = (cost, th, tw, mt)
     assert best is not None, "no tile for %dx%d" % (conv_h, conv_w)
     return best[1], best[2], best[3]
 
@@ -225,11 +228,14 @@ def conv_split(cout_pad):
 
 
 class Program:
-    def __init__(self, device):
+    def __init__(self, device, multi_lane=False):
         self.device = device
+        self.multi_lane = multi_lane
         self.ops = []        # (kind, lane, struct)
         self.keep = []       # everything the structs point to
         self.pool = {}       # numel -> [tensor]
+        self.pending = []    # buffers released inside a fork region: reusable only after the join
+        self.in_fork = False
         self.nbytes = 0
         self._c_ops = None
 
@@ -248,7 +254,10 @@ class Program:
 
     def release(self, *acts):
         for a in acts:
-            self.pool.setdefault(a.t.numel(), []).append(a.t)
+            if self.in_fork:
+                self.pending.append(a.t)
+            else:
+                self.pool.setdefault(a.t.numel(), []).append(a.t)
 
     # ---- ops ----
     def stem(self, st, n, h, w, in_ptr=0, lane=0):
@@ -340,10 +349,17 @@ class Program:
         return cur
 
     def fork(self, mask):
+        """lanes in `mask` (bits 1..3) start after everything issued so far on lane 0"""
         self.ops.append((cabi.OP_FORK, mask, None))
+        self.in_fork = True
 
     def join(self, mask):
+        """lane 0 continues after the lanes in `mask`; buffers freed inside the region become reusable"""
         self.ops.append((cabi.OP_JOIN, mask, None))
+        self.in_fork = False
+        for t in self.pending:
+            self.pool.setdefault(t.numel(), []).append(t)
+        self.pending = []
 
     # ---- run ----
     def finalize(self):
@@ -354,12 +370,27 @@ class Program:
         self._c_ops = arr
         self.uses_lanes = any(lane != 0 or kind in (cabi.OP_FORK, cabi.OP_JOIN) for kind, lane, _ in self.ops)
 
-    def run(self, streams=None, events=None):
+    def run(self, side_streams=None, events=None):
+        """side_streams: 3 torch.cuda.Stream for lanes 1..3 (None -> everything on the current stream)."""
         L = cabi.lib()
-        if streams is None:
-            cur = torch.cuda.current_stream(self.device).cuda_stream
+        cur = torch.cuda.current_stream(self.device).cuda_stream
+        if side_streams is None:
             streams = (C.c_void_p * 4)(cur, cur, cur, cur)
-        cabi.check(L.i2r_run_program(self._c_ops, len(self.ops), streams, events), "i2r_run_program")
+        else:
+            streams = (C.c_void_p * 4)(cur, *[s.cuda_stream for s in side_streams])
+        evs = None
+        if self.uses_lanes:
+            if events is None:
+                events = self._own_events()
+            evs = (C.c_void_p * 8)(*[e.cuda_event for e in events])
+        cabi.check(L.i2r_run_program(self._c_ops, len(self.ops), streams, evs), "i2r_run_program")
+
+    def _own_events(self):
+        if not hasattr(self, "_events"):
+            self._events = [torch.cuda.Event(enable_timing=False) for _ in range(8)]
+            for e in self._events:
+                e.record()  # forces creation of the underlying hipEvent_t
+        return self._events
 
 
 # ------------------------------------------------------------------------------------------------
@@ -409,12 +440,19 @@ class HRNetW48:
     def _emit_module(P, mod, xs):
         nb = mod["nb"]
         xs = list(xs)
+        mask = sum(1 << i for i in range(1, nb)) if P.multi_lane else 0
+        lane_of = (lambda i: i) if P.multi_lane else (lambda i: 0)
+        if mask:
+            P.fork(mask)  # branches are independent: one stream lane each
         for i in range(nb):
             for (c1, c2) in mod["blocks"][i]:
-                t = P.conv(xs[i], c1, relu=True)
-                y = P.conv(t, c2, relu=True, res1=xs[i])
+                t = P.conv(xs[i], c1, relu=True, lane=lane_of(i))
+                y = P.conv(t, c2, relu=True, res1=xs[i], lane=lane_of(i))
                 P.release(t, xs[i])
                 xs[i] = y
+        if mask:
+            P.join(mask)
+            P.fork(mask)  # each fused output is again its own lane (all read every branch, none writes them)
         outs = []
         for i in range(nb):
             # y = ((t_0 + t_1) + ...) in the reference's order (interformer_pureMulti.py:401-408). Identity terms are
@@ -432,7 +470,7 @@ class HRNetW48:
                     chain, up = mod["fuse"][(i, j)], 1
                 cur = xs[j]
                 for pc in chain[:-1]:
-                    nxt = P.conv(cur, pc, relu=True)
+                    nxt = P.conv(cur, pc, relu=True, lane=lane_of(i))
                     if cur is not xs[j]:
                         P.release(cur)
                     cur = nxt
@@ -443,11 +481,13 @@ class HRNetW48:
                 if y is None:
                     y = P.alloc(xs[i].n, xs[i].h, xs[i].w, xs[i].c)
                 P.conv(cur, chain[-1], relu=(jn >= nb), res1=res[0] if res else None,
-                       res2=res[1] if len(res) > 1 else None, up=up, out=y)
+                       res2=res[1] if len(res) > 1 else None, up=up, out=y, lane=lane_of(i))
                 if cur is not xs[j]:
                     P.release(cur)
                 acc, j = y, jn
             outs.append(y)
+        if mask:
+            P.join(mask)
         P.release(*xs)
         return outs
 
@@ -487,6 +527,8 @@ class Engine:
         assert self.device.type == "cuda", "the product path runs on the GPU only (device=%s)" % (device,)
         cabi.require_gfx950(self.device.index or 0)
         self.programs = {}
+        self.multi_lane = True  # HRNet branches on separate HIP streams
+        self.side_streams = [torch.cuda.Stream(device=self.device) for _ in range(3)]
         M = cfg["MODEL"]
         self.name = M["NAME"]
         pk = Packer(state_dict, self.device)
@@ -551,7 +593,7 @@ class Engine:
 
     def _build(self, S, H, W, length):
         M = self.cfg["MODEL"]
-        P = Program(self.device)
+        P = Program(self.device, multi_lane=self.multi_lane)
         patch = {}
         xs, patch["x"] = self.tower.emit(P, S, H, W)
         if self.name == "interformer_pureMulti":
@@ -620,7 +662,7 @@ class Engine:
         if "single" in patch:
             single = torch.empty_like(out)
             patch["single"].out = single.data_ptr()
-        P.run()
+        P.run(self.side_streams if P.uses_lanes else None)
         if self.name == "interformer" and self.return_dict:
             return {"single": single, "multi": out}
         return out

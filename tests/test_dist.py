@@ -1,0 +1,48 @@
+"""CPU, world_size 2 over gloo: the image sharding + heatmap all-gather used by bench.py --gpus N."""
+import os
+import socket
+
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from i2r_amd import dist as i2r_dist
+
+
+def test_shard_images_partitions_everything():
+    for length in ([4] * 8, [1, 6, 2, 3, 1, 1, 5], [3], [2, 2]):
+        for world in (1, 2, 4, 8):
+            if world > len(length):
+                continue
+            seen, crops = [], 0
+            for r in range(world):
+                lo, hi, off = i2r_dist.shard_images(length, r, world)
+                assert hi > lo and off == sum(length[:lo])
+                seen += list(range(lo, hi))
+                crops += sum(length[lo:hi])
+            assert seen == list(range(len(length))) and crops == sum(length)
+
+
+def _worker(rank, world, port, length):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        full = torch.arange(sum(length) * 2 * 3 * 2, dtype=torch.float32).view(sum(length), 2, 3, 2)
+        counts = []
+        for r in range(world):
+            lo, hi, off = i2r_dist.shard_images(length, r, world)
+            counts.append(sum(length[lo:hi]))
+        lo, hi, off = i2r_dist.shard_images(length, rank, world)
+        local = full[off:off + counts[rank]].clone()
+        got = i2r_dist.gather_heatmaps(local, counts)
+        assert torch.equal(got, full), (rank, got.shape)
+    finally:
+        dist.destroy_process_group()
+
+
+def test_gather_heatmaps_world2_gloo():
+    for length in ([4, 4], [1, 3, 2]):
+        with socket.socket() as s:
+            s.bind(("127.0.0.1", 0))
+            port = s.getsockname()[1]
+        mp.spawn(_worker, args=(2, port, length), nprocs=2, join=True)
