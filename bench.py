@@ -43,7 +43,11 @@ GFLOP_PER_CROP = 19.085 + 0.0849 * PERSONS  # BASELINE.md section 3 (N = 4 perso
 def conv_kernel_name(d):
     from i2r_amd.engine import conv_split
     nt, _ = conv_split(d.cout_pad)
-    return "conv_igemm_f32<MT=%d,NT=%d,WM=%d,WN=%d>" % (d.mt, nt, 4 // d.wn, d.wn)
+    return "conv_igemm_f32<%d, %d>" % (d.mt, nt)
+
+
+def conv_flop(d):
+    return 2.0 * d.n_img * d.conv_h * d.conv_w * d.cout * d.cin * d.ntaps
 
 
 def per_launch_timing(program, reps=3):
@@ -71,8 +75,10 @@ def per_launch_timing(program, reps=3):
                 continue
             ms = evs[i].elapsed_time(evs[i + 1])
             if kind == cabi.OP_CONV:
-                name = conv_kernel_name(st)
-                flop = 2.0 * st.n_img * st.conv_h * st.conv_w * st.cout * st.cin * st.ntaps
+                name, flop = conv_kernel_name(st), conv_flop(st)
+            elif kind == cabi.OP_CONV_GROUP:
+                members = [st.d[i].contents for i in range(st.n)]
+                name, flop = conv_kernel_name(members[0]), sum(conv_flop(m) for m in members)
             else:
                 name = {cabi.OP_STEM: "stem_conv_k", cabi.OP_MAXPOOL: "maxpool_k", cabi.OP_HEAD: "head_k",
                         cabi.OP_ENC_KV: "enc_kv_k", cabi.OP_ENC_LAYER: "enc_layer_k"}[kind]

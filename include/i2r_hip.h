@@ -82,6 +82,17 @@ typedef struct i2r_conv_desc {
 
 int i2r_conv(const i2r_conv_desc* d, void* stream);
 
+/* i2r_conv_grouped -- up to I2R_MAX_GROUP independent convolutions in ONE launch ("horizontal fusion"): the
+ * parallel branches of a HighResolutionModule (interformer_pureMulti.py:396-397) and the same-depth terms of its
+ * fuse sums (:401-408) have no mutual dependencies, and individually the low-resolution ones cannot fill 256 CUs.
+ * All descriptors must resolve to the same fragment blocking: cout_pad/16 divisible by the same NT, same mt. */
+#define I2R_MAX_GROUP 4
+/* block_map (optional, device int32[map_len]): dispatch order of the workgroups, entry = (member << 24) | index of
+ * the workgroup within that member; map_len must equal the total workgroup count
+ * (sum over members of n_img * ceil(conv_h/tile_h) * ceil(conv_w/tile_w) * cout_blocks). */
+int i2r_conv_grouped(const i2r_conv_desc* const* descs, int32_t n, const int32_t* block_map, int32_t map_len,
+                     void* stream);
+
 /* ------------------------------------------------------------------------------------------------
  * i2r_stem_conv -- first 3x3 stride-2 pad-1 conv of a tower (cin = 1..4) + folded BN + ReLU, reading the
  * boundary NCHW fp32 tensor and writing NHWC.
@@ -154,7 +165,7 @@ int i2r_encoder_layer(const i2r_encoder_desc* d, void* stream);
  * ------------------------------------------------------------------------------------------------ */
 enum {
     I2R_OP_CONV = 1, I2R_OP_STEM = 2, I2R_OP_MAXPOOL = 3, I2R_OP_HEAD = 4,
-    I2R_OP_ENC_KV = 5, I2R_OP_ENC_LAYER = 6, I2R_OP_FORK = 7, I2R_OP_JOIN = 8
+    I2R_OP_ENC_KV = 5, I2R_OP_ENC_LAYER = 6, I2R_OP_FORK = 7, I2R_OP_JOIN = 8, I2R_OP_CONV_GROUP = 9
 };
 
 typedef struct i2r_stem_args {
@@ -171,6 +182,13 @@ typedef struct i2r_head_args {
     const float* in; const float* w; const float* bias; float* out;
     int32_t n_img, h, w_, cin, in_cs, cout;
 } i2r_head_args;
+
+typedef struct i2r_conv_group_args {
+    const i2r_conv_desc* d[I2R_MAX_GROUP];
+    const int32_t* block_map;
+    int32_t n;
+    int32_t map_len;
+} i2r_conv_group_args;
 
 typedef struct i2r_op {
     int32_t kind;

@@ -12,7 +12,8 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libi2r_hip.so")
 
 MAX_TAPS = 9
-OP_CONV, OP_STEM, OP_MAXPOOL, OP_HEAD, OP_ENC_KV, OP_ENC_LAYER, OP_FORK, OP_JOIN = 1, 2, 3, 4, 5, 6, 7, 8
+OP_CONV, OP_STEM, OP_MAXPOOL, OP_HEAD, OP_ENC_KV, OP_ENC_LAYER, OP_FORK, OP_JOIN, OP_CONV_GROUP = 1, 2, 3, 4, 5, 6, 7, 8, 9
+MAX_GROUP = 4
 
 _fp = C.c_void_p  # device pointers travel as integers
 _i32 = C.c_int32
@@ -55,12 +56,16 @@ class HeadArgs(C.Structure):
                 ("n_img", _i32), ("h", _i32), ("w_", _i32), ("cin", _i32), ("in_cs", _i32), ("cout", _i32)]
 
 
+class ConvGroupArgs(C.Structure):
+    _fields_ = [("d", C.POINTER(ConvDesc) * MAX_GROUP), ("block_map", _fp), ("n", _i32), ("map_len", _i32)]
+
+
 class Op(C.Structure):
     _fields_ = [("kind", _i32), ("lane", _i32), ("args", C.c_void_p)]
 
 
 # every symbol include/i2r_hip.h declares (tests/test_cabi.py checks the built library exports them all)
-EXPORTS = ("i2r_conv", "i2r_stem_conv", "i2r_maxpool3x3s2", "i2r_head", "i2r_encoder_kv", "i2r_encoder_layer",
+EXPORTS = ("i2r_conv", "i2r_conv_grouped", "i2r_stem_conv", "i2r_maxpool3x3s2", "i2r_head", "i2r_encoder_kv", "i2r_encoder_layer",
            "i2r_run_program", "i2r_abi_version", "i2r_last_error", "i2r_device_check")
 
 _LIB = None
@@ -78,6 +83,7 @@ def load_library(path=LIB_PATH):
             "There is no CPU fallback for the product path." % path)
     L = C.CDLL(path)
     L.i2r_conv.argtypes = [C.POINTER(ConvDesc), C.c_void_p]
+    L.i2r_conv_grouped.argtypes = [C.POINTER(C.POINTER(ConvDesc)), _i32, _fp, _i32, C.c_void_p]
     L.i2r_stem_conv.argtypes = [_fp, _fp, _fp, _fp, _i32, _i32, _i32, _i32, _i32, _i32, C.c_void_p]
     L.i2r_maxpool3x3s2.argtypes = [_fp, _fp, _i32, _i32, _i32, _i32, _i32, _i32, C.c_void_p]
     L.i2r_head.argtypes = [_fp, _fp, _fp, _fp, _i32, _i32, _i32, _i32, _i32, _i32, C.c_void_p]

@@ -65,6 +65,11 @@ extern "C" int i2r_run_program(const i2r_op* ops, int32_t n_ops, void* const* st
         I2R_CHECK_ARG(streams || op.lane == 0, "i2r_run_program: op %d uses lane %d without streams", i, op.lane);
         switch (op.kind) {
             case I2R_OP_CONV: rc = i2r_conv((const i2r_conv_desc*)op.args, st); break;
+            case I2R_OP_CONV_GROUP: {
+                const i2r_conv_group_args* a = (const i2r_conv_group_args*)op.args;
+                rc = i2r_conv_grouped(a->d, a->n, a->block_map, a->map_len, st);
+                break;
+            }
             case I2R_OP_STEM: {
                 const i2r_stem_args* a = (const i2r_stem_args*)op.args;
                 rc = i2r_stem_conv(a->in, a->w, a->bias, a->out, a->n_img, a->cin, a->in_h, a->in_w, a->cout, a->out_cs, st);

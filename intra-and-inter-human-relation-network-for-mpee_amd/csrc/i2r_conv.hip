@@ -16,6 +16,8 @@
 //  * epilogue fuses folded-BN bias, up to two residual inputs, ReLU and the nearest-neighbour upsample
 //    scatter of the HRNet fuse layers (each destination element is owned by exactly one lane, so
 //    accumulating into `out` in place through res1 == out is race-free).
+#include <stdlib.h>
+
 #include "i2r_common.h"
 
 namespace {
@@ -37,19 +39,34 @@ struct ConvK {
     int tile_h, tile_w, tiles_y, tiles_x, n_cblk;
     int ph, pw, plane;  // patch dims (pixels) and plane stride (float4 slots, multiple of 16)
     int ck;             // channels staged per pass (multiple of 16)
+    int wn;             // waves along cout (1, 2, 4); waves along pixels = 4 / wn
+    int dbg;            // ablation switches (env I2R_CONV_DBG; tuning only): 1 no epilogue, 2 no staging loads, 4 no weight loads
 };
+
+// exchange a value with another lane of the same quad (DPP quad_perm; CTRL 0xB1 = [1,0,3,2], 0x4E = [2,3,0,1])
+template <int CTRL>
+__device__ __forceinline__ float quad_xchg(float x) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, x), CTRL, 0xF, 0xF, false));
+}
 
 constexpr int kMaxPP = 5;  // patch pixels per thread (256 threads) -> patches up to 1280 pixels
 
-template <int MT, int NT, int WM, int WN>
-__global__ __launch_bounds__(256) void conv_igemm_f32(const ConvK p) {
-    extern __shared__ __attribute__((aligned(16))) f32x4 lds[];
+constexpr int kMaxGroups = 4;
+struct ConvGroupK {
+    ConvK g[kMaxGroups];
+    int blk_end[kMaxGroups];  // exclusive prefix sums of workgroups per group
+    int n;
+    const int* blk_map;       // optional dispatch-order table: entry = (group << 24) | workgroup index within the group
+};
+
+template <int MT, int NT>
+__device__ __forceinline__ void conv_body(const ConvK& p, int bid, f32x4* lds) {
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
+    const int WN = p.wn;
     const int wm = wave / WN, wn = wave % WN;
     const int li = lane & 15, g = lane >> 4;
 
-    int bid = blockIdx.x;
     const int cb = bid % p.n_cblk;
     bid /= p.n_cblk;
     const int tile_x = bid % p.tiles_x;
@@ -114,7 +131,7 @@ __global__ __launch_bounds__(256) void conv_igemm_f32(const ConvK p) {
             for (int u = 0; u < 4; ++u)
 #pragma unroll
                 for (int j = 0; j < kMaxPP; ++j)
-                    if (j < npp) v[u][j] = *reinterpret_cast<const f32x4*>(p.in + goff[j] + c0 + (cg0 + u) * 4);
+                    if (j < npp && !(p.dbg & 2)) v[u][j] = *reinterpret_cast<const f32x4*>(p.in + goff[j] + c0 + (cg0 + u) * 4);
             if (p.in2) {
 #pragma unroll
                 for (int u = 0; u < 4; ++u)
@@ -144,7 +161,7 @@ __global__ __launch_bounds__(256) void conv_igemm_f32(const ConvK p) {
         int cs_n = 0, tx_n = 0, ty_n = 0;  // position of the next step to fetch
         auto fetch = [&](f32x4(&a)[MT], f32x4(&b)[NT]) {
 #pragma unroll
-            for (int nt = 0; nt < NT; ++nt) b[nt] = wp[nt * 16];
+            for (int nt = 0; nt < NT; ++nt) b[nt] = (p.dbg & 4) ? wp0[nt * 16] : wp[nt * 16];
             const int abase = (cs_n * 4 + g) * p.plane + ty_n * p.pw + tx_n;
 #pragma unroll
             for (int mt = 0; mt < MT; ++mt) a[mt] = lds[abase + ppix[mt]];
@@ -179,74 +196,98 @@ __global__ __launch_bounds__(256) void conv_igemm_f32(const ConvK p) {
         if (it < nit) fma_step(a0, b0);
     }
 
-    // ---- epilogue: D layout col = l&15 -> cout, rows 4g+r -> pixels ----
+    // ---- epilogue ----
+    // D layout: lane (li = l&15, g) holds channel n = nt*16 + li of pixels 4g + r (r = 0..3).  A 4x4 transpose inside each
+    // lane quad (two DPP butterfly stages, no LDS) turns that into: lane (q = li>>2, j = li&3, g) holds channels
+    // nt*16 + 4q .. +3 of pixel 4g + j, so bias / residual / store are 16-byte accesses (4x fewer VMEM instructions;
+    // the scalar-store epilogue measured 24 % of the kernel).
+    if ((p.dbg & 1) && acc[0][0][0] != 12345.678f) return;
+    const int j4 = li & 3, q4 = li >> 2;
+    const bool odd1 = j4 & 1, odd2 = j4 & 2;
 #pragma unroll
-    for (int nt = 0; nt < NT; ++nt) {
-        const int n = n_base + nt * 16 + li;
-        if (n >= p.cout) continue;
-        const float bv = p.bias[n];
+    for (int mt = 0; mt < MT; ++mt) {
+        const int m = (wm * MT + mt) * 16 + g * 4 + j4;
+        const int ty = m / p.tile_w, tx = m - ty * p.tile_w;
+        const int oy = oy0 + ty, ox = ox0 + tx;
+        const bool pvalid = m < tile_px && oy < p.conv_h && ox < p.conv_w;
+        const int by = oy * p.out_step + p.out_off_y, bx = ox * p.out_step + p.out_off_x;
 #pragma unroll
-        for (int mt = 0; mt < MT; ++mt) {
-            const int m0 = (wm * MT + mt) * 16 + g * 4;
-            int ty = m0 / p.tile_w, tx = m0 - ty * p.tile_w;
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int oy = oy0 + ty, ox = ox0 + tx;
-                if (m0 + r < tile_px && oy < p.conv_h && ox < p.conv_w) {
-                    const float v0 = acc[mt][nt][r] + bv;
-                    const int by = oy * p.out_step + p.out_off_y, bx = ox * p.out_step + p.out_off_x;
-                    for (int ry = 0; ry < p.rep; ++ry)
-                        for (int rx = 0; rx < p.rep; ++rx) {
-                            const size_t o = ((size_t)(img * p.out_h + by + ry) * p.out_w + bx + rx) * p.out_cs + n;
-                            float v = v0;
-                            if (p.res1) v += p.res1[o];
-                            if (p.res2) v += p.res2[o];
-                            if (p.relu) v = fmaxf(v, 0.f);
-                            if (p.res_post) v += p.res_post[o];
-                            p.out[o] = v;
-                        }
-                }
-                if (++tx == p.tile_w) { tx = 0; ++ty; }
+        for (int nt = 0; nt < NT; ++nt) {
+            f32x4 v = acc[mt][nt];
+            {   // stage 1: swap across lane pairs (j ^ 1) the elements (r ^ 1)
+                const float s0 = quad_xchg<0xB1>(odd1 ? v[0] : v[1]);
+                const float s1 = quad_xchg<0xB1>(odd1 ? v[2] : v[3]);
+                if (odd1) { v[0] = s0; v[2] = s1; } else { v[1] = s0; v[3] = s1; }
+                // stage 2: swap across lane pairs (j ^ 2) the element pairs (r ^ 2)
+                const float t0 = quad_xchg<0x4E>(odd2 ? v[0] : v[2]);
+                const float t1 = quad_xchg<0x4E>(odd2 ? v[1] : v[3]);
+                if (odd2) { v[0] = t0; v[1] = t1; } else { v[2] = t0; v[3] = t1; }
             }
+            const int n = n_base + nt * 16 + q4 * 4;
+            if (!pvalid || n >= p.cout_pad) continue;
+            v += *reinterpret_cast<const f32x4*>(p.bias + n);
+            const bool full = n + 4 <= p.cout;  // (cout % 4 != 0 only for padded-channel layers: scalar tail below)
+            for (int ry = 0; ry < p.rep; ++ry)
+                for (int rx = 0; rx < p.rep; ++rx) {
+                    const size_t o = ((size_t)(img * p.out_h + by + ry) * p.out_w + bx + rx) * p.out_cs + n;
+                    f32x4 t = v;
+                    if (full || n + 4 <= p.out_cs) {
+                        if (p.res1) t += *reinterpret_cast<const f32x4*>(p.res1 + o);
+                        if (p.res2) t += *reinterpret_cast<const f32x4*>(p.res2 + o);
+                        if (p.relu) { t[0] = fmaxf(t[0], 0.f); t[1] = fmaxf(t[1], 0.f); t[2] = fmaxf(t[2], 0.f); t[3] = fmaxf(t[3], 0.f); }
+                        if (p.res_post) t += *reinterpret_cast<const f32x4*>(p.res_post + o);
+                        if (!full) {  // channels >= cout are padding: keep them exactly zero
+#pragma unroll
+                            for (int e = 0; e < 4; ++e)
+                                if (n + e >= p.cout) t[e] = 0.f;
+                        }
+                        *reinterpret_cast<f32x4*>(p.out + o) = t;
+                    }
+                }
         }
     }
 }
 
-typedef void (*conv_fn)(const ConvK);
-
-template <int MT, int NT, int WN>
-conv_fn pick() {
-    return conv_igemm_f32<MT, NT, 4 / WN, WN>;
-}
-
-template <int NT, int WN>
-conv_fn pick_mt(int mt) {
-    switch (mt) {
-        case 1: return pick<1, NT, WN>();
-        case 2: return pick<2, NT, WN>();
-        case 3: return pick<3, NT, WN>();
-        case 4: return pick<4, NT, WN>();
+// One launch = up to kMaxGroups independent convolutions that share (MT, NT): "horizontal fusion" of the
+// HRNet branches / fuse terms so that the small low-resolution convs fill the chip together with the large one.
+template <int MT, int NT>
+__global__ __launch_bounds__(256) void conv_igemm_f32(const ConvGroupK grp) {
+    extern __shared__ __attribute__((aligned(16))) f32x4 lds[];
+    int bid = blockIdx.x, gi = 0, start = 0;
+    if (grp.blk_map) {
+        // host-chosen dispatch order (longest-processing-time packing over the CUs): members of a group have very
+        // different K, and with every workgroup resident from the start the hardware cannot rebalance later
+        const int v = grp.blk_map[bid];
+        gi = v >> 24;
+        bid = v & 0xFFFFFF;
+    } else {
+#pragma unroll
+        for (int i = 0; i < kMaxGroups - 1; ++i)
+            if (i + 1 < grp.n && bid >= grp.blk_end[i]) { gi = i + 1; start = grp.blk_end[i]; }
     }
-    return nullptr;
+    conv_body<MT, NT>(grp.g[gi], bid - start, lds);
 }
+
+typedef void (*conv_fn)(const ConvGroupK);
 
 template <int NT>
-conv_fn pick_wn(int wn, int mt) {
-    switch (wn) {
-        case 1: return pick_mt<NT, 1>(mt);
-        case 2: return pick_mt<NT, 2>(mt);
-        case 4: return pick_mt<NT, 4>(mt);
+conv_fn pick_mt(int mt) {
+    switch (mt) {
+        case 1: return conv_igemm_f32<1, NT>;
+        case 2: return conv_igemm_f32<2, NT>;
+        case 3: return conv_igemm_f32<3, NT>;
+        case 4: return conv_igemm_f32<4, NT>;
     }
     return nullptr;
 }
 
-conv_fn pick_kernel(int nt, int wn, int mt) {
+conv_fn pick_kernel(int nt, int mt) {
     switch (nt) {
-        case 1: return pick_wn<1>(wn, mt);
-        case 2: return pick_wn<2>(wn, mt);
-        case 3: return pick_wn<3>(wn, mt);
-        case 4: return pick_wn<4>(wn, mt);
-        case 5: return pick_wn<5>(wn, mt);
+        case 1: return pick_mt<1>(mt);
+        case 2: return pick_mt<2>(mt);
+        case 3: return pick_mt<3>(mt);
+        case 4: return pick_mt<4>(mt);
+        case 5: return pick_mt<5>(mt);
     }
     return nullptr;
 }
@@ -255,11 +296,12 @@ inline int cdiv(int a, int b) { return (a + b - 1) / b; }
 
 }  // namespace
 
-extern "C" int i2r_conv(const i2r_conv_desc* d, void* stream) {
+// validate one descriptor and derive its launch geometry; *nt_out/*mt_out: fragment blocking, *lds_out: LDS bytes
+static int prepare(const i2r_conv_desc* d, int force_mt, ConvK& k, int* nt_out, int* mt_out, size_t* lds_out, long long* nblk_out) {
     I2R_CHECK_ARG(d && d->in && d->w && d->bias && d->out, "i2r_conv: null pointer");
     I2R_CHECK_ARG(d->cin > 0 && d->cin % 16 == 0 && d->cin <= d->in_cs && d->in_cs % 4 == 0,
                   "i2r_conv: cin=%d must be a multiple of 16 and <= in_cs=%d (in_cs %% 4 == 0)", d->cin, d->in_cs);
-    I2R_CHECK_ARG(d->cout > 0 && d->cout_pad % 16 == 0 && d->cout <= d->cout_pad && d->cout <= d->out_cs,
+    I2R_CHECK_ARG(d->cout > 0 && d->cout_pad % 16 == 0 && d->cout <= d->cout_pad && d->cout <= d->out_cs && d->out_cs % 4 == 0,
                   "i2r_conv: cout=%d cout_pad=%d out_cs=%d", d->cout, d->cout_pad, d->out_cs);
     I2R_CHECK_ARG(d->stride == 1 || d->stride == 2, "i2r_conv: stride %d", d->stride);
     I2R_CHECK_ARG(d->ntaps >= 1 && d->ntaps <= I2R_MAX_TAPS, "i2r_conv: ntaps %d", d->ntaps);
@@ -292,7 +334,7 @@ extern "C" int i2r_conv(const i2r_conv_desc* d, void* stream) {
     const int wm = 4 / wn;
 
     // ---- tile ----
-    int th = d->tile_h, tw = d->tile_w, mt = d->mt;
+    int th = d->tile_h, tw = d->tile_w, mt = force_mt ? force_mt : d->mt;
     if (th == 0 || tw == 0) {
         tw = d->conv_w <= 16 ? d->conv_w : (d->conv_w % 16 == 0 ? 16 : (d->conv_w % 12 == 0 ? 12 : 8));
         if (mt == 0) mt = 2;
@@ -303,7 +345,6 @@ extern "C" int i2r_conv(const i2r_conv_desc* d, void* stream) {
     if (mt == 0) mt = cdiv(th * tw, wm * 16);
     I2R_CHECK_ARG(mt >= 1 && mt <= 4 && th * tw <= wm * mt * 16, "i2r_conv: tile %dx%d does not fit wm=%d mt=%d", th, tw, wm, mt);
 
-    ConvK k;
     k.in = d->in; k.in2 = d->in2; k.w = d->w; k.bias = d->bias; k.res1 = d->res1; k.res2 = d->res2; k.res_post = d->res_post; k.out = d->out;
     k.n_img = d->n_img; k.in_h = d->in_h; k.in_w = d->in_w; k.in_cs = d->in_cs; k.cin = d->cin;
     k.conv_h = d->conv_h; k.conv_w = d->conv_w; k.out_h = d->out_h; k.out_w = d->out_w; k.out_cs = d->out_cs;
@@ -324,25 +365,62 @@ extern "C" int i2r_conv(const i2r_conv_desc* d, void* stream) {
                       "i2r_conv: taps must form a dense row-major kh x kw grid");
     int ck = d->ck;
     if (ck == 0) {
-        const int budget = 72 * 1024;  // two workgroups per CU
-        ck = d->cin;
-        while (ck > 16 && (ck / 4) * k.plane * 16 > budget) {
-            // largest multiple of 16 below that still divides evenly enough (any multiple works: tail handled)
-            ck -= 16;
-        }
+        // small LDS footprint (<= ~20 KB) keeps >= 4 workgroups per CU resident, which is what hides the staging and
+        // epilogue phases behind other workgroups' MFMA work (measured: ck = 16..48 beats staging all of cin);
+        // equal-sized chunks avoid a short tail pass
+        const int budget = 20 * 1024;
+        int fit = (budget / (k.plane * 16)) * 4;
+        fit = fit < 16 ? 16 : fit / 16 * 16;
+        const int nchunk = cdiv(d->cin, fit);
+        ck = cdiv(cdiv(d->cin, nchunk), 16) * 16;
     }
     I2R_CHECK_ARG(ck % 16 == 0 && ck >= 16, "i2r_conv: ck=%d", ck);
     k.ck = ck;
     const size_t lds_bytes = (size_t)(ck / 4) * k.plane * 16;
     I2R_CHECK_ARG(lds_bytes <= 160 * 1024, "i2r_conv: LDS %zu B", lds_bytes);
 
-    conv_fn fn = pick_kernel(nt, wn, mt);
-    I2R_CHECK_ARG(fn != nullptr, "i2r_conv: no kernel for nt=%d wn=%d mt=%d", nt, wn, mt);
-    if (lds_bytes > 64 * 1024)
-        hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+    k.wn = wn;
+    {
+        static const int dbg = getenv("I2R_CONV_DBG") ? atoi(getenv("I2R_CONV_DBG")) : 0;
+        k.dbg = dbg;
+    }
     const long long nblk = (long long)d->n_img * k.tiles_y * k.tiles_x * k.n_cblk;
-    I2R_CHECK_ARG(nblk > 0 && nblk < (1ll << 31), "i2r_conv: grid");
-    hipLaunchKernelGGL(fn, dim3((unsigned)nblk), dim3(256), lds_bytes, (hipStream_t)stream, k);
+    I2R_CHECK_ARG(nblk > 0 && nblk < (1ll << 30), "i2r_conv: grid");
+    *nt_out = nt; *mt_out = mt; *lds_out = lds_bytes; *nblk_out = nblk;
+    return I2R_OK;
+}
+
+extern "C" int i2r_conv_grouped(const i2r_conv_desc* const* descs, int32_t n, const int32_t* block_map,
+                                int32_t map_len, void* stream) {
+    I2R_CHECK_ARG(descs && n >= 1 && n <= kMaxGroups, "i2r_conv_grouped: 1..%d descriptors", kMaxGroups);
+    ConvGroupK grp;
+    int nt0 = 0, mt0 = 0;
+    size_t lds_max = 0;
+    long long total = 0;
+    for (int i = 0; i < n; ++i) {
+        int nt, mt;
+        size_t lds;
+        long long nblk;
+        int rc = prepare(descs[i], mt0, grp.g[i], &nt, &mt, &lds, &nblk);
+        if (rc) return rc;
+        if (i == 0) { nt0 = nt; mt0 = mt; }
+        I2R_CHECK_ARG(nt == nt0 && mt == mt0, "i2r_conv_grouped: descriptor %d has fragment blocking (%d,%d) != (%d,%d)", i, mt, nt, mt0, nt0);
+        if (lds > lds_max) lds_max = lds;
+        total += nblk;
+        grp.blk_end[i] = (int)total;
+    }
+    for (int i = n; i < kMaxGroups; ++i) { grp.g[i] = grp.g[0]; grp.blk_end[i] = (int)total; }
+    grp.n = n;
+    grp.blk_map = block_map;
+    I2R_CHECK_ARG(block_map == nullptr || map_len == (int32_t)total, "i2r_conv_grouped: block_map has %d entries, grid has %lld", map_len, total);
+    I2R_CHECK_ARG(total < (1ll << 31), "i2r_conv_grouped: grid");
+    conv_fn fn = pick_kernel(nt0, mt0);
+    I2R_CHECK_ARG(fn != nullptr, "i2r_conv: no kernel for nt=%d mt=%d", nt0, mt0);
+    if (lds_max > 64 * 1024)
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_max);
+    hipLaunchKernelGGL(fn, dim3((unsigned)total), dim3(256), lds_max, (hipStream_t)stream, grp);
     I2R_CHECK_LAUNCH("i2r_conv");
     return I2R_OK;
 }
+
+extern "C" int i2r_conv(const i2r_conv_desc* d, void* stream) { return i2r_conv_grouped(&d, 1, nullptr, 0, stream); }

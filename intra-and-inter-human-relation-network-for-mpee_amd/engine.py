@@ -191,15 +191,15 @@ class Act:
         return self.t.data_ptr()
 
 
-_MT_EFF = {1: 0.62, 2: 0.9, 3: 1.0, 4: 1.0}  # measured on MI355X (tools/sweep_conv.py): B-fragment reuse per wave
+_MT_EFF = {1: 0.62, 2: 0.9, 3: 1.0, 4: 0.9}  # measured on MI355X (tools/sweep_conv.py): B-fragment reuse per wave
 
 
-def choose_tile(conv_h, conv_w, wm, stride, max_d, n_img, n_cblk):
+def choose_tile(conv_h, conv_w, wm, stride, max_d, n_img, n_cblk, force_mt=0, want_cost=False):
     """(tile_h, tile_w, mt) for a workgroup of wm M-waves.  Cost model fitted to tools/sweep_conv.py on MI355X:
     time ~ rounds of 256 workgroups x padded pixels per workgroup / per-wave efficiency(mt), plus a halo-staging term."""
     best = None
     cands_w = sorted({w for w in (conv_w, 48, 32, 24, 16, 12, 8, 6, 4) if w <= conv_w and w <= 48})
-    for mt in (1, 2, 3, 4):
+    for mt in ((force_mt,) if force_mt else (1, 2, 3, 4)):
         cap = wm * mt * 16
         for tw in cands_w:
             th = min(conv_h, cap // tw)
@@ -216,7 +216,31 @@ def choose_tile(conv_h, conv_w, wm, stride, max_d, n_img, n_cblk):
             if best is None or cost < best[0] - 1e-9:
                 best = (cost, th, tw, mt)
     assert best is not None, "no tile for %dx%d" % (conv_h, conv_w)
+    if want_cost:
+        return best
     return best[1], best[2], best[3]
+
+
+def lpt_block_order(counts, works, n_cu=256):
+    """Dispatch order for a grouped launch whose members have different per-workgroup work (K): longest-processing-
+    time packing of all workgroups onto n_cu bins, emitted round by round (bin0[r], bin1[r], ...), so the first n_cu
+    workgroups (one per CU) are the heaviest and every CU ends up with about the same total. Entry = member << 24 | idx."""
+    import heapq
+    items = sorted(((w, g, i) for g, (c, w) in enumerate(zip(counts, works)) for i in range(c)),
+                   key=lambda t: (-t[0], t[1], t[2]))
+    heap = [(0, b) for b in range(n_cu)]
+    bins = [[] for _ in range(n_cu)]
+    for w, g, i in items:
+        load, b = heapq.heappop(heap)
+        bins[b].append((g << 24) | i)
+        heapq.heappush(heap, (load + w, b))
+    out, r = [], 0
+    while len(out) < len(items):
+        for b in range(n_cu):
+            if r < len(bins[b]):
+                out.append(bins[b][r])
+        r += 1
+    return out
 
 
 def conv_split(cout_pad):
@@ -267,7 +291,7 @@ class Program:
         return out, a
 
     def conv(self, x, pc, relu=False, res1=None, res2=None, res_post=None, in2=None, up=1, out=None, out_step=1,
-             out_off=(0, 0), out_hw=None, lane=0):
+             out_off=(0, 0), out_hw=None, lane=0, group=None):
         assert x.cs >= pc.cin_pad and x.c == pc.cin, "conv input channels %d/%d vs weight %d" % (x.c, x.cs, pc.cin)
         k = pc.ksize
         if pc.stride == 1:
@@ -298,8 +322,59 @@ class Program:
         max_d = max(max(t) for t in pc.taps)
         th, tw, mt = choose_tile(conv_h, conv_w, 4 // wn, pc.stride, max_d, x.n, n_cblk)
         d.tile_h, d.tile_w, d.mt, d.wn, d.ck = th, tw, mt, wn, 0
-        self.ops.append((cabi.OP_CONV, lane, d))
+        if group is not None:
+            group.append((d, (conv_h, conv_w, 4 // wn, pc.stride, max_d, x.n, n_cblk), nt))
+        else:
+            self.ops.append((cabi.OP_CONV, lane, d))
         return out
+
+    def flush_group(self, group, lane=0):
+        """Emit the convs collected in `group` as ONE grouped launch (same NT required; a common mt is chosen by the
+        cost model; heaviest-K members first so the long workgroups start early)."""
+        if not group:
+            return
+        nts = {g[2] for g in group}
+        if len(group) == 1 or len(nts) != 1 or len(group) > cabi.MAX_GROUP:
+            for d, _, _ in group:
+                self.ops.append((cabi.OP_CONV, lane, d))
+            del group[:]
+            return
+        best = None
+        for mt in (2, 3, 4, 1):
+            try:
+                tiles = [choose_tile(*geo, force_mt=mt, want_cost=True) for _, geo, _ in group]
+            except AssertionError:
+                continue
+            # one launch: workgroups of all members share the chip -> rounds over the SUM of workgroups
+            blocks = 0
+            work = 0.0
+            for (d, geo, _), t in zip(group, tiles):
+                conv_h, conv_w, wm, stride, max_d, n_img, n_cblk = geo
+                nb = -(-conv_h // t[1]) * -(-conv_w // t[2]) * n_img * n_cblk
+                blocks += nb
+                work += nb * (wm * mt * 16 / _MT_EFF[mt]) * d.cin * d.ntaps
+            cost = work * max(1.0, 256.0 / blocks)
+            if best is None or cost < best[0]:
+                best = (cost, mt, tiles)
+        _, mt, tiles = best
+        order = sorted(range(len(group)), key=lambda i: -(group[i][0].cin * group[i][0].ntaps))
+        a = cabi.ConvGroupArgs()
+        counts, works = [], []
+        for slot, i in enumerate(order):
+            d, geo, _ = group[i]
+            d.tile_h, d.tile_w, d.mt = tiles[i][1], tiles[i][2], mt
+            a.d[slot] = C.pointer(d)
+            self.keep.append(d)
+            conv_h, conv_w, wm, stride, max_d, n_img, n_cblk = geo
+            counts.append(-(-conv_h // d.tile_h) * -(-conv_w // d.tile_w) * n_img * n_cblk)
+            works.append(d.cin * d.ntaps)
+        a.n = len(group)
+        if len(set(works)) > 1:
+            bm = torch.tensor(lpt_block_order(counts, works), dtype=torch.int32, device=self.device)
+            self.keep.append(bm)
+            a.block_map, a.map_len = bm.data_ptr(), bm.numel()
+        self.ops.append((cabi.OP_CONV_GROUP, lane, a))
+        del group[:]
 
     def deconv(self, x, pcs, relu=True, res_post=None, lane=0):
         """ConvTranspose(k4,s2,p1)+BN(+ReLU)(+post-ReLU residual) as four parity convs writing the interleaved 2x output."""
@@ -438,58 +513,74 @@ class HRNetW48:
 
     @staticmethod
     def _emit_module(P, mod, xs):
+        """HighResolutionModule.forward (interformer_pureMulti.py:392-410) as grouped launches: block k of every branch
+        goes out in one launch, and the fuse sums are evaluated level by level (one launch per dependency depth)."""
         nb = mod["nb"]
         xs = list(xs)
-        mask = sum(1 << i for i in range(1, nb)) if P.multi_lane else 0
-        lane_of = (lambda i: i) if P.multi_lane else (lambda i: 0)
-        if mask:
-            P.fork(mask)  # branches are independent: one stream lane each
-        for i in range(nb):
-            for (c1, c2) in mod["blocks"][i]:
-                t = P.conv(xs[i], c1, relu=True, lane=lane_of(i))
-                y = P.conv(t, c2, relu=True, res1=xs[i], lane=lane_of(i))
+        nblk = max(len(b) for b in mod["blocks"])
+        for k in range(nblk):
+            grp, ts = [], {}
+            for i in range(nb):
+                if k < len(mod["blocks"][i]):
+                    ts[i] = P.conv(xs[i], mod["blocks"][i][k][0], relu=True, group=grp)
+            P.flush_group(grp)
+            for i, t in ts.items():
+                y = P.conv(t, mod["blocks"][i][k][1], relu=True, res1=xs[i], group=grp)
                 P.release(t, xs[i])
                 xs[i] = y
-        if mask:
-            P.join(mask)
-            P.fork(mask)  # each fused output is again its own lane (all read every branch, none writes them)
-        outs = []
+            P.flush_group(grp)
+        # fuse: per output i an ordered chain of launches ((src, pc, kwargs) steps); y = ((t_0 + t_1) + ...) in the
+        # reference's order, identity terms folded into a neighbouring conv's residual inputs, running sum in place in y
+        chains = []
         for i in range(nb):
-            # y = ((t_0 + t_1) + ...) in the reference's order (interformer_pureMulti.py:401-408). Identity terms are
-            # folded into a neighbouring conv's residual inputs; the running sum is accumulated in place in `y`.
-            acc, y, j = None, None, 0
+            steps, acc, j = [], None, 0
+            y = None
             while j < nb:
                 if j == i:
                     assert acc is None
-                    acc = xs[i]
+                    acc = "x"
                     j += 1
                     continue
-                if j > i:
-                    chain, up = [mod["fuse"][(i, j)]], 2 ** (j - i)
-                else:
-                    chain, up = mod["fuse"][(i, j)], 1
-                cur = xs[j]
+                chain, up = ([mod["fuse"][(i, j)]], 2 ** (j - i)) if j > i else (mod["fuse"][(i, j)], 1)
                 for pc in chain[:-1]:
-                    nxt = P.conv(cur, pc, relu=True, lane=lane_of(i))
-                    if cur is not xs[j]:
-                        P.release(cur)
-                    cur = nxt
+                    steps.append(("mid", j, pc))
                 res = [acc] if acc is not None else []
                 if j + 1 == i:
-                    res.append(xs[i])
+                    res.append("x")
                 jn = j + 2 if j + 1 == i else j + 1
-                if y is None:
-                    y = P.alloc(xs[i].n, xs[i].h, xs[i].w, xs[i].c)
-                P.conv(cur, chain[-1], relu=(jn >= nb), res1=res[0] if res else None,
-                       res2=res[1] if len(res) > 1 else None, up=up, out=y, lane=lane_of(i))
-                if cur is not xs[j]:
-                    P.release(cur)
-                acc, j = y, jn
-            outs.append(y)
-        if mask:
-            P.join(mask)
+                steps.append(("sum", j, chain[-1], res, up, jn >= nb))
+                acc, j = "y", jn
+            chains.append(steps)
+        ys = [None] * nb
+        cur = [None] * nb      # running intermediate of a down-sampling chain
+        pos = [0] * nb
+        while any(pos[i] < len(chains[i]) for i in range(nb)):
+            grp, rel = [], []
+            for i in range(nb):
+                if pos[i] >= len(chains[i]):
+                    continue
+                st = chains[i][pos[i]]
+                pos[i] += 1
+                src = cur[i] if cur[i] is not None else xs[st[1]]
+                if st[0] == "mid":
+                    nxt = P.conv(src, st[2], relu=True, group=grp)
+                    if cur[i] is not None:
+                        rel.append(cur[i])
+                    cur[i] = nxt
+                else:
+                    _, j, pc, res, up, final = st
+                    if ys[i] is None:
+                        ys[i] = P.alloc(xs[i].n, xs[i].h, xs[i].w, xs[i].c)
+                    rr = [xs[i] if r == "x" else ys[i] for r in res]
+                    P.conv(src, pc, relu=final, res1=rr[0] if rr else None, res2=rr[1] if len(rr) > 1 else None,
+                           up=up, out=ys[i], group=grp)
+                    if cur[i] is not None:
+                        rel.append(cur[i])
+                        cur[i] = None
+            P.flush_group(grp)
+            P.release(*rel)
         P.release(*xs)
-        return outs
+        return ys
 
     def emit(self, P, n, h, w):
         """-> (list of branch Acts, stem StemArgs to patch the input pointer into)."""
@@ -527,7 +618,7 @@ class Engine:
         assert self.device.type == "cuda", "the product path runs on the GPU only (device=%s)" % (device,)
         cabi.require_gfx950(self.device.index or 0)
         self.programs = {}
-        self.multi_lane = True  # HRNet branches on separate HIP streams
+        self.multi_lane = False  # (grouped launches replaced per-branch stream lanes)
         self.side_streams = [torch.cuda.Stream(device=self.device) for _ in range(3)]
         M = cfg["MODEL"]
         self.name = M["NAME"]

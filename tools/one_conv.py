@@ -1,0 +1,41 @@
+"""GPU profiling aid: run the grouped 3-branch stage-3 conv (48@64x48 + 96@32x24 + 192@16x12, S=32) N times."""
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import torch
+
+import i2r_amd  # noqa
+from i2r_amd import engine, synth
+
+DEV = torch.device("cuda:0")
+S = int(sys.argv[1]) if len(sys.argv) > 1 else 32
+N = int(sys.argv[2]) if len(sys.argv) > 2 else 10
+mode = sys.argv[3] if len(sys.argv) > 3 else "group"
+P = engine.Program(DEV)
+grp = []
+for (c, h, w) in [(48, 64, 48), (96, 32, 24), (192, 16, 12)]:
+    sd = {"c.weight": torch.from_numpy(synth._sym(1, "w%d" % c, (c, c, 3, 3), 0.05))}
+    pc = engine.Packer(sd, DEV).conv("c", None)
+    P.keep.append(pc)
+    x = P.alloc(S, h, w, c)
+    x.t.normal_()
+    r = P.alloc(S, h, w, c)
+    r.t.normal_()
+    P.conv(x, pc, relu=True, res1=r, group=grp if mode == "group" else None)
+if mode == "group":
+    P.flush_group(grp)
+P.finalize()
+for _ in range(3):
+    P.run()
+torch.cuda.synchronize()
+e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+e0.record()
+for _ in range(N):
+    P.run()
+e1.record()
+torch.cuda.synchronize()
+ms = e0.elapsed_time(e1) / N
+flop = sum(2.0 * S * h * w * c * c * 9 for (c, h, w) in [(48, 64, 48), (96, 32, 24), (192, 16, 12)])
+print("%s S=%d: %.1f us per program  %.1f TF" % (mode, S, ms * 1e3, flop / ms / 1e9))
