@@ -90,6 +90,17 @@ def per_launch_timing(program, reps=3):
     return stats, reps
 
 
+def hbm_traffic():
+    """HBM bytes per launch of the dominant (grouped stage-3 conv) kernel from the committed PMC passes
+    (profiles/round1_hbm_traffic.json: separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE runs, FETCH_SIZE doubled per
+    MI355X_MICROARCH.md).  bench.py itself cannot collect PMC counters; null when the profile is absent."""
+    try:
+        with open(os.path.join(ROOT, "profiles", "round1_hbm_traffic.json")) as f:
+            return round(json.load(f)["hbm_bytes_per_launch"])
+    except (OSError, KeyError, ValueError):
+        return None
+
+
 def cpu_baseline(cfg, sd, budget_s=20.0):
     """The CPU oracle (a port of the reference forward) timed on this host; bounded to ~budget_s seconds."""
     import i2r_cpu
@@ -205,7 +216,7 @@ def main():
             conv_flop = sum(s[2] for k, s in stats.items() if k.startswith("conv_igemm"))
             out["roofline"] = {
                 "bound": "mfma", "kernel": dom, "achieved": round(ach, 2), "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-                "frac": round(ach / FP32_MFMA_PEAK_TFLOPS, 4), "traffic": None,
+                "frac": round(ach / FP32_MFMA_PEAK_TFLOPS, 4), "traffic": hbm_traffic(),
                 "launches_per_step": cnt // reps, "avg_launch_us": round(ms / cnt * 1e3, 2),
                 "gflop_per_launch": round(flop / cnt / 1e9, 4),
                 "share_of_step_kernel_time": round(ms / total_ms, 3),
