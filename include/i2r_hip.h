@@ -73,7 +73,7 @@ typedef struct i2r_conv_desc {
     int32_t ntaps;
     int32_t dy[I2R_MAX_TAPS], dx[I2R_MAX_TAPS];
     int32_t out_step, out_off_y, out_off_x, rep;
-    int32_t relu;
+    int32_t relu;                  /* activation: 0 none, 1 ReLU, 2 exact-erf GELU */
     int32_t tile_h, tile_w;        /* output tile per workgroup (0 = let the library choose) */
     int32_t ck;                    /* input channels staged in LDS per pass (0 = choose) */
     int32_t wn;                    /* waves along cout in the 4-wave workgroup: 1, 2 or 4 (0 = choose) */
@@ -112,6 +112,33 @@ int i2r_maxpool3x3s2(const float* in, float* out, int32_t n_img, int32_t in_h, i
  * w: float[cout][cin] (the nn.Conv2d weight as is), bias[cout]. out: [n_img, cout, h, w]. */
 int i2r_head(const float* in, const float* w, const float* bias, float* out_nchw, int32_t n_img, int32_t h,
              int32_t w_, int32_t cin, int32_t in_cs, int32_t cout, void* stream);
+
+/* ---- HRFormer-B glue (reference lib/models/hrformer.py) ---------------------------------------------------- */
+/* i2r_layernorm -- nn.LayerNorm(c, eps) over the channels of every pixel/token of an NHWC tensor
+ * (GeneralTransformerBlock.norm1/norm2, hrformer.py:1198,1235-1237). w, b: [cs] zero-padded. */
+int i2r_layernorm(const float* in, const float* w, const float* b, float* out, int32_t npix, int32_t c, int32_t cs,
+                  float eps, void* stream);
+
+/* i2r_window_attn -- the softmax(q k^T) v core of InterlacedPoolAttention / MHA_ over 7x7 windows
+ * (hrformer.py:1164-1180, 692-935): centre zero-padding to multiples of 7 (:947-956), window gather (:978-987),
+ * heads = c / head_dim, q scaled by head_dim^-0.5 (:780), NO relative-position bias (:883-885), de-pad (:958-964).
+ * qkv: [n, h, w, 3*cs] holding q | k | v projections of the LayerNorm-ed tokens (a 1x1 i2r_conv with the stacked
+ * q/k/v_proj weights); bias_qkv: [3*cs] = the projections of a zero token (what padded tokens contribute).
+ * out: [n, h, w, cs] attention output BEFORE out_proj. head_dim <= 40. */
+int i2r_window_attn(const float* qkv, const float* bias_qkv, float* out, int32_t n_img, int32_t h, int32_t w, int32_t c,
+                    int32_t cs, int32_t heads, void* stream);
+
+/* i2r_dwconv3x3 -- depth-wise 3x3 conv, pad 1, stride 1|2, + bias (eval BN folded) + activation (0 none, 1 ReLU,
+ * 2 GELU): MlpDWBN.dw3x3+norm2+act2 (hrformer.py:1070-1080,1106-1108) and the DW down-sampling hops of the fuse
+ * layers (:1651-1704). w: [9][cs] (tap-major), bias [cs]. */
+int i2r_dwconv3x3(const float* in, const float* w, const float* bias, float* out, int32_t n_img, int32_t in_h, int32_t in_w,
+                  int32_t c, int32_t cs, int32_t stride, int32_t act, void* stream);
+
+/* i2r_upsample_bilinear_add -- out = act(res + F.interpolate(low, scale_factor=scale, mode='bilinear',
+ * align_corners=False)): the up-sampling terms of HighResolutionTransformerModule.forward (hrformer.py:1629-1646,
+ * 1718-1730). res may alias out. */
+int i2r_upsample_bilinear_add(const float* low, const float* res, float* out, int32_t n_img, int32_t low_h, int32_t low_w,
+                              int32_t scale, int32_t c, int32_t cs, int32_t act, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * i2r_encoder_desc -- one DETR-style post-norm encoder layer over variable-length token groups
@@ -165,7 +192,8 @@ int i2r_encoder_layer(const i2r_encoder_desc* d, void* stream);
  * ------------------------------------------------------------------------------------------------ */
 enum {
     I2R_OP_CONV = 1, I2R_OP_STEM = 2, I2R_OP_MAXPOOL = 3, I2R_OP_HEAD = 4,
-    I2R_OP_ENC_KV = 5, I2R_OP_ENC_LAYER = 6, I2R_OP_FORK = 7, I2R_OP_JOIN = 8, I2R_OP_CONV_GROUP = 9
+    I2R_OP_ENC_KV = 5, I2R_OP_ENC_LAYER = 6, I2R_OP_FORK = 7, I2R_OP_JOIN = 8, I2R_OP_CONV_GROUP = 9,
+    I2R_OP_LAYERNORM = 10, I2R_OP_WINATTN = 11, I2R_OP_DWCONV = 12, I2R_OP_UPSAMPLE = 13
 };
 
 typedef struct i2r_stem_args {
@@ -182,6 +210,26 @@ typedef struct i2r_head_args {
     const float* in; const float* w; const float* bias; float* out;
     int32_t n_img, h, w_, cin, in_cs, cout;
 } i2r_head_args;
+
+typedef struct i2r_ln_args {
+    const float* in; const float* w; const float* b; float* out;
+    int32_t npix, c, cs; float eps;
+} i2r_ln_args;
+
+typedef struct i2r_winattn_args {
+    const float* qkv; const float* bias; float* out;
+    int32_t n_img, h, w_, c, cs, heads;
+} i2r_winattn_args;
+
+typedef struct i2r_dw_args {
+    const float* in; const float* w; const float* bias; float* out;
+    int32_t n_img, in_h, in_w, c, cs, stride, act;
+} i2r_dw_args;
+
+typedef struct i2r_up_args {
+    const float* low; const float* res; float* out;
+    int32_t n_img, low_h, low_w, scale, c, cs, act;
+} i2r_up_args;
 
 typedef struct i2r_conv_group_args {
     const i2r_conv_desc* d[I2R_MAX_GROUP];

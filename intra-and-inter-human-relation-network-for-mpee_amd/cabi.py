@@ -14,6 +14,7 @@ LIB_PATH = os.path.join(_HERE, "libi2r_hip.so")
 MAX_TAPS = 9
 OP_CONV, OP_STEM, OP_MAXPOOL, OP_HEAD, OP_ENC_KV, OP_ENC_LAYER, OP_FORK, OP_JOIN, OP_CONV_GROUP = 1, 2, 3, 4, 5, 6, 7, 8, 9
 MAX_GROUP = 4
+OP_LAYERNORM, OP_WINATTN, OP_DWCONV, OP_UPSAMPLE = 10, 11, 12, 13
 
 _fp = C.c_void_p  # device pointers travel as integers
 _i32 = C.c_int32
@@ -56,6 +57,25 @@ class HeadArgs(C.Structure):
                 ("n_img", _i32), ("h", _i32), ("w_", _i32), ("cin", _i32), ("in_cs", _i32), ("cout", _i32)]
 
 
+class LnArgs(C.Structure):
+    _fields_ = [("in_", _fp), ("w", _fp), ("b", _fp), ("out", _fp), ("npix", _i32), ("c", _i32), ("cs", _i32), ("eps", C.c_float)]
+
+
+class WinAttnArgs(C.Structure):
+    _fields_ = [("qkv", _fp), ("bias", _fp), ("out", _fp),
+                ("n_img", _i32), ("h", _i32), ("w_", _i32), ("c", _i32), ("cs", _i32), ("heads", _i32)]
+
+
+class DwArgs(C.Structure):
+    _fields_ = [("in_", _fp), ("w", _fp), ("bias", _fp), ("out", _fp),
+                ("n_img", _i32), ("in_h", _i32), ("in_w", _i32), ("c", _i32), ("cs", _i32), ("stride", _i32), ("act", _i32)]
+
+
+class UpArgs(C.Structure):
+    _fields_ = [("low", _fp), ("res", _fp), ("out", _fp),
+                ("n_img", _i32), ("low_h", _i32), ("low_w", _i32), ("scale", _i32), ("c", _i32), ("cs", _i32), ("act", _i32)]
+
+
 class ConvGroupArgs(C.Structure):
     _fields_ = [("d", C.POINTER(ConvDesc) * MAX_GROUP), ("block_map", _fp), ("n", _i32), ("map_len", _i32)]
 
@@ -65,7 +85,8 @@ class Op(C.Structure):
 
 
 # every symbol include/i2r_hip.h declares (tests/test_cabi.py checks the built library exports them all)
-EXPORTS = ("i2r_conv", "i2r_conv_grouped", "i2r_stem_conv", "i2r_maxpool3x3s2", "i2r_head", "i2r_encoder_kv", "i2r_encoder_layer",
+EXPORTS = ("i2r_conv", "i2r_conv_grouped", "i2r_stem_conv", "i2r_maxpool3x3s2", "i2r_head", "i2r_layernorm", "i2r_window_attn", "i2r_dwconv3x3",
+           "i2r_upsample_bilinear_add", "i2r_encoder_kv", "i2r_encoder_layer",
            "i2r_run_program", "i2r_abi_version", "i2r_last_error", "i2r_device_check")
 
 _LIB = None
@@ -87,6 +108,10 @@ def load_library(path=LIB_PATH):
     L.i2r_stem_conv.argtypes = [_fp, _fp, _fp, _fp, _i32, _i32, _i32, _i32, _i32, _i32, C.c_void_p]
     L.i2r_maxpool3x3s2.argtypes = [_fp, _fp, _i32, _i32, _i32, _i32, _i32, _i32, C.c_void_p]
     L.i2r_head.argtypes = [_fp, _fp, _fp, _fp, _i32, _i32, _i32, _i32, _i32, _i32, C.c_void_p]
+    L.i2r_layernorm.argtypes = [_fp, _fp, _fp, _fp, _i32, _i32, _i32, C.c_float, C.c_void_p]
+    L.i2r_window_attn.argtypes = [_fp, _fp, _fp, _i32, _i32, _i32, _i32, _i32, _i32, C.c_void_p]
+    L.i2r_dwconv3x3.argtypes = [_fp, _fp, _fp, _fp, _i32, _i32, _i32, _i32, _i32, _i32, _i32, C.c_void_p]
+    L.i2r_upsample_bilinear_add.argtypes = [_fp, _fp, _fp, _i32, _i32, _i32, _i32, _i32, _i32, _i32, C.c_void_p]
     L.i2r_encoder_kv.argtypes = [C.POINTER(EncoderDesc), C.c_void_p]
     L.i2r_encoder_layer.argtypes = [C.POINTER(EncoderDesc), C.c_void_p]
     L.i2r_run_program.argtypes = [C.POINTER(Op), _i32, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p)]

@@ -85,6 +85,26 @@ extern "C" int i2r_run_program(const i2r_op* ops, int32_t n_ops, void* const* st
                 rc = i2r_head(a->in, a->w, a->bias, a->out, a->n_img, a->h, a->w_, a->cin, a->in_cs, a->cout, st);
                 break;
             }
+            case I2R_OP_LAYERNORM: {
+                const i2r_ln_args* a = (const i2r_ln_args*)op.args;
+                rc = i2r_layernorm(a->in, a->w, a->b, a->out, a->npix, a->c, a->cs, a->eps, st);
+                break;
+            }
+            case I2R_OP_WINATTN: {
+                const i2r_winattn_args* a = (const i2r_winattn_args*)op.args;
+                rc = i2r_window_attn(a->qkv, a->bias, a->out, a->n_img, a->h, a->w_, a->c, a->cs, a->heads, st);
+                break;
+            }
+            case I2R_OP_DWCONV: {
+                const i2r_dw_args* a = (const i2r_dw_args*)op.args;
+                rc = i2r_dwconv3x3(a->in, a->w, a->bias, a->out, a->n_img, a->in_h, a->in_w, a->c, a->cs, a->stride, a->act, st);
+                break;
+            }
+            case I2R_OP_UPSAMPLE: {
+                const i2r_up_args* a = (const i2r_up_args*)op.args;
+                rc = i2r_upsample_bilinear_add(a->low, a->res, a->out, a->n_img, a->low_h, a->low_w, a->scale, a->c, a->cs, a->act, st);
+                break;
+            }
             case I2R_OP_ENC_KV: rc = i2r_encoder_kv((const i2r_encoder_desc*)op.args, st); break;
             case I2R_OP_ENC_LAYER: rc = i2r_encoder_layer((const i2r_encoder_desc*)op.args, st); break;
             default: i2r_set_error("i2r_run_program: op %d unknown kind %d", i, op.kind); return I2R_E_ARG;

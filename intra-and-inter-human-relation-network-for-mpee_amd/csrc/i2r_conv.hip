@@ -234,7 +234,12 @@ __device__ __forceinline__ void conv_body(const ConvK& p, int bid, f32x4* lds) {
                     if (full || n + 4 <= p.out_cs) {
                         if (p.res1) t += *reinterpret_cast<const f32x4*>(p.res1 + o);
                         if (p.res2) t += *reinterpret_cast<const f32x4*>(p.res2 + o);
-                        if (p.relu) { t[0] = fmaxf(t[0], 0.f); t[1] = fmaxf(t[1], 0.f); t[2] = fmaxf(t[2], 0.f); t[3] = fmaxf(t[3], 0.f); }
+                        if (p.relu == 1) {
+                            t[0] = fmaxf(t[0], 0.f); t[1] = fmaxf(t[1], 0.f); t[2] = fmaxf(t[2], 0.f); t[3] = fmaxf(t[3], 0.f);
+                        } else if (p.relu == 2) {  // exact-erf GELU (HRFormer MlpDWBN, hrformer.py:1197)
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) t[e] = 0.5f * t[e] * (1.f + erff(t[e] * 0.70710678118654752f));
+                        }
                         if (p.res_post) t += *reinterpret_cast<const f32x4*>(p.res_post + o);
                         if (!full) {  // channels >= cout are padding: keep them exactly zero
 #pragma unroll

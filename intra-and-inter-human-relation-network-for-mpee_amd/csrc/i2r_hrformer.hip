@@ -1,0 +1,255 @@
+// HRFormer-B building blocks that are not convolutions: channel LayerNorm, 7x7-window multi-head attention,
+// depth-wise 3x3 conv (+folded BN, +GELU/ReLU) and bilinear-upsample-accumulate of the multi-scale fuse.
+// All are HBM / LDS-bound glue around the MFMA conv kernel (window attention is 5 % of the HRFormer FLOPs).
+#include "i2r_common.h"
+
+namespace {
+
+__device__ __forceinline__ float gelu_exact(float x) { return 0.5f * x * (1.f + erff(x * 0.70710678118654752f)); }
+
+__device__ __forceinline__ f32x4 act4(f32x4 v, int act) {
+    if (act == 1) {
+        v[0] = fmaxf(v[0], 0.f); v[1] = fmaxf(v[1], 0.f); v[2] = fmaxf(v[2], 0.f); v[3] = fmaxf(v[3], 0.f);
+    } else if (act == 2) {
+        v[0] = gelu_exact(v[0]); v[1] = gelu_exact(v[1]); v[2] = gelu_exact(v[2]); v[3] = gelu_exact(v[3]);
+    }
+    return v;
+}
+
+// ---- LayerNorm over the c real channels of each pixel; 16 lanes per pixel, values cached in registers ----
+constexpr int kLnMaxChunks = 10;  // 16 lanes x 10 float4 = 640 channels
+__global__ __launch_bounds__(256) void layernorm_k(const float* __restrict__ in, const float* __restrict__ w,
+                                                   const float* __restrict__ b, float* __restrict__ out, int npix, int c,
+                                                   int cs, float eps) {
+    const int l16 = threadIdx.x & 15;
+    const long long pix = ((long long)blockIdx.x * 256 + threadIdx.x) >> 4;
+    const bool ok = pix < npix;
+    const int nch = cs >> 2;
+    const float* row = in + (size_t)(ok ? pix : 0) * cs;
+    f32x4 v[kLnMaxChunks];
+    float s = 0.f;
+#pragma unroll
+    for (int k = 0; k < kLnMaxChunks; ++k) {
+        const int ch = l16 + 16 * k;
+        v[k] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        if (ch < nch) v[k] = *reinterpret_cast<const f32x4*>(row + ch * 4);
+        s += (v[k][0] + v[k][1]) + (v[k][2] + v[k][3]);  // pad channels are exact zeros
+    }
+    s += __shfl_xor(s, 1); s += __shfl_xor(s, 2); s += __shfl_xor(s, 4); s += __shfl_xor(s, 8);
+    const float mean = s / (float)c;
+    float q = 0.f;
+#pragma unroll
+    for (int k = 0; k < kLnMaxChunks; ++k) {
+        const int ch = l16 + 16 * k;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const float t = (ch * 4 + e < c) ? v[k][e] - mean : 0.f;
+            q += t * t;
+        }
+    }
+    q += __shfl_xor(q, 1); q += __shfl_xor(q, 2); q += __shfl_xor(q, 4); q += __shfl_xor(q, 8);
+    const float rstd = rsqrtf(q / (float)c + eps);
+    if (!ok) return;
+#pragma unroll
+    for (int k = 0; k < kLnMaxChunks; ++k) {
+        const int ch = l16 + 16 * k;
+        if (ch < nch) {
+            const f32x4 wv = *reinterpret_cast<const f32x4*>(w + ch * 4), bv = *reinterpret_cast<const f32x4*>(b + ch * 4);
+            f32x4 o;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) o[e] = (v[k][e] - mean) * rstd * wv[e] + bv[e];  // padded w = b = 0 -> 0
+            *reinterpret_cast<f32x4*>(out + (size_t)pix * cs + ch * 4) = o;
+        }
+    }
+}
+
+// ---- 7x7 window attention: one wave per (crop, window, head); lane t < 49 owns query token t ----
+// qkv: [n, h, w, 3*cs] (q | k | v, each cs wide, head hh at channels hh*hd..); tokens of the zero-padded border are
+// not stored: their projections equal the bias vector (LayerNorm output is padded with zeros BEFORE q/k/v_proj).
+template <int HDP>  // head_dim padded to a multiple of 4 (39 -> 40)
+__global__ __launch_bounds__(64) void window_attn_k(const float* __restrict__ qkv, const float* __restrict__ bias,
+                                                    float* __restrict__ out, int n_img, int h, int w, int cs, int heads,
+                                                    int hd, int nwy, int nwx, int pad_top, int pad_left, float scale) {
+    __shared__ __attribute__((aligned(16))) float Ks[49 * HDP];
+    __shared__ __attribute__((aligned(16))) float Vs[49 * HDP];
+    const int t = threadIdx.x;
+    int bid = blockIdx.x;
+    const int hh = bid % heads; bid /= heads;
+    const int wx = bid % nwx; bid /= nwx;
+    const int wy = bid % nwy;
+    const int img = bid / nwy;
+    const int ty = t / 7, tx = t - ty * 7;
+    const int y = wy * 7 + ty - pad_top, x = wx * 7 + tx - pad_left;
+    const bool live = t < 49;
+    const bool inside = live && y >= 0 && y < h && x >= 0 && x < w;
+    const size_t pix = ((size_t)img * h + (inside ? y : 0)) * w + (inside ? x : 0);
+    const float* qp = inside ? qkv + pix * 3 * cs + hh * hd : bias + hh * hd;
+    const int kstep = inside ? cs : cs;  // k at +cs, v at +2cs in both the tensor row and the bias vector
+    float q[HDP];
+#pragma unroll
+    for (int d = 0; d < HDP; ++d) {
+        q[d] = 0.f;
+        if (live && d < hd) {
+            q[d] = qp[d] * scale;
+            Ks[t * HDP + d] = qp[kstep + d];
+            Vs[t * HDP + d] = qp[2 * kstep + d];
+        } else if (live) {
+            Ks[t * HDP + d] = 0.f;
+            Vs[t * HDP + d] = 0.f;
+        }
+    }
+    __syncthreads();
+    float p[49];
+    float mx = -__builtin_inff();
+#pragma unroll
+    for (int j = 0; j < 49; ++j) {
+        float s = 0.f;
+#pragma unroll
+        for (int d4 = 0; d4 < HDP / 4; ++d4) {
+            const f32x4 kv = *reinterpret_cast<const f32x4*>(Ks + j * HDP + d4 * 4);
+            s = fmaf(q[d4 * 4], kv[0], s); s = fmaf(q[d4 * 4 + 1], kv[1], s);
+            s = fmaf(q[d4 * 4 + 2], kv[2], s); s = fmaf(q[d4 * 4 + 3], kv[3], s);
+        }
+        p[j] = s;
+        mx = fmaxf(mx, s);
+    }
+    float sum = 0.f;
+#pragma unroll
+    for (int j = 0; j < 49; ++j) {
+        p[j] = __expf(p[j] - mx);
+        sum += p[j];
+    }
+    const float inv = 1.f / sum;
+    float o[HDP];
+#pragma unroll
+    for (int d = 0; d < HDP; ++d) o[d] = 0.f;
+#pragma unroll
+    for (int j = 0; j < 49; ++j) {
+        const float pj = p[j];
+#pragma unroll
+        for (int d4 = 0; d4 < HDP / 4; ++d4) {
+            const f32x4 vv = *reinterpret_cast<const f32x4*>(Vs + j * HDP + d4 * 4);
+            o[d4 * 4] = fmaf(pj, vv[0], o[d4 * 4]); o[d4 * 4 + 1] = fmaf(pj, vv[1], o[d4 * 4 + 1]);
+            o[d4 * 4 + 2] = fmaf(pj, vv[2], o[d4 * 4 + 2]); o[d4 * 4 + 3] = fmaf(pj, vv[3], o[d4 * 4 + 3]);
+        }
+    }
+    if (inside) {
+        float* op = out + pix * cs + hh * hd;
+#pragma unroll
+        for (int d = 0; d < HDP; ++d)
+            if (d < hd) op[d] = o[d] * inv;
+        if (hh == heads - 1)  // keep the padded channels (c .. cs-1) of the row exactly zero
+            for (int ch = heads * hd; ch < cs; ++ch) out[pix * cs + ch] = 0.f;
+    }
+}
+
+// ---- depth-wise 3x3 conv, pad 1, stride 1|2, + bias (BN folded) + activation; thread = pixel x 4 channels ----
+__global__ __launch_bounds__(256) void dwconv3x3_k(const float* __restrict__ in, const float* __restrict__ w,
+                                                   const float* __restrict__ bias, float* __restrict__ out, int n_img, int in_h,
+                                                   int in_w, int out_h, int out_w, int c4, int cs, int stride, int act) {
+    const long long gid = (long long)blockIdx.x * 256 + threadIdx.x;
+    const int cg = (int)(gid % c4);
+    const long long pix = gid / c4;
+    if (pix >= (long long)n_img * out_h * out_w) return;
+    const int ox = (int)(pix % out_w);
+    const int oy = (int)((pix / out_w) % out_h);
+    const int img = (int)(pix / ((long long)out_w * out_h));
+    f32x4 acc = *reinterpret_cast<const f32x4*>(bias + cg * 4);
+#pragma unroll
+    for (int ky = 0; ky < 3; ++ky) {
+        const int iy = oy * stride - 1 + ky;
+        if (iy < 0 || iy >= in_h) continue;
+#pragma unroll
+        for (int kx = 0; kx < 3; ++kx) {
+            const int ix = ox * stride - 1 + kx;
+            if (ix < 0 || ix >= in_w) continue;
+            const f32x4 v = *reinterpret_cast<const f32x4*>(in + ((size_t)(img * in_h + iy) * in_w + ix) * cs + cg * 4);
+            const f32x4 wv = *reinterpret_cast<const f32x4*>(w + (ky * 3 + kx) * cs + cg * 4);
+            acc[0] = fmaf(v[0], wv[0], acc[0]); acc[1] = fmaf(v[1], wv[1], acc[1]);
+            acc[2] = fmaf(v[2], wv[2], acc[2]); acc[3] = fmaf(v[3], wv[3], acc[3]);
+        }
+    }
+    *reinterpret_cast<f32x4*>(out + (size_t)pix * cs + cg * 4) = act4(acc, act);
+}
+
+// ---- out = act(res + bilinear_upsample(low)), align_corners = False, integer scale ----
+__global__ __launch_bounds__(256) void upsample_add_k(const float* __restrict__ low, const float* __restrict__ res,
+                                                      float* __restrict__ out, int n_img, int lh, int lw, int scale, int c4, int cs,
+                                                      int act) {
+    const int H = lh * scale, W = lw * scale;
+    const long long gid = (long long)blockIdx.x * 256 + threadIdx.x;
+    const int cg = (int)(gid % c4);
+    const long long pix = gid / c4;
+    if (pix >= (long long)n_img * H * W) return;
+    const int ox = (int)(pix % W);
+    const int oy = (int)((pix / W) % H);
+    const int img = (int)(pix / ((long long)W * H));
+    // PyTorch upsample_bilinear2d, align_corners=False: src = max((dst + 0.5) / scale - 0.5, 0)
+    const float rs = 1.f / (float)scale;
+    const float sy = fmaxf(((float)oy + 0.5f) * rs - 0.5f, 0.f), sx = fmaxf(((float)ox + 0.5f) * rs - 0.5f, 0.f);
+    const int y0 = (int)sy, x0 = (int)sx;
+    const int y1 = y0 + (y0 < lh - 1 ? 1 : 0), x1 = x0 + (x0 < lw - 1 ? 1 : 0);
+    const float ly = sy - (float)y0, lx = sx - (float)x0, hy = 1.f - ly, hx = 1.f - lx;
+    const float* base = low + (size_t)img * lh * lw * cs + cg * 4;
+    const f32x4 v00 = *reinterpret_cast<const f32x4*>(base + ((size_t)y0 * lw + x0) * cs);
+    const f32x4 v01 = *reinterpret_cast<const f32x4*>(base + ((size_t)y0 * lw + x1) * cs);
+    const f32x4 v10 = *reinterpret_cast<const f32x4*>(base + ((size_t)y1 * lw + x0) * cs);
+    const f32x4 v11 = *reinterpret_cast<const f32x4*>(base + ((size_t)y1 * lw + x1) * cs);
+    f32x4 r = *reinterpret_cast<const f32x4*>(res + (size_t)pix * cs + cg * 4);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) r[e] += hy * (hx * v00[e] + lx * v01[e]) + ly * (hx * v10[e] + lx * v11[e]);
+    *reinterpret_cast<f32x4*>(out + (size_t)pix * cs + cg * 4) = act4(r, act);
+}
+
+}  // namespace
+
+extern "C" int i2r_layernorm(const float* in, const float* w, const float* b, float* out, int32_t npix, int32_t c, int32_t cs,
+                             float eps, void* stream) {
+    I2R_CHECK_ARG(in && w && b && out, "i2r_layernorm: null pointer");
+    I2R_CHECK_ARG(c > 0 && c <= cs && cs % 4 == 0 && cs <= 16 * 4 * kLnMaxChunks, "i2r_layernorm: c=%d cs=%d", c, cs);
+    const long long nthr = (long long)npix * 16;
+    hipLaunchKernelGGL(layernorm_k, dim3((unsigned)((nthr + 255) / 256)), dim3(256), 0, (hipStream_t)stream, in, w, b, out, npix, c,
+                       cs, eps);
+    I2R_CHECK_LAUNCH("i2r_layernorm");
+    return I2R_OK;
+}
+
+extern "C" int i2r_window_attn(const float* qkv, const float* bias_qkv, float* out, int32_t n_img, int32_t h, int32_t w, int32_t c,
+                               int32_t cs, int32_t heads, void* stream) {
+    I2R_CHECK_ARG(qkv && bias_qkv && out, "i2r_window_attn: null pointer");
+    I2R_CHECK_ARG(heads > 0 && c % heads == 0 && c <= cs, "i2r_window_attn: c=%d heads=%d", c, heads);
+    const int hd = c / heads;
+    I2R_CHECK_ARG(hd <= 40, "i2r_window_attn: head_dim %d > 40 unsupported", hd);
+    const int nwy = (h + 6) / 7, nwx = (w + 6) / 7;
+    const int pad_top = (nwy * 7 - h) / 2, pad_left = (nwx * 7 - w) / 2;
+    const float scale = 1.0f / sqrtf((float)hd);
+    const long long nblk = (long long)n_img * nwy * nwx * heads;
+    I2R_CHECK_ARG(nblk < (1ll << 31), "i2r_window_attn: grid");
+    hipLaunchKernelGGL(window_attn_k<40>, dim3((unsigned)nblk), dim3(64), 0, (hipStream_t)stream, qkv, bias_qkv, out, n_img, h, w,
+                       cs, heads, hd, nwy, nwx, pad_top, pad_left, scale);
+    I2R_CHECK_LAUNCH("i2r_window_attn");
+    return I2R_OK;
+}
+
+extern "C" int i2r_dwconv3x3(const float* in, const float* w, const float* bias, float* out, int32_t n_img, int32_t in_h,
+                             int32_t in_w, int32_t c, int32_t cs, int32_t stride, int32_t act, void* stream) {
+    I2R_CHECK_ARG(in && w && bias && out && in != out, "i2r_dwconv3x3: bad pointers");
+    I2R_CHECK_ARG(c > 0 && c <= cs && cs % 4 == 0 && (stride == 1 || stride == 2) && act >= 0 && act <= 2, "i2r_dwconv3x3: args");
+    const int out_h = (in_h - 1) / stride + 1, out_w = (in_w - 1) / stride + 1;
+    const long long nthr = (long long)n_img * out_h * out_w * (cs / 4);
+    hipLaunchKernelGGL(dwconv3x3_k, dim3((unsigned)((nthr + 255) / 256)), dim3(256), 0, (hipStream_t)stream, in, w, bias, out, n_img,
+                       in_h, in_w, out_h, out_w, cs / 4, cs, stride, act);
+    I2R_CHECK_LAUNCH("i2r_dwconv3x3");
+    return I2R_OK;
+}
+
+extern "C" int i2r_upsample_bilinear_add(const float* low, const float* res, float* out, int32_t n_img, int32_t low_h,
+                                         int32_t low_w, int32_t scale, int32_t c, int32_t cs, int32_t act, void* stream) {
+    I2R_CHECK_ARG(low && res && out, "i2r_upsample_bilinear_add: null pointer");
+    I2R_CHECK_ARG(scale >= 1 && c <= cs && cs % 4 == 0 && act >= 0 && act <= 2, "i2r_upsample_bilinear_add: args");
+    const long long nthr = (long long)n_img * low_h * scale * low_w * scale * (cs / 4);
+    hipLaunchKernelGGL(upsample_add_k, dim3((unsigned)((nthr + 255) / 256)), dim3(256), 0, (hipStream_t)stream, low, res, out, n_img,
+                       low_h, low_w, scale, cs / 4, cs, act);
+    I2R_CHECK_LAUNCH("i2r_upsample_bilinear_add");
+    return I2R_OK;
+}

@@ -168,6 +168,35 @@ class Packer:
         t.update(d=d, cs=cs, dff_pad=fs)
         return t
 
+    def dw(self, conv_key, bn_key, eps=1e-5):
+        """depth-wise 3x3 [C,1,3,3] (+bias) + BN -> tap-major [9][cs] weights + [cs] bias."""
+        w = self.sd[conv_key + ".weight"]
+        c = w.shape[0]
+        assert tuple(w.shape[1:]) == (1, 3, 3)
+        wf, bf = fold_bn(w, self._bn(bn_key), self.sd.get(conv_key + ".bias"), eps)
+        cs = _r16(c)
+        wp = torch.zeros(9, cs, dtype=torch.float64)
+        wp[:, :c] = wf.view(c, 9).t()
+        bp = torch.zeros(cs, dtype=torch.float64)
+        bp[:c] = bf
+        return dict(w=self._dev(wp.float()), bias=self._dev(bp.float()), c=c, cs=cs)
+
+    def ln(self, key, c):
+        cs = _r16(c)
+        w, b = torch.zeros(cs), torch.zeros(cs)
+        w[:c], b[:c] = self.sd[key + ".weight"], self.sd[key + ".bias"]
+        return dict(w=self._dev(w), b=self._dev(b), c=c, cs=cs)
+
+    def qkv(self, p, c):
+        """stacked q/k/v_proj as one 1x1 conv with 3*cs outputs (q | k | v, each cs wide, zero rows for the padding)."""
+        cs = _r16(c)
+        W = torch.zeros(3 * cs, c, dtype=torch.float64)
+        b = torch.zeros(3 * cs, dtype=torch.float64)
+        for i, n in enumerate(("q_proj", "k_proj", "v_proj")):
+            W[i * cs:i * cs + c] = self.sd["%s.%s.weight" % (p, n)].double()
+            b[i * cs:i * cs + c] = self.sd["%s.%s.bias" % (p, n)].double()
+        return self.linear_as_conv(W, b)
+
     def table(self, key, rows, d):
         """[rows, 1, d] parameter (TransPose-H pos_embedding) -> [rows, cs] device table."""
         v = self.sd[key].reshape(rows, d)
@@ -286,12 +315,13 @@ class Program:
     # ---- ops ----
     def stem(self, st, n, h, w, in_ptr=0, lane=0):
         out = self.alloc(n, (h - 1) // 2 + 1, (w - 1) // 2 + 1, st["cout"])
+        self.keep.append(st)
         a = cabi.StemArgs(in_ptr, st["w"].data_ptr(), st["bias"].data_ptr(), out.ptr, n, st["cin"], h, w, st["cout"], out.cs)
         self.ops.append((cabi.OP_STEM, lane, a))
         return out, a
 
     def conv(self, x, pc, relu=False, res1=None, res2=None, res_post=None, in2=None, up=1, out=None, out_step=1,
-             out_off=(0, 0), out_hw=None, lane=0, group=None):
+             out_off=(0, 0), out_hw=None, lane=0, group=None, act=None):
         assert x.cs >= pc.cin_pad and x.c == pc.cin, "conv input channels %d/%d vs weight %d" % (x.c, x.cs, pc.cin)
         k = pc.ksize
         if pc.stride == 1:
@@ -304,6 +334,7 @@ class Program:
             oh, ow = out_hw if out_hw else (conv_h * out_step, conv_w * out_step)
             out = self.alloc(x.n, oh, ow, pc.cout)
         assert out.cs >= pc.cout_pad or out.cs >= pc.cout
+        self.keep.append(pc)  # the descriptor holds raw pointers: keep the packed weights alive with the program
         d = cabi.ConvDesc()
         d.in_, d.in2, d.w, d.bias = x.ptr, (in2.ptr if in2 is not None else None), pc.w.data_ptr(), pc.bias.data_ptr()
         d.res1 = res1.ptr if res1 is not None else None
@@ -316,7 +347,8 @@ class Program:
         d.ntaps = len(pc.taps)
         for i, (dy, dx) in enumerate(pc.taps):
             d.dy[i], d.dx[i] = dy, dx
-        d.out_step, d.out_off_y, d.out_off_x, d.rep, d.relu = out_step, out_off[0], out_off[1], up, int(relu)
+        d.out_step, d.out_off_y, d.out_off_x, d.rep = out_step, out_off[0], out_off[1], up
+        d.relu = int(relu) if act is None else act  # 0 none, 1 ReLU, 2 GELU
         nt, wn = conv_split(pc.cout_pad)
         n_cblk = (pc.cout_pad // 16) // (nt * wn)
         max_d = max(max(t) for t in pc.taps)
@@ -389,7 +421,39 @@ class Program:
         self.ops.append((cabi.OP_MAXPOOL, lane, a))
         return out
 
+    def layernorm(self, x, ln, eps=1e-6, lane=0):
+        out = self.alloc(x.n, x.h, x.w, x.c)
+        self.keep.append(ln)
+        a = cabi.LnArgs(x.ptr, ln["w"].data_ptr(), ln["b"].data_ptr(), out.ptr, x.n * x.h * x.w, x.c, x.cs, eps)
+        self.ops.append((cabi.OP_LAYERNORM, lane, a))
+        return out
+
+    def winattn(self, qkv, bias, c, heads, lane=0):
+        cs = _r16(c)
+        assert qkv.cs == 3 * cs
+        out = self.alloc(qkv.n, qkv.h, qkv.w, c)
+        self.keep.append(bias)
+        a = cabi.WinAttnArgs(qkv.ptr, bias.data_ptr(), out.ptr, qkv.n, qkv.h, qkv.w, c, cs, heads)
+        self.ops.append((cabi.OP_WINATTN, lane, a))
+        return out
+
+    def dwconv(self, x, dw, stride=1, act=0, lane=0):
+        assert x.c == dw["c"] and x.cs == dw["cs"]
+        out = self.alloc(x.n, (x.h - 1) // stride + 1, (x.w - 1) // stride + 1, x.c)
+        self.keep.append(dw)
+        a = cabi.DwArgs(x.ptr, dw["w"].data_ptr(), dw["bias"].data_ptr(), out.ptr, x.n, x.h, x.w, x.c, x.cs, stride, act)
+        self.ops.append((cabi.OP_DWCONV, lane, a))
+        return out
+
+    def upsample_add(self, low, res, out, act=0, lane=0):
+        scale = out.h // low.h
+        assert low.h * scale == out.h and low.w * scale == out.w and low.cs == out.cs == res.cs
+        a = cabi.UpArgs(low.ptr, res.ptr, out.ptr, low.n, low.h, low.w, scale, low.c, low.cs, act)
+        self.ops.append((cabi.OP_UPSAMPLE, lane, a))
+        return out
+
     def head(self, x, hd, out_ptr=0, lane=0):
+        self.keep.append(hd)
         a = cabi.HeadArgs(x.ptr, hd["w"].data_ptr(), hd["bias"].data_ptr(), out_ptr, x.n, x.h, x.w, hd["cin"], x.cs, hd["cout"])
         self.ops.append((cabi.OP_HEAD, lane, a))
         return a
@@ -406,6 +470,7 @@ class Program:
         assert all(o % 4 == 0 for o in grp_off_host), "token group offsets must be multiples of 4"
         nq = sum(-(-(grp_off_host[i + 1] - grp_off_host[i]) // 32) for i in range(len(grp_off_host) - 1))
         cur = x
+        self.keep.append(layers)
         for L in layers:
             assert L["cs"] == cs
             out = self.alloc(x.n, x.h, x.w, x.c)
@@ -608,6 +673,158 @@ class HRNetW48:
         return xs, stem_args
 
 
+class HRFormerB:
+    """Packed HRFormer-B tower (reference hrformer.py:2057-2092, arch :2489-2525) + program emitter."""
+
+    def __init__(self, pk, p):
+        from .arch_hrformer import STAGES
+        b = p + "backbone."
+        self.stem1 = pk.stem(b + "conv1", b + "bn1")
+        self.conv2 = pk.conv(b + "conv2", b + "bn2", stride=2)
+        self.layer1 = []
+        for blk in range(2):
+            q = "%slayer1.%d" % (b, blk)
+            d = dict(c1=pk.conv(q + ".conv1", q + ".bn1"), c2=pk.conv(q + ".conv2", q + ".bn2"), c3=pk.conv(q + ".conv3", q + ".bn3"))
+            if (q + ".downsample.0.weight") in pk.sd:
+                d["ds"] = pk.conv(q + ".downsample.0", q + ".downsample.1")
+            self.layer1.append(d)
+        self.stages = []
+        pre = [256]
+        for sname, tname in (("stage2", "transition1"), ("stage3", "transition2"), ("stage4", "transition3")):
+            st = STAGES[sname]
+            ch = st["num_channels"]
+            trans = []
+            for i in range(st["num_branches"]):
+                if i < len(pre):
+                    trans.append(pk.conv("%s%s.%d.0" % (b, tname, i), "%s%s.%d.1" % (b, tname, i)) if ch[i] != pre[i] else None)
+                else:
+                    trans.append(pk.conv("%s%s.%d.0.0" % (b, tname, i), "%s%s.%d.0.1" % (b, tname, i), stride=2))
+            mods = []
+            for m in range(st["num_modules"]):
+                multiscale = not (sname == "stage4" and m == st["num_modules"] - 1)
+                mods.append(self._module(pk, "%s%s.%d" % (b, sname, m), st, multiscale))
+            self.stages.append(dict(trans=trans, mods=mods, n_pre=len(pre)))
+            pre = list(ch)
+
+    @staticmethod
+    def _module(pk, q, st, multiscale):
+        nb, ch = st["num_branches"], st["num_channels"]
+        mod = dict(nb=nb, n_out=nb if multiscale else 1, blocks=[], fuse={})
+        for i in range(nb):
+            blks = []
+            for k in range(st["num_blocks"][i]):
+                r = "%s.branches.%d.%d" % (q, i, k)
+                blks.append(dict(c=ch[i], heads=st["num_heads"][i], ln1=pk.ln(r + ".norm1", ch[i]), ln2=pk.ln(r + ".norm2", ch[i]),
+                                 qkv=pk.qkv(r + ".attn.attn", ch[i]),
+                                 out=pk.linear_as_conv(pk.sd[r + ".attn.attn.out_proj.weight"], pk.sd[r + ".attn.attn.out_proj.bias"]),
+                                 fc1=pk.conv(r + ".mlp.fc1", r + ".mlp.norm1"), dw=pk.dw(r + ".mlp.dw3x3", r + ".mlp.norm2"),
+                                 fc2=pk.conv(r + ".mlp.fc2", r + ".mlp.norm3")))
+            mod["blocks"].append(blks)
+        for i in range(mod["n_out"]):
+            for j in range(nb):
+                r = "%s.fuse_layers.%d.%d" % (q, i, j)
+                if j > i:
+                    mod["fuse"][(i, j)] = pk.conv(r + ".0", r + ".1")
+                elif j < i:
+                    mod["fuse"][(i, j)] = [(pk.dw("%s.%d.0" % (r, k), "%s.%d.1" % (r, k)), pk.conv("%s.%d.2" % (r, k), "%s.%d.3" % (r, k)))
+                                           for k in range(i - j)]
+        return mod
+
+    @staticmethod
+    def _emit_block(P, blk, x):
+        """GeneralTransformerBlock.forward (hrformer.py:1230-1240): x += attn(LN1 x); x += mlp(LN2 x)."""
+        n1 = P.layernorm(x, blk["ln1"])
+        qkv = P.conv(n1, blk["qkv"])
+        P.release(n1)
+        a = P.winattn(qkv, blk["qkv"].bias, blk["c"], blk["heads"])
+        P.release(qkv)
+        x1 = P.conv(a, blk["out"], res1=x)
+        P.release(a, x)
+        n2 = P.layernorm(x1, blk["ln2"])
+        h1 = P.conv(n2, blk["fc1"], act=2)
+        P.release(n2)
+        h2 = P.dwconv(h1, blk["dw"], 1, act=2)
+        P.release(h1)
+        x2 = P.conv(h2, blk["fc2"], act=2, res_post=x1)
+        P.release(h2, x1)
+        return x2
+
+    @classmethod
+    def _emit_module(cls, P, mod, xs):
+        nb = mod["nb"]
+        xs = list(xs)
+        for i in range(nb):
+            for blk in mod["blocks"][i]:
+                xs[i] = cls._emit_block(P, blk, xs[i])
+        outs = []
+        for i in range(mod["n_out"]):
+            # y = ((t_0 + t_1) + ...) then ReLU (hrformer.py:1716-1731); identity terms ride as residual inputs
+            acc, y, j = None, None, 0
+            while j < nb:
+                if j == i:
+                    assert acc is None
+                    acc = xs[i]
+                    j += 1
+                    continue
+                if y is None:
+                    y = P.alloc(xs[i].n, xs[i].h, xs[i].w, xs[i].c)
+                if j > i:  # 1x1 conv + BN at low resolution, then bilinear up-sample and accumulate
+                    t = P.conv(xs[j], mod["fuse"][(i, j)])
+                    P.upsample_add(t, acc, y, act=1 if j + 1 >= nb else 0)
+                    P.release(t)
+                    jn = j + 1
+                else:
+                    cur = xs[j]
+                    hops = mod["fuse"][(i, j)]
+                    for k, (dw, pc) in enumerate(hops):
+                        d = P.dwconv(cur, dw, 2, act=0)
+                        if cur is not xs[j]:
+                            P.release(cur)
+                        if k < len(hops) - 1:
+                            cur = P.conv(d, pc, relu=True)
+                            P.release(d)
+                        else:
+                            res = [acc] if acc is not None else []
+                            if j + 1 == i:
+                                res.append(xs[i])
+                            jn = j + 2 if j + 1 == i else j + 1
+                            P.conv(d, pc, relu=(jn >= nb), res1=res[0] if res else None, res2=res[1] if len(res) > 1 else None, out=y)
+                            P.release(d)
+                acc, j = y, jn
+            outs.append(y)
+        P.release(*xs)
+        return outs
+
+    def emit(self, P, n, h, w):
+        a, stem_args = P.stem(self.stem1, n, h, w)
+        x = P.conv(a, self.conv2, relu=True)
+        P.release(a)
+        for blk in self.layer1:
+            t1 = P.conv(x, blk["c1"], relu=True)
+            t2 = P.conv(t1, blk["c2"], relu=True)
+            res = P.conv(x, blk["ds"]) if "ds" in blk else x
+            y = P.conv(t2, blk["c3"], relu=True, res1=res)
+            P.release(t1, t2, x)
+            if res is not x:
+                P.release(res)
+            x = y
+        ys = [x]
+        for st in self.stages:
+            xs = []
+            for i, pc in enumerate(st["trans"]):
+                if i < st["n_pre"]:
+                    xs.append(P.conv(ys[i], pc, relu=True) if pc is not None else ys[i])
+                else:
+                    xs.append(P.conv(ys[-1], pc, relu=True))
+            for i, pc in enumerate(st["trans"]):  # inputs replaced by a transition conv are dead now
+                if i < st["n_pre"] and pc is not None and not any(ys[i] is x_ for x_ in xs):
+                    P.release(ys[i])
+            for mod in st["mods"]:
+                xs = self._emit_module(P, mod, xs)
+            ys = xs
+        return ys, stem_args
+
+
 class Engine:
     """Packed model + program cache for one device. Built by models/_base.I2RModule."""
 
@@ -639,17 +856,24 @@ class Engine:
             self.head = pk.head("final_layer")
         elif self.name == "interformer":
             sf = M["SINGLEFORMER"]
-            assert sf == "transpose_h", "SINGLEFORMER=%r is not wired into the HIP engine yet" % (sf,)
+            self.singleformer = sf
             p = "singleformer."
-            self.tower = HRNetW48(pk, p, M["EXTRA"])
-            self.res_layer = M["HRNET_RES_LAYER"]
-            self.reduce = pk.conv(p + "reduce")
-            w, h = M["IMAGE_SIZE"]
-            self.single_tokens = (h // 2 ** self.res_layer // 4) * (w // 2 ** self.res_layer // 4)
-            self.single_pos = pk.table(p + "pos_embedding", self.single_tokens, d) if M["POS_EMBEDDING"] != "none" else None
-            self.single_layers = [pk.encoder_layer("%sglobal_encoder.layers.%d" % (p, l), d, dff)
-                                  for l in range(M["ENCODER_LAYERS"])]
-            self.single_head = pk.head(p + "final_layer")
+            if sf == "transpose_h":
+                self.tower = HRNetW48(pk, p, M["EXTRA"])
+                self.res_layer = M["HRNET_RES_LAYER"]
+                self.reduce = pk.conv(p + "reduce")
+                w, h = M["IMAGE_SIZE"]
+                self.single_tokens = (h // 2 ** self.res_layer // 4) * (w // 2 ** self.res_layer // 4)
+                self.single_pos = pk.table(p + "pos_embedding", self.single_tokens, d) if M["POS_EMBEDDING"] != "none" else None
+                self.single_layers = [pk.encoder_layer("%sglobal_encoder.layers.%d" % (p, l), d, dff)
+                                      for l in range(M["ENCODER_LAYERS"])]
+                self.single_head = pk.head(p + "final_layer")
+            elif sf == "hrformer":
+                assert d == 78, "HRFormer-B emits 78 channels (hrformer.py:2527)"
+                self.tower = HRFormerB(pk, p)
+                self.single_head = pk.head(p + "keypoint_head.final_layer")
+            else:
+                raise NotImplementedError("MODEL.SINGLEFORMER=%r" % (sf,))
             self.use_pos = bool(M["USE_MULTI_POS"])
             if self.use_pos:
                 assert M["MULTI_POS_EMBEDDING"] == "conv", "only MULTI_POS_EMBEDDING 'conv' is wired"
@@ -692,13 +916,16 @@ class Engine:
             P.release(*xs)
             single_feat = None
         else:
-            f = P.conv(xs[self.res_layer], self.reduce)
-            P.release(*xs)
-            tok = f.h * f.w
-            assert tok == self.single_tokens, "input size does not match MODEL.IMAGE_SIZE (pos_embedding rows)"
-            g = P.encoder(f, self.single_layers, [i * tok for i in range(S + 1)],
-                          pos=self.single_pos.data_ptr() if self.single_pos is not None else 0, pos_period=tok)
-            P.release(f)
+            if self.singleformer == "hrformer":
+                g = xs[0]
+            else:
+                f = P.conv(xs[self.res_layer], self.reduce)
+                P.release(*xs)
+                tok = f.h * f.w
+                assert tok == self.single_tokens, "input size does not match MODEL.IMAGE_SIZE (pos_embedding rows)"
+                g = P.encoder(f, self.single_layers, [i * tok for i in range(S + 1)],
+                              pos=self.single_pos.data_ptr() if self.single_pos is not None else 0, pos_period=tok)
+                P.release(f)
             single_feat = g
             if self.return_dict:
                 patch["single"] = P.head(g, self.single_head)

@@ -44,7 +44,7 @@ class I2RModule(nn.Module):
                 mod = mod._modules[p]
             leaf = parts[-1]
             val = torch.from_numpy(synth.make_tensor(key, shape, dtype, seed=1234))
-            if leaf in ("running_mean", "running_var", "num_batches_tracked"):
+            if leaf in ("running_mean", "running_var", "num_batches_tracked") or dtype == "int64":
                 mod.register_buffer(leaf, val)
             else:
                 mod.register_parameter(leaf, nn.Parameter(val, requires_grad=False))

@@ -100,6 +100,8 @@ def make_tensor(key, shape, dtype, seed=0):
         std = (1.0 / fan_in) ** 0.5
         if leaf == "in_proj_weight" or re.search(r"(q_proj|k_proj)\.weight$", key):
             std *= 2.5  # sharper-than-uniform attention maps
+        if "attn.attn.out_proj" in key:
+            std *= 0.3  # HRFormer: 44 un-normalised residual attention branches in a row -- keep the stream O(1)
         return _sym(seed, key, shape, std * 3 ** 0.5)
     return _sym(seed, key, shape, 0.5)
 

@@ -208,3 +208,89 @@ def test_encoder_sine_table_period():
     out = P.encoder(to_act(P, feat), [L], [i * h * w for i in range(S + 1)], pos=tdev.data_ptr(), pos_period=h * w)
     run(P)
     assert (from_act(out) - ref).abs().max().item() < 2e-4
+
+
+# ---------------------------------------------------------------------------------------------------------
+# HRFormer-B glue kernels
+# ---------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("c,h,w", [(78, 16, 12), (156, 9, 7), (624, 8, 6)])
+def test_layernorm(c, h, w):
+    sd = {"n.weight": _rand((c,), "lnw%d" % c, 0.3) + 1.0, "n.bias": _rand((c,), "lnb%d" % c, 0.2)}
+    x = _rand((3, c, h, w), "lnx%d" % c, 2.0)
+    ref = F.layer_norm(x.permute(0, 2, 3, 1), (c,), sd["n.weight"], sd["n.bias"], 1e-6).permute(0, 3, 1, 2)
+    P = engine.Program(torch.device(DEV))
+    out = P.layernorm(to_act(P, x), engine.Packer(sd, torch.device(DEV)).ln("n", c))
+    run(P)
+    assert (from_act(out) - ref).abs().max().item() < 2e-5
+    assert out.t.view(-1, out.cs)[:, c:].abs().max().item() == 0.0 if out.cs > c else True
+
+
+@pytest.mark.parametrize("c,heads,h,w", [(78, 2, 64, 48), (156, 4, 32, 24), (312, 8, 16, 12), (624, 16, 8, 6), (78, 2, 24, 18)])
+def test_window_attention_block_matches_oracle(c, heads, h, w):
+    """LN -> q/k/v conv -> window attention -> out_proj + residual == x + attn(LN1 x) of the oracle."""
+    import i2r_cpu_hrformer as H
+    tag = "wa%d_%d" % (c, h)
+    p = "b.attn.attn"
+    sd = {"b.norm1.weight": _rand((c,), "n1w" + tag, 0.3) + 1.0, "b.norm1.bias": _rand((c,), "n1b" + tag, 0.2)}
+    for n in ("q_proj", "k_proj", "v_proj", "out_proj"):
+        sd["%s.%s.weight" % (p, n)] = _rand((c, c), n + "w" + tag, 2.0 * (3.0 / c) ** 0.5)
+        sd["%s.%s.bias" % (p, n)] = _rand((c,), n + "b" + tag, 0.3)
+    x = _rand((2, c, h, w), "x" + tag)
+    t = x.permute(0, 2, 3, 1)
+    n1 = F.layer_norm(t, (c,), sd["b.norm1.weight"], sd["b.norm1.bias"], 1e-6)
+    ref = (t + H.window_attention(sd, p, n1, heads)).permute(0, 3, 1, 2)
+    P = engine.Program(torch.device(DEV))
+    pk = engine.Packer(sd, torch.device(DEV))
+    xa = to_act(P, x)
+    n1a = P.layernorm(xa, pk.ln("b.norm1", c))
+    qkvw = pk.qkv(p, c)
+    qkv = P.conv(n1a, qkvw)
+    a = P.winattn(qkv, qkvw.bias, c, heads)
+    out = P.conv(a, pk.linear_as_conv(sd[p + ".out_proj.weight"], sd[p + ".out_proj.bias"]), res1=xa)
+    run(P)
+    err = (from_act(out) - ref).abs().max().item()
+    assert err < 2e-4, "window attention c=%d max-abs %.3e" % (c, err)
+
+
+@pytest.mark.parametrize("c,stride,act", [(312, 1, 2), (78, 2, 0), (160, 2, 1)])
+def test_dwconv(c, stride, act):
+    sd = {"d.weight": _rand((c, 1, 3, 3), "dww%d" % c, 0.5), "d.bias": _rand((c,), "dwb%d" % c, 0.2),
+          "b.weight": _rand((c,), "dwg%d" % c, 0.5) + 1.0, "b.bias": _rand((c,), "dwbb%d" % c, 0.3),
+          "b.running_mean": _rand((c,), "dwm%d" % c, 0.3), "b.running_var": _rand((c,), "dwv%d" % c, 0.4) + 1.0}
+    x = _rand((2, c, 17, 12), "dwx%d" % c)
+    ref = F.conv2d(x, sd["d.weight"], sd["d.bias"], stride=stride, padding=1, groups=c)
+    ref = F.batch_norm(ref, sd["b.running_mean"], sd["b.running_var"], sd["b.weight"], sd["b.bias"], False, 0.0, 1e-5)
+    ref = F.gelu(ref) if act == 2 else F.relu(ref) if act == 1 else ref
+    P = engine.Program(torch.device(DEV))
+    out = P.dwconv(to_act(P, x), engine.Packer(sd, torch.device(DEV)).dw("d", "b"), stride, act)
+    run(P)
+    assert (from_act(out) - ref).abs().max().item() < 5e-5
+
+
+@pytest.mark.parametrize("scale", [2, 4, 8])
+def test_upsample_bilinear_add(scale):
+    low = _rand((2, 78, 6, 5), "upl%d" % scale)
+    res = _rand((2, 78, 6 * scale, 5 * scale), "upr%d" % scale)
+    ref = F.relu(res + F.interpolate(low, scale_factor=scale, mode="bilinear", align_corners=False))
+    P = engine.Program(torch.device(DEV))
+    la, ra = to_act(P, low), to_act(P, res)
+    out = P.alloc(2, 6 * scale, 5 * scale, 78)
+    P.upsample_add(la, ra, out, act=1)
+    run(P)
+    assert (from_act(out) - ref).abs().max().item() < 1e-5
+
+
+def test_conv_gelu_and_post_residual():
+    sd = {"c.weight": _rand((78, 312, 1, 1), "gw", 0.08), "c.bias": _rand((78,), "gb", 0.2),
+          "b.weight": _rand((78,), "gg", 0.5) + 1.0, "b.bias": _rand((78,), "gbb", 0.3),
+          "b.running_mean": _rand((78,), "gm", 0.3), "b.running_var": _rand((78,), "gv", 0.4) + 1.0}
+    x = _rand((2, 312, 16, 12), "gx")
+    post = _rand((2, 78, 16, 12), "gp")
+    ref = F.batch_norm(F.conv2d(x, sd["c.weight"], sd["c.bias"]), sd["b.running_mean"], sd["b.running_var"], sd["b.weight"],
+                       sd["b.bias"], False, 0.0, 1e-5)
+    ref = F.gelu(ref) + post
+    P = engine.Program(torch.device(DEV))
+    out = P.conv(to_act(P, x), engine.Packer(sd, torch.device(DEV)).conv("c", "b"), act=2, res_post=to_act(P, post))
+    run(P)
+    assert (from_act(out) - ref).abs().max().item() < 1e-4
+    assert out.t.view(-1, out.cs)[:, 78:].abs().max().item() == 0.0

@@ -26,10 +26,11 @@ def test_oracle_matches_reference_golden(tag):
     z = i2r_cpu.forward(sd, cfg, x, m, length, collect)
     outs = z if isinstance(z, dict) else {"multi": z}
     for k, t in outs.items():
-        np.testing.assert_allclose(probe_of(t, tag + k), g["probe_out_" + k], rtol=0, atol=2e-5)
+        scale = max(1.0, float(np.abs(g["probe_out_" + k]).max()))
+        np.testing.assert_allclose(probe_of(t, tag + k), g["probe_out_" + k], rtol=0, atol=2e-5 * scale)
         if "out_" + k in g:
             assert t.shape == g["out_" + k].shape
-            assert np.abs(t.numpy() - g["out_" + k]).max() < 2e-5
+            assert np.abs(t.numpy() - g["out_" + k]).max() < 2e-5 * max(1.0, float(np.abs(g["out_" + k]).max()))
     # per-stage probes localise any drift
     n = 0
     for k, t in _flatten(collect).items():
