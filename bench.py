@@ -81,7 +81,8 @@ def per_launch_timing(program, reps=3):
                 name, flop = conv_kernel_name(members[0]), sum(conv_flop(m) for m in members)
             else:
                 name = {cabi.OP_STEM: "stem_conv_k", cabi.OP_MAXPOOL: "maxpool_k", cabi.OP_HEAD: "head_k",
-                        cabi.OP_ENC_KV: "enc_kv_k", cabi.OP_ENC_LAYER: "enc_layer_k"}[kind]
+                        cabi.OP_ENC_KV: "enc_kv_k", cabi.OP_ENC_LAYER: "enc_layer_k", cabi.OP_LAYERNORM: "layernorm_k",
+                        cabi.OP_WINATTN: "window_attn_k", cabi.OP_DWCONV: "dwconv3x3_k", cabi.OP_UPSAMPLE: "upsample_add_k"}[kind]
                 flop = 0.0
             s = stats.setdefault(name, [0, 0.0, 0.0])
             s[0] += 1
@@ -133,6 +134,8 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=30)
     ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--config", default="w48_pure_en6", help="workload config (default = BASELINE configs[1]); others are "
+                    "exploratory: tph_192_p6_b4, hrt_192_p4_b4, coco_hrt_288_p2_b4")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     args = ap.parse_args()
@@ -150,7 +153,9 @@ def main():
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         dist.init_process_group("nccl", device_id=dev)  # RCCL
 
-    cfg = config.load_config("w48_pure_en6")
+    cfg = config.load_config(args.config)
+    if args.config != "w48_pure_en6":
+        args.no_cpu_baseline = True
     sd = synth.make_state_dict(arch.param_spec(cfg))
     net = eval("models." + cfg.MODEL.NAME + ".get_pose_net")(cfg, is_train=False)
     net.load_state_dict(sd, strict=True)
@@ -162,11 +167,14 @@ def main():
     length = length_all[lo:hi]
     counts = [sum(length_all[a:b]) for a, b in
               [i2r_dist.shard_images(length_all, r, world)[:2] for r in range(world)]]
-    x, m, _ = synth.make_inputs(length, 256, 192, seed=rank)
+    W_, H_ = cfg.MODEL.IMAGE_SIZE
+    x, m, _ = synth.make_inputs(length, H_, W_, seed=rank)
     x, m = x.to(dev), m.to(dev)
 
     def step():
         y = net(x, m, length)
+        if isinstance(y, dict):
+            y = y["multi"]
         if world > 1:
             y = i2r_dist.gather_heatmaps(y, counts)
         return y
@@ -198,11 +206,11 @@ def main():
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 4),
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
         "config": {"workload": "vanilla I2R-Net HRNet-W48-S 256x192, 6 encoder layers, fp32, random weights "
-                               "(BASELINE configs[1]: w48_pure_en6)",
+                               "(BASELINE configs[1]: w48_pure_en6)" if args.config == "w48_pure_en6" else args.config + " (exploratory, fp32)",
                    "images_per_gpu": IMAGES_PER_GPU, "persons_per_image": PERSONS, "crops_per_gpu_step": sum(length),
                    "parallelism": "dp%d (images sharded, RCCL all-gather of heatmaps)" % world if world > 1 else "single GPU",
                    "gflop_per_crop": round(GFLOP_PER_CROP, 3)},
-        "model_tflops": round(value * GFLOP_PER_CROP / 1e3, 2),
+        "model_tflops": round(value * GFLOP_PER_CROP / 1e3, 2) if args.config == "w48_pure_en6" else None,
     }
     if rank == 0:
         if not args.no_roofline:

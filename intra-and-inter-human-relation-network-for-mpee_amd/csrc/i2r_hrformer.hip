@@ -67,11 +67,12 @@ __global__ __launch_bounds__(256) void layernorm_k(const float* __restrict__ in,
 // qkv: [n, h, w, 3*cs] (q | k | v, each cs wide, head hh at channels hh*hd..); tokens of the zero-padded border are
 // not stored: their projections equal the bias vector (LayerNorm output is padded with zeros BEFORE q/k/v_proj).
 template <int HDP>  // head_dim padded to a multiple of 4 (39 -> 40)
-__global__ __launch_bounds__(64) void window_attn_k(const float* __restrict__ qkv, const float* __restrict__ bias,
+__global__ __launch_bounds__(64, 4) void window_attn_k(const float* __restrict__ qkv, const float* __restrict__ bias,
                                                     float* __restrict__ out, int n_img, int h, int w, int cs, int heads,
                                                     int hd, int nwy, int nwx, int pad_top, int pad_left, float scale) {
     __shared__ __attribute__((aligned(16))) float Ks[49 * HDP];
     __shared__ __attribute__((aligned(16))) float Vs[49 * HDP];
+    __shared__ float Ps[49 * 64];
     const int t = threadIdx.x;
     int bid = blockIdx.x;
     const int hh = bid % heads; bid /= heads;
@@ -99,9 +100,9 @@ __global__ __launch_bounds__(64) void window_attn_k(const float* __restrict__ qk
         }
     }
     __syncthreads();
-    float p[49];
+    // scores go through a lane-private LDS column (Ps[j][t]) instead of 49 registers: q[] and o[] already take 80
     float mx = -__builtin_inff();
-#pragma unroll
+#pragma unroll 2
     for (int j = 0; j < 49; ++j) {
         float s = 0.f;
 #pragma unroll
@@ -110,22 +111,17 @@ __global__ __launch_bounds__(64) void window_attn_k(const float* __restrict__ qk
             s = fmaf(q[d4 * 4], kv[0], s); s = fmaf(q[d4 * 4 + 1], kv[1], s);
             s = fmaf(q[d4 * 4 + 2], kv[2], s); s = fmaf(q[d4 * 4 + 3], kv[3], s);
         }
-        p[j] = s;
+        Ps[j * 64 + t] = s;
         mx = fmaxf(mx, s);
     }
     float sum = 0.f;
-#pragma unroll
-    for (int j = 0; j < 49; ++j) {
-        p[j] = __expf(p[j] - mx);
-        sum += p[j];
-    }
-    const float inv = 1.f / sum;
     float o[HDP];
 #pragma unroll
     for (int d = 0; d < HDP; ++d) o[d] = 0.f;
-#pragma unroll
+#pragma unroll 2
     for (int j = 0; j < 49; ++j) {
-        const float pj = p[j];
+        const float pj = __expf(Ps[j * 64 + t] - mx);
+        sum += pj;
 #pragma unroll
         for (int d4 = 0; d4 < HDP / 4; ++d4) {
             const f32x4 vv = *reinterpret_cast<const f32x4*>(Vs + j * HDP + d4 * 4);
@@ -133,6 +129,7 @@ __global__ __launch_bounds__(64) void window_attn_k(const float* __restrict__ qk
             o[d4 * 4 + 2] = fmaf(pj, vv[2], o[d4 * 4 + 2]); o[d4 * 4 + 3] = fmaf(pj, vv[3], o[d4 * 4 + 3]);
         }
     }
+    const float inv = 1.f / sum;
     if (inside) {
         float* op = out + pix * cs + hh * hd;
 #pragma unroll
