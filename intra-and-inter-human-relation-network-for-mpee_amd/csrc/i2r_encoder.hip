@@ -118,17 +118,42 @@ __device__ __forceinline__ void layer_norm(f32x4 (&y)[DC], const float* w, const
     }
 }
 
-constexpr int kKeyTile = 64;
+// one output fragment (16 features x 16 tokens) of  Y^T = W X^T (+bias):  acc += sum_c W[16nt+li][16c+4g..] * x[c]
+template <int KC>
+__device__ __forceinline__ void load_wrow(f32x4 (&wr)[KC], const float* W, int ld, int nt, int li, int g) {
+    const float* row = W + (size_t)(16 * nt + li) * ld + 4 * g;
+#pragma unroll
+    for (int c = 0; c < KC; ++c) wr[c] = ld4(row + 16 * c);
+}
+template <int KC>
+__device__ __forceinline__ f32x4 frag_mm(const f32x4 (&wr)[KC], const f32x4 (&x)[KC], f32x4 acc) {
+#pragma unroll
+    for (int c = 0; c < KC; ++c)
+#pragma unroll
+        for (int s = 0; s < 4; ++s) acc = mfma16(wr[c][s], x[c][s], acc);
+    return acc;
+}
+// Y^T[NF frags] = W[NF*16, KC*16] X^T + b, weight rows software-pipelined one fragment ahead (two named register sets)
+template <int NF, int KC, typename Epi>
+__device__ __forceinline__ void gemm_T(const float* W, const float* bias, int ld, const f32x4 (&x)[KC], int li, int g, Epi epi) {
+    f32x4 w0[KC], w1[KC];
+    load_wrow<KC>(w0, W, ld, 0, li, g);
+#pragma unroll
+    for (int nt = 0; nt < NF; nt += 2) {
+        if (nt + 1 < NF) load_wrow<KC>(w1, W, ld, nt + 1, li, g);
+        epi(nt, frag_mm<KC>(w0, x, ld4(bias + 16 * nt + 4 * g)));
+        if (nt + 1 < NF) {
+            if (nt + 2 < NF) load_wrow<KC>(w0, W, ld, nt + 2, li, g);
+            epi(nt + 1, frag_mm<KC>(w1, x, ld4(bias + 16 * (nt + 1) + 4 * g)));
+        }
+    }
+}
 
-// ---- attention + output projection + LN1 + FFN + LN2: NW waves x 16 queries ----
+// ---- attention + output projection + LN1 + FFN + LN2: NW waves x 16 queries; K / V^T fragments stream from L2
+//      straight into registers (no LDS, no barrier), prefetched one 16-key fragment ahead ----
 template <int DC, int FC, int NW>
 __global__ __launch_bounds__(NW * 64) void enc_layer_k(const EncK p) {
-    extern __shared__ __attribute__((aligned(16))) float smem[];
     constexpr int cs = DC * 16, dff = FC * 16;
-    constexpr int KS = cs + 4;        // K tile row stride (floats)
-    constexpr int VS = kKeyTile + 4;  // V^T tile row stride
-    float* Ks = smem;                 // [64][KS]
-    float* Vs = smem + kKeyTile * KS; // [cs][VS]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int li = lane & 15, g = lane >> 4;
     constexpr int QT = NW * 16;
@@ -142,7 +167,9 @@ __global__ __launch_bounds__(NW * 64) void enc_layer_k(const EncK p) {
         if (b < nq) break;
         b -= nq;
     }
-    const int qtok = gs + b * QT + wave * 16 + li;
+    const int q0 = gs + b * QT + wave * 16;
+    if (q0 >= ge) return;  // (whole wave past the end of the group)
+    const int qtok = q0 + li;
     const bool qvalid = qtok < ge;
     const int qrow = qvalid ? qtok : ge - 1;
     const int prow = p.pos_period > 0 ? qrow % p.pos_period : qrow;
@@ -156,17 +183,7 @@ __global__ __launch_bounds__(NW * 64) void enc_layer_k(const EncK p) {
             xq[c] = xs[c];
             if (p.pos) xq[c] += ld4(p.pos + (size_t)prow * cs + 16 * c + 4 * g);
         }
-#pragma unroll
-        for (int nt = 0; nt < DC; ++nt) {
-            f32x4 a = ld4(p.b_in + 16 * nt + 4 * g);
-#pragma unroll
-            for (int c = 0; c < DC; ++c) {
-                const f32x4 wq = ld4(p.w_in + (size_t)(16 * nt + li) * cs + 16 * c + 4 * g);
-#pragma unroll
-                for (int s = 0; s < 4; ++s) a = mfma16(wq[s], xq[c][s], a);
-            }
-            q[nt] = a * p.qscale;
-        }
+        gemm_T<DC, DC>(p.w_in, p.b_in, cs, xq, li, g, [&](int nt, f32x4 a) { q[nt] = a * p.qscale; });
     }
 
     f32x4 o[DC];
@@ -174,69 +191,63 @@ __global__ __launch_bounds__(NW * 64) void enc_layer_k(const EncK p) {
     for (int nt = 0; nt < DC; ++nt) o[nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
     float m_run = -__builtin_inff(), l_run = 0.f;
 
-    for (int kt0 = gs; kt0 < ge; kt0 += kKeyTile) {
-        if (kt0 != gs) __syncthreads();
-        // stage K tile rows (zero beyond the group) and V^T tile (zero beyond the group)
-        for (int e = tid; e < kKeyTile * DC * 4; e += NW * 64) {
-            const int key = e / (DC * 4), c4 = e - key * (DC * 4);
-            f32x4 v = (f32x4){0.f, 0.f, 0.f, 0.f};
-            if (kt0 + key < ge) v = ld4(p.kbuf + (size_t)(kt0 + key) * cs + c4 * 4);
-            *reinterpret_cast<f32x4*>(Ks + key * KS + c4 * 4) = v;
-        }
-        for (int e = tid; e < cs * (kKeyTile / 4); e += NW * 64) {
-            const int dim = e / (kKeyTile / 4), k4 = e - dim * (kKeyTile / 4);
-            f32x4 v = ld4(p.vbuf + (size_t)dim * p.n_tok_pad + kt0 + k4 * 4);
+    // A operands of one 16-key fragment: K rows (lane = key li) and V^T rows (lane = dim li), 4 consecutive k each
+    auto fetch_kv = [&](int k0, f32x4(&ka)[DC], f32x4(&va)[DC]) {
+        const int krow = min(k0 + li, ge - 1);  // clamp: rows past the group are masked below
+        const float* kp = p.kbuf + (size_t)krow * cs + 4 * g;
+        const float* vp = p.vbuf + (size_t)li * p.n_tok_pad + k0 + 4 * g;
 #pragma unroll
-            for (int r = 0; r < 4; ++r)
-                if (kt0 + k4 * 4 + r >= ge) v[r] = 0.f;
-            *reinterpret_cast<f32x4*>(Vs + dim * VS + k4 * 4) = v;
+        for (int c = 0; c < DC; ++c) {
+            ka[c] = ld4(kp + 16 * c);
+            va[c] = ld4(vp + (size_t)16 * c * p.n_tok_pad);
         }
-        __syncthreads();
-
-        // S^T[key][query]
-        f32x4 st[4];
+    };
+    auto attend = [&](int k0, const f32x4(&ka)[DC], const f32x4(&va)[DC]) {
+        f32x4 st = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int c = 0; c < DC; ++c)
+#pragma unroll
+            for (int s = 0; s < 4; ++s) st = mfma16(ka[c][s], q[c][s], st);  // S^T[key 4g+r][query li]
         float mx = -__builtin_inff();
 #pragma unroll
-        for (int kf = 0; kf < 4; ++kf) {
-            f32x4 a = (f32x4){0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-            for (int c = 0; c < DC; ++c) {
-                const f32x4 kv = ld4(Ks + (kf * 16 + li) * KS + 16 * c + 4 * g);
-#pragma unroll
-                for (int s = 0; s < 4; ++s) a = mfma16(kv[s], q[c][s], a);
-            }
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                if (kt0 + kf * 16 + 4 * g + r >= ge) a[r] = -__builtin_inff();
-                mx = fmaxf(mx, a[r]);
-            }
-            st[kf] = a;
+        for (int r = 0; r < 4; ++r) {
+            if (k0 + 4 * g + r >= ge) st[r] = -__builtin_inff();
+            mx = fmaxf(mx, st[r]);
         }
         mx = xmax(mx);
         const float m_new = fmaxf(m_run, mx);
         const float alpha = __expf(m_run - m_new);
         float ls = 0.f;
 #pragma unroll
-        for (int kf = 0; kf < 4; ++kf)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const float e = __expf(st[kf][r] - m_new);
-                st[kf][r] = e;
-                ls += e;
-            }
+        for (int r = 0; r < 4; ++r) {
+            st[r] = __expf(st[r] - m_new);
+            ls += st[r];
+        }
         l_run = l_run * alpha + ls;
         m_run = m_new;
 #pragma unroll
-        for (int nt = 0; nt < DC; ++nt) o[nt] *= alpha;
-        // O^T[dim][query] += V^T[dim][key] P^T[key][query]
+        for (int nt = 0; nt < DC; ++nt) {
+            f32x4 acc = o[nt] * alpha;
 #pragma unroll
-        for (int kf = 0; kf < 4; ++kf)
-#pragma unroll
-            for (int nt = 0; nt < DC; ++nt) {
-                const f32x4 vv = ld4(Vs + (16 * nt + li) * VS + kf * 16 + 4 * g);
-#pragma unroll
-                for (int s = 0; s < 4; ++s) o[nt] = mfma16(vv[s], st[kf][s], o[nt]);
-            }
+            for (int s = 0; s < 4; ++s) acc = mfma16(va[nt][s], st[s], acc);  // O^T[dim][query] += V^T[dim][key] P^T
+            o[nt] = acc;
+        }
+    };
+    {
+        f32x4 ka0[DC], va0[DC], ka1[DC], va1[DC];
+        fetch_kv(gs, ka0, va0);
+        int k0 = gs;
+        for (; k0 + 32 <= ge; k0 += 32) {
+            fetch_kv(k0 + 16, ka1, va1);
+            attend(k0, ka0, va0);
+            fetch_kv(min(k0 + 32, ge - 1) & ~3, ka0, va0);  // (look-ahead past the end is clamped and unused)
+            attend(k0 + 16, ka1, va1);
+        }
+        if (k0 < ge) {
+            if (k0 + 16 < ge) fetch_kv(k0 + 16, ka1, va1);
+            attend(k0, ka0, va0);
+            if (k0 + 16 < ge) attend(k0 + 16, ka1, va1);
+        }
     }
     {
         const float inv = 1.f / xsum(l_run);
@@ -246,46 +257,18 @@ __global__ __launch_bounds__(NW * 64) void enc_layer_k(const EncK p) {
 
     // out-proj + residual + LN1
     f32x4 x1[DC];
-#pragma unroll
-    for (int nt = 0; nt < DC; ++nt) {
-        f32x4 a = ld4(p.b_out + 16 * nt + 4 * g);
-#pragma unroll
-        for (int c = 0; c < DC; ++c) {
-            const f32x4 wv = ld4(p.w_out + (size_t)(16 * nt + li) * cs + 16 * c + 4 * g);
-#pragma unroll
-            for (int s = 0; s < 4; ++s) a = mfma16(wv[s], o[c][s], a);
-        }
-        x1[nt] = xs[nt] + a;
-    }
+    gemm_T<DC, DC>(p.w_out, p.b_out, cs, o, li, g, [&](int nt, f32x4 a) { x1[nt] = xs[nt] + a; });
     layer_norm<DC>(x1, p.ln1_w, p.ln1_b, p.d, p.ln_eps, g);
 
     // FFN
     f32x4 h[FC];
-#pragma unroll
-    for (int ft = 0; ft < FC; ++ft) {
-        f32x4 a = ld4(p.b1 + 16 * ft + 4 * g);
-#pragma unroll
-        for (int c = 0; c < DC; ++c) {
-            const f32x4 wv = ld4(p.w1 + (size_t)(16 * ft + li) * cs + 16 * c + 4 * g);
-#pragma unroll
-            for (int s = 0; s < 4; ++s) a = mfma16(wv[s], x1[c][s], a);
-        }
+    gemm_T<FC, DC>(p.w1, p.b1, cs, x1, li, g, [&](int ft, f32x4 a) {
 #pragma unroll
         for (int r = 0; r < 4; ++r) a[r] = fmaxf(a[r], 0.f);
         h[ft] = a;
-    }
+    });
     f32x4 y[DC];
-#pragma unroll
-    for (int nt = 0; nt < DC; ++nt) {
-        f32x4 a = ld4(p.b2 + 16 * nt + 4 * g);
-#pragma unroll
-        for (int c = 0; c < FC; ++c) {
-            const f32x4 wv = ld4(p.w2 + (size_t)(16 * nt + li) * dff + 16 * c + 4 * g);
-#pragma unroll
-            for (int s = 0; s < 4; ++s) a = mfma16(wv[s], h[c][s], a);
-        }
-        y[nt] = x1[nt] + a;
-    }
+    gemm_T<DC, FC>(p.w2, p.b2, dff, h, li, g, [&](int nt, f32x4 a) { y[nt] = x1[nt] + a; });
     layer_norm<DC>(y, p.ln2_w, p.ln2_b, p.d, p.ln_eps, g);
     if (qvalid) {
 #pragma unroll
@@ -331,11 +314,10 @@ extern "C" int i2r_encoder_layer(const i2r_encoder_desc* d, void* stream) {
     if (rc) return rc;
     I2R_CHECK_ARG(d->n_qtiles32 > 0, "i2r_encoder_layer: n_qtiles32");
     constexpr int NW = 2;
-    const size_t lds = (size_t)(kKeyTile * (d->cs + 4) + d->cs * (kKeyTile + 4)) * sizeof(float);
     if (d->cs == 96)
-        hipLaunchKernelGGL((enc_layer_k<6, 12, NW>), dim3((unsigned)d->n_qtiles32), dim3(NW * 64), lds, (hipStream_t)stream, k);
+        hipLaunchKernelGGL((enc_layer_k<6, 12, NW>), dim3((unsigned)d->n_qtiles32), dim3(NW * 64), 0, (hipStream_t)stream, k);
     else
-        hipLaunchKernelGGL((enc_layer_k<5, 12, NW>), dim3((unsigned)d->n_qtiles32), dim3(NW * 64), lds, (hipStream_t)stream, k);
+        hipLaunchKernelGGL((enc_layer_k<5, 12, NW>), dim3((unsigned)d->n_qtiles32), dim3(NW * 64), 0, (hipStream_t)stream, k);
     I2R_CHECK_LAUNCH("i2r_encoder_layer");
     return I2R_OK;
 }
