@@ -40,10 +40,13 @@ IMAGES_PER_GPU, PERSONS = 8, 4
 GFLOP_PER_CROP = 19.085 + 0.0849 * PERSONS  # BASELINE.md section 3 (N = 4 persons / image)
 
 
-def conv_kernel_name(d):
-    from i2r_amd.engine import conv_split
-    nt, _ = conv_split(d.cout_pad)
-    return "conv_igemm_f32<%d, %d>" % (d.mt, nt)
+def conv_kernel_name(members):
+    """rocprof-visible instantiation name conv_igemm_f32<MT, NT, CAP, PF>, asked from the library itself."""
+    import ctypes as C
+    arr = (C.POINTER(cabi.ConvDesc) * len(members))(*[C.pointer(m) for m in members])
+    buf = C.create_string_buffer(96)
+    cabi.check(cabi.lib().i2r_conv_kernel_name(arr, len(members), buf, 96), "i2r_conv_kernel_name")
+    return buf.value.decode()
 
 
 def conv_flop(d):
@@ -75,10 +78,10 @@ def per_launch_timing(program, reps=3):
                 continue
             ms = evs[i].elapsed_time(evs[i + 1])
             if kind == cabi.OP_CONV:
-                name, flop = conv_kernel_name(st), conv_flop(st)
+                name, flop = conv_kernel_name([st]), conv_flop(st)
             elif kind == cabi.OP_CONV_GROUP:
                 members = [st.d[i].contents for i in range(st.n)]
-                name, flop = conv_kernel_name(members[0]), sum(conv_flop(m) for m in members)
+                name, flop = conv_kernel_name(members), sum(conv_flop(m) for m in members)
             else:
                 name = {cabi.OP_STEM: "stem_conv_k", cabi.OP_MAXPOOL: "maxpool_k", cabi.OP_HEAD: "head_k",
                         cabi.OP_ENC_KV: "enc_kv_k", cabi.OP_ENC_LAYER: "enc_layer_k", cabi.OP_LAYERNORM: "layernorm_k",

@@ -113,6 +113,10 @@ int i2r_maxpool3x3s2(const float* in, float* out, int32_t n_img, int32_t in_h, i
 int i2r_head(const float* in, const float* w, const float* bias, float* out_nchw, int32_t n_img, int32_t h,
              int32_t w_, int32_t cin, int32_t in_cs, int32_t cout, void* stream);
 
+/* i2r_conv_kernel_name -- which instantiation conv_igemm_f32<MT, NT, CAP, PF> a (grouped) launch resolves to, as it
+ * appears in rocprofv3 kernel traces (used by bench.py to key its per-kernel roofline numbers). No launch happens. */
+int i2r_conv_kernel_name(const i2r_conv_desc* const* descs, int32_t n, char* buf, int32_t buflen);
+
 /* ---- HRFormer-B glue (reference lib/models/hrformer.py) ---------------------------------------------------- */
 /* i2r_layernorm -- nn.LayerNorm(c, eps) over the channels of every pixel/token of an NHWC tensor
  * (GeneralTransformerBlock.norm1/norm2, hrformer.py:1198,1235-1237). w, b: [cs] zero-padded. */

@@ -59,7 +59,7 @@ struct ConvGroupK {
     const int* blk_map;       // optional dispatch-order table: entry = (group << 24) | workgroup index within the group
 };
 
-template <int MT, int NT>
+template <int MT, int NT, int CAP, int PF>
 __device__ __forceinline__ void conv_body(const ConvK& p, int bid, f32x4* lds) {
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
@@ -79,10 +79,11 @@ __device__ __forceinline__ void conv_body(const ConvK& p, int bid, f32x4* lds) {
 
     // patch pixel -> global float offset of channel 0 (clamped to 0 outside the image, with a validity bit);
     // channel independent, so computed once
-    int goff[kMaxPP];
-    bool gval[kMaxPP];
+    constexpr int NPP = PF > 0 ? PF : kMaxPP;
+    int goff[NPP];
+    bool gval[NPP];
 #pragma unroll
-    for (int j = 0; j < kMaxPP; ++j) {
+    for (int j = 0; j < NPP; ++j) {
         const int pp = tid + j * 256;
         goff[j] = 0;
         gval[j] = false;
@@ -119,39 +120,10 @@ __device__ __forceinline__ void conv_body(const ConvK& p, int bid, f32x4* lds) {
     // lane's weight pointer: float4 index ((tap*cin4 + cg) * cout_pad + n)
     const f32x4* wq = reinterpret_cast<const f32x4*>(p.w) + n_base + li;
 
-    for (int c0 = 0; c0 < p.cin; c0 += p.ck) {
-        const int ckc = min(p.ck, p.cin - c0);
-        const int ncg = ckc >> 2;
-        if (c0 != 0) __syncthreads();
-        // ---- stage the patch: lds[cg][pp] = in[pixel(pp)][c0 + 4cg .. +3]; 4 channel groups per trip so the
-        //      global loads of a trip are all in flight before the first LDS store waits for them ----
-        for (int cg0 = 0; cg0 < ncg; cg0 += 4) {
-            f32x4 v[4][kMaxPP];
-#pragma unroll
-            for (int u = 0; u < 4; ++u)
-#pragma unroll
-                for (int j = 0; j < kMaxPP; ++j)
-                    if (j < npp && !(p.dbg & 2)) v[u][j] = *reinterpret_cast<const f32x4*>(p.in + goff[j] + c0 + (cg0 + u) * 4);
-            if (p.in2) {
-#pragma unroll
-                for (int u = 0; u < 4; ++u)
-#pragma unroll
-                    for (int j = 0; j < kMaxPP; ++j)
-                        if (j < npp) v[u][j] += *reinterpret_cast<const f32x4*>(p.in2 + goff[j] + c0 + (cg0 + u) * 4);
-            }
-#pragma unroll
-            for (int u = 0; u < 4; ++u)
-#pragma unroll
-                for (int j = 0; j < kMaxPP; ++j) {
-                    const int pp = tid + j * 256;
-                    if (j < npp && pp < phw)
-                        lds[(cg0 + u) * p.plane + pp] = gval[j] ? v[u][j] : (f32x4){0.f, 0.f, 0.f, 0.f};
-                }
-        }
-        __syncthreads();
-
-        // ---- K loop over (tap, 16-channel step), software-pipelined one step ahead with two named register
-        //      sets (no register copies, so the compiler's vmcnt/lgkmcnt waits land at the first use) ----
+    // ---- one channel chunk: K loop over (tap, 16-channel step) reading the staged patch `buf`, software-pipelined
+    //      one step ahead with two named register sets (no register copies, so the compiler's vmcnt/lgkmcnt waits land
+    //      at the first use); `mid` runs right after the first operand fetch (used to launch the next chunk's loads) ----
+    auto run_chunk = [&](const f32x4* buf, int c0, int ckc, auto&& mid) {
         const int ncs = ckc >> 4;
         const int nit = p.ntaps * ncs;
         const f32x4* const wp0 = wq + (size_t)((c0 >> 2) + g) * p.cout_pad;  // step (tap 0, cs 0) of this chunk
@@ -164,7 +136,7 @@ __device__ __forceinline__ void conv_body(const ConvK& p, int bid, f32x4* lds) {
             for (int nt = 0; nt < NT; ++nt) b[nt] = (p.dbg & 4) ? wp0[nt * 16] : wp[nt * 16];
             const int abase = (cs_n * 4 + g) * p.plane + ty_n * p.pw + tx_n;
 #pragma unroll
-            for (int mt = 0; mt < MT; ++mt) a[mt] = lds[abase + ppix[mt]];
+            for (int mt = 0; mt < MT; ++mt) a[mt] = buf[abase + ppix[mt]];
             if (++cs_n == ncs) {
                 cs_n = 0;
                 wp += inc_tap;
@@ -186,6 +158,7 @@ __device__ __forceinline__ void conv_body(const ConvK& p, int bid, f32x4* lds) {
         };
         f32x4 a0[MT], a1[MT], b0[NT], b1[NT];
         fetch(a0, b0);
+        mid();
         int it = 0;
         for (; it + 2 <= nit; it += 2) {
             fetch(a1, b1);
@@ -194,6 +167,87 @@ __device__ __forceinline__ void conv_body(const ConvK& p, int bid, f32x4* lds) {
             fma_step(a1, b1);
         }
         if (it < nit) fma_step(a0, b0);
+    };
+
+    if constexpr (PF > 0) {
+        // ---- double-buffered staging: chunks of 4*ckg channels (ckg <= CAP); the NEXT chunk's patch is loaded into
+        //      registers while the MFMAs of the current chunk run, and written to the other LDS buffer afterwards
+        //      (one barrier per chunk) ----
+        f32x4 v[CAP][PF];
+        const int ckg = p.ck >> 2;
+        auto stage_load = [&](int c0) {
+#pragma unroll
+            for (int u = 0; u < CAP; ++u)
+                if (u < ckg) {
+#pragma unroll
+                    for (int j = 0; j < PF; ++j)
+                        if (!(p.dbg & 2)) v[u][j] = *reinterpret_cast<const f32x4*>(p.in + goff[j] + c0 + u * 4);
+                }
+            if (p.in2) {
+#pragma unroll
+                for (int u = 0; u < CAP; ++u)
+                    if (u < ckg) {
+#pragma unroll
+                        for (int j = 0; j < PF; ++j) v[u][j] += *reinterpret_cast<const f32x4*>(p.in2 + goff[j] + c0 + u * 4);
+                    }
+            }
+        };
+        auto stage_store = [&](f32x4* buf) {
+#pragma unroll
+            for (int u = 0; u < CAP; ++u)
+                if (u < ckg) {
+#pragma unroll
+                    for (int j = 0; j < PF; ++j) {
+                        const int pp = tid + j * 256;
+                        if (pp < phw) buf[u * p.plane + pp] = gval[j] ? v[u][j] : (f32x4){0.f, 0.f, 0.f, 0.f};
+                    }
+                }
+        };
+        const int npass = p.cin / p.ck;
+        stage_load(0);
+        stage_store(lds);
+        __syncthreads();
+        for (int pass = 0; pass < npass; ++pass) {
+            f32x4* cur = lds + (pass & 1) * ckg * p.plane;
+            f32x4* nxt = lds + ((pass + 1) & 1) * ckg * p.plane;
+            const bool more = pass + 1 < npass;
+            run_chunk(cur, pass * p.ck, p.ck, [&]() { if (more) stage_load((pass + 1) * p.ck); });
+            if (more) stage_store(nxt);
+            __syncthreads();
+        }
+    } else {
+        for (int c0 = 0; c0 < p.cin; c0 += p.ck) {
+            const int ckc = min(p.ck, p.cin - c0);
+            const int ncg = ckc >> 2;
+            if (c0 != 0) __syncthreads();
+            // ---- stage the patch: lds[cg][pp] = in[pixel(pp)][c0 + 4cg .. +3]; 4 channel groups per trip so the
+            //      global loads of a trip are all in flight before the first LDS store waits for them ----
+            for (int cg0 = 0; cg0 < ncg; cg0 += 4) {
+                f32x4 v[4][kMaxPP];
+#pragma unroll
+                for (int u = 0; u < 4; ++u)
+#pragma unroll
+                    for (int j = 0; j < kMaxPP; ++j)
+                        if (j < npp && !(p.dbg & 2)) v[u][j] = *reinterpret_cast<const f32x4*>(p.in + goff[j] + c0 + (cg0 + u) * 4);
+                if (p.in2) {
+#pragma unroll
+                    for (int u = 0; u < 4; ++u)
+#pragma unroll
+                        for (int j = 0; j < kMaxPP; ++j)
+                            if (j < npp) v[u][j] += *reinterpret_cast<const f32x4*>(p.in2 + goff[j] + c0 + (cg0 + u) * 4);
+                }
+#pragma unroll
+                for (int u = 0; u < 4; ++u)
+#pragma unroll
+                    for (int j = 0; j < kMaxPP; ++j) {
+                        const int pp = tid + j * 256;
+                        if (j < npp && pp < phw)
+                            lds[(cg0 + u) * p.plane + pp] = gval[j] ? v[u][j] : (f32x4){0.f, 0.f, 0.f, 0.f};
+                    }
+            }
+            __syncthreads();
+            run_chunk(lds, c0, ckc, []() {});
+        }
     }
 
     // ---- epilogue ----
@@ -255,7 +309,7 @@ __device__ __forceinline__ void conv_body(const ConvK& p, int bid, f32x4* lds) {
 
 // One launch = up to kMaxGroups independent convolutions that share (MT, NT): "horizontal fusion" of the
 // HRNet branches / fuse terms so that the small low-resolution convs fill the chip together with the large one.
-template <int MT, int NT>
+template <int MT, int NT, int CAP, int PF>
 __global__ __launch_bounds__(256) void conv_igemm_f32(const ConvGroupK grp) {
     extern __shared__ __attribute__((aligned(16))) f32x4 lds[];
     int bid = blockIdx.x, gi = 0, start = 0;
@@ -270,30 +324,39 @@ __global__ __launch_bounds__(256) void conv_igemm_f32(const ConvGroupK grp) {
         for (int i = 0; i < kMaxGroups - 1; ++i)
             if (i + 1 < grp.n && bid >= grp.blk_end[i]) { gi = i + 1; start = grp.blk_end[i]; }
     }
-    conv_body<MT, NT>(grp.g[gi], bid - start, lds);
+    conv_body<MT, NT, CAP, PF>(grp.g[gi], bid - start, lds);
 }
 
 typedef void (*conv_fn)(const ConvGroupK);
 
-template <int NT>
+template <int NT, int CAP, int PF>
 conv_fn pick_mt(int mt) {
     switch (mt) {
-        case 1: return conv_igemm_f32<1, NT>;
-        case 2: return conv_igemm_f32<2, NT>;
-        case 3: return conv_igemm_f32<3, NT>;
-        case 4: return conv_igemm_f32<4, NT>;
+        case 1: return conv_igemm_f32<1, NT, CAP, PF>;
+        case 2: return conv_igemm_f32<2, NT, CAP, PF>;
+        case 3: return conv_igemm_f32<3, NT, CAP, PF>;
+        case 4: return conv_igemm_f32<4, NT, CAP, PF>;
     }
     return nullptr;
 }
 
-conv_fn pick_kernel(int nt, int mt) {
+template <int CAP, int PF>
+conv_fn pick_nt(int nt, int mt) {
     switch (nt) {
-        case 1: return pick_mt<1>(mt);
-        case 2: return pick_mt<2>(mt);
-        case 3: return pick_mt<3>(mt);
-        case 4: return pick_mt<4>(mt);
-        case 5: return pick_mt<5>(mt);
+        case 3: return pick_mt<3, CAP, PF>(mt);
+        case 4: return pick_mt<4, CAP, PF>(mt);
+        case 5: return pick_mt<5, CAP, PF>(mt);
     }
+    return nullptr;
+}
+
+// staging variant: pf 0 = synchronous staging (any patch size / ck); pf 1|2 = double-buffered chunks for patches of up to
+// 256|512 pixels with up to cap (4 or 12) channel groups of prefetch registers
+conv_fn pick_kernel(int nt, int mt, int cap, int pf) {
+    if (pf == 0) return pick_nt<4, 0>(nt, mt);
+    if (pf == 1 && cap == 4) return pick_nt<4, 1>(nt, mt);
+    if (pf == 1 && cap == 12) return pick_nt<12, 1>(nt, mt);
+    if (pf == 2 && cap == 4) return pick_nt<4, 2>(nt, mt);
     return nullptr;
 }
 
@@ -302,7 +365,8 @@ inline int cdiv(int a, int b) { return (a + b - 1) / b; }
 }  // namespace
 
 // validate one descriptor and derive its launch geometry; *nt_out/*mt_out: fragment blocking, *lds_out: LDS bytes
-static int prepare(const i2r_conv_desc* d, int force_mt, ConvK& k, int* nt_out, int* mt_out, size_t* lds_out, long long* nblk_out) {
+static int prepare(const i2r_conv_desc* d, int force_mt, int force_cap, int force_pf, ConvK& k, int* nt_out, int* mt_out, int* cap_out,
+                   int* pf_out, size_t* lds_out, long long* nblk_out) {
     I2R_CHECK_ARG(d && d->in && d->w && d->bias && d->out, "i2r_conv: null pointer");
     I2R_CHECK_ARG(d->cin > 0 && d->cin % 16 == 0 && d->cin <= d->in_cs && d->in_cs % 4 == 0,
                   "i2r_conv: cin=%d must be a multiple of 16 and <= in_cs=%d (in_cs %% 4 == 0)", d->cin, d->in_cs);
@@ -326,8 +390,9 @@ static int prepare(const i2r_conv_desc* d, int force_mt, ConvK& k, int* nt_out, 
     // ---- fragment decomposition of the output channels ----
     const int nfrag = d->cout_pad / 16;
     int nt = 0;
-    for (int cand : {3, 4, 5, 2, 1})
+    for (int cand : {3, 4, 5})
         if (nfrag % cand == 0) { nt = cand; break; }
+    I2R_CHECK_ARG(nt != 0, "i2r_conv: cout_pad=%d is not a multiple of 48, 64 or 80", d->cout_pad);
     int wn = d->wn;
     if (wn == 0) {
         const int nb = nfrag / nt;
@@ -368,22 +433,41 @@ static int prepare(const i2r_conv_desc* d, int force_mt, ConvK& k, int* nt_out, 
     for (int t = 0; t < d->ntaps; ++t)
         I2R_CHECK_ARG(d->dy[t] == t / k.tap_kw && d->dx[t] == t % k.tap_kw && d->ntaps == (max_dy + 1) * (max_dx + 1),
                       "i2r_conv: taps must form a dense row-major kh x kw grid");
-    int ck = d->ck;
-    if (ck == 0) {
-        // small LDS footprint (<= ~20 KB) keeps >= 4 workgroups per CU resident, which is what hides the staging and
-        // epilogue phases behind other workgroups' MFMA work (measured: ck = 16..48 beats staging all of cin);
-        // equal-sized chunks avoid a short tail pass
-        const int budget = 20 * 1024;
-        int fit = (budget / (k.plane * 16)) * 4;
-        fit = fit < 16 ? 16 : fit / 16 * 16;
-        const int nchunk = cdiv(d->cin, fit);
-        ck = cdiv(cdiv(d->cin, nchunk), 16) * 16;
+    // staging variant: double-buffered chunks when the patch fits 1-2 pixels per thread (the common case); a grouped
+    // launch must agree on one variant (force_pf: -1 = free choice, else force_cap/force_pf are imposed)
+    const int npp = cdiv(k.ph * k.pw, 256);
+    static const int pf_env = getenv("I2R_CONV_PF") ? atoi(getenv("I2R_CONV_PF")) : 1;  // tuning switch: 0 disables prefetch
+    const int cin_g = d->cin / 4;
+    int pf = (pf_env && d->ck == 0 && npp <= 2 && cin_g % 4 == 0) ? npp : 0;
+    int cap = 4;
+    if (force_pf >= 0) {
+        I2R_CHECK_ARG(force_pf == 0 || (npp <= force_pf && d->ck == 0 && cin_g % 4 == 0), "i2r_conv: grouped members disagree on the staging mode");
+        pf = force_pf;
     }
-    I2R_CHECK_ARG(ck % 16 == 0 && ck >= 16, "i2r_conv: ck=%d", ck);
+    int ck = d->ck;
+    size_t lds_bytes;
+    if (pf > 0) {
+        int ckg = 4;
+        const int cap_lim = force_pf >= 0 ? force_cap : (pf == 1 ? 12 : 4);
+        for (int cand : {12, 8, 4})
+            if (cand <= cap_lim && cin_g % cand == 0 && (size_t)2 * cand * k.plane * 16 <= 40 * 1024) { ckg = cand; break; }
+        cap = force_pf >= 0 ? force_cap : (ckg > 4 ? 12 : 4);
+        ck = ckg * 4;
+        lds_bytes = (size_t)2 * ckg * k.plane * 16;
+    } else {
+        if (ck == 0) {
+            // small LDS footprint (<= ~20 KB) keeps >= 4 workgroups per CU resident; equal-sized chunks avoid a short tail pass
+            const int budget = 20 * 1024;
+            int fit = (budget / (k.plane * 16)) * 4;
+            fit = fit < 16 ? 16 : fit / 16 * 16;
+            const int nchunk = cdiv(d->cin, fit);
+            ck = cdiv(cdiv(d->cin, nchunk), 16) * 16;
+        }
+        I2R_CHECK_ARG(ck % 16 == 0 && ck >= 16, "i2r_conv: ck=%d", ck);
+        lds_bytes = (size_t)(ck / 4) * k.plane * 16;
+    }
     k.ck = ck;
-    const size_t lds_bytes = (size_t)(ck / 4) * k.plane * 16;
     I2R_CHECK_ARG(lds_bytes <= 160 * 1024, "i2r_conv: LDS %zu B", lds_bytes);
-
     k.wn = wn;
     {
         static const int dbg = getenv("I2R_CONV_DBG") ? atoi(getenv("I2R_CONV_DBG")) : 0;
@@ -391,24 +475,43 @@ static int prepare(const i2r_conv_desc* d, int force_mt, ConvK& k, int* nt_out, 
     }
     const long long nblk = (long long)d->n_img * k.tiles_y * k.tiles_x * k.n_cblk;
     I2R_CHECK_ARG(nblk > 0 && nblk < (1ll << 30), "i2r_conv: grid");
-    *nt_out = nt; *mt_out = mt; *lds_out = lds_bytes; *nblk_out = nblk;
+    *nt_out = nt; *mt_out = mt; *cap_out = cap; *pf_out = pf; *lds_out = lds_bytes; *nblk_out = nblk;
     return I2R_OK;
 }
 
-extern "C" int i2r_conv_grouped(const i2r_conv_desc* const* descs, int32_t n, const int32_t* block_map,
-                                int32_t map_len, void* stream) {
+static int resolve(const i2r_conv_desc* const* descs, int32_t n, ConvGroupK& grp, int* nt0_, int* mt0_, int* cap0_, int* pf0_,
+                   size_t* lds_, long long* total_) {
     I2R_CHECK_ARG(descs && n >= 1 && n <= kMaxGroups, "i2r_conv_grouped: 1..%d descriptors", kMaxGroups);
-    ConvGroupK grp;
-    int nt0 = 0, mt0 = 0;
+    int nt0 = 0, mt0 = 0, pf0 = -1, cap0 = 4;
     size_t lds_max = 0;
     long long total = 0;
+    if (n > 1) {  // members must share the staging variant: the most general one any member needs
+        pf0 = 0;
+        cap0 = 4;
+        bool all_pf = true;
+        for (int i = 0; i < n; ++i) {
+            ConvK tmp;
+            int nt, mt, cap, pf;
+            size_t lds;
+            long long nblk;
+            int rc = prepare(descs[i], mt0, 4, -1, tmp, &nt, &mt, &cap, &pf, &lds, &nblk);
+            if (rc) return rc;
+            if (i == 0) mt0 = mt;
+            if (pf == 0) all_pf = false;
+            if (pf > pf0) pf0 = pf;
+            if (cap > cap0) cap0 = cap;
+        }
+        if (!all_pf) pf0 = 0;
+        if (pf0 != 1) cap0 = 4;
+        mt0 = 0;
+    }
     for (int i = 0; i < n; ++i) {
-        int nt, mt;
+        int nt, mt, cap, pf;
         size_t lds;
         long long nblk;
-        int rc = prepare(descs[i], mt0, grp.g[i], &nt, &mt, &lds, &nblk);
+        int rc = prepare(descs[i], mt0, cap0, pf0, grp.g[i], &nt, &mt, &cap, &pf, &lds, &nblk);
         if (rc) return rc;
-        if (i == 0) { nt0 = nt; mt0 = mt; }
+        if (i == 0) { nt0 = nt; mt0 = mt; pf0 = pf; cap0 = cap; }
         I2R_CHECK_ARG(nt == nt0 && mt == mt0, "i2r_conv_grouped: descriptor %d has fragment blocking (%d,%d) != (%d,%d)", i, mt, nt, mt0, nt0);
         if (lds > lds_max) lds_max = lds;
         total += nblk;
@@ -416,11 +519,23 @@ extern "C" int i2r_conv_grouped(const i2r_conv_desc* const* descs, int32_t n, co
     }
     for (int i = n; i < kMaxGroups; ++i) { grp.g[i] = grp.g[0]; grp.blk_end[i] = (int)total; }
     grp.n = n;
+    I2R_CHECK_ARG(total < (1ll << 31), "i2r_conv_grouped: grid");
+    *nt0_ = nt0; *mt0_ = mt0; *cap0_ = cap0; *pf0_ = pf0; *lds_ = lds_max; *total_ = total;
+    return I2R_OK;
+}
+
+extern "C" int i2r_conv_grouped(const i2r_conv_desc* const* descs, int32_t n, const int32_t* block_map,
+                                int32_t map_len, void* stream) {
+    ConvGroupK grp;
+    int nt0, mt0, cap0, pf0;
+    size_t lds_max;
+    long long total;
+    int rc = resolve(descs, n, grp, &nt0, &mt0, &cap0, &pf0, &lds_max, &total);
+    if (rc) return rc;
     grp.blk_map = block_map;
     I2R_CHECK_ARG(block_map == nullptr || map_len == (int32_t)total, "i2r_conv_grouped: block_map has %d entries, grid has %lld", map_len, total);
-    I2R_CHECK_ARG(total < (1ll << 31), "i2r_conv_grouped: grid");
-    conv_fn fn = pick_kernel(nt0, mt0);
-    I2R_CHECK_ARG(fn != nullptr, "i2r_conv: no kernel for nt=%d mt=%d", nt0, mt0);
+    conv_fn fn = pick_kernel(nt0, mt0, cap0, pf0);
+    I2R_CHECK_ARG(fn != nullptr, "i2r_conv: no kernel for nt=%d mt=%d cap=%d pf=%d", nt0, mt0, cap0, pf0);
     if (lds_max > 64 * 1024)
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_max);
     hipLaunchKernelGGL(fn, dim3((unsigned)total), dim3(256), lds_max, (hipStream_t)stream, grp);
@@ -429,3 +544,15 @@ extern "C" int i2r_conv_grouped(const i2r_conv_desc* const* descs, int32_t n, co
 }
 
 extern "C" int i2r_conv(const i2r_conv_desc* d, void* stream) { return i2r_conv_grouped(&d, 1, nullptr, 0, stream); }
+
+extern "C" int i2r_conv_kernel_name(const i2r_conv_desc* const* descs, int32_t n, char* buf, int32_t buflen) {
+    ConvGroupK grp;
+    int nt0, mt0, cap0, pf0;
+    size_t lds_max;
+    long long total;
+    int rc = resolve(descs, n, grp, &nt0, &mt0, &cap0, &pf0, &lds_max, &total);
+    if (rc) return rc;
+    I2R_CHECK_ARG(buf && buflen > 0, "i2r_conv_kernel_name: buffer");
+    snprintf(buf, (size_t)buflen, "conv_igemm_f32<%d, %d, %d, %d>", mt0, nt0, cap0, pf0);
+    return I2R_OK;
+}

@@ -274,7 +274,7 @@ def lpt_block_order(counts, works, n_cu=256):
 
 def conv_split(cout_pad):
     nfrag = cout_pad // 16
-    nt = next(c for c in (3, 4, 5, 2, 1) if nfrag % c == 0)  # same rule as csrc/i2r_conv.hip
+    nt = next(c for c in (3, 4, 5) if nfrag % c == 0)  # same rule as csrc/i2r_conv.hip
     nb = nfrag // nt
     wn = 4 if nb % 4 == 0 else 2 if nb % 2 == 0 else 1
     return nt, wn
