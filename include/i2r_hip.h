@@ -98,9 +98,11 @@ int i2r_conv_grouped(const i2r_conv_desc* const* descs, int32_t n, const int32_t
  * boundary NCHW fp32 tensor and writing NHWC.
  * Replaces: conv1+bn1+relu (interformer_pureMulti.py:677-679) and PositionEmbeddingImage conv1+bn1+relu
  * (position_embedding.py:99-101).   w: float[9][cin][cout], bias[cout]; cout % 16 == 0.
+ * n_src: the input holds n_src images; output images n_src..n_img-1 (n_img == 2*n_src) are computed from the
+ * horizontally mirrored input (np.flip(input, 3) of the flip test, lib/core/function.py:145-150); n_src == n_img: none.
  * ------------------------------------------------------------------------------------------------ */
 int i2r_stem_conv(const float* in_nchw, const float* w, const float* bias, float* out_nhwc, int32_t n_img,
-                  int32_t cin, int32_t in_h, int32_t in_w, int32_t cout, int32_t out_cs, void* stream);
+                  int32_t cin, int32_t in_h, int32_t in_w, int32_t cout, int32_t out_cs, int32_t n_src, void* stream);
 
 /* i2r_maxpool3x3s2 -- nn.MaxPool2d(kernel_size=3, stride=2, padding=1) on NHWC
  * (interformer.py:162,260-264; position_embedding.py:9,106-109).  c % 4 == 0. */
@@ -116,6 +118,21 @@ int i2r_head(const float* in, const float* w, const float* bias, float* out_nchw
 /* i2r_conv_kernel_name -- which instantiation conv_igemm_f32<MT, NT, CAP, PF> a (grouped) launch resolves to, as it
  * appears in rocprofv3 kernel traces (used by bench.py to key its per-kernel roofline numbers). No launch happens. */
 int i2r_conv_kernel_name(const i2r_conv_desc* const* descs, int32_t n, char* buf, int32_t buflen);
+
+/* ---- after the forward: flip-test merge and keypoint decode -------------------------------- */
+/* i2r_flip_merge -- out = (y + flip_back(y_flipped)) * 0.5  with flip_back = reverse W + swap left/right joints
+ * (lib/core/function.py:142-162, lib/utils/transforms.py:16-30). joint_map: device int32[joints], the joint whose mirrored
+ * heatmap lands in channel j (identity for unpaired joints). NCHW fp32 [n, joints, h, w]. */
+int i2r_flip_merge(const float* y, const float* y_flipped, const int32_t* joint_map, float* out, int32_t n, int32_t joints,
+                   int32_t h, int32_t w, void* stream);
+
+/* i2r_decode -- get_final_preds (lib/core/inference.py:90-112): arg-max (:20-48), Gaussian blur with kernel TEST.BLUR_KERNEL
+ * on a zero-bordered copy re-normalised to the original max (:73-87; cv2.GaussianBlur(sigma=0) => sigma =
+ * 0.3*((k-1)*0.5-1)+0.8), log(max(.,1e-10)), second-order Taylor refinement (:51-70), inverse crop affine with rot 0
+ * (lib/utils/transforms.py:50-101: scale about the centres by (scale[0]*200-1)/(w-1)).
+ * heatmaps [n, joints, h, w]; center, scale [n, 2] (unused when transform_back == 0); preds [n, joints, 2]; maxvals [n, joints]. */
+int i2r_decode(const float* heatmaps, const float* center, const float* scale, float* preds, float* maxvals, int32_t n,
+               int32_t joints, int32_t h, int32_t w, int32_t blur_kernel, int32_t transform_back, void* stream);
 
 /* ---- HRFormer-B glue (reference lib/models/hrformer.py) ---------------------------------------------------- */
 /* i2r_layernorm -- nn.LayerNorm(c, eps) over the channels of every pixel/token of an NHWC tensor
@@ -202,7 +219,7 @@ enum {
 
 typedef struct i2r_stem_args {
     const float* in; const float* w; const float* bias; float* out;
-    int32_t n_img, cin, in_h, in_w, cout, out_cs;
+    int32_t n_img, cin, in_h, in_w, cout, out_cs, n_src;
 } i2r_stem_args;
 
 typedef struct i2r_pool_args {

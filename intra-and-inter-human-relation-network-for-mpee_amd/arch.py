@@ -218,10 +218,40 @@ def interformer_spec(cfg):
     return spec
 
 
+def interformer_2stage_spec(cfg):
+    """interformer_2stage.InterFormer (:208-281): the older sibling of interformer.InterFormer -- same math, own encoder
+    classes, up-sampling layers named deconv_layers (multiplex, the default) or deconv_layers1..3 (deconv)."""
+    M = cfg["MODEL"]
+    extra = M["EXTRA"]
+    d = M["DIM_MODEL"]
+    assert M["SINGLEFORMER"] == "transpose_h", "interformer_2stage is shipped with the TransPose-H first stage only"
+    assert not M["DOMAIN_TRANS"], "DOMAIN_TRANS is false in every shipped config"
+    spec = Spec()
+    spec.extend(transpose_h_spec(cfg, "singleformer."))
+    multi_position_embedding(spec, "multi_position_embedding", M["MULTI_POS_EMBEDDING"], d, M["TRANS_SIZE"],
+                             M["MULTI_POS_EMBEDDING_DIM"])
+    for l in range(M["ENCODER_MULTI_LAYERS"]):
+        spec.encoder_layer("multi_global_encoder.layers.%d" % l, d, M["DIM_FEEDFORWARD"])
+    planes = extra["NUM_DECONV_FILTERS"][0]
+    up = M["UPSAMPLE_TYPE"]
+    names = {"multiplex": ["deconv_layers"], "deconv": ["deconv_layers1", "deconv_layers2", "deconv_layers3"]}
+    if up not in names:
+        raise NotImplementedError("UPSAMPLE_TYPE=%r" % up)
+    for n in names[up]:
+        spec.append((n + ".0.weight", (planes, planes, 4, 4), F32))
+        if extra["DECONV_WITH_BIAS"]:
+            spec.append((n + ".0.bias", (planes,), F32))
+        spec.bn(n + ".1", planes)
+    spec.conv("final_layer", M["NUM_JOINTS"], d, extra["FINAL_CONV_KERNEL"], bias=True)
+    return spec
+
+
 def param_spec(cfg):
     name = cfg["MODEL"]["NAME"]
     if name == "interformer_pureMulti":
         return vanilla_spec(cfg)
     if name == "interformer":
         return interformer_spec(cfg)
+    if name == "interformer_2stage":
+        return interformer_2stage_spec(cfg)
     raise NotImplementedError("MODEL.NAME=%r" % name)

@@ -10,7 +10,7 @@ namespace {
 template <int CIN>
 __global__ __launch_bounds__(256) void stem_conv_k(const float* __restrict__ in, const float* __restrict__ w,
                                                    const float* __restrict__ bias, float* __restrict__ out, int n_img,
-                                                   int in_h, int in_w, int out_h, int out_w, int cout, int out_cs) {
+                                                   int in_h, int in_w, int out_h, int out_w, int cout, int out_cs, int n_src) {
     const int groups = cout >> 4;
     const long long gid = (long long)blockIdx.x * 256 + threadIdx.x;
     const int cg = (int)(gid % groups);
@@ -19,6 +19,9 @@ __global__ __launch_bounds__(256) void stem_conv_k(const float* __restrict__ in,
     const int ox = (int)(pix % out_w);
     const int oy = (int)((pix / out_w) % out_h);
     const int img = (int)(pix / ((long long)out_w * out_h));
+    // images >= n_src are the horizontally MIRRORED copies of images 0..n_src-1 (flip test batched into one forward)
+    const int simg = img % n_src;
+    const bool mirror = img >= n_src;
 
     float acc[16];
 #pragma unroll
@@ -32,7 +35,7 @@ __global__ __launch_bounds__(256) void stem_conv_k(const float* __restrict__ in,
             const bool ok = iy >= 0 && iy < in_h && ix >= 0 && ix < in_w;
 #pragma unroll
             for (int ci = 0; ci < CIN; ++ci) {
-                const float x = ok ? in[((size_t)(img * CIN + ci) * in_h + iy) * in_w + ix] : 0.f;
+                const float x = ok ? in[((size_t)(simg * CIN + ci) * in_h + iy) * in_w + (mirror ? in_w - 1 - ix : ix)] : 0.f;
                 const f32x4* wr = reinterpret_cast<const f32x4*>(w + ((ky * 3 + kx) * CIN + ci) * cout + cg * 16);
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
@@ -115,8 +118,9 @@ __global__ __launch_bounds__(256) void head_k(const float* __restrict__ in, cons
 }  // namespace
 
 extern "C" int i2r_stem_conv(const float* in_nchw, const float* w, const float* bias, float* out_nhwc, int32_t n_img,
-                             int32_t cin, int32_t in_h, int32_t in_w, int32_t cout, int32_t out_cs, void* stream) {
+                             int32_t cin, int32_t in_h, int32_t in_w, int32_t cout, int32_t out_cs, int32_t n_src, void* stream) {
     I2R_CHECK_ARG(in_nchw && w && bias && out_nhwc, "i2r_stem_conv: null pointer");
+    I2R_CHECK_ARG(n_src >= 1 && (n_img == n_src || n_img == 2 * n_src), "i2r_stem_conv: n_img=%d n_src=%d", n_img, n_src);
     I2R_CHECK_ARG(cout > 0 && cout % 16 == 0 && out_cs >= cout && out_cs % 4 == 0, "i2r_stem_conv: cout=%d out_cs=%d", cout, out_cs);
     I2R_CHECK_ARG(cin == 1 || cin == 3, "i2r_stem_conv: cin=%d (1 or 3)", cin);
     const int out_h = (in_h - 1) / 2 + 1, out_w = (in_w - 1) / 2 + 1;
@@ -124,10 +128,10 @@ extern "C" int i2r_stem_conv(const float* in_nchw, const float* w, const float* 
     const unsigned nblk = (unsigned)((nthr + 255) / 256);
     if (cin == 3)
         hipLaunchKernelGGL(stem_conv_k<3>, dim3(nblk), dim3(256), 0, (hipStream_t)stream, in_nchw, w, bias, out_nhwc, n_img,
-                           in_h, in_w, out_h, out_w, cout, out_cs);
+                           in_h, in_w, out_h, out_w, cout, out_cs, n_src);
     else
         hipLaunchKernelGGL(stem_conv_k<1>, dim3(nblk), dim3(256), 0, (hipStream_t)stream, in_nchw, w, bias, out_nhwc, n_img,
-                           in_h, in_w, out_h, out_w, cout, out_cs);
+                           in_h, in_w, out_h, out_w, cout, out_cs, n_src);
     I2R_CHECK_LAUNCH("i2r_stem_conv");
     return I2R_OK;
 }

@@ -313,10 +313,12 @@ class Program:
                 self.pool.setdefault(a.t.numel(), []).append(a.t)
 
     # ---- ops ----
-    def stem(self, st, n, h, w, in_ptr=0, lane=0):
+    def stem(self, st, n, h, w, in_ptr=0, lane=0, n_src=None):
+        """n_src < n: crops n_src.. are computed from the mirrored input (flip test batched into the same forward)."""
         out = self.alloc(n, (h - 1) // 2 + 1, (w - 1) // 2 + 1, st["cout"])
         self.keep.append(st)
-        a = cabi.StemArgs(in_ptr, st["w"].data_ptr(), st["bias"].data_ptr(), out.ptr, n, st["cin"], h, w, st["cout"], out.cs)
+        a = cabi.StemArgs(in_ptr, st["w"].data_ptr(), st["bias"].data_ptr(), out.ptr, n, st["cin"], h, w, st["cout"], out.cs,
+                          n if n_src is None else n_src)
         self.ops.append((cabi.OP_STEM, lane, a))
         return out, a
 
@@ -647,9 +649,9 @@ class HRNetW48:
         P.release(*xs)
         return ys
 
-    def emit(self, P, n, h, w):
+    def emit(self, P, n, h, w, n_src=None):
         """-> (list of branch Acts, stem StemArgs to patch the input pointer into)."""
-        a, stem_args = P.stem(self.stem1, n, h, w)
+        a, stem_args = P.stem(self.stem1, n, h, w, n_src=n_src)
         b = P.conv(a, self.conv2, relu=True)
         P.release(a)
         x = b
@@ -795,8 +797,8 @@ class HRFormerB:
         P.release(*xs)
         return outs
 
-    def emit(self, P, n, h, w):
-        a, stem_args = P.stem(self.stem1, n, h, w)
+    def emit(self, P, n, h, w, n_src=None):
+        a, stem_args = P.stem(self.stem1, n, h, w, n_src=n_src)
         x = P.conv(a, self.conv2, relu=True)
         P.release(a)
         for blk in self.layer1:
@@ -854,7 +856,7 @@ class Engine:
             self.layers = [pk.encoder_layer("global_encoder.layers.%d" % l, d, dff) for l in range(M["ENCODER_LAYERS"])]
             self.deconvs = [pk.deconv("deconv_layers.0", "deconv_layers.1")] * 2  # the same layer twice (:774-775)
             self.head = pk.head("final_layer")
-        elif self.name == "interformer":
+        elif self.name in ("interformer", "interformer_2stage"):
             sf = M["SINGLEFORMER"]
             self.singleformer = sf
             p = "singleformer."
@@ -882,7 +884,11 @@ class Engine:
             self.layers = [pk.encoder_layer("multi_global_encoder.layers.%d" % l, d, dff)
                            for l in range(M["ENCODER_MULTI_LAYERS"])]
             up = M["UPSAMPLE_TYPE"]
-            if up == "deconv":
+            if up == "deconv" and self.name == "interformer_2stage":  # deconv_layers1..3, as many as pooling steps (:366-379)
+                w4 = M["IMAGE_SIZE"][0] // 4
+                n = int(math.log(w4 // (w4 >> int(math.log(w4 // M["TRANS_SIZE"][-1], 2))), 2))
+                self.deconvs = [pk.deconv("deconv_layers%d.0" % (i + 1), "deconv_layers%d.1" % (i + 1)) for i in range(n)]
+            elif up == "deconv":
                 n = int(math.log(M["HEATMAP_SIZE"][0] // M["TRANS_SIZE"][1], 2))
                 self.deconvs = [pk.deconv("upsample_layer.deconv_layers.%d.0" % i, "upsample_layer.deconv_layers.%d.1" % i)
                                 for i in range(n)]
@@ -896,8 +902,8 @@ class Engine:
             raise NotImplementedError("MODEL.NAME=%r" % self.name)
 
     # ---- program construction ----
-    def _pos_branch(self, P, n, h, w, trans_w):
-        a, pe_args = P.stem(self.pe_stem, n, h, w)
+    def _pos_branch(self, P, n, h, w, trans_w, n_src=None):
+        a, pe_args = P.stem(self.pe_stem, n, h, w, n_src=n_src)
         b = P.conv(a, self.pe_conv2, relu=True)
         P.release(a)
         for _ in range(int(math.log(b.w // trans_w, 2))):
@@ -906,11 +912,16 @@ class Engine:
             b = c
         return b, pe_args
 
-    def _build(self, S, H, W, length):
+    def _build(self, S, H, W, length, flip=False):
+        """flip: the flip test of validate() (lib/core/function.py:142-162) batched into the same forward -- crops S..2S-1 are
+        the mirrored copies (mirroring happens inside the stem kernels), every image appears twice as a token group."""
         M = self.cfg["MODEL"]
         P = Program(self.device, multi_lane=self.multi_lane)
         patch = {}
-        xs, patch["x"] = self.tower.emit(P, S, H, W)
+        n_src = S
+        if flip:
+            S, length = 2 * S, list(length) + list(length)
+        xs, patch["x"] = self.tower.emit(P, S, H, W, n_src=n_src)
         if self.name == "interformer_pureMulti":
             f = P.conv(xs[-1], self.reduce)
             P.release(*xs)
@@ -937,7 +948,7 @@ class Engine:
                 f = c
         pos_ptr = 0
         if self.use_pos:
-            pos, patch["pos_mask"] = self._pos_branch(P, S, H, W, M["TRANS_SIZE"][-1])
+            pos, patch["pos_mask"] = self._pos_branch(P, S, H, W, M["TRANS_SIZE"][-1], n_src=n_src)
             assert (pos.h, pos.w, pos.cs) == (f.h, f.w, f.cs)
             pos_ptr = pos.ptr
         tok = f.h * f.w
@@ -955,16 +966,19 @@ class Engine:
         P.finalize()
         return P, patch
 
-    def forward(self, x, pos_mask, length):
+    def forward(self, x, pos_mask, length, flip_joint_map=None):
+        """flip_joint_map (device int32 [J], see caller.joint_map): run the flip test in the same forward and return the merged
+        'multi' heatmaps (the reference merges only outputs['multi'], function.py:137-162)."""
         M = self.cfg["MODEL"]
         assert x.dim() == 4 and x.shape[1] == 3 and x.dtype == torch.float32
         S, _, H, W = x.shape
         assert S == sum(length), "sum(length)=%d != number of crops %d" % (sum(length), S)
         assert all(n >= 1 for n in length), "every image needs at least one person"
         x = x.to(self.device).contiguous()
-        key = (S, H, W, tuple(length))
+        flip = flip_joint_map is not None
+        key = (S, H, W, tuple(length), flip)
         if key not in self.programs:
-            self.programs[key] = self._build(S, H, W, list(length))
+            self.programs[key] = self._build(S, H, W, list(length), flip)
         P, patch = self.programs[key]
         J = M["NUM_JOINTS"]
         patch["x"].in_ = x.data_ptr()
@@ -974,13 +988,20 @@ class Engine:
             assert pm.shape == (S, 1, H, W)
             patch["pos_mask"].in_ = pm.data_ptr()
             keep.append(pm)
-        out = torch.empty(S, J, H // 4, W // 4, dtype=torch.float32, device=self.device)
+        n_out = 2 * S if flip else S
+        out = torch.empty(n_out, J, H // 4, W // 4, dtype=torch.float32, device=self.device)
         patch["multi"].out = out.data_ptr()
         single = None
         if "single" in patch:
             single = torch.empty_like(out)
             patch["single"].out = single.data_ptr()
         P.run(self.side_streams if P.uses_lanes else None)
-        if self.name == "interformer" and self.return_dict:
+        if flip:
+            merged = torch.empty(S, J, H // 4, W // 4, dtype=torch.float32, device=self.device)
+            st = torch.cuda.current_stream(self.device).cuda_stream
+            cabi.check(cabi.lib().i2r_flip_merge(out.data_ptr(), out[S:].data_ptr(), flip_joint_map.data_ptr(), merged.data_ptr(),
+                                                 S, J, H // 4, W // 4, st), "i2r_flip_merge")
+            return merged
+        if self.name != "interformer_pureMulti" and self.return_dict:
             return {"single": single, "multi": out}
         return out

@@ -88,6 +88,17 @@ class I2RModule(nn.Module):
             self._engine_key = dev
         return self._engine
 
+    def forward_flip(self, x, pos_mask, length, flip_pairs):
+        """Flip test of validate() (lib/core/function.py:142-162) in ONE batched forward: returns
+        (model(x)['multi'] + flip_back(model(flip(x))['multi'], flip_pairs)) * 0.5 ."""
+        from ..caller import joint_map
+        if torch.is_tensor(length):
+            length = length.tolist()
+        eng = self.engine()
+        jm = joint_map(flip_pairs, self.cfg["MODEL"]["NUM_JOINTS"]).to(eng.device)
+        with torch.no_grad():
+            return eng.forward(x, pos_mask, [int(n) for n in length], flip_joint_map=jm)
+
     def forward(self, x, pos_mask, length):
         """model(input, pos_mask, length) -- reference lib/core/function.py:135."""
         if torch.is_tensor(length):

@@ -303,7 +303,13 @@ def forward_two_stage(sd, cfg, x, pos_mask, length, collect=None):
     if collect is not None:
         collect["encoder"] = f
     up = M["UPSAMPLE_TYPE"]
-    if up == "deconv":  # interformer.DeConv :67-127 -- log2(HEATMAP_W // TRANS_SIZE[1]) distinct layers
+    if M["NAME"] == "interformer_2stage":  # interformer_2stage.py:366-379: as many layers as pooling steps were taken
+        n = int(math.log(feat.shape[-1] // f.shape[-1], 2))
+        for i in range(n):
+            key = "deconv_layers" if up == "multiplex" else "deconv_layers%d" % (i + 1)
+            assert up in ("multiplex", "deconv")
+            f = _deconv_bn_relu(sd, key + ".0", key + ".1", f)
+    elif up == "deconv":  # interformer.DeConv :67-127 -- log2(HEATMAP_W // TRANS_SIZE[1]) distinct layers
         n = int(math.log(M["HEATMAP_SIZE"][0] // M["TRANS_SIZE"][1], 2))
         for i in range(n):
             f = _deconv_bn_relu(sd, "upsample_layer.deconv_layers.%d.0" % i,
@@ -326,6 +332,6 @@ def forward(sd, cfg, x, pos_mask, length, collect=None):
     with torch.no_grad():
         if name == "interformer_pureMulti":
             return forward_vanilla(sd, cfg, x, pos_mask, length, collect)
-        if name == "interformer":
+        if name in ("interformer", "interformer_2stage"):
             return forward_two_stage(sd, cfg, x, pos_mask, length, collect)
     raise NotImplementedError("MODEL.NAME=%r" % name)

@@ -38,6 +38,7 @@ CASES = [
     ("tph_l21", "tph_192_p6_b4", [2, 1], (256, 192), True),
     ("hrt_l21", "hrt_192_p4_b4", [2, 1], (256, 192), True),
     ("hrt288_l2", "coco_hrt_288_p2_b4", [2], (384, 288), False),     # 96x72 maps, 24x18 inter-human tokens
+    ("tph2s_l12", "coco_tph_192_p4_b4", [1, 2], (256, 192), False),  # interformer_2stage wiring (multiplex deconv, multi-pos)
 ]
 
 
