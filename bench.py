@@ -234,6 +234,16 @@ def main():
                 "all_conv_tflops": round(conv_flop / (conv_ms * 1e-3) / 1e12, 2),
                 "per_kernel_ms_per_step": {k: round(s[1] / reps, 3) for k, s in sorted(stats.items(), key=lambda kv: -kv[1][1])},
             }
+            if args.config == "w48_pure_en6":
+                # attention blocks (north_star): QKV/out projections + QK^T/AV + FFN of the 6 encoder layers, algorithmic FLOPs
+                d_, dff_, tok = 96, 192, 192
+                per_tok = 2 * d_ * d_ * 4 + 2 * 2 * d_ * dff_ + 2 * 2 * d_ * (PERSONS * tok)
+                att_flop = per_tok * sum(length) * tok * cfg.MODEL.ENCODER_LAYERS
+                att_ms = sum(s[1] for k, s in stats.items() if k.startswith("enc_")) / reps
+                att = att_flop / (att_ms * 1e-3) / 1e12
+                out["roofline"]["attention_blocks"] = {"kernels": "enc_kv_k + enc_layer_k", "gflop_per_step": round(att_flop / 1e9, 3),
+                                                       "ms_per_step": round(att_ms, 3), "achieved": round(att, 2),
+                                                       "peak": FP32_MFMA_PEAK_TFLOPS, "frac": round(att / FP32_MFMA_PEAK_TFLOPS, 4)}
         if not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(cfg, sd)
         print(json.dumps(out))
