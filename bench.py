@@ -139,6 +139,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--config", default="w48_pure_en6", help="workload config (default = BASELINE configs[1]); others are "
                     "exploratory: tph_192_p6_b4, hrt_192_p4_b4, coco_hrt_288_p2_b4")
+    ap.add_argument("--precision", default="fp32", choices=["fp32", "bf16", "fp16"],
+                    help="MFMA operand type of the conv kernels (default fp32 = the BASELINE configs[1] parity mode)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     args = ap.parse_args()
@@ -162,7 +164,7 @@ def main():
     sd = synth.make_state_dict(arch.param_spec(cfg))
     net = eval("models." + cfg.MODEL.NAME + ".get_pose_net")(cfg, is_train=False)
     net.load_state_dict(sd, strict=True)
-    net = net.to(dev)
+    net = net.to(dev).set_precision(args.precision)
 
     # global workload: world * 8 images of 4 persons; this rank's contiguous shard
     length_all = [PERSONS] * (IMAGES_PER_GPU * world)
@@ -207,7 +209,7 @@ def main():
     out = {
         "metric": "images/sec (256x192 crops) I2R-Net HRNet-W48 inference", "value": round(value, 2), "unit": "images/sec",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 4),
-        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": {"fp32": "f32", "bf16": "bf16", "fp16": "f16"}[args.precision], "data": "synthetic",
         "config": {"workload": "vanilla I2R-Net HRNet-W48-S 256x192, 6 encoder layers, fp32, random weights "
                                "(BASELINE configs[1]: w48_pure_en6)" if args.config == "w48_pure_en6" else args.config + " (exploratory, fp32)",
                    "images_per_gpu": IMAGES_PER_GPU, "persons_per_image": PERSONS, "crops_per_gpu_step": sum(length),

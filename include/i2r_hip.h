@@ -78,6 +78,8 @@ typedef struct i2r_conv_desc {
     int32_t ck;                    /* input channels staged in LDS per pass (0 = choose) */
     int32_t wn;                    /* waves along cout in the 4-wave workgroup: 1, 2 or 4 (0 = choose) */
     int32_t mt;                    /* 16-pixel fragments per wave, 1..4 (0 = derive from the tile) */
+    int32_t dtype;                 /* MFMA operand type: 0 fp32 (w = k4 fp32), 1 bf16, 2 f16 (w = "k8" [tap][cin32/8][cout_pad][8],
+                                      cin zero-padded to a multiple of 32; activations stay fp32 in HBM, accumulate fp32) */
 } i2r_conv_desc;
 
 int i2r_conv(const i2r_conv_desc* d, void* stream);

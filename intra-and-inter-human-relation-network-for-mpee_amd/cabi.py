@@ -28,7 +28,7 @@ class ConvDesc(C.Structure):
         ("cout", _i32), ("cout_pad", _i32), ("stride", _i32), ("iy0", _i32), ("ix0", _i32), ("ntaps", _i32),
         ("dy", _i32 * MAX_TAPS), ("dx", _i32 * MAX_TAPS),
         ("out_step", _i32), ("out_off_y", _i32), ("out_off_x", _i32), ("rep", _i32), ("relu", _i32),
-        ("tile_h", _i32), ("tile_w", _i32), ("ck", _i32), ("wn", _i32), ("mt", _i32),
+        ("tile_h", _i32), ("tile_w", _i32), ("ck", _i32), ("wn", _i32), ("mt", _i32), ("dtype", _i32),
     ]
 
 

@@ -40,6 +40,7 @@ struct ConvK {
     int ph, pw, plane;  // patch dims (pixels) and plane stride (float4 slots, multiple of 16)
     int ck;             // channels staged per pass (multiple of 16)
     int wn;             // waves along cout (1, 2, 4); waves along pixels = 4 / wn
+    int dtype;          // 0 fp32 MFMA, 1 bf16, 2 f16 (fp32 accumulate, fp32 activations in HBM)
     int dbg;            // ablation switches (env I2R_CONV_DBG; tuning only): 1 no epilogue, 2 no staging loads, 4 no weight loads
 };
 
@@ -58,6 +59,225 @@ struct ConvGroupK {
     int n;
     const int* blk_map;       // optional dispatch-order table: entry = (group << 24) | workgroup index within the group
 };
+
+// ---- epilogue (shared by the fp32 and the bf16/f16 MFMA bodies: the C/D register layout is dtype independent) ----
+// D layout: lane (li = l&15, g) holds channel n = nt*16 + li of pixels 4g + r (r = 0..3).  A 4x4 transpose inside each
+// lane quad (two DPP butterfly stages, no LDS) turns that into: lane (q = li>>2, j = li&3, g) holds channels
+// nt*16 + 4q .. +3 of pixel 4g + j, so bias / residual / store are 16-byte accesses (4x fewer VMEM instructions;
+// the scalar-store epilogue measured 24 % of the kernel).
+template <int MT, int NT>
+__device__ __forceinline__ void conv_epilogue(const ConvK& p, f32x4 (&acc)[MT][NT], int img, int oy0, int ox0, int wm, int n_base,
+                                              int li, int g, int tile_px) {
+    if ((p.dbg & 1) && acc[0][0][0] != 12345.678f) return;
+    const int j4 = li & 3, q4 = li >> 2;
+    const bool odd1 = j4 & 1, odd2 = j4 & 2;
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) {
+        const int m = (wm * MT + mt) * 16 + g * 4 + j4;
+        const int ty = m / p.tile_w, tx = m - ty * p.tile_w;
+        const int oy = oy0 + ty, ox = ox0 + tx;
+        const bool pvalid = m < tile_px && oy < p.conv_h && ox < p.conv_w;
+        const int by = oy * p.out_step + p.out_off_y, bx = ox * p.out_step + p.out_off_x;
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) {
+            f32x4 v = acc[mt][nt];
+            {   // stage 1: swap across lane pairs (j ^ 1) the elements (r ^ 1)
+                const float s0 = quad_xchg<0xB1>(odd1 ? v[0] : v[1]);
+                const float s1 = quad_xchg<0xB1>(odd1 ? v[2] : v[3]);
+                if (odd1) { v[0] = s0; v[2] = s1; } else { v[1] = s0; v[3] = s1; }
+                // stage 2: swap across lane pairs (j ^ 2) the element pairs (r ^ 2)
+                const float t0 = quad_xchg<0x4E>(odd2 ? v[0] : v[2]);
+                const float t1 = quad_xchg<0x4E>(odd2 ? v[1] : v[3]);
+                if (odd2) { v[0] = t0; v[1] = t1; } else { v[2] = t0; v[3] = t1; }
+            }
+            const int n = n_base + nt * 16 + q4 * 4;
+            if (!pvalid || n >= p.cout_pad) continue;
+            v += *reinterpret_cast<const f32x4*>(p.bias + n);
+            const bool full = n + 4 <= p.cout;  // (cout % 4 != 0 only for padded-channel layers: scalar tail below)
+            for (int ry = 0; ry < p.rep; ++ry)
+                for (int rx = 0; rx < p.rep; ++rx) {
+                    const size_t o = ((size_t)(img * p.out_h + by + ry) * p.out_w + bx + rx) * p.out_cs + n;
+                    f32x4 t = v;
+                    if (full || n + 4 <= p.out_cs) {
+                        if (p.res1) t += *reinterpret_cast<const f32x4*>(p.res1 + o);
+                        if (p.res2) t += *reinterpret_cast<const f32x4*>(p.res2 + o);
+                        if (p.relu == 1) {
+                            t[0] = fmaxf(t[0], 0.f); t[1] = fmaxf(t[1], 0.f); t[2] = fmaxf(t[2], 0.f); t[3] = fmaxf(t[3], 0.f);
+                        } else if (p.relu == 2) {  // exact-erf GELU (HRFormer MlpDWBN, hrformer.py:1197)
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) t[e] = 0.5f * t[e] * (1.f + erff(t[e] * 0.70710678118654752f));
+                        }
+                        if (p.res_post) t += *reinterpret_cast<const f32x4*>(p.res_post + o);
+                        if (!full) {  // channels >= cout are padding: keep them exactly zero
+#pragma unroll
+                            for (int e = 0; e < 4; ++e)
+                                if (n + e >= p.cout) t[e] = 0.f;
+                        }
+                        *reinterpret_cast<f32x4*>(p.out + o) = t;
+                    }
+                }
+        }
+    }
+}
+
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+
+// 8 fp32 -> 8 bf16/f16 packed in 16 bytes (v_cvt_pk_*): the low-precision MFMA operand image of one (pixel, 8-channel group)
+template <int DT>
+__device__ __forceinline__ f32x4 pack8(f32x4 a, f32x4 b) {
+    if constexpr (DT == 1) {
+        bf16x8 v;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) { v[i] = (__bf16)a[i]; v[i + 4] = (__bf16)b[i]; }
+        return __builtin_bit_cast(f32x4, v);
+    } else {
+        f16x8 v;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) { v[i] = (_Float16)a[i]; v[i + 4] = (_Float16)b[i]; }
+        return __builtin_bit_cast(f32x4, v);
+    }
+}
+template <int DT>
+__device__ __forceinline__ f32x4 mfma32_lp(f32x4 a, f32x4 b, f32x4 c) {  // D = A(16x32) B(32x16) + C, fp32 accumulate
+    if constexpr (DT == 1)
+        return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
+    else
+        return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
+}
+
+// ---- bf16 / f16 MFMA body (BASELINE configs 3-5): same tiling, patch-in-LDS and epilogue as the fp32 body, but
+//  * activations (fp32 in HBM) are converted while staging: one LDS slot = 8 channels of a patch pixel (16 B), planes
+//    lds[cg8][patch_pixel]; weights are pre-packed "k8" bf16/f16 [tap][cin32/8][cout_pad][8];
+//  * one v_mfma_f32_16x16x32_{bf16,f16} contracts 32 channels: lane (l&15, g = l>>4) supplies channels 8g..8g+7, i.e. one
+//    ds_read_b128 (A) / one 16-byte global load (B) per MFMA operand; accumulation stays fp32.
+template <int MT, int NT, int DT>
+__device__ __forceinline__ void conv_body_lp(const ConvK& p, int bid, f32x4* lds) {
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6;
+    const int WN = p.wn;
+    const int wm = wave / WN, wn = wave % WN;
+    const int li = lane & 15, g = lane >> 4;
+
+    const int cb = bid % p.n_cblk;
+    bid /= p.n_cblk;
+    const int tile_x = bid % p.tiles_x;
+    bid /= p.tiles_x;
+    const int tile_y = bid % p.tiles_y;
+    const int img = bid / p.tiles_y;
+    const int oy0 = tile_y * p.tile_h, ox0 = tile_x * p.tile_w;
+    const int py0 = oy0 * p.stride + p.iy0, px0 = ox0 * p.stride + p.ix0;
+    const int phw = p.ph * p.pw;
+
+    int goff[kMaxPP];
+    bool gval[kMaxPP];
+#pragma unroll
+    for (int j = 0; j < kMaxPP; ++j) {
+        const int pp = tid + j * 256;
+        goff[j] = 0;
+        gval[j] = false;
+        if (pp < phw) {
+            const int py = pp / p.pw, px = pp - py * p.pw;
+            const int iy = py0 + py, ix = px0 + px;
+            if (iy >= 0 && iy < p.in_h && ix >= 0 && ix < p.in_w) {
+                goff[j] = ((img * p.in_h + iy) * p.in_w + ix) * p.in_cs;
+                gval[j] = true;
+            }
+        }
+    }
+    const int npp = (phw + 255) >> 8;
+    const int tile_px = p.tile_h * p.tile_w;
+    int ppix[MT];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) {
+        int m = (wm * MT + mt) * 16 + li;
+        if (m >= tile_px) m = 0;
+        const int ty = m / p.tile_w, tx = m - ty * p.tile_w;
+        ppix[mt] = ty * p.stride * p.pw + tx * p.stride;
+    }
+    f32x4 acc[MT][NT];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    const int n_base = (cb * WN + wn) * NT * 16;
+    const int g8_real = p.cin >> 3;             // 8-channel groups that exist in the activation tensor
+    const int g8_pad = (g8_real + 3) & ~3;      // padded to whole 32-channel MFMA steps (zero weights / zero LDS beyond)
+    const f32x4* wq = reinterpret_cast<const f32x4*>(p.w) + n_base + li;  // 16-byte units: ((tap*g8_pad + cg8) * cout_pad + n)
+    const int ckg = p.ck >> 3;                  // groups staged per pass (multiple of 4)
+
+    for (int G0 = 0; G0 < g8_pad; G0 += ckg) {
+        const int ng = min(ckg, g8_pad - G0);
+        if (G0 != 0) __syncthreads();
+        for (int cg = 0; cg < ng; cg += 2) {  // two groups per trip: 4 float4 global loads in flight per patch pixel
+            f32x4 v[2][kMaxPP];
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                const bool real = G0 + cg + u < g8_real;
+#pragma unroll
+                for (int j = 0; j < kMaxPP; ++j) {
+                    v[u][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+                    if (j < npp && real && gval[j]) {
+                        const float* src = p.in + goff[j] + (G0 + cg + u) * 8;
+                        v[u][j] = pack8<DT>(*reinterpret_cast<const f32x4*>(src), *reinterpret_cast<const f32x4*>(src + 4));
+                    }
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < 2; ++u)
+#pragma unroll
+                for (int j = 0; j < kMaxPP; ++j) {
+                    const int pp = tid + j * 256;
+                    if (j < npp && pp < phw) lds[(cg + u) * p.plane + pp] = v[u][j];
+                }
+        }
+        __syncthreads();
+
+        const int ncs = ng >> 2;
+        const int nit = p.ntaps * ncs;
+        const f32x4* const wp0 = wq + (size_t)(G0 + g) * p.cout_pad;
+        const f32x4* wp = wp0;
+        const size_t inc_cs = (size_t)4 * p.cout_pad;
+        const size_t inc_tap = (size_t)(g8_pad - (ncs - 1) * 4) * p.cout_pad;
+        int cs_n = 0, tx_n = 0, ty_n = 0;
+        auto fetch = [&](f32x4(&a)[MT], f32x4(&b)[NT]) {
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) b[nt] = wp[nt * 16];
+            const int abase = (cs_n * 4 + g) * p.plane + ty_n * p.pw + tx_n;
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) a[mt] = lds[abase + ppix[mt]];
+            if (++cs_n == ncs) {
+                cs_n = 0;
+                wp += inc_tap;
+                if (++tx_n == p.tap_kw) {
+                    tx_n = 0;
+                    if (++ty_n == p.tap_kh) { ty_n = 0; wp = wp0; }
+                }
+            } else {
+                wp += inc_cs;
+            }
+        };
+        auto fma_step = [&](const f32x4(&a)[MT], const f32x4(&b)[NT]) {
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = mfma32_lp<DT>(a[mt], b[nt], acc[mt][nt]);
+        };
+        f32x4 a0[MT], a1[MT], b0[NT], b1[NT];
+        fetch(a0, b0);
+        int it = 0;
+        for (; it + 2 <= nit; it += 2) {
+            fetch(a1, b1);
+            fma_step(a0, b0);
+            fetch(a0, b0);
+            fma_step(a1, b1);
+        }
+        if (it < nit) fma_step(a0, b0);
+    }
+    conv_epilogue<MT, NT>(p, acc, img, oy0, ox0, wm, n_base, li, g, tile_px);
+}
 
 template <int MT, int NT, int CAP, int PF>
 __device__ __forceinline__ void conv_body(const ConvK& p, int bid, f32x4* lds) {
@@ -250,61 +470,7 @@ __device__ __forceinline__ void conv_body(const ConvK& p, int bid, f32x4* lds) {
         }
     }
 
-    // ---- epilogue ----
-    // D layout: lane (li = l&15, g) holds channel n = nt*16 + li of pixels 4g + r (r = 0..3).  A 4x4 transpose inside each
-    // lane quad (two DPP butterfly stages, no LDS) turns that into: lane (q = li>>2, j = li&3, g) holds channels
-    // nt*16 + 4q .. +3 of pixel 4g + j, so bias / residual / store are 16-byte accesses (4x fewer VMEM instructions;
-    // the scalar-store epilogue measured 24 % of the kernel).
-    if ((p.dbg & 1) && acc[0][0][0] != 12345.678f) return;
-    const int j4 = li & 3, q4 = li >> 2;
-    const bool odd1 = j4 & 1, odd2 = j4 & 2;
-#pragma unroll
-    for (int mt = 0; mt < MT; ++mt) {
-        const int m = (wm * MT + mt) * 16 + g * 4 + j4;
-        const int ty = m / p.tile_w, tx = m - ty * p.tile_w;
-        const int oy = oy0 + ty, ox = ox0 + tx;
-        const bool pvalid = m < tile_px && oy < p.conv_h && ox < p.conv_w;
-        const int by = oy * p.out_step + p.out_off_y, bx = ox * p.out_step + p.out_off_x;
-#pragma unroll
-        for (int nt = 0; nt < NT; ++nt) {
-            f32x4 v = acc[mt][nt];
-            {   // stage 1: swap across lane pairs (j ^ 1) the elements (r ^ 1)
-                const float s0 = quad_xchg<0xB1>(odd1 ? v[0] : v[1]);
-                const float s1 = quad_xchg<0xB1>(odd1 ? v[2] : v[3]);
-                if (odd1) { v[0] = s0; v[2] = s1; } else { v[1] = s0; v[3] = s1; }
-                // stage 2: swap across lane pairs (j ^ 2) the element pairs (r ^ 2)
-                const float t0 = quad_xchg<0x4E>(odd2 ? v[0] : v[2]);
-                const float t1 = quad_xchg<0x4E>(odd2 ? v[1] : v[3]);
-                if (odd2) { v[0] = t0; v[1] = t1; } else { v[2] = t0; v[3] = t1; }
-            }
-            const int n = n_base + nt * 16 + q4 * 4;
-            if (!pvalid || n >= p.cout_pad) continue;
-            v += *reinterpret_cast<const f32x4*>(p.bias + n);
-            const bool full = n + 4 <= p.cout;  // (cout % 4 != 0 only for padded-channel layers: scalar tail below)
-            for (int ry = 0; ry < p.rep; ++ry)
-                for (int rx = 0; rx < p.rep; ++rx) {
-                    const size_t o = ((size_t)(img * p.out_h + by + ry) * p.out_w + bx + rx) * p.out_cs + n;
-                    f32x4 t = v;
-                    if (full || n + 4 <= p.out_cs) {
-                        if (p.res1) t += *reinterpret_cast<const f32x4*>(p.res1 + o);
-                        if (p.res2) t += *reinterpret_cast<const f32x4*>(p.res2 + o);
-                        if (p.relu == 1) {
-                            t[0] = fmaxf(t[0], 0.f); t[1] = fmaxf(t[1], 0.f); t[2] = fmaxf(t[2], 0.f); t[3] = fmaxf(t[3], 0.f);
-                        } else if (p.relu == 2) {  // exact-erf GELU (HRFormer MlpDWBN, hrformer.py:1197)
-#pragma unroll
-                            for (int e = 0; e < 4; ++e) t[e] = 0.5f * t[e] * (1.f + erff(t[e] * 0.70710678118654752f));
-                        }
-                        if (p.res_post) t += *reinterpret_cast<const f32x4*>(p.res_post + o);
-                        if (!full) {  // channels >= cout are padding: keep them exactly zero
-#pragma unroll
-                            for (int e = 0; e < 4; ++e)
-                                if (n + e >= p.cout) t[e] = 0.f;
-                        }
-                        *reinterpret_cast<f32x4*>(p.out + o) = t;
-                    }
-                }
-        }
-    }
+    conv_epilogue<MT, NT>(p, acc, img, oy0, ox0, wm, n_base, li, g, tile_px);
 }
 
 // One launch = up to kMaxGroups independent convolutions that share (MT, NT): "horizontal fusion" of the
@@ -327,7 +493,49 @@ __global__ __launch_bounds__(256) void conv_igemm_f32(const ConvGroupK grp) {
     conv_body<MT, NT, CAP, PF>(grp.g[gi], bid - start, lds);
 }
 
+template <int MT, int NT, int DT>
+__global__ __launch_bounds__(256) void conv_igemm_lp(const ConvGroupK grp) {
+    extern __shared__ __attribute__((aligned(16))) f32x4 lds[];
+    int bid = blockIdx.x, gi = 0, start = 0;
+    if (grp.blk_map) {
+        const int v = grp.blk_map[bid];
+        gi = v >> 24;
+        bid = v & 0xFFFFFF;
+    } else {
+#pragma unroll
+        for (int i = 0; i < kMaxGroups - 1; ++i)
+            if (i + 1 < grp.n && bid >= grp.blk_end[i]) { gi = i + 1; start = grp.blk_end[i]; }
+    }
+    conv_body_lp<MT, NT, DT>(grp.g[gi], bid - start, lds);
+}
+
 typedef void (*conv_fn)(const ConvGroupK);
+
+template <int NT, int DT>
+conv_fn pick_lp_mt(int mt) {
+    switch (mt) {
+        case 1: return conv_igemm_lp<1, NT, DT>;
+        case 2: return conv_igemm_lp<2, NT, DT>;
+        case 3: return conv_igemm_lp<3, NT, DT>;
+        case 4: return conv_igemm_lp<4, NT, DT>;
+    }
+    return nullptr;
+}
+template <int DT>
+conv_fn pick_lp_nt(int nt, int mt) {
+    switch (nt) {
+        case 3: return pick_lp_mt<3, DT>(mt);
+        case 4: return pick_lp_mt<4, DT>(mt);
+        case 5: return pick_lp_mt<5, DT>(mt);
+    }
+    return nullptr;
+}
+conv_fn pick_lp(int nt, int mt, int dtype) {
+    if (dtype == 1) return pick_lp_nt<1>(nt, mt);
+    if (dtype == 2) return pick_lp_nt<2>(nt, mt);
+    return nullptr;
+}
+
 
 template <int NT, int CAP, int PF>
 conv_fn pick_mt(int mt) {
@@ -373,6 +581,7 @@ static int prepare(const i2r_conv_desc* d, int force_mt, int force_cap, int forc
     I2R_CHECK_ARG(d->cout > 0 && d->cout_pad % 16 == 0 && d->cout <= d->cout_pad && d->cout <= d->out_cs && d->out_cs % 4 == 0,
                   "i2r_conv: cout=%d cout_pad=%d out_cs=%d", d->cout, d->cout_pad, d->out_cs);
     I2R_CHECK_ARG(d->stride == 1 || d->stride == 2, "i2r_conv: stride %d", d->stride);
+    I2R_CHECK_ARG(d->dtype >= 0 && d->dtype <= 2 && (d->dtype == 0 || d->in2 == nullptr), "i2r_conv: dtype %d", d->dtype);
     I2R_CHECK_ARG(d->ntaps >= 1 && d->ntaps <= I2R_MAX_TAPS, "i2r_conv: ntaps %d", d->ntaps);
     I2R_CHECK_ARG(d->rep >= 1 && d->out_step >= 1, "i2r_conv: rep/out_step");
     I2R_CHECK_ARG((d->conv_h - 1) * d->out_step + d->out_off_y + d->rep <= d->out_h &&
@@ -438,7 +647,7 @@ static int prepare(const i2r_conv_desc* d, int force_mt, int force_cap, int forc
     const int npp = cdiv(k.ph * k.pw, 256);
     static const int pf_env = getenv("I2R_CONV_PF") ? atoi(getenv("I2R_CONV_PF")) : 1;  // tuning switch: 0 disables prefetch
     const int cin_g = d->cin / 4;
-    int pf = (pf_env && d->ck == 0 && npp <= 2 && cin_g % 4 == 0) ? npp : 0;
+    int pf = (pf_env && d->dtype == 0 && d->ck == 0 && npp <= 2 && cin_g % 4 == 0) ? npp : 0;
     int cap = 4;
     if (force_pf >= 0) {
         I2R_CHECK_ARG(force_pf == 0 || (npp <= force_pf && d->ck == 0 && cin_g % 4 == 0), "i2r_conv: grouped members disagree on the staging mode");
@@ -454,6 +663,15 @@ static int prepare(const i2r_conv_desc* d, int force_mt, int force_cap, int forc
         cap = force_pf >= 0 ? force_cap : (ckg > 4 ? 12 : 4);
         ck = ckg * 4;
         lds_bytes = (size_t)2 * ckg * k.plane * 16;
+    } else if (d->dtype != 0) {
+        // bf16/f16 body: LDS slots hold 8 channels; stage whole 32-channel steps, <= ~24 KB per pass
+        const int g8_pad = (d->cin / 8 + 3) / 4 * 4;
+        int fit = (24 * 1024 / (k.plane * 16)) / 4 * 4;
+        if (fit < 4) fit = 4;
+        const int nchunk = cdiv(g8_pad, fit);
+        const int ckg = cdiv(cdiv(g8_pad, nchunk), 4) * 4;
+        ck = ckg * 8;
+        lds_bytes = (size_t)ckg * k.plane * 16;
     } else {
         if (ck == 0) {
             // small LDS footprint (<= ~20 KB) keeps >= 4 workgroups per CU resident; equal-sized chunks avoid a short tail pass
@@ -469,6 +687,7 @@ static int prepare(const i2r_conv_desc* d, int force_mt, int force_cap, int forc
     k.ck = ck;
     I2R_CHECK_ARG(lds_bytes <= 160 * 1024, "i2r_conv: LDS %zu B", lds_bytes);
     k.wn = wn;
+    k.dtype = d->dtype;
     {
         static const int dbg = getenv("I2R_CONV_DBG") ? atoi(getenv("I2R_CONV_DBG")) : 0;
         k.dbg = dbg;
@@ -513,6 +732,7 @@ static int resolve(const i2r_conv_desc* const* descs, int32_t n, ConvGroupK& grp
         if (rc) return rc;
         if (i == 0) { nt0 = nt; mt0 = mt; pf0 = pf; cap0 = cap; }
         I2R_CHECK_ARG(nt == nt0 && mt == mt0, "i2r_conv_grouped: descriptor %d has fragment blocking (%d,%d) != (%d,%d)", i, mt, nt, mt0, nt0);
+        I2R_CHECK_ARG(descs[i]->dtype == descs[0]->dtype, "i2r_conv_grouped: members mix compute dtypes");
         if (lds > lds_max) lds_max = lds;
         total += nblk;
         grp.blk_end[i] = (int)total;
@@ -534,8 +754,8 @@ extern "C" int i2r_conv_grouped(const i2r_conv_desc* const* descs, int32_t n, co
     if (rc) return rc;
     grp.blk_map = block_map;
     I2R_CHECK_ARG(block_map == nullptr || map_len == (int32_t)total, "i2r_conv_grouped: block_map has %d entries, grid has %lld", map_len, total);
-    conv_fn fn = pick_kernel(nt0, mt0, cap0, pf0);
-    I2R_CHECK_ARG(fn != nullptr, "i2r_conv: no kernel for nt=%d mt=%d cap=%d pf=%d", nt0, mt0, cap0, pf0);
+    conv_fn fn = descs[0]->dtype ? pick_lp(nt0, mt0, descs[0]->dtype) : pick_kernel(nt0, mt0, cap0, pf0);
+    I2R_CHECK_ARG(fn != nullptr, "i2r_conv: no kernel for nt=%d mt=%d cap=%d pf=%d dtype=%d", nt0, mt0, cap0, pf0, descs[0]->dtype);
     if (lds_max > 64 * 1024)
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_max);
     hipLaunchKernelGGL(fn, dim3((unsigned)total), dim3(256), lds_max, (hipStream_t)stream, grp);
@@ -553,6 +773,9 @@ extern "C" int i2r_conv_kernel_name(const i2r_conv_desc* const* descs, int32_t n
     int rc = resolve(descs, n, grp, &nt0, &mt0, &cap0, &pf0, &lds_max, &total);
     if (rc) return rc;
     I2R_CHECK_ARG(buf && buflen > 0, "i2r_conv_kernel_name: buffer");
-    snprintf(buf, (size_t)buflen, "conv_igemm_f32<%d, %d, %d, %d>", mt0, nt0, cap0, pf0);
+    if (descs[0]->dtype)
+        snprintf(buf, (size_t)buflen, "conv_igemm_lp<%d, %d, %d>", mt0, nt0, descs[0]->dtype);
+    else
+        snprintf(buf, (size_t)buflen, "conv_igemm_f32<%d, %d, %d, %d>", mt0, nt0, cap0, pf0);
     return I2R_OK;
 }

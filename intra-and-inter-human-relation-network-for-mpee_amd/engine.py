@@ -49,20 +49,43 @@ def pack_k4(w_taps, cin_pad, cout_pad):
     return full.view(nt, cin_pad // 4, 4, cout_pad).permute(0, 1, 3, 2).contiguous().float()
 
 
-class PackedConv:
-    __slots__ = ("w", "bias", "cin", "cin_pad", "cout", "cout_pad", "taps", "iy0", "ix0", "stride", "ksize")
+PRECISIONS = {"fp32": 0, "bf16": 1, "fp16": 2}
 
-    def __init__(self, w, bias, cin, cout, taps, iy0, ix0, stride, ksize):
+
+def pack_k8(w_taps, cin_pad, cout_pad, tdtype):
+    """w_taps [ntaps, cin, cout] -> 16-bit [ntaps, g8_pad, cout_pad, 8] (cin zero-padded to whole 32-channel MFMA steps)."""
+    nt, cin, cout = w_taps.shape
+    g8_pad = (cin_pad // 8 + 3) // 4 * 4
+    full = torch.zeros(nt, g8_pad * 8, cout_pad, dtype=torch.float64)
+    full[:, :cin, :cout] = w_taps
+    return full.float().to(tdtype).view(nt, g8_pad, 8, cout_pad).permute(0, 1, 3, 2).contiguous()
+
+
+class PackedConv:
+    __slots__ = ("w", "bias", "cin", "cin_pad", "cout", "cout_pad", "taps", "iy0", "ix0", "stride", "ksize", "dtype")
+
+    def __init__(self, w, bias, cin, cout, taps, iy0, ix0, stride, ksize, cin_pad=None, dtype=0):
         self.w, self.bias = w, bias
-        self.cin, self.cin_pad = cin, w.shape[1] * 4
+        self.cin, self.cin_pad = cin, (w.shape[1] * 4 if cin_pad is None else cin_pad)
         self.cout, self.cout_pad = cout, w.shape[2]
         self.taps, self.iy0, self.ix0, self.stride, self.ksize = taps, iy0, ix0, stride, ksize
+        self.dtype = dtype
 
 
 class Packer:
-    def __init__(self, sd, device):
+    def __init__(self, sd, device, precision="fp32"):
         self.sd = {k: v.detach().to("cpu") for k, v in sd.items()}
         self.device = device
+        self.dtype = PRECISIONS[precision]  # MFMA operand type of the conv kernels (accumulation / storage stay fp32)
+
+    def _pc(self, w_taps, bias, cin, cout, taps, iy0, ix0, stride, ksize):
+        """PackedConv in this packer's MFMA operand type."""
+        cin_pad, cout_pad = _r16(cin), _r16(cout)
+        if self.dtype == 0:
+            w = pack_k4(w_taps, cin_pad, cout_pad)
+        else:
+            w = pack_k8(w_taps, cin_pad, cout_pad, torch.bfloat16 if self.dtype == 1 else torch.float16)
+        return PackedConv(self._dev(w), bias, cin, cout, taps, iy0, ix0, stride, ksize, cin_pad=cin_pad, dtype=self.dtype)
 
     def _bn(self, key):
         if key is None:
@@ -84,8 +107,7 @@ class Packer:
         bias = torch.zeros(cout_pad, dtype=torch.float64)
         bias[:cout] = bf
         pad = kh // 2
-        return PackedConv(self._dev(pack_k4(w_taps, _r16(cin), cout_pad)), self._dev(bias.float()), cin, cout, taps,
-                          -pad, -pad, stride, kh)
+        return self._pc(w_taps, self._dev(bias.float()), cin, cout, taps, -pad, -pad, stride, kh)
 
     def linear_as_conv(self, w, b):
         """[out, in] matrix + bias -> 1x1 PackedConv."""
@@ -93,8 +115,7 @@ class Packer:
         cout_pad = _r16(cout)
         bias = torch.zeros(cout_pad, dtype=torch.float64)
         bias[:cout] = b.double()
-        return PackedConv(self._dev(pack_k4(w.double().t().reshape(1, cin, cout), _r16(cin), cout_pad)),
-                          self._dev(bias.float()), cin, cout, [(0, 0)], 0, 0, 1, 1)
+        return self._pc(w.double().t().reshape(1, cin, cout), self._dev(bias.float()), cin, cout, [(0, 0)], 0, 0, 1, 1)
 
     def deconv(self, deconv_key, bn_key, eps=1e-5):
         """ConvTranspose2d(k=4, s=2, p=1) [Cin, Cout, 4, 4] (+BN) -> {(py,px): PackedConv with 2x2 taps}.
@@ -120,8 +141,7 @@ class Packer:
                         taps.append((dy, dx))
                         mats.append(wf[:, :, ky, kx].t())  # [Cin, Cout]
                 w_taps = torch.stack(mats, 0)
-                out[(py, px)] = PackedConv(self._dev(pack_k4(w_taps, _r16(cin), cout_pad)), bias, cin, cout, taps,
-                                           -1 if py == 0 else 0, -1 if px == 0 else 0, 1, 2)
+                out[(py, px)] = self._pc(w_taps, bias, cin, cout, taps, -1 if py == 0 else 0, -1 if px == 0 else 0, 1, 2)
         return out
 
     def stem(self, conv_key, bn_key, eps=1e-5):
@@ -356,6 +376,7 @@ class Program:
         max_d = max(max(t) for t in pc.taps)
         th, tw, mt = choose_tile(conv_h, conv_w, 4 // wn, pc.stride, max_d, x.n, n_cblk)
         d.tile_h, d.tile_w, d.mt, d.wn, d.ck = th, tw, mt, wn, 0
+        d.dtype = pc.dtype
         if group is not None:
             group.append((d, (conv_h, conv_w, 4 // wn, pc.stride, max_d, x.n, n_cblk), nt))
         else:
@@ -830,8 +851,9 @@ class HRFormerB:
 class Engine:
     """Packed model + program cache for one device. Built by models/_base.I2RModule."""
 
-    def __init__(self, cfg, state_dict, device):
+    def __init__(self, cfg, state_dict, device, precision="fp32"):
         cabi.lib()  # fail loudly here when the HIP library is absent
+        self.precision = precision
         self.cfg = cfg
         self.device = torch.device(device)
         assert self.device.type == "cuda", "the product path runs on the GPU only (device=%s)" % (device,)
@@ -841,7 +863,7 @@ class Engine:
         self.side_streams = [torch.cuda.Stream(device=self.device) for _ in range(3)]
         M = cfg["MODEL"]
         self.name = M["NAME"]
-        pk = Packer(state_dict, self.device)
+        pk = Packer(state_dict, self.device, precision)
         d, dff = M["DIM_MODEL"], M["DIM_FEEDFORWARD"]
         assert M["N_HEAD"] == 1, "the shipped configs use single-head attention (N_HEAD=1)"
         assert not M["NORMALIZE_BEFORE"], "NORMALIZE_BEFORE is false in every shipped config (post-norm only)"

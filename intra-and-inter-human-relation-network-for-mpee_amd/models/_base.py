@@ -34,6 +34,7 @@ class I2RModule(nn.Module):
         self.cfg = cfg
         self._engine = None
         self._engine_key = None
+        self.precision = "fp32"  # MFMA operand type of the conv kernels: 'fp32' (reference parity), 'bf16', 'fp16'
         spec = arch.param_spec(cfg) if spec is None else spec
         for key, shape, dtype in spec:
             parts = key.split(".")
@@ -63,6 +64,15 @@ class I2RModule(nn.Module):
                     p.data.copy_(sine_position_embedding(hh, ww, p.shape[2]))
 
     # ---- engine lifecycle ----
+    def set_precision(self, precision):
+        """'fp32' (default: exact-fp32 MFMA, the 1e-3 parity mode), 'bf16' or 'fp16' (BASELINE configs 3-5: 16-bit MFMA
+        operands, fp32 accumulation and fp32 activations in HBM)."""
+        from ..engine import PRECISIONS
+        assert precision in PRECISIONS, precision
+        self.precision = precision
+        self._invalidate()
+        return self
+
     def _invalidate(self):
         self._engine = None
 
@@ -84,7 +94,7 @@ class I2RModule(nn.Module):
                 "(model.cuda()) -- there is no CPU execution path in the product (the CPU oracle lives in oracle/).")
         if self._engine is None or self._engine_key != dev:
             from ..engine import Engine
-            self._engine = Engine(self.cfg, self.state_dict(), dev)
+            self._engine = Engine(self.cfg, self.state_dict(), dev, self.precision)
             self._engine_key = dev
         return self._engine
 

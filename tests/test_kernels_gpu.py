@@ -294,3 +294,29 @@ def test_conv_gelu_and_post_residual():
     run(P)
     assert (from_act(out) - ref).abs().max().item() < 1e-4
     assert out.t.view(-1, out.cs)[:, 78:].abs().max().item() == 0.0
+
+
+# ---------------------------------------------------------------------------------------------------------
+# bf16 / f16 MFMA conv variant (BASELINE configs 3-5): 16-bit operands, fp32 accumulate, fp32 activations
+# ---------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("precision,tdt", [("bf16", torch.bfloat16), ("fp16", torch.float16)])
+@pytest.mark.parametrize("cin,cout,k,stride,h,w", [(48, 48, 3, 1, 64, 48), (96, 192, 3, 2, 32, 24), (256, 64, 1, 1, 16, 12),
+                                                   (78, 78, 3, 1, 16, 12), (192, 96, 1, 1, 16, 12)])
+def test_conv_low_precision(precision, tdt, cin, cout, k, stride, h, w):
+    """Against a reference that rounds activations and (BN-folded) weights to the 16-bit type and accumulates in fp32:
+    that is exactly what the MFMA computes, so the tolerance is fp32-accumulation-order only."""
+    tag = "lp%s_%d_%d_%d" % (precision, cin, cout, k)
+    sd = {"c.weight": _rand((cout, cin, k, k), "w" + tag, (6.0 / (cin * k * k)) ** 0.5)}
+    x = _rand((2, cin, h, w), "x" + tag)
+    res = _rand((2, cout, (h - 1) // stride + 1, (w - 1) // stride + 1), "r" + tag)
+    xq, wq = x.to(tdt).float(), sd["c.weight"].to(tdt).float()
+    ref = F.relu(F.conv2d(xq, wq, None, stride=stride, padding=k // 2) + res)
+    P = engine.Program(torch.device(DEV))
+    pc = engine.Packer(sd, torch.device(DEV), precision).conv("c", None, stride=stride)
+    out = P.conv(to_act(P, x), pc, relu=True, res1=to_act(P, res))
+    run(P)
+    err = (from_act(out) - ref).abs().max().item()
+    assert err < 5e-4, "%s conv max-abs %.3e" % (precision, err)
+    # and it is a 16-bit computation: close to, but not the same as, the fp32 result
+    exact = F.relu(F.conv2d(x, sd["c.weight"], None, stride=stride, padding=k // 2) + res)
+    assert (from_act(out) - exact).abs().max().item() < (0.05 if precision == "bf16" else 0.01)

@@ -81,3 +81,31 @@ def test_full_size_batch_properties():
     assert (one - y[8:12]).abs().max().item() < 1e-4
     ref = i2r_cpu.forward(sd, cfg, x[8:12], m[8:12], [4])
     assert (one - ref).abs().max().item() < TOL
+
+
+# 16-bit MFMA modes (BASELINE configs 3-5).  BASELINE defines 1e-3 for fp32 only; the tolerances stated here are relative to
+# the fp32 CPU oracle on the same inputs:  bf16: max-abs <= 5 % of max|ref| and rms error <= 2 % of rms(ref);
+#                                          fp16: max-abs <= 1 % of max|ref| and rms error <= 0.3 % of rms(ref)
+# (measured on MI355X, tools/lp_error.py: bf16 0.4-3.1 % / 0.4-1.1 %, fp16 0.05-0.4 % / 0.05-0.14 %).
+LP_TOL = {"bf16": (5e-2, 2e-2), "fp16": (1e-2, 3e-3)}
+
+
+@pytest.mark.parametrize("tag,precision", [("tph_l21", "bf16"), ("hrt_l21", "bf16"), ("hrt288_l2", "fp16"), ("w48_l213", "bf16")])
+def test_low_precision_modes_within_stated_tolerance(tag, precision):
+    cfg, sd, x, m, length, g = setup(tag)
+    net = _net(cfg, sd, CASES[tag])
+    try:
+        y = net.set_precision(precision)(x.cuda(), m.cuda(), length)
+        torch.cuda.synchronize()
+    finally:
+        net.set_precision("fp32")
+    outs = y if isinstance(y, dict) else {"multi": y}
+    zs = i2r_cpu.forward(sd, cfg, x, m, length)
+    zs = zs if isinstance(zs, dict) else {"multi": zs}
+    tol_max, tol_rms = LP_TOL[precision]
+    for k, t in outs.items():
+        d = t.cpu() - zs[k]
+        assert torch.isfinite(t).all()
+        assert d.abs().max().item() <= tol_max * zs[k].abs().max().item(), (tag, k, d.abs().max().item())
+        assert d.pow(2).mean().sqrt().item() <= tol_rms * zs[k].pow(2).mean().sqrt().item()
+        assert d.abs().max().item() > 1e-4  # it really is the 16-bit path
