@@ -203,6 +203,13 @@ typedef struct i2r_encoder_desc {
     int32_t pos_period;    /* 0: pos row = token; >0: pos row = token % pos_period */
     int32_t n_qtiles32;    /* sum over groups of ceil(group_len / 32): the query-tile count (host knows lengths) */
     float ln_eps;
+    /* 16-bit MFMA mode (dtype 1 bf16 / 2 f16; cs == 96, group offsets multiples of 32): q-proj, QK^T, PV, out-proj and FFN run
+     * on v_mfma_f32_16x16x32 with fp32 accumulation; kbuf / vbuf then hold 16-bit data (same byte budget is enough).
+     * w_*_lp: the matrices above as 16-bit [out][in] with the columns of every 32-block permuted to
+     * new position 8g + 4*half + r  <-  column 32c + 16*half + 4g + r  (g < 4, half < 2, r < 4). */
+    int32_t dtype;
+    int32_t n_qtiles16, n_qtiles64;   /* like n_qtiles32 for 16- and 64-query tiles */
+    const void* w_in_lp; const void* w_out_lp; const void* w1_lp; const void* w2_lp;
 } i2r_encoder_desc;
 
 int i2r_encoder_kv(const i2r_encoder_desc* d, void* stream);

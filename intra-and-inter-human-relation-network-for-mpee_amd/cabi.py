@@ -38,7 +38,8 @@ class EncoderDesc(C.Structure):
         ("w_in", _fp), ("b_in", _fp), ("w_out", _fp), ("b_out", _fp), ("ln1_w", _fp), ("ln1_b", _fp),
         ("w1", _fp), ("b1", _fp), ("w2", _fp), ("b2", _fp), ("ln2_w", _fp), ("ln2_b", _fp),
         ("n_tok", _i32), ("n_grp", _i32), ("d", _i32), ("cs", _i32), ("dff_pad", _i32), ("pos_period", _i32),
-        ("n_qtiles32", _i32), ("ln_eps", C.c_float),
+        ("n_qtiles32", _i32), ("ln_eps", C.c_float), ("dtype", _i32), ("n_qtiles16", _i32), ("n_qtiles64", _i32),
+        ("w_in_lp", _fp), ("w_out_lp", _fp), ("w1_lp", _fp), ("w2_lp", _fp),
     ]
 
 

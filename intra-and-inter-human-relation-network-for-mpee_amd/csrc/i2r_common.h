@@ -14,6 +14,33 @@ __device__ __forceinline__ f32x4 mfma16(float a, float b, f32x4 c) {
     return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
 }
 
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+
+// 8 fp32 -> 8 bf16/f16 packed in 16 bytes (v_cvt_pk_*): the low-precision MFMA operand image of one (pixel, 8-channel group)
+template <int DT>
+__device__ __forceinline__ f32x4 pack8(f32x4 a, f32x4 b) {
+    if constexpr (DT == 1) {
+        bf16x8 v;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) { v[i] = (__bf16)a[i]; v[i + 4] = (__bf16)b[i]; }
+        return __builtin_bit_cast(f32x4, v);
+    } else {
+        f16x8 v;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) { v[i] = (_Float16)a[i]; v[i + 4] = (_Float16)b[i]; }
+        return __builtin_bit_cast(f32x4, v);
+    }
+}
+template <int DT>
+__device__ __forceinline__ f32x4 mfma32_lp(f32x4 a, f32x4 b, f32x4 c) {  // D = A(16x32) B(32x16) + C, fp32 accumulate
+    if constexpr (DT == 1)
+        return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
+    else
+        return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
+}
+
+
 void i2r_set_error(const char* fmt, ...);
 
 #define I2R_CHECK_ARG(cond, ...)            \

@@ -29,6 +29,8 @@ struct EncK {
     const float* ln2_w; const float* ln2_b;
     int n_tok, n_tok_pad, n_grp, d, cs, dff_pad, pos_period;
     float ln_eps, qscale;
+    // 16-bit MFMA mode: weights as bf16/f16 [out][in] with the columns of every 32-block permuted to the MFMA operand order
+    const void* w_in_lp; const void* w_out_lp; const void* w1_lp; const void* w2_lp;
 };
 
 __device__ __forceinline__ f32x4 ld4(const float* p) { return *reinterpret_cast<const f32x4*>(p); }
@@ -276,6 +278,266 @@ __global__ __launch_bounds__(NW * 64) void enc_layer_k(const EncK p) {
     }
 }
 
+// =====================================================================================================================
+// 16-bit MFMA variant (BASELINE config 3: bf16 compute, fp32 accumulate; f16 for config 5)
+// ---------------------------------------------------------------------------------------------------------------------
+// v_mfma_f32_16x16x32_{bf16,f16} contracts 32 k-values: lane (l&15, g = l>>4) supplies 8 of them.  The fp32 D layout of the
+// previous GEMM gives a lane the features {16nt + 4g + r}; two neighbouring fragments (nt = 2c, 2c+1) packed together are
+// 8 features of the 32-block c -- a PERMUTATION of the block (new position 8g + 4*half + r  <-  feature 32c + 16*half + 4g + r)
+// that is applied consistently to both MFMA operands: the host permutes the weight columns the same way
+// (engine.Packer.encoder_layer_lp), enc_kv_lp_k writes K rows and V^T key-blocks in that order.  So the register-to-register
+// chaining of the fp32 kernel carries over with a pack8() between GEMMs.
+__device__ __forceinline__ f32x4 ld16(const void* base, size_t elem_off) {  // 16 bytes = 8 16-bit elements at element offset
+    return *reinterpret_cast<const f32x4*>(reinterpret_cast<const unsigned short*>(base) + elem_off);
+}
+
+// K (permuted rows, 16-bit) and V^T (permuted 32-key blocks, 16-bit); projections themselves stay on the exact-fp32 MFMA
+template <int DC, int DT>
+__global__ __launch_bounds__(64) void enc_kv_lp_k(const EncK p) {
+    const int lane = threadIdx.x, li = lane & 15, g = lane >> 4;
+    const int cs = DC * 16;
+    const int t0 = blockIdx.x * 32;
+    f32x4 xs[2][DC], xq[2][DC];
+    int tok[2];
+#pragma unroll
+    for (int tf = 0; tf < 2; ++tf) {
+        tok[tf] = t0 + tf * 16 + li;
+        const int row = min(tok[tf], p.n_tok - 1);
+        const int prow = p.pos_period > 0 ? row % p.pos_period : row;
+#pragma unroll
+        for (int c = 0; c < DC; ++c) {
+            xs[tf][c] = ld4(p.src + (size_t)row * cs + 16 * c + 4 * g);
+            xq[tf][c] = xs[tf][c];
+            if (p.pos) xq[tf][c] += ld4(p.pos + (size_t)prow * cs + 16 * c + 4 * g);
+        }
+    }
+    unsigned short* k16 = reinterpret_cast<unsigned short*>(p.kbuf);
+    unsigned short* v16 = reinterpret_cast<unsigned short*>(p.vbuf);
+#pragma unroll
+    for (int c = 0; c < DC / 2; ++c) {
+        f32x4 ak[2][2], av[2][2];  // [half][tf]
+#pragma unroll
+        for (int half = 0; half < 2; ++half) {
+            const int nt = 2 * c + half;
+            ak[half][0] = ak[half][1] = ld4(p.b_in + cs + 16 * nt + 4 * g);
+            av[half][0] = av[half][1] = ld4(p.b_in + 2 * cs + 16 * nt + 4 * g);
+#pragma unroll
+            for (int cc = 0; cc < DC; ++cc) {
+                const f32x4 wk = ld4(p.w_in + (size_t)(cs + 16 * nt + li) * cs + 16 * cc + 4 * g);
+                const f32x4 wv = ld4(p.w_in + (size_t)(2 * cs + 16 * nt + li) * cs + 16 * cc + 4 * g);
+#pragma unroll
+                for (int s = 0; s < 4; ++s)
+#pragma unroll
+                    for (int tf = 0; tf < 2; ++tf) {
+                        ak[half][tf] = mfma16(wk[s], xq[tf][cc][s], ak[half][tf]);
+                        av[half][tf] = mfma16(wv[s], xs[tf][cc][s], av[half][tf]);
+                    }
+            }
+        }
+#pragma unroll
+        for (int tf = 0; tf < 2; ++tf) {
+            if (tok[tf] >= p.n_tok) continue;
+            // K row: 8 consecutive 16-bit elements = this lane's slice of 32-block c
+            *reinterpret_cast<f32x4*>(k16 + (size_t)tok[tf] * cs + c * 32 + g * 8) = pack8<DT>(ak[0][tf], ak[1][tf]);
+            // V^T: element (feature, key) lives at  feature * n_tok_pad + 32*(key/32) + 8*((key%16)/4) + 4*((key%32)/16) + key%4
+            const int t = tok[tf];
+            const size_t kpos = (size_t)(t & ~31) + 8 * ((t & 15) >> 2) + 4 * ((t & 31) >> 4) + (t & 3);
+            const f32x4 pv = pack8<DT>(av[0][tf], av[1][tf]);  // elements 0-3: features 32c+4g+r, 4-7: 32c+16+4g+r
+            const unsigned short* e = reinterpret_cast<const unsigned short*>(&pv);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                v16[(size_t)(32 * c + 4 * g + r) * p.n_tok_pad + kpos] = e[r];
+                v16[(size_t)(32 * c + 16 + 4 * g + r) * p.n_tok_pad + kpos] = e[4 + r];
+            }
+        }
+    }
+}
+
+// Y^T[NF frags] = W16[NF*16, KC*32] X^T + b for QF token fragments at once (the weight rows are fetched once per fragment row)
+template <int NF, int KC, int QF, int DT, typename Epi>
+__device__ __forceinline__ void gemm_T_lp(const void* W, const float* bias, int ld, const f32x4 (&x)[QF][KC], int li, int g, Epi epi) {
+    f32x4 w0[KC], w1[KC];
+    auto loadw = [&](f32x4(&w)[KC], int nt) {
+#pragma unroll
+        for (int c = 0; c < KC; ++c) w[c] = ld16(W, (size_t)(16 * nt + li) * ld + c * 32 + g * 8);
+    };
+    auto mm = [&](const f32x4(&w)[KC], int nt) {
+        const f32x4 b = ld4(bias + 16 * nt + 4 * g);
+#pragma unroll
+        for (int qf = 0; qf < QF; ++qf) {
+            f32x4 acc = b;
+#pragma unroll
+            for (int c = 0; c < KC; ++c) acc = mfma32_lp<DT>(w[c], x[qf][c], acc);
+            epi(nt, qf, acc);
+        }
+    };
+    loadw(w0, 0);
+#pragma unroll
+    for (int nt = 0; nt < NF; nt += 2) {
+        if (nt + 1 < NF) loadw(w1, nt + 1);
+        mm(w0, nt);
+        if (nt + 1 < NF) {
+            if (nt + 2 < NF) loadw(w0, nt + 2);
+            mm(w1, nt + 1);
+        }
+    }
+}
+
+template <int DC, int FC, int QF, int DT>
+__global__ __launch_bounds__(64) void enc_layer_lp_k(const EncK p) {
+    constexpr int cs = DC * 16, dff = FC * 16, KC = DC / 2, FKC = FC / 2;
+    const int lane = threadIdx.x, li = lane & 15, g = lane >> 4;
+    constexpr int QT = QF * 16;
+    int b = blockIdx.x, gs = 0, ge = 0;
+    for (int grp = 0; grp < p.n_grp; ++grp) {
+        gs = p.grp_off[grp];
+        ge = p.grp_off[grp + 1];
+        const int nq = (ge - gs + QT - 1) / QT;
+        if (b < nq) break;
+        b -= nq;
+    }
+    const int q0 = gs + b * QT;
+    int qrow[QF];
+#pragma unroll
+    for (int qf = 0; qf < QF; ++qf) qrow[qf] = min(q0 + qf * 16 + li, ge - 1);
+
+    // ---- q projection: B operand = packed (src + pos) ----
+    f32x4 qB[QF][KC];
+    {
+        f32x4 xB[QF][KC];
+#pragma unroll
+        for (int qf = 0; qf < QF; ++qf) {
+            const int prow = p.pos_period > 0 ? qrow[qf] % p.pos_period : qrow[qf];
+#pragma unroll
+            for (int c = 0; c < KC; ++c) {
+                f32x4 a0 = ld4(p.src + (size_t)qrow[qf] * cs + 32 * c + 4 * g), a1 = ld4(p.src + (size_t)qrow[qf] * cs + 32 * c + 16 + 4 * g);
+                if (p.pos) {
+                    a0 += ld4(p.pos + (size_t)prow * cs + 32 * c + 4 * g);
+                    a1 += ld4(p.pos + (size_t)prow * cs + 32 * c + 16 + 4 * g);
+                }
+                xB[qf][c] = pack8<DT>(a0, a1);
+            }
+        }
+        f32x4 q32[QF][DC];
+        gemm_T_lp<DC, KC, QF, DT>(p.w_in_lp, p.b_in, cs, xB, li, g, [&](int nt, int qf, f32x4 a) { q32[qf][nt] = a * p.qscale; });
+#pragma unroll
+        for (int qf = 0; qf < QF; ++qf)
+#pragma unroll
+            for (int c = 0; c < KC; ++c) qB[qf][c] = pack8<DT>(q32[qf][2 * c], q32[qf][2 * c + 1]);
+    }
+
+    // ---- flash attention over 32-key blocks; K rows / V^T blocks stream from L2 into registers, one block ahead ----
+    f32x4 o[QF][DC];
+    float m_run[QF], l_run[QF];
+#pragma unroll
+    for (int qf = 0; qf < QF; ++qf) {
+        m_run[qf] = -__builtin_inff();
+        l_run[qf] = 0.f;
+#pragma unroll
+        for (int nt = 0; nt < DC; ++nt) o[qf][nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    }
+    auto fetch_kv = [&](int k0, f32x4(&ka)[2][KC], f32x4(&va)[DC]) {
+#pragma unroll
+        for (int kf = 0; kf < 2; ++kf) {
+            const int krow = min(k0 + 16 * kf + li, ge - 1);
+#pragma unroll
+            for (int c = 0; c < KC; ++c) ka[kf][c] = ld16(p.kbuf, (size_t)krow * cs + c * 32 + g * 8);
+        }
+#pragma unroll
+        for (int nt = 0; nt < DC; ++nt) va[nt] = ld16(p.vbuf, (size_t)(16 * nt + li) * p.n_tok_pad + k0 + g * 8);
+    };
+    auto attend = [&](int k0, const f32x4(&ka)[2][KC], const f32x4(&va)[DC]) {
+#pragma unroll
+        for (int qf = 0; qf < QF; ++qf) {
+            f32x4 st[2];
+            float mx = -__builtin_inff();
+#pragma unroll
+            for (int kf = 0; kf < 2; ++kf) {
+                f32x4 a = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int c = 0; c < KC; ++c) a = mfma32_lp<DT>(ka[kf][c], qB[qf][c], a);  // S^T[key 16kf+4g+r][query li]
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    if (k0 + 16 * kf + 4 * g + r >= ge) a[r] = -__builtin_inff();
+                    mx = fmaxf(mx, a[r]);
+                }
+                st[kf] = a;
+            }
+            mx = xmax(mx);
+            const float m_new = fmaxf(m_run[qf], mx);
+            const float alpha = __expf(m_run[qf] - m_new);
+            float ls = 0.f;
+#pragma unroll
+            for (int kf = 0; kf < 2; ++kf)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    st[kf][r] = __expf(st[kf][r] - m_new);
+                    ls += st[kf][r];
+                }
+            l_run[qf] = l_run[qf] * alpha + ls;
+            m_run[qf] = m_new;
+            const f32x4 pB = pack8<DT>(st[0], st[1]);  // keys {4g+r} U {16+4g+r} of the block: the order V^T blocks are stored in
+#pragma unroll
+            for (int nt = 0; nt < DC; ++nt) o[qf][nt] = mfma32_lp<DT>(va[nt], pB, o[qf][nt] * alpha);
+        }
+    };
+    {
+        f32x4 ka0[2][KC], va0[DC], ka1[2][KC], va1[DC];
+        fetch_kv(gs, ka0, va0);
+        int k0 = gs;
+        for (; k0 + 64 <= ge; k0 += 64) {
+            fetch_kv(k0 + 32, ka1, va1);
+            attend(k0, ka0, va0);
+            fetch_kv(min(k0 + 64, (ge - 1) & ~31), ka0, va0);  // (look-ahead past the end re-reads the last block, unused)
+            attend(k0 + 32, ka1, va1);
+        }
+        if (k0 < ge) {
+            if (k0 + 32 < ge) fetch_kv(k0 + 32, ka1, va1);
+            attend(k0, ka0, va0);
+            if (k0 + 32 < ge) attend(k0 + 32, ka1, va1);
+        }
+    }
+
+    // ---- out-proj + residual + LN1, FFN, + residual + LN2 (per query fragment; weights shared across fragments) ----
+    f32x4 oB[QF][KC];
+#pragma unroll
+    for (int qf = 0; qf < QF; ++qf) {
+        const float inv = 1.f / xsum(l_run[qf]);
+#pragma unroll
+        for (int c = 0; c < KC; ++c) oB[qf][c] = pack8<DT>(o[qf][2 * c] * inv, o[qf][2 * c + 1] * inv);
+    }
+    f32x4 x1[QF][DC];
+    gemm_T_lp<DC, KC, QF, DT>(p.w_out_lp, p.b_out, cs, oB, li, g, [&](int nt, int qf, f32x4 a) {
+        x1[qf][nt] = ld4(p.src + (size_t)qrow[qf] * cs + 16 * nt + 4 * g) + a;
+    });
+    f32x4 x1B[QF][KC];
+#pragma unroll
+    for (int qf = 0; qf < QF; ++qf) {
+        layer_norm<DC>(x1[qf], p.ln1_w, p.ln1_b, p.d, p.ln_eps, g);
+#pragma unroll
+        for (int c = 0; c < KC; ++c) x1B[qf][c] = pack8<DT>(x1[qf][2 * c], x1[qf][2 * c + 1]);
+    }
+    f32x4 hB[QF][FKC];
+    {
+        f32x4 hprev[QF];
+        gemm_T_lp<FC, KC, QF, DT>(p.w1_lp, p.b1, cs, x1B, li, g, [&](int ft, int qf, f32x4 a) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) a[r] = fmaxf(a[r], 0.f);
+            if (ft & 1) hB[qf][ft >> 1] = pack8<DT>(hprev[qf], a); else hprev[qf] = a;
+        });
+    }
+    gemm_T_lp<DC, FKC, QF, DT>(p.w2_lp, p.b2, dff, hB, li, g, [&](int nt, int qf, f32x4 a) { x1[qf][nt] += a; });
+#pragma unroll
+    for (int qf = 0; qf < QF; ++qf) {
+        layer_norm<DC>(x1[qf], p.ln2_w, p.ln2_b, p.d, p.ln_eps, g);
+        const int qtok = q0 + qf * 16 + li;
+        if (qtok < ge) {
+#pragma unroll
+            for (int nt = 0; nt < DC; ++nt) *reinterpret_cast<f32x4*>(p.out + (size_t)qtok * cs + 16 * nt + 4 * g) = x1[qf][nt];
+        }
+    }
+}
+
 int fill(const i2r_encoder_desc* d, EncK& k) {
     I2R_CHECK_ARG(d && d->src && d->kbuf && d->vbuf && d->out && d->grp_off && d->w_in && d->b_in && d->w_out && d->b_out &&
                       d->ln1_w && d->ln1_b && d->w1 && d->b1 && d->w2 && d->b2 && d->ln2_w && d->ln2_b,
@@ -290,6 +552,11 @@ int fill(const i2r_encoder_desc* d, EncK& k) {
     k.n_tok = d->n_tok; k.n_tok_pad = ((d->n_tok + 63) / 64) * 64 + 64; k.n_grp = d->n_grp; k.d = d->d; k.cs = d->cs;
     k.dff_pad = d->dff_pad; k.pos_period = d->pos_period; k.ln_eps = d->ln_eps;
     k.qscale = 1.0f / sqrtf((float)d->d);
+    k.w_in_lp = d->w_in_lp; k.w_out_lp = d->w_out_lp; k.w1_lp = d->w1_lp; k.w2_lp = d->w2_lp;
+    I2R_CHECK_ARG(d->dtype >= 0 && d->dtype <= 2, "i2r_encoder: dtype %d", d->dtype);
+    if (d->dtype != 0)
+        I2R_CHECK_ARG(d->cs == 96 && d->w_in_lp && d->w_out_lp && d->w1_lp && d->w2_lp && d->n_qtiles16 > 0 && d->n_qtiles64 > 0,
+                      "i2r_encoder: the 16-bit MFMA mode needs cs == 96 and the permuted 16-bit weights");
     return I2R_OK;
 }
 
@@ -300,7 +567,11 @@ extern "C" int i2r_encoder_kv(const i2r_encoder_desc* d, void* stream) {
     int rc = fill(d, k);
     if (rc) return rc;
     const unsigned nblk = (unsigned)((d->n_tok + 31) / 32);
-    if (d->cs == 96)
+    if (d->dtype == 1)
+        hipLaunchKernelGGL((enc_kv_lp_k<6, 1>), dim3(nblk), dim3(64), 0, (hipStream_t)stream, k);
+    else if (d->dtype == 2)
+        hipLaunchKernelGGL((enc_kv_lp_k<6, 2>), dim3(nblk), dim3(64), 0, (hipStream_t)stream, k);
+    else if (d->cs == 96)
         hipLaunchKernelGGL(enc_kv_k<6>, dim3(nblk), dim3(64), 0, (hipStream_t)stream, k);
     else
         hipLaunchKernelGGL(enc_kv_k<5>, dim3(nblk), dim3(64), 0, (hipStream_t)stream, k);
@@ -313,6 +584,20 @@ extern "C" int i2r_encoder_layer(const i2r_encoder_desc* d, void* stream) {
     int rc = fill(d, k);
     if (rc) return rc;
     I2R_CHECK_ARG(d->n_qtiles32 > 0, "i2r_encoder_layer: n_qtiles32");
+    if (d->dtype != 0) {
+        // 64 queries per wave when that still gives >= 2 waves per SIMD-pair of the chip, else 16 (more, shorter waves)
+        const bool big = d->n_qtiles64 >= 512;
+        const unsigned grid = (unsigned)(big ? d->n_qtiles64 : d->n_qtiles16);
+        if (d->dtype == 1) {
+            if (big) hipLaunchKernelGGL((enc_layer_lp_k<6, 12, 4, 1>), dim3(grid), dim3(64), 0, (hipStream_t)stream, k);
+            else hipLaunchKernelGGL((enc_layer_lp_k<6, 12, 1, 1>), dim3(grid), dim3(64), 0, (hipStream_t)stream, k);
+        } else {
+            if (big) hipLaunchKernelGGL((enc_layer_lp_k<6, 12, 4, 2>), dim3(grid), dim3(64), 0, (hipStream_t)stream, k);
+            else hipLaunchKernelGGL((enc_layer_lp_k<6, 12, 1, 2>), dim3(grid), dim3(64), 0, (hipStream_t)stream, k);
+        }
+        I2R_CHECK_LAUNCH("i2r_encoder_layer");
+        return I2R_OK;
+    }
     constexpr int NW = 2;
     if (d->cs == 96)
         hipLaunchKernelGGL((enc_layer_k<6, 12, NW>), dim3((unsigned)d->n_qtiles32), dim3(NW * 64), 0, (hipStream_t)stream, k);

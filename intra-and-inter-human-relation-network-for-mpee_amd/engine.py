@@ -184,8 +184,21 @@ class Packer:
             w1=padm(s[p + ".linear1.weight"], fs, cs), b1=padv(s[p + ".linear1.bias"], fs),
             w2=padm(s[p + ".linear2.weight"], cs, fs), b2=padv(s[p + ".linear2.bias"], cs),
             ln2_w=padv(s[p + ".norm2.weight"], cs), ln2_b=padv(s[p + ".norm2.bias"], cs))
+        lp = {}
+        if self.dtype != 0 and cs == 96:
+            # 16-bit copies for the 16-bit MFMA encoder: columns of every 32-block permuted to the operand order
+            # new position 8g + 4*half + r  <-  column 32c + 16*half + 4g + r   (csrc/i2r_encoder.hip)
+            tdt = torch.bfloat16 if self.dtype == 1 else torch.float16
+
+            def perm(m):
+                rows, cols = m.shape
+                v = m.view(rows, cols // 32, 2, 4, 4)          # [row, c, half, g, r]
+                return v.permute(0, 1, 3, 2, 4).reshape(rows, cols).to(tdt).contiguous()   # [row, c, g, half, r]
+            lp = dict(w_in_lp=perm(t["w_in"]), w_out_lp=perm(t["w_out"]), w1_lp=perm(t["w1"]), w2_lp=perm(t["w2"]))
+            lp = {k: self._dev(v) for k, v in lp.items()}
         t = {k: self._dev(v.float()) for k, v in t.items()}
-        t.update(d=d, cs=cs, dff_pad=fs)
+        t.update(lp)
+        t.update(d=d, cs=cs, dff_pad=fs, dtype=self.dtype if lp else 0)
         return t
 
     def dw(self, conv_key, bn_key, eps=1e-5):
@@ -491,7 +504,9 @@ class Program:
         goff = torch.tensor(grp_off_host, dtype=torch.int32, device=self.device)
         self.keep += [kbuf, vbuf, goff]
         assert all(o % 4 == 0 for o in grp_off_host), "token group offsets must be multiples of 4"
-        nq = sum(-(-(grp_off_host[i + 1] - grp_off_host[i]) // 32) for i in range(len(grp_off_host) - 1))
+        lens = [grp_off_host[i + 1] - grp_off_host[i] for i in range(len(grp_off_host) - 1)]
+        nq, nq16, nq64 = (sum(-(-l // t) for l in lens) for t in (32, 16, 64))
+        lp_ok = all(o % 32 == 0 for o in grp_off_host)  # the 16-bit kernels walk absolute 32-key blocks
         cur = x
         self.keep.append(layers)
         for L in layers:
@@ -504,6 +519,9 @@ class Program:
                 setattr(d, name, L[name].data_ptr())
             d.n_tok, d.n_grp, d.d, d.cs, d.dff_pad = n_tok, len(grp_off_host) - 1, L["d"], cs, L["dff_pad"]
             d.pos_period, d.n_qtiles32, d.ln_eps = pos_period, nq, 1e-5
+            if L.get("dtype", 0) and lp_ok:
+                d.dtype, d.n_qtiles16, d.n_qtiles64 = L["dtype"], nq16, nq64
+                d.w_in_lp, d.w_out_lp, d.w1_lp, d.w2_lp = (L[k].data_ptr() for k in ("w_in_lp", "w_out_lp", "w1_lp", "w2_lp"))
             self.ops.append((cabi.OP_ENC_KV, lane, d))
             self.ops.append((cabi.OP_ENC_LAYER, lane, d))
             if cur is not x:

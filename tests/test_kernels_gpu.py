@@ -320,3 +320,38 @@ def test_conv_low_precision(precision, tdt, cin, cout, k, stride, h, w):
     # and it is a 16-bit computation: close to, but not the same as, the fp32 result
     exact = F.relu(F.conv2d(x, sd["c.weight"], None, stride=stride, padding=k // 2) + res)
     assert (from_act(out) - exact).abs().max().item() < (0.05 if precision == "bf16" else 0.01)
+
+
+@pytest.mark.parametrize("precision", ["bf16", "fp16"])
+@pytest.mark.parametrize("length,hw,period", [([3, 1, 2], (16, 12), 0), ([1] * 3, (64, 48), 3072), ([5], (16, 12), 0)])
+def test_encoder_layer_low_precision(precision, length, hw, period):
+    """16-bit MFMA encoder layer vs the fp32 oracle layer: tolerance = 16-bit operand rounding (outputs are LayerNorm-ed, O(1))."""
+    d, (h, w) = 96, hw
+    S = sum(length)
+    tag = "lpenc%d_%d" % (S, h)
+    sd = _encoder_sd(d, 192, tag)
+    feat = _rand((S, d, h, w), "f" + tag)
+    sd2 = {k.replace("L.", "E.layers.0."): v for k, v in sd.items()}
+    if period:
+        table = _rand((h * w, d), "t" + tag, 0.5)
+        tok = feat.flatten(2).transpose(1, 2)
+        ref = i2r_cpu.encoder_layer(sd2, "E.layers.0", tok, table[None], None).transpose(1, 2).reshape(S, d, h, w)
+    else:
+        pos = _rand((S, d, h, w), "p" + tag, 0.5)
+        ref = i2r_cpu.inter_human_encoder(sd2, "E", 1, feat, pos, length)
+    P = engine.Program(torch.device(DEV))
+    L = engine.Packer(sd, torch.device(DEV), precision).encoder_layer("L", d, 192)
+    assert L["dtype"] != 0
+    offs = [0]
+    for n in length:
+        offs.append(offs[-1] + n * h * w)
+    if period:
+        tdev = table.to(DEV)
+        out = P.encoder(to_act(P, feat), [L], offs, pos=tdev.data_ptr(), pos_period=period)
+    else:
+        out = P.encoder(to_act(P, feat), [L], offs, pos=to_act(P, pos).ptr)
+    assert P.ops[-1][2].dtype != 0  # the 16-bit kernels were selected
+    run(P)
+    err = (from_act(out) - ref).abs()
+    tol_max, tol_mean = (0.12, 0.012) if precision == "bf16" else (0.02, 0.002)
+    assert err.max().item() < tol_max and err.mean().item() < tol_mean, (err.max().item(), err.mean().item())
