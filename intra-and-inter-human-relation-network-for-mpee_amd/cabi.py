@@ -8,6 +8,8 @@ Build: ``python -m i2r_amd.build`` / ``__graft_entry__.build()`` (hipcc --offloa
 import ctypes as C
 import os
 
+import torch  # noqa: F401  -- must be loaded BEFORE libi2r_hip.so so both share torch's HIP runtime (libamdhip64) instance
+
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libi2r_hip.so")
 
