@@ -11,11 +11,15 @@ template <int CIN>
 __global__ __launch_bounds__(256) void stem_conv_k(const float* __restrict__ in, const float* __restrict__ w,
                                                    const float* __restrict__ bias, float* __restrict__ out, int n_img,
                                                    int in_h, int in_w, int out_h, int out_w, int cout, int out_cs, int n_src) {
+    extern __shared__ __attribute__((aligned(16))) float wl[];  // [9*CIN][cout] weights + [cout] bias
+    for (int i = threadIdx.x; i < (9 * CIN + 1) * cout; i += 256) wl[i] = i < 9 * CIN * cout ? w[i] : bias[i - 9 * CIN * cout];
+    __syncthreads();
     const int groups = cout >> 4;
     const long long gid = (long long)blockIdx.x * 256 + threadIdx.x;
     const int cg = (int)(gid % groups);
-    const long long pix = gid / groups;
-    if (pix >= (long long)n_img * out_h * out_w) return;
+    const long long pix_raw = gid / groups;
+    const bool valid = pix_raw < (long long)n_img * out_h * out_w;
+    const long long pix = valid ? pix_raw : 0;
     const int ox = (int)(pix % out_w);
     const int oy = (int)((pix / out_w) % out_h);
     const int img = (int)(pix / ((long long)out_w * out_h));
@@ -23,31 +27,41 @@ __global__ __launch_bounds__(256) void stem_conv_k(const float* __restrict__ in,
     const int simg = img % n_src;
     const bool mirror = img >= n_src;
 
-    float acc[16];
-#pragma unroll
-    for (int j = 0; j < 16; ++j) acc[j] = bias[cg * 16 + j];
+    // input taps first (9*CIN scalars), then the FMAs against the LDS-resident weights (same address across the 16 lanes
+    // of a channel group -> LDS broadcast); keeps the kernel at ~60 VGPRs instead of hoisting 108 weight loads
+    float xin[9 * CIN];
 #pragma unroll
     for (int ky = 0; ky < 3; ++ky) {
         const int iy = oy * 2 - 1 + ky;
 #pragma unroll
         for (int kx = 0; kx < 3; ++kx) {
             const int ix = ox * 2 - 1 + kx;
-            const bool ok = iy >= 0 && iy < in_h && ix >= 0 && ix < in_w;
+            const bool ok = valid && iy >= 0 && iy < in_h && ix >= 0 && ix < in_w;
 #pragma unroll
-            for (int ci = 0; ci < CIN; ++ci) {
-                const float x = ok ? in[((size_t)(simg * CIN + ci) * in_h + iy) * in_w + (mirror ? in_w - 1 - ix : ix)] : 0.f;
-                const f32x4* wr = reinterpret_cast<const f32x4*>(w + ((ky * 3 + kx) * CIN + ci) * cout + cg * 16);
-#pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    const f32x4 wv = wr[q];
-                    acc[q * 4 + 0] = fmaf(x, wv[0], acc[q * 4 + 0]);
-                    acc[q * 4 + 1] = fmaf(x, wv[1], acc[q * 4 + 1]);
-                    acc[q * 4 + 2] = fmaf(x, wv[2], acc[q * 4 + 2]);
-                    acc[q * 4 + 3] = fmaf(x, wv[3], acc[q * 4 + 3]);
-                }
-            }
+            for (int ci = 0; ci < CIN; ++ci)
+                xin[(ky * 3 + kx) * CIN + ci] = ok ? in[((size_t)(simg * CIN + ci) * in_h + iy) * in_w + (mirror ? in_w - 1 - ix : ix)] : 0.f;
         }
     }
+    float acc[16];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const f32x4 bv = *reinterpret_cast<const f32x4*>(wl + 9 * CIN * cout + cg * 16 + q * 4);
+        acc[q * 4] = bv[0]; acc[q * 4 + 1] = bv[1]; acc[q * 4 + 2] = bv[2]; acc[q * 4 + 3] = bv[3];
+    }
+#pragma unroll 3
+    for (int t = 0; t < 9 * CIN; ++t) {
+        const float x = xin[t];
+        const f32x4* wr = reinterpret_cast<const f32x4*>(wl + t * cout + cg * 16);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const f32x4 wv = wr[q];
+            acc[q * 4 + 0] = fmaf(x, wv[0], acc[q * 4 + 0]);
+            acc[q * 4 + 1] = fmaf(x, wv[1], acc[q * 4 + 1]);
+            acc[q * 4 + 2] = fmaf(x, wv[2], acc[q * 4 + 2]);
+            acc[q * 4 + 3] = fmaf(x, wv[3], acc[q * 4 + 3]);
+        }
+    }
+    if (!valid) return;
     f32x4* o = reinterpret_cast<f32x4*>(out + (size_t)pix * out_cs + cg * 16);
 #pragma unroll
     for (int q = 0; q < 4; ++q)
@@ -127,10 +141,10 @@ extern "C" int i2r_stem_conv(const float* in_nchw, const float* w, const float* 
     const long long nthr = (long long)n_img * out_h * out_w * (cout / 16);
     const unsigned nblk = (unsigned)((nthr + 255) / 256);
     if (cin == 3)
-        hipLaunchKernelGGL(stem_conv_k<3>, dim3(nblk), dim3(256), 0, (hipStream_t)stream, in_nchw, w, bias, out_nhwc, n_img,
+        hipLaunchKernelGGL(stem_conv_k<3>, dim3(nblk), dim3(256), (size_t)(27 + 1) * cout * sizeof(float), (hipStream_t)stream, in_nchw, w, bias, out_nhwc, n_img,
                            in_h, in_w, out_h, out_w, cout, out_cs, n_src);
     else
-        hipLaunchKernelGGL(stem_conv_k<1>, dim3(nblk), dim3(256), 0, (hipStream_t)stream, in_nchw, w, bias, out_nhwc, n_img,
+        hipLaunchKernelGGL(stem_conv_k<1>, dim3(nblk), dim3(256), (size_t)(9 + 1) * cout * sizeof(float), (hipStream_t)stream, in_nchw, w, bias, out_nhwc, n_img,
                            in_h, in_w, out_h, out_w, cout, out_cs, n_src);
     I2R_CHECK_LAUNCH("i2r_stem_conv");
     return I2R_OK;
