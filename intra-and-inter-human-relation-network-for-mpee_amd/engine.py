@@ -321,6 +321,7 @@ class Program:
         self.keep = []       # everything the structs point to
         self.pool = {}       # numel -> [tensor]
         self.pending = []    # buffers released inside a fork region: reusable only after the join
+        self.groupings = []  # (grouping, tokens per crop) of encoders whose groups follow `length` (set_groups)
         self.in_fork = False
         self.nbytes = 0
         self._c_ops = None
@@ -494,21 +495,20 @@ class Program:
         self.ops.append((cabi.OP_HEAD, lane, a))
         return a
 
-    def encoder(self, x, layers, grp_off_host, pos=None, pos_period=0, lane=0):
-        """x: Act viewed as tokens [n*h*w, cs]; grp_off_host: python list of token offsets per group."""
+    def encoder(self, x, layers, grp_off_host, pos=None, pos_period=0, lane=0, regroupable=False):
+        """x: Act viewed as tokens [n*h*w, cs]; grp_off_host: python list of token offsets per group.
+        regroupable: the grouping (persons per image) may be changed later with set_groups() without rebuilding the program:
+        the offset table gets capacity for one group per crop."""
         n_tok = x.n * x.h * x.w
         cs = x.cs
         n_pad = (n_tok + 63) // 64 * 64 + 64
         kbuf = torch.empty(n_tok * cs, dtype=torch.float32, device=self.device)
         vbuf = torch.zeros(cs * n_pad, dtype=torch.float32, device=self.device)
-        goff = torch.tensor(grp_off_host, dtype=torch.int32, device=self.device)
+        goff = torch.zeros(x.n + 1, dtype=torch.int32, device=self.device)
         self.keep += [kbuf, vbuf, goff]
-        assert all(o % 4 == 0 for o in grp_off_host), "token group offsets must be multiples of 4"
-        lens = [grp_off_host[i + 1] - grp_off_host[i] for i in range(len(grp_off_host) - 1)]
-        nq, nq16, nq64 = (sum(-(-l // t) for l in lens) for t in (32, 16, 64))
-        lp_ok = all(o % 32 == 0 for o in grp_off_host)  # the 16-bit kernels walk absolute 32-key blocks
         cur = x
         self.keep.append(layers)
+        descs = []
         for L in layers:
             assert L["cs"] == cs
             out = self.alloc(x.n, x.h, x.w, x.c)
@@ -517,17 +517,37 @@ class Program:
             d.kbuf, d.vbuf, d.out, d.grp_off = kbuf.data_ptr(), vbuf.data_ptr(), out.ptr, goff.data_ptr()
             for name in ("w_in", "b_in", "w_out", "b_out", "ln1_w", "ln1_b", "w1", "b1", "w2", "b2", "ln2_w", "ln2_b"):
                 setattr(d, name, L[name].data_ptr())
-            d.n_tok, d.n_grp, d.d, d.cs, d.dff_pad = n_tok, len(grp_off_host) - 1, L["d"], cs, L["dff_pad"]
-            d.pos_period, d.n_qtiles32, d.ln_eps = pos_period, nq, 1e-5
-            if L.get("dtype", 0) and lp_ok:
-                d.dtype, d.n_qtiles16, d.n_qtiles64 = L["dtype"], nq16, nq64
+            d.n_tok, d.d, d.cs, d.dff_pad = n_tok, L["d"], cs, L["dff_pad"]
+            d.pos_period, d.ln_eps = pos_period, 1e-5
+            if L.get("dtype", 0):
                 d.w_in_lp, d.w_out_lp, d.w1_lp, d.w2_lp = (L[k].data_ptr() for k in ("w_in_lp", "w_out_lp", "w1_lp", "w2_lp"))
+            descs.append((d, L.get("dtype", 0)))
             self.ops.append((cabi.OP_ENC_KV, lane, d))
             self.ops.append((cabi.OP_ENC_LAYER, lane, d))
             if cur is not x:
                 self.release(cur)
             cur = out
+        grouping = dict(descs=descs, goff=goff, current=None)
+        self.set_groups(grouping, grp_off_host)
+        if regroupable:
+            self.groupings.append((grouping, x.h * x.w))
         return cur
+
+    def set_groups(self, grouping, grp_off_host):
+        """(Re)define the token groups of an encoder stack: uploads the offset table and patches the per-layer descriptors."""
+        offs = tuple(int(o) for o in grp_off_host)
+        if grouping["current"] == offs:
+            return
+        assert all(o % 4 == 0 for o in offs), "token group offsets must be multiples of 4"
+        assert len(offs) <= grouping["goff"].numel()
+        lens = [offs[i + 1] - offs[i] for i in range(len(offs) - 1)]
+        nq, nq16, nq64 = (sum(-(-l // t) for l in lens) for t in (32, 16, 64))
+        lp_ok = all(o % 32 == 0 for o in offs)  # the 16-bit kernels walk absolute 32-key blocks
+        grouping["goff"][:len(offs)].copy_(torch.tensor(offs, dtype=torch.int32))
+        for d, dt in grouping["descs"]:
+            d.n_grp, d.n_qtiles32, d.n_qtiles16, d.n_qtiles64 = len(offs) - 1, nq, nq16, nq64
+            d.dtype = dt if lp_ok else 0
+        grouping["current"] = offs
 
     def fork(self, mask):
         """lanes in `mask` (bits 1..3) start after everything issued so far on lane 0"""
@@ -995,7 +1015,7 @@ class Engine:
         offs = [0]
         for n in length:
             offs.append(offs[-1] + n * tok)
-        e = P.encoder(f, self.layers, offs, pos=pos_ptr)
+        e = P.encoder(f, self.layers, offs, pos=pos_ptr, regroupable=True)
         for i, dc in enumerate(self.deconvs):
             last = i == len(self.deconvs) - 1
             # 2-stage models add the first-stage features AFTER the deconv's ReLU (x = single_res + x, interformer.py:315)
@@ -1016,10 +1036,20 @@ class Engine:
         assert all(n >= 1 for n in length), "every image needs at least one person"
         x = x.to(self.device).contiguous()
         flip = flip_joint_map is not None
-        key = (S, H, W, tuple(length), flip)
+        # one program per (S, H, W, flip): the launch list and every buffer depend on the crop count only; the persons-per-image
+        # grouping enters through the encoder's offset table, which is re-uploaded when `length` changes
+        key = (S, H, W, flip)
         if key not in self.programs:
+            if len(self.programs) >= 8:  # bounded cache (each program owns ~20 MB of activations per crop)
+                self.programs.pop(next(iter(self.programs)))
             self.programs[key] = self._build(S, H, W, list(length), flip)
         P, patch = self.programs[key]
+        glen = list(length) + list(length) if flip else list(length)
+        for grouping, tok in P.groupings:
+            offs = [0]
+            for n in glen:
+                offs.append(offs[-1] + n * tok)
+            P.set_groups(grouping, offs)
         J = M["NUM_JOINTS"]
         patch["x"].in_ = x.data_ptr()
         keep = [x]

@@ -109,3 +109,15 @@ def test_low_precision_modes_within_stated_tolerance(tag, precision):
         assert d.abs().max().item() <= tol_max * zs[k].abs().max().item(), (tag, k, d.abs().max().item())
         assert d.pow(2).mean().sqrt().item() <= tol_rms * zs[k].pow(2).mean().sqrt().item()
         assert d.abs().max().item() > 1e-4  # it really is the 16-bit path
+
+
+def test_regrouping_same_crop_count_reuses_program():
+    """Same S, different persons-per-image: one cached program, only the encoder's group offsets change."""
+    cfg, sd, x, m, length, g = setup("w48_l213")
+    net = _net(cfg, sd, "w48_pure_en6")
+    eng = net.engine()
+    for lens in ([2, 1, 3], [3, 3], [6], [1] * 6, [2, 1, 3]):
+        y = net(x.cuda(), m.cuda(), lens).cpu()
+        ref = i2r_cpu.forward(sd, cfg, x, m, lens)
+        assert (y - ref).abs().max().item() < TOL, lens
+    assert sum(1 for k in eng.programs if k[0] == 6 and not k[3]) == 1
