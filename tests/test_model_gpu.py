@@ -121,3 +121,33 @@ def test_regrouping_same_crop_count_reuses_program():
         ref = i2r_cpu.forward(sd, cfg, x, m, lens)
         assert (y - ref).abs().max().item() < TOL, lens
     assert sum(1 for k in eng.programs if k[0] == 6 and not k[3]) == 1
+
+
+def test_tools_test_py_flow_dataparallel_and_checkpoint(tmp_path):
+    """The consumer's own sequence (reference tools/test.py:87-118, lib/core/function.py:113-140): factory by name through a
+    package called `models`, torch.load + load_state_dict(strict=False), DataParallel(...).cuda(), eval(), CPU inputs + list."""
+    import sys
+    from i2r_amd import config, models as our_models
+    cfg, sd, x, m, length, g = setup("w48_l31")
+    ckpt = tmp_path / "model.pth"
+    torch.save(sd, ckpt)                                   # a bare state_dict, like TEST.MODEL_FILE
+    saved = sys.modules.get("models")
+    sys.modules["models"] = our_models                     # what `import models` resolves to when lib/ is replaced
+    try:
+        import models  # noqa: F401
+        model = eval("models." + cfg.MODEL.NAME + ".get_pose_net")(cfg, is_train=False)      # tools/test.py:87-89
+        model.load_state_dict(torch.load(ckpt, map_location="cpu"), strict=False)             # :93-96
+        model = torch.nn.DataParallel(model, device_ids=list(cfg.GPUS)).cuda()               # :118
+        model.eval()                                                                          # function.py:113
+        with torch.no_grad():
+            outputs = model(x, m, length)                                                     # function.py:135 (CPU tensors in)
+        output = outputs["multi"] if isinstance(outputs, dict) else outputs                   # :137-140
+    finally:
+        if saved is None:
+            sys.modules.pop("models", None)
+        else:
+            sys.modules["models"] = saved
+    assert output.is_cuda and output.shape == (4, 14, 64, 48)
+    assert np.abs(output.cpu().numpy() - g["out_multi"]).max() < TOL
+    out2 = (output + output) * 0.5                                                            # consumers do arithmetic on it (:162)
+    assert torch.equal(out2, output)
