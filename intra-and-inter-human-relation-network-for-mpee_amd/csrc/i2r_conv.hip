@@ -256,6 +256,11 @@ __device__ __forceinline__ void conv_body_lp(const ConvK& p, int bid, f32x4* lds
 template <int MT, int NT, int CAP, int PF>
 __device__ __forceinline__ void conv_body(const ConvK& p, int bid, f32x4* lds) {
     const int tid = threadIdx.x;
+    // tuning aid (I2R_CONV_DBG & 8): per-workgroup phase time stamps (s_memtime) into the buffer passed as res2
+    unsigned long long ts0 = 0, ts1 = 0, ts2 = 0;
+    const bool stamp = (p.dbg & 8) != 0;
+    const int bid_stamp = bid;
+    if (stamp) ts0 = __builtin_amdgcn_s_memtime();
     const int lane = tid & 63, wave = tid >> 6;
     const int WN = p.wn;
     const int wm = wave / WN, wn = wave % WN;
@@ -401,6 +406,7 @@ __device__ __forceinline__ void conv_body(const ConvK& p, int bid, f32x4* lds) {
         stage_load(0);
         stage_store(lds);
         __syncthreads();
+        if (stamp) ts1 = __builtin_amdgcn_s_memtime();
         for (int pass = 0; pass < npass; ++pass) {
             f32x4* cur = lds + (pass & 1) * ckg * p.plane;
             f32x4* nxt = lds + ((pass + 1) & 1) * ckg * p.plane;
@@ -444,6 +450,19 @@ __device__ __forceinline__ void conv_body(const ConvK& p, int bid, f32x4* lds) {
         }
     }
 
+    if (stamp) {
+        ts2 = __builtin_amdgcn_s_memtime();
+        ConvK q = p;
+        q.res2 = nullptr;
+        conv_epilogue<MT, NT>(q, acc, img, oy0, ox0, wm, n_base, li, g, tile_px);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        const unsigned long long ts3 = __builtin_amdgcn_s_memtime();
+        if (tid == 0) {
+            unsigned long long* o = reinterpret_cast<unsigned long long*>(const_cast<float*>(p.res2)) + (size_t)bid_stamp * 4;
+            o[0] = ts0; o[1] = ts1; o[2] = ts2; o[3] = ts3;
+        }
+        return;
+    }
     conv_epilogue<MT, NT>(p, acc, img, oy0, ox0, wm, n_base, li, g, tile_px);
 }
 
