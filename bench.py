@@ -176,16 +176,29 @@ def main():
     x, m, _ = synth.make_inputs(length, H_, W_, seed=rank)
     x, m = x.to(dev), m.to(dev)
 
+    pending = [None]
+
     def step():
+        """one forward over this rank's images; N > 1: the all-gather of step k is waited for after step k+1 has been issued"""
         y = net(x, m, length)
         if isinstance(y, dict):
             y = y["multi"]
         if world > 1:
-            y = i2r_dist.gather_heatmaps(y, counts)
+            h = i2r_dist.gather_heatmaps_async(y, counts)
+            if pending[0] is not None:
+                y = pending[0].wait()
+            pending[0] = h
+        return y
+
+    def drain(y):
+        if pending[0] is not None:
+            y = pending[0].wait()
+            pending[0] = None
         return y
 
     for _ in range(args.warmup):
-        step()
+        y = step()
+    drain(y)
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
@@ -193,6 +206,7 @@ def main():
     t0 = time.perf_counter()
     for _ in range(args.steps):
         y = step()
+    y = drain(y)
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()

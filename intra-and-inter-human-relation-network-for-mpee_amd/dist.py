@@ -28,6 +28,38 @@ def shard_images(length, rank, world):
     return lo, hi, sum(length[:lo])
 
 
+class PendingGather:
+    """Handle of an in-flight heat-map all-gather (see gather_heatmaps_async)."""
+
+    def __init__(self, work, out, counts, smax, shape):
+        self.work, self.out, self.counts, self.smax, self.shape = work, out, counts, smax, shape
+
+    def wait(self):
+        if self.work is not None:
+            self.work.wait()
+            self.work = None
+        if all(c == self.smax for c in self.counts):
+            return self.out
+        out = self.out.view(len(self.counts), self.smax, *self.shape)
+        return torch.cat([out[r, :c] for r, c in enumerate(self.counts)], dim=0)
+
+
+def gather_heatmaps_async(local, counts, group=None):
+    """Start the per-step all-gather without blocking the launch stream: the collective runs on RCCL's own stream over
+    xGMI while the NEXT forward's kernels are being issued/executed; call .wait() on the returned handle when the gathered
+    heat-maps are needed (bench.py waits one step later, i.e. communication of step k overlaps compute of step k+1)."""
+    world = dist.get_world_size(group)
+    assert len(counts) == world and local.shape[0] == counts[dist.get_rank(group)]
+    smax = max(counts)
+    pad = local
+    if local.shape[0] < smax:
+        pad = torch.zeros((smax,) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device)
+        pad[:local.shape[0]] = local
+    out = torch.empty((world * smax,) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device)
+    work = dist.all_gather_into_tensor(out, pad.contiguous(), group=group, async_op=True)
+    return PendingGather(work, out, list(counts), smax, tuple(local.shape[1:]))
+
+
 def gather_heatmaps(local, counts, group=None):
     """local: [S_r, J, h, w] on this rank; counts: crops per rank (list, same on all ranks) -> [sum(counts), J, h, w].
 

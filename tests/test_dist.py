@@ -36,6 +36,9 @@ def _worker(rank, world, port, length):
         local = full[off:off + counts[rank]].clone()
         got = i2r_dist.gather_heatmaps(local, counts)
         assert torch.equal(got, full), (rank, got.shape)
+        h1 = i2r_dist.gather_heatmaps_async(local, counts)       # two collectives in flight, waited in order (bench.py pattern)
+        h2 = i2r_dist.gather_heatmaps_async(local * 2, counts)
+        assert torch.equal(h1.wait(), full) and torch.equal(h2.wait(), full * 2)
     finally:
         dist.destroy_process_group()
 
