@@ -210,6 +210,10 @@ typedef struct i2r_encoder_desc {
     int32_t dtype;
     int32_t n_qtiles16, n_qtiles64;   /* like n_qtiles32 for 16- and 64-query tiles */
     const void* w_in_lp; const void* w_out_lp; const void* w1_lp; const void* w2_lp;
+    /* fp32 mode: fuse the K / V projection of the NEXT layer into this launch (the layer output is still in registers):
+     * next_w_in / next_b_in = the next layer's padded in_proj (its k and v rows are used), written to next_kbuf / next_vbuf
+     * (layouts as kbuf / vbuf, distinct buffers).  All null = no fusion (then the next layer needs i2r_encoder_kv). */
+    const float* next_w_in; const float* next_b_in; float* next_kbuf; float* next_vbuf;
 } i2r_encoder_desc;
 
 int i2r_encoder_kv(const i2r_encoder_desc* d, void* stream);

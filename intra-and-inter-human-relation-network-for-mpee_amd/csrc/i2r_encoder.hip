@@ -10,6 +10,8 @@
 // chains register-to-register: no LDS transposes, no intermediate HBM round trips.  Only K / V^T tiles of the
 // group go through LDS (shared by the waves of a workgroup).  Softmax / LayerNorm reductions over features
 // or keys are in-lane sums + two __shfl_xor (16, 32).
+#include <stdlib.h>
+
 #include "i2r_common.h"
 
 namespace {
@@ -31,6 +33,8 @@ struct EncK {
     float ln_eps, qscale;
     // 16-bit MFMA mode: weights as bf16/f16 [out][in] with the columns of every 32-block permuted to the MFMA operand order
     const void* w_in_lp; const void* w_out_lp; const void* w1_lp; const void* w2_lp;
+    // fused K/V projection of the NEXT layer (enc_layer4_k): its in_proj (k, v rows used), destination buffers; null = none
+    const float* next_w_in; const float* next_b_in; float* next_kbuf; float* next_vbuf;
 };
 
 __device__ __forceinline__ f32x4 ld4(const float* p) { return *reinterpret_cast<const f32x4*>(p); }
@@ -275,6 +279,223 @@ __global__ __launch_bounds__(NW * 64) void enc_layer_k(const EncK p) {
     if (qvalid) {
 #pragma unroll
         for (int nt = 0; nt < DC; ++nt) *reinterpret_cast<f32x4*>(p.out + (size_t)qtok * cs + 16 * nt + 4 * g) = y[nt];
+    }
+}
+
+// =====================================================================================================================
+// fp32 encoder layer, 4 waves per 16-query tile (enc_layer4_k) -- the default fp32 kernel
+// ---------------------------------------------------------------------------------------------------------------------
+// The vanilla inter-human encoder has only 6144 tokens = 384 query fragments for 1024 SIMDs, so one-wave-per-fragment is
+// latency-bound.  Here a workgroup of 4 waves owns one fragment: the KEYS are split 4 ways (each wave runs its own online
+// softmax over every 4th 16-key fragment, partial (m, l, O) merged through LDS), and the GEMMs of the layer tail are split
+// by OUTPUT fragments (wave w computes fragments w, w+4, ...), activations exchanged through LDS (a few KB).  The K / V
+// projection of the NEXT layer is fused into the tail (the layer output is already in registers), removing the separate
+// enc_kv launch for all layers but the first.
+template <int KC>
+__device__ __forceinline__ f32x4 row_mm(const float* W, int ld, int nt, const f32x4 (&x)[KC], f32x4 acc, int li, int g) {
+    f32x4 w[KC];
+    load_wrow<KC>(w, W, ld, nt, li, g);
+    return frag_mm<KC>(w, x, acc);
+}
+
+template <int DC, int FC>
+__global__ __launch_bounds__(256) void enc_layer4_k(const EncK p) {
+    constexpr int cs = DC * 16, dff = FC * 16;
+    // LDS (float4 units): exchange area X[max(FC,DC)][64] + partial-O area O[4][DC][64] + (m,l) area ML[4][2][16]
+    __shared__ f32x4 Xs[(FC > DC ? FC : DC) * 64];
+    __shared__ f32x4 Os[4 * DC * 64];
+    __shared__ float MLs[4 * 2 * 16];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int li = lane & 15, g = lane >> 4;
+
+    int b = blockIdx.x, gs = 0, ge = 0;
+    for (int grp = 0; grp < p.n_grp; ++grp) {
+        gs = p.grp_off[grp];
+        ge = p.grp_off[grp + 1];
+        const int nq = (ge - gs + 15) >> 4;
+        if (b < nq) break;
+        b -= nq;
+    }
+    const int qtok = gs + b * 16 + li;
+    const bool qvalid = qtok < ge;
+    const int qrow = qvalid ? qtok : ge - 1;
+    const int prow = p.pos_period > 0 ? qrow % p.pos_period : qrow;
+
+    // ---- inputs (every wave keeps the tile's src and src+pos fragments: 2 x DC float4) ----
+    f32x4 xs[DC], xq[DC];
+#pragma unroll
+    for (int c = 0; c < DC; ++c) {
+        xs[c] = ld4(p.src + (size_t)qrow * cs + 16 * c + 4 * g);
+        xq[c] = xs[c];
+        if (p.pos) xq[c] += ld4(p.pos + (size_t)prow * cs + 16 * c + 4 * g);
+    }
+    // ---- q projection, output fragments split over the waves, exchanged through LDS ----
+    for (int nt = wave; nt < DC; nt += 4)
+        Xs[nt * 64 + lane] = row_mm<DC>(p.w_in, cs, nt, xq, ld4(p.b_in + 16 * nt + 4 * g), li, g) * p.qscale;
+    __syncthreads();
+    f32x4 q[DC];
+#pragma unroll
+    for (int c = 0; c < DC; ++c) q[c] = Xs[c * 64 + lane];
+
+    // ---- attention over this wave's key fragments (kf = wave, wave+4, ...), prefetched one fragment ahead ----
+    f32x4 o[DC];
+#pragma unroll
+    for (int nt = 0; nt < DC; ++nt) o[nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    float m_run = -__builtin_inff(), l_run = 0.f;
+    auto fetch_kv = [&](int k0, f32x4(&ka)[DC], f32x4(&va)[DC]) {
+        const int krow = min(k0 + li, ge - 1);
+        const float* kp = p.kbuf + (size_t)krow * cs + 4 * g;
+        const float* vp = p.vbuf + (size_t)li * p.n_tok_pad + k0 + 4 * g;
+#pragma unroll
+        for (int c = 0; c < DC; ++c) {
+            ka[c] = ld4(kp + 16 * c);
+            va[c] = ld4(vp + (size_t)16 * c * p.n_tok_pad);
+        }
+    };
+    auto attend = [&](int k0, const f32x4(&ka)[DC], const f32x4(&va)[DC]) {
+        f32x4 st = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int c = 0; c < DC; ++c)
+#pragma unroll
+            for (int s = 0; s < 4; ++s) st = mfma16(ka[c][s], q[c][s], st);
+        float mx = -__builtin_inff();
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            if (k0 + 4 * g + r >= ge) st[r] = -__builtin_inff();
+            mx = fmaxf(mx, st[r]);
+        }
+        mx = xmax(mx);
+        const float m_new = fmaxf(m_run, mx);
+        const float alpha = __expf(m_run - m_new);
+        float ls = 0.f;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            st[r] = __expf(st[r] - m_new);
+            ls += st[r];
+        }
+        l_run = l_run * alpha + ls;
+        m_run = m_new;
+#pragma unroll
+        for (int nt = 0; nt < DC; ++nt) {
+            f32x4 acc = o[nt] * alpha;
+#pragma unroll
+            for (int s = 0; s < 4; ++s) acc = mfma16(va[nt][s], st[s], acc);
+            o[nt] = acc;
+        }
+    };
+    {
+        f32x4 ka0[DC], va0[DC], ka1[DC], va1[DC];
+        int k0 = gs + wave * 16;
+        if (k0 < ge) fetch_kv(k0, ka0, va0);
+        for (; k0 + 64 < ge; k0 += 128) {          // two fragments (k0, k0+64) per trip, each prefetched under the other
+            fetch_kv(k0 + 64, ka1, va1);
+            attend(k0, ka0, va0);
+            if (k0 + 128 < ge) fetch_kv(k0 + 128, ka0, va0);
+            attend(k0 + 64, ka1, va1);
+        }
+        if (k0 < ge) attend(k0, ka0, va0);
+    }
+    // ---- merge the four partial softmax states ----
+    l_run = xsum(l_run);
+    if (g == 0) {
+        MLs[(wave * 2 + 0) * 16 + li] = m_run;
+        MLs[(wave * 2 + 1) * 16 + li] = l_run;
+    }
+#pragma unroll
+    for (int nt = 0; nt < DC; ++nt) Os[(wave * DC + nt) * 64 + lane] = o[nt];
+    __syncthreads();
+    f32x4 oc[DC];
+    {
+        float mw[4], m = -__builtin_inff();
+#pragma unroll
+        for (int w = 0; w < 4; ++w) {
+            mw[w] = MLs[(w * 2) * 16 + li];
+            m = fmaxf(m, mw[w]);
+        }
+        float l = 0.f, sc[4];
+#pragma unroll
+        for (int w = 0; w < 4; ++w) {
+            sc[w] = __expf(mw[w] - m);  // a wave without keys has m = -inf, l = 0, O = 0 -> scale 0
+            l += MLs[(w * 2 + 1) * 16 + li] * sc[w];
+        }
+        const float inv = 1.f / l;
+#pragma unroll
+        for (int nt = 0; nt < DC; ++nt) {
+            f32x4 a = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int w = 0; w < 4; ++w) a += Os[(w * DC + nt) * 64 + lane] * sc[w];
+            oc[nt] = a * inv;
+        }
+    }
+    // ---- out-proj + residual (split by output fragment) -> LDS -> LayerNorm 1 on the full row in every wave ----
+    for (int nt = wave; nt < DC; nt += 4) {
+        f32x4 xsn;
+#pragma unroll
+        for (int c = 0; c < DC; ++c)
+            if (c == nt) xsn = xs[c];
+        Xs[nt * 64 + lane] = xsn + row_mm<DC>(p.w_out, cs, nt, oc, ld4(p.b_out + 16 * nt + 4 * g), li, g);
+    }
+    __syncthreads();
+    f32x4 x1[DC];
+#pragma unroll
+    for (int c = 0; c < DC; ++c) x1[c] = Xs[c * 64 + lane];
+    layer_norm<DC>(x1, p.ln1_w, p.ln1_b, p.d, p.ln_eps, g);
+    __syncthreads();  // everyone has read Xs before FFN1 overwrites it
+    // ---- FFN ----
+    for (int ft = wave; ft < FC; ft += 4) {
+        f32x4 a = row_mm<DC>(p.w1, cs, ft, x1, ld4(p.b1 + 16 * ft + 4 * g), li, g);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) a[r] = fmaxf(a[r], 0.f);
+        Xs[ft * 64 + lane] = a;
+    }
+    __syncthreads();
+    f32x4 h[FC];
+#pragma unroll
+    for (int c = 0; c < FC; ++c) h[c] = Xs[c * 64 + lane];
+    __syncthreads();
+    for (int nt = wave; nt < DC; nt += 4) {
+        f32x4 x1n;
+#pragma unroll
+        for (int c = 0; c < DC; ++c)
+            if (c == nt) x1n = x1[c];
+        Xs[nt * 64 + lane] = x1n + row_mm<FC>(p.w2, dff, nt, h, ld4(p.b2 + 16 * nt + 4 * g), li, g);
+    }
+    __syncthreads();
+    f32x4 y[DC];
+#pragma unroll
+    for (int c = 0; c < DC; ++c) y[c] = Xs[c * 64 + lane];
+    layer_norm<DC>(y, p.ln2_w, p.ln2_b, p.d, p.ln_eps, g);
+    if (qvalid) {
+        for (int nt = wave; nt < DC; nt += 4) {
+            f32x4 yn;
+#pragma unroll
+            for (int c = 0; c < DC; ++c)
+                if (c == nt) yn = y[c];
+            *reinterpret_cast<f32x4*>(p.out + (size_t)qtok * cs + 16 * nt + 4 * g) = yn;
+        }
+    }
+    // ---- K / V of the next layer from the layer output still in registers ----
+    if (p.next_w_in) {
+        f32x4 yq[DC];
+#pragma unroll
+        for (int c = 0; c < DC; ++c) {
+            yq[c] = y[c];
+            if (p.pos) yq[c] += ld4(p.pos + (size_t)prow * cs + 16 * c + 4 * g);
+        }
+        for (int f = wave; f < 2 * DC; f += 4) {  // fragments 0..DC-1: K rows, DC..2DC-1: V rows
+            const bool isv = f >= DC;
+            const int nt = isv ? f - DC : f;
+            const int wrow = (isv ? 2 : 1) * cs;
+            const f32x4 a = row_mm<DC>(p.next_w_in + (size_t)wrow * cs, cs, nt, isv ? y : yq, ld4(p.next_b_in + wrow + 16 * nt + 4 * g), li, g);
+            if (qvalid) {
+                if (!isv) {
+                    *reinterpret_cast<f32x4*>(p.next_kbuf + (size_t)qtok * cs + 16 * nt + 4 * g) = a;
+                } else {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) p.next_vbuf[(size_t)(16 * nt + 4 * g + r) * p.n_tok_pad + qtok] = a[r];
+                }
+            }
+        }
     }
 }
 
@@ -553,6 +774,9 @@ int fill(const i2r_encoder_desc* d, EncK& k) {
     k.dff_pad = d->dff_pad; k.pos_period = d->pos_period; k.ln_eps = d->ln_eps;
     k.qscale = 1.0f / sqrtf((float)d->d);
     k.w_in_lp = d->w_in_lp; k.w_out_lp = d->w_out_lp; k.w1_lp = d->w1_lp; k.w2_lp = d->w2_lp;
+    k.next_w_in = d->next_w_in; k.next_b_in = d->next_b_in; k.next_kbuf = d->next_kbuf; k.next_vbuf = d->next_vbuf;
+    I2R_CHECK_ARG(!d->next_w_in || (d->next_b_in && d->next_kbuf && d->next_vbuf && d->next_kbuf != d->kbuf && d->next_vbuf != d->vbuf && d->dtype == 0),
+                  "i2r_encoder: fused next-layer K/V needs its own buffers (fp32 mode only)");
     I2R_CHECK_ARG(d->dtype >= 0 && d->dtype <= 2, "i2r_encoder: dtype %d", d->dtype);
     if (d->dtype != 0)
         I2R_CHECK_ARG(d->cs == 96 && d->w_in_lp && d->w_out_lp && d->w1_lp && d->w2_lp && d->n_qtiles16 > 0 && d->n_qtiles64 > 0,
@@ -598,11 +822,20 @@ extern "C" int i2r_encoder_layer(const i2r_encoder_desc* d, void* stream) {
         I2R_CHECK_LAUNCH("i2r_encoder_layer");
         return I2R_OK;
     }
-    constexpr int NW = 2;
-    if (d->cs == 96)
-        hipLaunchKernelGGL((enc_layer_k<6, 12, NW>), dim3((unsigned)d->n_qtiles32), dim3(NW * 64), 0, (hipStream_t)stream, k);
-    else
-        hipLaunchKernelGGL((enc_layer_k<5, 12, NW>), dim3((unsigned)d->n_qtiles32), dim3(NW * 64), 0, (hipStream_t)stream, k);
+    static const int v2 = getenv("I2R_ENC_V2") ? atoi(getenv("I2R_ENC_V2")) : 0;  // tuning switch: the one-wave-per-fragment kernel
+    if (v2 && !d->next_w_in) {
+        constexpr int NW = 2;
+        if (d->cs == 96)
+            hipLaunchKernelGGL((enc_layer_k<6, 12, NW>), dim3((unsigned)d->n_qtiles32), dim3(NW * 64), 0, (hipStream_t)stream, k);
+        else
+            hipLaunchKernelGGL((enc_layer_k<5, 12, NW>), dim3((unsigned)d->n_qtiles32), dim3(NW * 64), 0, (hipStream_t)stream, k);
+    } else {
+        I2R_CHECK_ARG(d->n_qtiles16 > 0, "i2r_encoder_layer: n_qtiles16");
+        if (d->cs == 96)
+            hipLaunchKernelGGL((enc_layer4_k<6, 12>), dim3((unsigned)d->n_qtiles16), dim3(256), 0, (hipStream_t)stream, k);
+        else
+            hipLaunchKernelGGL((enc_layer4_k<5, 12>), dim3((unsigned)d->n_qtiles16), dim3(256), 0, (hipStream_t)stream, k);
+    }
     I2R_CHECK_LAUNCH("i2r_encoder_layer");
     return I2R_OK;
 }

@@ -502,27 +502,36 @@ class Program:
         n_tok = x.n * x.h * x.w
         cs = x.cs
         n_pad = (n_tok + 63) // 64 * 64 + 64
-        kbuf = torch.empty(n_tok * cs, dtype=torch.float32, device=self.device)
-        vbuf = torch.zeros(cs * n_pad, dtype=torch.float32, device=self.device)
+        # fp32 mode: the K/V projection of layer i+1 is fused into the tail of layer i (ping-pong K/V buffers); the 16-bit
+        # capable stacks keep one enc_kv launch per layer (they may fall back to fp32 kernels per call, see set_groups)
+        fuse_kv = all(not L.get("dtype", 0) for L in layers) and len(layers) > 1
+        nbuf = 2 if fuse_kv else 1
+        kbufs = [torch.empty(n_tok * cs, dtype=torch.float32, device=self.device) for _ in range(nbuf)]
+        vbufs = [torch.zeros(cs * n_pad, dtype=torch.float32, device=self.device) for _ in range(nbuf)]
         goff = torch.zeros(x.n + 1, dtype=torch.int32, device=self.device)
-        self.keep += [kbuf, vbuf, goff]
+        self.keep += kbufs + vbufs + [goff]
         cur = x
         self.keep.append(layers)
         descs = []
-        for L in layers:
+        for i, L in enumerate(layers):
             assert L["cs"] == cs
             out = self.alloc(x.n, x.h, x.w, x.c)
             d = cabi.EncoderDesc()
             d.src, d.pos = cur.ptr, (pos if pos else None)
-            d.kbuf, d.vbuf, d.out, d.grp_off = kbuf.data_ptr(), vbuf.data_ptr(), out.ptr, goff.data_ptr()
+            d.kbuf, d.vbuf, d.out, d.grp_off = kbufs[i % nbuf].data_ptr(), vbufs[i % nbuf].data_ptr(), out.ptr, goff.data_ptr()
             for name in ("w_in", "b_in", "w_out", "b_out", "ln1_w", "ln1_b", "w1", "b1", "w2", "b2", "ln2_w", "ln2_b"):
                 setattr(d, name, L[name].data_ptr())
             d.n_tok, d.d, d.cs, d.dff_pad = n_tok, L["d"], cs, L["dff_pad"]
             d.pos_period, d.ln_eps = pos_period, 1e-5
             if L.get("dtype", 0):
                 d.w_in_lp, d.w_out_lp, d.w1_lp, d.w2_lp = (L[k].data_ptr() for k in ("w_in_lp", "w_out_lp", "w1_lp", "w2_lp"))
+            if fuse_kv and i + 1 < len(layers):
+                nxt = layers[i + 1]
+                d.next_w_in, d.next_b_in = nxt["w_in"].data_ptr(), nxt["b_in"].data_ptr()
+                d.next_kbuf, d.next_vbuf = kbufs[(i + 1) % nbuf].data_ptr(), vbufs[(i + 1) % nbuf].data_ptr()
             descs.append((d, L.get("dtype", 0)))
-            self.ops.append((cabi.OP_ENC_KV, lane, d))
+            if i == 0 or not fuse_kv:
+                self.ops.append((cabi.OP_ENC_KV, lane, d))
             self.ops.append((cabi.OP_ENC_LAYER, lane, d))
             if cur is not x:
                 self.release(cur)
