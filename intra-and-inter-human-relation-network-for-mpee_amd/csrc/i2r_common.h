@@ -40,6 +40,23 @@ __device__ __forceinline__ f32x4 mfma32_lp(f32x4 a, f32x4 b, f32x4 c) {  // D = 
         return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
 }
 
+// exchange a value with another lane of the same quad (DPP quad_perm; CTRL 0xB1 = [1,0,3,2], 0x4E = [2,3,0,1])
+template <int CTRL>
+__device__ __forceinline__ float quad_xchg(float x) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, x), CTRL, 0xF, 0xF, false));
+}
+// 4x4 transpose inside each quad of consecutive lanes (two DPP butterfly stages, no LDS): with j = lane & 3,
+// out(lane j)[r] = in(lane r of the quad)[j]
+__device__ __forceinline__ f32x4 quad_transpose(f32x4 v, int j) {
+    const bool odd1 = j & 1, odd2 = j & 2;
+    const float s0 = quad_xchg<0xB1>(odd1 ? v[0] : v[1]);
+    const float s1 = quad_xchg<0xB1>(odd1 ? v[2] : v[3]);
+    if (odd1) { v[0] = s0; v[2] = s1; } else { v[1] = s0; v[3] = s1; }
+    const float t0 = quad_xchg<0x4E>(odd2 ? v[0] : v[2]);
+    const float t1 = quad_xchg<0x4E>(odd2 ? v[1] : v[3]);
+    if (odd2) { v[0] = t0; v[1] = t1; } else { v[2] = t0; v[3] = t1; }
+    return v;
+}
 
 void i2r_set_error(const char* fmt, ...);
 

@@ -44,12 +44,6 @@ struct ConvK {
     int dbg;            // ablation switches (env I2R_CONV_DBG; tuning only): 1 no epilogue, 2 no staging loads, 4 no weight loads
 };
 
-// exchange a value with another lane of the same quad (DPP quad_perm; CTRL 0xB1 = [1,0,3,2], 0x4E = [2,3,0,1])
-template <int CTRL>
-__device__ __forceinline__ float quad_xchg(float x) {
-    return __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, x), CTRL, 0xF, 0xF, false));
-}
-
 constexpr int kMaxPP = 5;  // patch pixels per thread (256 threads) -> patches up to 1280 pixels
 
 constexpr int kMaxGroups = 4;
@@ -70,7 +64,6 @@ __device__ __forceinline__ void conv_epilogue(const ConvK& p, f32x4 (&acc)[MT][N
                                               int li, int g, int tile_px) {
     if ((p.dbg & 1) && acc[0][0][0] != 12345.678f) return;
     const int j4 = li & 3, q4 = li >> 2;
-    const bool odd1 = j4 & 1, odd2 = j4 & 2;
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt) {
         const int m = (wm * MT + mt) * 16 + g * 4 + j4;
@@ -81,15 +74,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvK& p, f32x4 (&acc)[MT][N
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt) {
             f32x4 v = acc[mt][nt];
-            {   // stage 1: swap across lane pairs (j ^ 1) the elements (r ^ 1)
-                const float s0 = quad_xchg<0xB1>(odd1 ? v[0] : v[1]);
-                const float s1 = quad_xchg<0xB1>(odd1 ? v[2] : v[3]);
-                if (odd1) { v[0] = s0; v[2] = s1; } else { v[1] = s0; v[3] = s1; }
-                // stage 2: swap across lane pairs (j ^ 2) the element pairs (r ^ 2)
-                const float t0 = quad_xchg<0x4E>(odd2 ? v[0] : v[2]);
-                const float t1 = quad_xchg<0x4E>(odd2 ? v[1] : v[3]);
-                if (odd2) { v[0] = t0; v[1] = t1; } else { v[2] = t0; v[3] = t1; }
-            }
+            v = quad_transpose(v, j4);
             const int n = n_base + nt * 16 + q4 * 4;
             if (!pvalid || n >= p.cout_pad) continue;
             v += *reinterpret_cast<const f32x4*>(p.bias + n);

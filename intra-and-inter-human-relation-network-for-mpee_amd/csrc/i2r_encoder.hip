@@ -2,14 +2,21 @@
 // TransPose-H intra-human encoder), fp32 on the matrix pipe.
 //
 // Formulation ("token-per-lane-column"): every GEMM is computed TRANSPOSED,  Y^T[f][t] = W[f][:] . X^T[:][t],
-// with the weight matrix as the MFMA A operand (read as 16-byte rows of the reference's own row-major
-// [out][in] nn.Linear weights) and the activations as the B operand.  The 16x16x4 fp32 MFMA returns
+// with the weight matrix as the MFMA A operand and the activations as the B operand.  The 16x16x4 fp32 MFMA returns
 // D with col = l&15 = token and rows 4*(l>>4)+r = feature -- which is exactly the B-operand register
 // image the NEXT GEMM needs (token = l&15, k-group = l>>4, 4 consecutive features per float4).  So
 // q-proj -> S^T = K Q^T -> softmax -> O^T = V^T P^T -> out-proj -> +res -> LN1 -> FFN1 -> ReLU -> FFN2 -> +res -> LN2
-// chains register-to-register: no LDS transposes, no intermediate HBM round trips.  Only K / V^T tiles of the
-// group go through LDS (shared by the waves of a workgroup).  Softmax / LayerNorm reductions over features
-// or keys are in-lane sums + two __shfl_xor (16, 32).
+// chains register-to-register: no LDS transposes, no intermediate HBM round trips.  Softmax / LayerNorm reductions over
+// features or keys are in-lane sums + two __shfl_xor (16, 32).
+//
+// Operand images in memory ("fragment-packed"): an A operand fragment (16 rows x 16 k) is what 64 lanes fetch with ONE
+// 16-byte load each -- lane (li = l&15, g = l>>4) takes row li, k = 4g..4g+3.  Reading that from a row-major matrix makes
+// every quad of consecutive lanes touch 4 different rows, and the texture addresser then needs 64 cycles per load
+// instruction instead of 16 (tools/probe/load_pattern.hip: 9.6 vs 30 TB/s aggregate L2->register) -- the one-wave-per-
+// fragment kernels were bound by exactly that.  So every A operand is stored in lane order:
+//     packed[((rb * KC + c) * 64 + l) * 4 + r] = M[16*rb + (l&15)][16*c + 4*(l>>4) + r]        (KC = columns / 16)
+// i.e. one load instruction = 1 KB contiguous.  Weights are packed like this by the host (engine.pack_frag); the K rows
+// and V^T rows of the attention are WRITTEN like this by the kernels that produce them (per 16-key fragment of a group).
 #include <stdlib.h>
 
 #include "i2r_common.h"
@@ -29,12 +36,13 @@ struct EncK {
     const float* w1; const float* b1;
     const float* w2; const float* b2;
     const float* ln2_w; const float* ln2_b;
-    int n_tok, n_tok_pad, n_grp, d, cs, dff_pad, pos_period;
+    int n_tok, n_tok_pad, n_grp, d, cs, dff_pad, pos_period, n_qtiles;
     float ln_eps, qscale;
     // 16-bit MFMA mode: weights as bf16/f16 [out][in] with the columns of every 32-block permuted to the MFMA operand order
     const void* w_in_lp; const void* w_out_lp; const void* w1_lp; const void* w2_lp;
     // fused K/V projection of the NEXT layer (enc_layer4_k): its in_proj (k, v rows used), destination buffers; null = none
     const float* next_w_in; const float* next_b_in; float* next_kbuf; float* next_vbuf;
+    long long* stamp;  // tuning only (env I2R_ENC_STAMP = device address): 8 s_memtime stamps per wave
 };
 
 __device__ __forceinline__ f32x4 ld4(const float* p) { return *reinterpret_cast<const f32x4*>(p); }
@@ -50,53 +58,99 @@ __device__ __forceinline__ float xmax(float v) {
     return v;
 }
 
-// ---- K / V projection: one wave = 32 tokens ----
+// ---- which (group, 16-token tile) is tile v?  64 groups per trip: lane-parallel prefix sum of the tile counts ----
+struct Tile {
+    int gs, ge;  // token range of the group
+    int j;       // tile index inside the group
+    int base;    // global index of the group's first tile (= fragment index of its first 16 keys in kbuf / vbuf)
+};
+__device__ __forceinline__ void load_groups(const EncK& p, int gi, int& s0, int& e0) {
+    s0 = e0 = 0;
+    if (gi < p.n_grp) {
+        s0 = p.grp_off[gi];
+        e0 = p.grp_off[gi + 1];
+    }
+}
+// (s0, e0) = load_groups(lane), issued by the caller ahead of other loads so the table's latency overlaps them
+__device__ __forceinline__ Tile locate_tile(const EncK& p, int v, int lane, int s0, int e0) {
+    Tile t = {0, 0, 0, 0};
+    int b = v;
+    for (int base = 0; base < p.n_grp; base += 64) {
+        if (base > 0) load_groups(p, base + lane, s0, e0);
+        const int nq = (e0 - s0 + 15) >> 4;
+        int inc = nq;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            const int u = __shfl_up(inc, d);
+            if (lane >= d) inc += u;
+        }
+        const int total = __shfl(inc, 63);
+        if (b < total) {
+            const int src = __ffsll((long long)__ballot(inc > b)) - 1;
+            t.gs = __shfl(s0, src);
+            t.ge = __shfl(e0, src);
+            b -= __shfl(inc - nq, src);
+            break;
+        }
+        b -= total;
+    }
+    t.gs = __builtin_amdgcn_readfirstlane(t.gs);
+    t.ge = __builtin_amdgcn_readfirstlane(t.ge);
+    t.j = __builtin_amdgcn_readfirstlane(b);
+    t.base = v - t.j;
+    return t;
+}
+
+// store one 16-token fragment of K (as the A operand of S^T = K Q^T) and of V^T (A operand of O^T = V^T P^T), fragment-packed.
+// k / v: D-layout fragments nt of the projections (lane (li, g): token li, features 16nt + 4g + r).
+__device__ __forceinline__ void store_kv_frag(float* kbuf, float* vbuf, int frag, int DCn, int nt, f32x4 k, f32x4 v, bool has_k, bool has_v,
+                                              int lane) {
+    const int li = lane & 15, g = lane >> 4;
+    const size_t base = ((size_t)frag * DCn + nt) * 64;
+    if (has_k) *reinterpret_cast<f32x4*>(kbuf + (base + lane) * 4) = k;  // K[key li][16nt + 4g + r]: already the operand image
+    if (has_v) {
+        // V^T[dim 16nt + li'][key 4g' + r']: a 4x4 transpose inside the lane quads moves (key li, dims 4g + r) to
+        // (dim 4g + (li&3), keys 4(li>>2) + r')  ->  operand lane li' = 4g + (li&3), g' = li >> 2
+        const f32x4 tv = quad_transpose(v, li & 3);
+        *reinterpret_cast<f32x4*>(vbuf + (base + 4 * g + (li & 3) + 16 * (li >> 2)) * 4) = tv;
+    }
+}
+
+// ---- K / V projection of one 16-token tile per wave (first layer of a stack; later layers get theirs from the fused tail) ----
 template <int DC>
 __global__ __launch_bounds__(64) void enc_kv_k(const EncK p) {
     const int lane = threadIdx.x, li = lane & 15, g = lane >> 4;
     const int cs = DC * 16;
-    const int t0 = blockIdx.x * 32;
-    f32x4 xs[2][DC], xq[2][DC];
-    int tok[2];
+    int s0, e0;
+    load_groups(p, lane, s0, e0);
+    const Tile t = locate_tile(p, blockIdx.x, lane, s0, e0);
+    const int tok = t.gs + 16 * t.j + li;
+    const bool valid = tok < t.ge;
+    const int row = valid ? tok : t.ge - 1;
+    const int prow = p.pos_period > 0 ? row % p.pos_period : row;
+    f32x4 xs[DC], xq[DC];
 #pragma unroll
-    for (int tf = 0; tf < 2; ++tf) {
-        tok[tf] = t0 + tf * 16 + li;
-        const int row = min(tok[tf], p.n_tok - 1);
-        const int prow = p.pos_period > 0 ? row % p.pos_period : row;
-#pragma unroll
-        for (int c = 0; c < DC; ++c) {
-            xs[tf][c] = ld4(p.src + (size_t)row * cs + 16 * c + 4 * g);
-            xq[tf][c] = xs[tf][c];
-            if (p.pos) xq[tf][c] += ld4(p.pos + (size_t)prow * cs + 16 * c + 4 * g);
-        }
+    for (int c = 0; c < DC; ++c) {
+        xs[c] = ld4(p.src + (size_t)row * cs + 16 * c + 4 * g);
+        xq[c] = xs[c];
+        if (p.pos) xq[c] += ld4(p.pos + (size_t)prow * cs + 16 * c + 4 * g);
     }
-    // K rows of w_in: [cs, 2cs); V rows: [2cs, 3cs)
+    // K rows of w_in: row blocks [DC, 2DC); V rows: [2DC, 3DC)
 #pragma unroll
     for (int nt = 0; nt < DC; ++nt) {
-        f32x4 ak[2], av[2];
-        ak[0] = ak[1] = ld4(p.b_in + cs + 16 * nt + 4 * g);
-        av[0] = av[1] = ld4(p.b_in + 2 * cs + 16 * nt + 4 * g);
+        f32x4 ak = ld4(p.b_in + cs + 16 * nt + 4 * g), av = ld4(p.b_in + 2 * cs + 16 * nt + 4 * g);
 #pragma unroll
         for (int c = 0; c < DC; ++c) {
-            const f32x4 wk = ld4(p.w_in + (size_t)(cs + 16 * nt + li) * cs + 16 * c + 4 * g);
-            const f32x4 wv = ld4(p.w_in + (size_t)(2 * cs + 16 * nt + li) * cs + 16 * c + 4 * g);
+            const f32x4 wk = ld4(p.w_in + (((size_t)(DC + nt) * DC + c) * 64 + lane) * 4);
+            const f32x4 wv = ld4(p.w_in + (((size_t)(2 * DC + nt) * DC + c) * 64 + lane) * 4);
 #pragma unroll
             for (int s = 0; s < 4; ++s) {
-#pragma unroll
-                for (int tf = 0; tf < 2; ++tf) {
-                    ak[tf] = mfma16(wk[s], xq[tf][c][s], ak[tf]);
-                    av[tf] = mfma16(wv[s], xs[tf][c][s], av[tf]);
-                }
+                ak = mfma16(wk[s], xq[c][s], ak);
+                av = mfma16(wv[s], xs[c][s], av);
             }
         }
-#pragma unroll
-        for (int tf = 0; tf < 2; ++tf) {
-            if (tok[tf] < p.n_tok) {
-                *reinterpret_cast<f32x4*>(p.kbuf + (size_t)tok[tf] * cs + 16 * nt + 4 * g) = ak[tf];
-#pragma unroll
-                for (int r = 0; r < 4; ++r) p.vbuf[(size_t)(16 * nt + 4 * g + r) * p.n_tok_pad + tok[tf]] = av[tf][r];
-            }
-        }
+        if (!valid) av = (f32x4){0.f, 0.f, 0.f, 0.f};  // keys past the group: masked scores, but V must stay finite
+        store_kv_frag(p.kbuf, p.vbuf, t.base + t.j, DC, nt, ak, av, true, true, lane);
     }
 }
 
@@ -124,12 +178,13 @@ __device__ __forceinline__ void layer_norm(f32x4 (&y)[DC], const float* w, const
     }
 }
 
-// one output fragment (16 features x 16 tokens) of  Y^T = W X^T (+bias):  acc += sum_c W[16nt+li][16c+4g..] * x[c]
+// one output fragment (16 features x 16 tokens) of  Y^T = W X^T (+bias):  acc += sum_c W[16nt+li][16c+4g..] * x[c];
+// W fragment-packed (see the header): the KC loads of a fragment are 1 KB contiguous each
 template <int KC>
-__device__ __forceinline__ void load_wrow(f32x4 (&wr)[KC], const float* W, int ld, int nt, int li, int g) {
-    const float* row = W + (size_t)(16 * nt + li) * ld + 4 * g;
+__device__ __forceinline__ void load_wrow(f32x4 (&wr)[KC], const float* W, int nt, int lane) {
+    const float* f = W + ((size_t)nt * KC * 64 + lane) * 4;
 #pragma unroll
-    for (int c = 0; c < KC; ++c) wr[c] = ld4(row + 16 * c);
+    for (int c = 0; c < KC; ++c) wr[c] = ld4(f + c * 256);
 }
 template <int KC>
 __device__ __forceinline__ f32x4 frag_mm(const f32x4 (&wr)[KC], const f32x4 (&x)[KC], f32x4 acc) {
@@ -139,149 +194,6 @@ __device__ __forceinline__ f32x4 frag_mm(const f32x4 (&wr)[KC], const f32x4 (&x)
         for (int s = 0; s < 4; ++s) acc = mfma16(wr[c][s], x[c][s], acc);
     return acc;
 }
-// Y^T[NF frags] = W[NF*16, KC*16] X^T + b, weight rows software-pipelined one fragment ahead (two named register sets)
-template <int NF, int KC, typename Epi>
-__device__ __forceinline__ void gemm_T(const float* W, const float* bias, int ld, const f32x4 (&x)[KC], int li, int g, Epi epi) {
-    f32x4 w0[KC], w1[KC];
-    load_wrow<KC>(w0, W, ld, 0, li, g);
-#pragma unroll
-    for (int nt = 0; nt < NF; nt += 2) {
-        if (nt + 1 < NF) load_wrow<KC>(w1, W, ld, nt + 1, li, g);
-        epi(nt, frag_mm<KC>(w0, x, ld4(bias + 16 * nt + 4 * g)));
-        if (nt + 1 < NF) {
-            if (nt + 2 < NF) load_wrow<KC>(w0, W, ld, nt + 2, li, g);
-            epi(nt + 1, frag_mm<KC>(w1, x, ld4(bias + 16 * (nt + 1) + 4 * g)));
-        }
-    }
-}
-
-// ---- attention + output projection + LN1 + FFN + LN2: NW waves x 16 queries; K / V^T fragments stream from L2
-//      straight into registers (no LDS, no barrier), prefetched one 16-key fragment ahead ----
-template <int DC, int FC, int NW>
-__global__ __launch_bounds__(NW * 64) void enc_layer_k(const EncK p) {
-    constexpr int cs = DC * 16, dff = FC * 16;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int li = lane & 15, g = lane >> 4;
-    constexpr int QT = NW * 16;
-
-    // which (group, query tile) is this workgroup?
-    int b = blockIdx.x, gs = 0, ge = 0;
-    for (int grp = 0; grp < p.n_grp; ++grp) {
-        gs = p.grp_off[grp];
-        ge = p.grp_off[grp + 1];
-        const int nq = (ge - gs + QT - 1) / QT;
-        if (b < nq) break;
-        b -= nq;
-    }
-    const int q0 = gs + b * QT + wave * 16;
-    if (q0 >= ge) return;  // (whole wave past the end of the group)
-    const int qtok = q0 + li;
-    const bool qvalid = qtok < ge;
-    const int qrow = qvalid ? qtok : ge - 1;
-    const int prow = p.pos_period > 0 ? qrow % p.pos_period : qrow;
-
-    f32x4 xs[DC], q[DC];
-    {
-        f32x4 xq[DC];
-#pragma unroll
-        for (int c = 0; c < DC; ++c) {
-            xs[c] = ld4(p.src + (size_t)qrow * cs + 16 * c + 4 * g);
-            xq[c] = xs[c];
-            if (p.pos) xq[c] += ld4(p.pos + (size_t)prow * cs + 16 * c + 4 * g);
-        }
-        gemm_T<DC, DC>(p.w_in, p.b_in, cs, xq, li, g, [&](int nt, f32x4 a) { q[nt] = a * p.qscale; });
-    }
-
-    f32x4 o[DC];
-#pragma unroll
-    for (int nt = 0; nt < DC; ++nt) o[nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    float m_run = -__builtin_inff(), l_run = 0.f;
-
-    // A operands of one 16-key fragment: K rows (lane = key li) and V^T rows (lane = dim li), 4 consecutive k each
-    auto fetch_kv = [&](int k0, f32x4(&ka)[DC], f32x4(&va)[DC]) {
-        const int krow = min(k0 + li, ge - 1);  // clamp: rows past the group are masked below
-        const float* kp = p.kbuf + (size_t)krow * cs + 4 * g;
-        const float* vp = p.vbuf + (size_t)li * p.n_tok_pad + k0 + 4 * g;
-#pragma unroll
-        for (int c = 0; c < DC; ++c) {
-            ka[c] = ld4(kp + 16 * c);
-            va[c] = ld4(vp + (size_t)16 * c * p.n_tok_pad);
-        }
-    };
-    auto attend = [&](int k0, const f32x4(&ka)[DC], const f32x4(&va)[DC]) {
-        f32x4 st = (f32x4){0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-        for (int c = 0; c < DC; ++c)
-#pragma unroll
-            for (int s = 0; s < 4; ++s) st = mfma16(ka[c][s], q[c][s], st);  // S^T[key 4g+r][query li]
-        float mx = -__builtin_inff();
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            if (k0 + 4 * g + r >= ge) st[r] = -__builtin_inff();
-            mx = fmaxf(mx, st[r]);
-        }
-        mx = xmax(mx);
-        const float m_new = fmaxf(m_run, mx);
-        const float alpha = __expf(m_run - m_new);
-        float ls = 0.f;
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            st[r] = __expf(st[r] - m_new);
-            ls += st[r];
-        }
-        l_run = l_run * alpha + ls;
-        m_run = m_new;
-#pragma unroll
-        for (int nt = 0; nt < DC; ++nt) {
-            f32x4 acc = o[nt] * alpha;
-#pragma unroll
-            for (int s = 0; s < 4; ++s) acc = mfma16(va[nt][s], st[s], acc);  // O^T[dim][query] += V^T[dim][key] P^T
-            o[nt] = acc;
-        }
-    };
-    {
-        f32x4 ka0[DC], va0[DC], ka1[DC], va1[DC];
-        fetch_kv(gs, ka0, va0);
-        int k0 = gs;
-        for (; k0 + 32 <= ge; k0 += 32) {
-            fetch_kv(k0 + 16, ka1, va1);
-            attend(k0, ka0, va0);
-            fetch_kv(min(k0 + 32, ge - 1) & ~3, ka0, va0);  // (look-ahead past the end is clamped and unused)
-            attend(k0 + 16, ka1, va1);
-        }
-        if (k0 < ge) {
-            if (k0 + 16 < ge) fetch_kv(k0 + 16, ka1, va1);
-            attend(k0, ka0, va0);
-            if (k0 + 16 < ge) attend(k0 + 16, ka1, va1);
-        }
-    }
-    {
-        const float inv = 1.f / xsum(l_run);
-#pragma unroll
-        for (int nt = 0; nt < DC; ++nt) o[nt] *= inv;
-    }
-
-    // out-proj + residual + LN1
-    f32x4 x1[DC];
-    gemm_T<DC, DC>(p.w_out, p.b_out, cs, o, li, g, [&](int nt, f32x4 a) { x1[nt] = xs[nt] + a; });
-    layer_norm<DC>(x1, p.ln1_w, p.ln1_b, p.d, p.ln_eps, g);
-
-    // FFN
-    f32x4 h[FC];
-    gemm_T<FC, DC>(p.w1, p.b1, cs, x1, li, g, [&](int ft, f32x4 a) {
-#pragma unroll
-        for (int r = 0; r < 4; ++r) a[r] = fmaxf(a[r], 0.f);
-        h[ft] = a;
-    });
-    f32x4 y[DC];
-    gemm_T<DC, FC>(p.w2, p.b2, dff, h, li, g, [&](int nt, f32x4 a) { y[nt] = x1[nt] + a; });
-    layer_norm<DC>(y, p.ln2_w, p.ln2_b, p.d, p.ln_eps, g);
-    if (qvalid) {
-#pragma unroll
-        for (int nt = 0; nt < DC; ++nt) *reinterpret_cast<f32x4*>(p.out + (size_t)qtok * cs + 16 * nt + 4 * g) = y[nt];
-    }
-}
-
 // =====================================================================================================================
 // fp32 encoder layer, 4 waves per 16-query tile (enc_layer4_k) -- the default fp32 kernel
 // ---------------------------------------------------------------------------------------------------------------------
@@ -291,110 +203,155 @@ __global__ __launch_bounds__(NW * 64) void enc_layer_k(const EncK p) {
 // by OUTPUT fragments (wave w computes fragments w, w+4, ...), activations exchanged through LDS (a few KB).  The K / V
 // projection of the NEXT layer is fused into the tail (the layer output is already in registers), removing the separate
 // enc_kv launch for all layers but the first.
-template <int KC>
-__device__ __forceinline__ f32x4 row_mm(const float* W, int ld, int nt, const f32x4 (&x)[KC], f32x4 acc, int li, int g) {
-    f32x4 w[KC];
-    load_wrow<KC>(w, W, ld, nt, li, g);
-    return frag_mm<KC>(w, x, acc);
-}
-
 template <int DC, int FC>
-__global__ __launch_bounds__(256) void enc_layer4_k(const EncK p) {
+__global__ __launch_bounds__(256, 2) void enc_layer4_k(const EncK p) {
     constexpr int cs = DC * 16, dff = FC * 16;
+    constexpr int SD = (DC + 3) / 4, SF = (FC + 3) / 4, SK = (2 * DC + 3) / 4;  // output-fragment slots per wave of each GEMM
     // LDS (float4 units): exchange area X[max(FC,DC)][64] + partial-O area O[4][DC][64] + (m,l) area ML[4][2][16]
     __shared__ f32x4 Xs[(FC > DC ? FC : DC) * 64];
     __shared__ f32x4 Os[4 * DC * 64];
     __shared__ float MLs[4 * 2 * 16];
+    // the small per-feature vectors of the layer tail, staged once (read back as 16-byte broadcasts; no VMEM latency in the tail)
+    constexpr int P_BOUT = 0, P_LN1W = cs, P_LN1B = 2 * cs, P_B1 = 3 * cs, P_B2 = 3 * cs + dff, P_LN2W = 4 * cs + dff,
+                  P_LN2B = 5 * cs + dff, P_BKV = 6 * cs + dff, P_END = 8 * cs + dff;
+    __shared__ __attribute__((aligned(16))) float Ps[P_END];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int li = lane & 15, g = lane >> 4;
+#define STAMP(i) do { if (p.stamp && lane == 0) p.stamp[((size_t)blockIdx.x * 4 + wave) * 8 + (i)] = (long long)__builtin_amdgcn_s_memtime(); } while (0)
+    STAMP(0);
 
-    int b = blockIdx.x, gs = 0, ge = 0;
-    for (int grp = 0; grp < p.n_grp; ++grp) {
-        gs = p.grp_off[grp];
-        ge = p.grp_off[grp + 1];
-        const int nq = (ge - gs + 15) >> 4;
-        if (b < nq) break;
-        b -= nq;
+    // Every GEMM of the layer hands wave w the output fragments w, w+4, ... ("slots"; a slot past the end is computed on a
+    // clamped row and not written).  The weight rows of a slot are fetched one phase AHEAD of their use (they depend on
+    // nothing but the wave id), so their L2 latency hides under the previous phase's exchange / barrier / LayerNorm.
+    int gs0, ge0;
+    load_groups(p, lane, gs0, ge0);  // (first: everything below waits in issue order)
+    f32x4 wq[SD][DC], bq[SD];
+#pragma unroll
+    for (int s = 0; s < SD; ++s) {
+        load_wrow<DC>(wq[s], p.w_in, min(wave + 4 * s, DC - 1), lane);
+        bq[s] = ld4(p.b_in + 16 * min(wave + 4 * s, DC - 1) + 4 * g);
     }
+    f32x4 pstage = (f32x4){0.f, 0.f, 0.f, 0.f};
+    {   // one 16-byte piece per thread of the concatenated tail vectors (P_END / 4 <= 256 pieces)
+        static_assert(P_END <= 1024, "tail vector staging: one piece per thread");
+        const int i = tid * 4;
+        const float* sp = p.b_out;
+        int o = i;
+        if (i >= P_LN1W) sp = p.ln1_w, o = i - P_LN1W;
+        if (i >= P_LN1B) sp = p.ln1_b, o = i - P_LN1B;
+        if (i >= P_B1) sp = p.b1, o = i - P_B1;
+        if (i >= P_B2) sp = p.b2, o = i - P_B2;
+        if (i >= P_LN2W) sp = p.ln2_w, o = i - P_LN2W;
+        if (i >= P_LN2B) sp = p.ln2_b, o = i - P_LN2B;
+        if (i >= P_BKV) sp = p.next_b_in, o = cs + i - P_BKV;
+        if (i < P_END && sp) pstage = ld4(sp + o);
+    }
+    // ---- which (group, query tile)?  Workgroup b runs on XCD b % 8: give every XCD a contiguous run of tiles, so the K / V
+    //      of one group are read through ONE L2 instead of all eight ----
+    const int per_xcd = gridDim.x >> 3;
+    const int v = (blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3);
+    if (v >= p.n_qtiles) return;
+    const Tile t = locate_tile(p, v, lane, gs0, ge0);
+    if (tid * 4 < P_END) *reinterpret_cast<f32x4*>(Ps + tid * 4) = pstage;  // (visible after the barrier that follows the q projection)
+    const int gs = t.gs, ge = t.ge, b = t.j;
+    const int nfrag = (ge - gs + 15) >> 4;
     const int qtok = gs + b * 16 + li;
     const bool qvalid = qtok < ge;
     const int qrow = qvalid ? qtok : ge - 1;
     const int prow = p.pos_period > 0 ? qrow % p.pos_period : qrow;
 
-    // ---- inputs (every wave keeps the tile's src and src+pos fragments: 2 x DC float4) ----
-    f32x4 xs[DC], xq[DC];
+    // A operands of the group's jj-th 16-key fragment (fragment-packed: 2 x DC contiguous 1 KB loads)
+    auto fetch_kv = [&](int jj, f32x4(&ka)[DC], f32x4(&va)[DC]) {
+        const size_t f = ((size_t)(t.base + jj) * DC * 64 + lane) * 4;
 #pragma unroll
-    for (int c = 0; c < DC; ++c) {
-        xs[c] = ld4(p.src + (size_t)qrow * cs + 16 * c + 4 * g);
-        xq[c] = xs[c];
-        if (p.pos) xq[c] += ld4(p.pos + (size_t)prow * cs + 16 * c + 4 * g);
-    }
-    // ---- q projection, output fragments split over the waves, exchanged through LDS ----
-    for (int nt = wave; nt < DC; nt += 4)
-        Xs[nt * 64 + lane] = row_mm<DC>(p.w_in, cs, nt, xq, ld4(p.b_in + 16 * nt + 4 * g), li, g) * p.qscale;
-    __syncthreads();
+        for (int c = 0; c < DC; ++c) {
+            ka[c] = ld4(p.kbuf + f + c * 256);
+            va[c] = ld4(p.vbuf + f + c * 256);
+        }
+    };
+    f32x4 ka0[DC], va0[DC], ka1[DC], va1[DC];
     f32x4 q[DC];
+    {
+        f32x4 xq[DC];
+#pragma unroll
+        for (int c = 0; c < DC; ++c) {
+            xq[c] = ld4(p.src + (size_t)qrow * cs + 16 * c + 4 * g);
+            if (p.pos) xq[c] += ld4(p.pos + (size_t)prow * cs + 16 * c + 4 * g);
+        }
+        fetch_kv(min(wave, nfrag - 1), ka0, va0);  // first key fragment of this wave: in flight under the q projection
+        __builtin_amdgcn_sched_barrier(0);
+        // ---- q projection (scaled by d^-1/2 * log2 e: the softmax below works in base 2), exchanged through LDS ----
+#pragma unroll
+        for (int s = 0; s < SD; ++s) {
+            const int nt = min(wave + 4 * s, DC - 1);
+            const f32x4 a = frag_mm<DC>(wq[s], xq, bq[s]) * (p.qscale * 1.4426950408889634f);
+            if (wave + 4 * s < DC) Xs[nt * 64 + lane] = a;
+        }
+    }
+    __syncthreads();
 #pragma unroll
     for (int c = 0; c < DC; ++c) q[c] = Xs[c * 64 + lane];
+    STAMP(1);
 
-    // ---- attention over this wave's key fragments (kf = wave, wave+4, ...), prefetched one fragment ahead ----
+    // ---- attention over this wave's key fragments (wave, wave+4, ...), each prefetched a whole fragment ahead.
+    //      Online softmax with a LAZY reference: the running reference m (per query, base-2 units) is only raised -- and O, l
+    //      rescaled -- when some score exceeds it by more than 2^10; otherwise p = 2^(s-m) <= 1024 is accumulated as is.
+    //      The normalisation O / l at the end is exact either way (same reference in numerator and denominator). ----
     f32x4 o[DC];
 #pragma unroll
     for (int nt = 0; nt < DC; ++nt) o[nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    float m_run = -__builtin_inff(), l_run = 0.f;
-    auto fetch_kv = [&](int k0, f32x4(&ka)[DC], f32x4(&va)[DC]) {
-        const int krow = min(k0 + li, ge - 1);
-        const float* kp = p.kbuf + (size_t)krow * cs + 4 * g;
-        const float* vp = p.vbuf + (size_t)li * p.n_tok_pad + k0 + 4 * g;
-#pragma unroll
-        for (int c = 0; c < DC; ++c) {
-            ka[c] = ld4(kp + 16 * c);
-            va[c] = ld4(vp + (size_t)16 * c * p.n_tok_pad);
-        }
-    };
+    float m_run = -__builtin_inff(), l_run = 0.f;  // l_run: this lane's keys only (summed over the 4 lanes of a query at the end)
     auto attend = [&](int k0, const f32x4(&ka)[DC], const f32x4(&va)[DC]) {
         f32x4 st = (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int c = 0; c < DC; ++c)
 #pragma unroll
-            for (int s = 0; s < 4; ++s) st = mfma16(ka[c][s], q[c][s], st);
-        float mx = -__builtin_inff();
+            for (int s = 0; s < 4; ++s) st = mfma16(ka[c][s], q[c][s], st);  // S^T[key 4g+r][query li]
+        if (k0 + 16 > ge) {  // (wave-uniform) ragged last fragment of the group
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+                if (k0 + 4 * g + r >= ge) st[r] = -__builtin_inff();
+        }
+        const float mx = fmaxf(fmaxf(st[0], st[1]), fmaxf(st[2], st[3]));
+        if (__any(mx > m_run + 10.f)) {  // (wave-uniform, rare after the first fragment)
+            const float m_new = fmaxf(m_run, xmax(mx));
+            const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);  // first time: 2^-inf = 0
+            l_run *= alpha;
+#pragma unroll
+            for (int nt = 0; nt < DC; ++nt) o[nt] *= alpha;
+            m_run = m_new;
+        }
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-            if (k0 + 4 * g + r >= ge) st[r] = -__builtin_inff();
-            mx = fmaxf(mx, st[r]);
+            st[r] = __builtin_amdgcn_exp2f(st[r] - m_run);
+            l_run += st[r];
         }
-        mx = xmax(mx);
-        const float m_new = fmaxf(m_run, mx);
-        const float alpha = __expf(m_run - m_new);
-        float ls = 0.f;
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            st[r] = __expf(st[r] - m_new);
-            ls += st[r];
-        }
-        l_run = l_run * alpha + ls;
-        m_run = m_new;
+        for (int s = 0; s < 4; ++s)
 #pragma unroll
-        for (int nt = 0; nt < DC; ++nt) {
-            f32x4 acc = o[nt] * alpha;
-#pragma unroll
-            for (int s = 0; s < 4; ++s) acc = mfma16(va[nt][s], st[s], acc);
-            o[nt] = acc;
-        }
+            for (int nt = 0; nt < DC; ++nt) o[nt] = mfma16(va[nt][s], st[s], o[nt]);  // O^T[dim][query] += V^T[dim][key] P^T
     };
     {
-        f32x4 ka0[DC], va0[DC], ka1[DC], va1[DC];
-        int k0 = gs + wave * 16;
-        if (k0 < ge) fetch_kv(k0, ka0, va0);
-        for (; k0 + 64 < ge; k0 += 128) {          // two fragments (k0, k0+64) per trip, each prefetched under the other
-            fetch_kv(k0 + 64, ka1, va1);
-            attend(k0, ka0, va0);
-            if (k0 + 128 < ge) fetch_kv(k0 + 128, ka0, va0);
-            attend(k0 + 64, ka1, va1);
+        int jj = wave;
+        for (; jj + 4 < nfrag; jj += 8) {  // two fragments (jj, jj+4) per trip, each fetched under the other's arithmetic
+            fetch_kv(jj + 4, ka1, va1);
+            __builtin_amdgcn_sched_barrier(0);
+            attend(gs + 16 * jj, ka0, va0);
+            fetch_kv(jj + 8 < nfrag ? jj + 8 : jj, ka0, va0);  // (past the end: harmless re-read)
+            __builtin_amdgcn_sched_barrier(0);
+            attend(gs + 16 * jj + 64, ka1, va1);
         }
-        if (k0 < ge) attend(k0, ka0, va0);
+        if (jj < nfrag) attend(gs + 16 * jj, ka0, va0);
     }
+    STAMP(2);
+    // out-proj rows of this wave's slots: in flight under the merge
+    f32x4 wo[SD][DC], res[SD];
+#pragma unroll
+    for (int s = 0; s < SD; ++s) {
+        load_wrow<DC>(wo[s], p.w_out, min(wave + 4 * s, DC - 1), lane);
+        res[s] = ld4(p.src + (size_t)qrow * cs + 16 * min(wave + 4 * s, DC - 1) + 4 * g);
+    }
+    __builtin_amdgcn_sched_barrier(0);
     // ---- merge the four partial softmax states ----
     l_run = xsum(l_run);
     if (g == 0) {
@@ -415,7 +372,7 @@ __global__ __launch_bounds__(256) void enc_layer4_k(const EncK p) {
         float l = 0.f, sc[4];
 #pragma unroll
         for (int w = 0; w < 4; ++w) {
-            sc[w] = __expf(mw[w] - m);  // a wave without keys has m = -inf, l = 0, O = 0 -> scale 0
+            sc[w] = __builtin_amdgcn_exp2f(mw[w] - m);  // a wave without keys has m = -inf, l = 0, O = 0 -> scale 0
             l += MLs[(w * 2 + 1) * 16 + li] * sc[w];
         }
         const float inv = 1.f / l;
@@ -427,76 +384,109 @@ __global__ __launch_bounds__(256) void enc_layer4_k(const EncK p) {
             oc[nt] = a * inv;
         }
     }
-    // ---- out-proj + residual (split by output fragment) -> LDS -> LayerNorm 1 on the full row in every wave ----
-    for (int nt = wave; nt < DC; nt += 4) {
-        f32x4 xsn;
+    STAMP(3);
+    // ---- out-proj + residual (this wave's slots) -> LDS -> LayerNorm 1 on the full row in every wave ----
+    f32x4 w1r[SF][DC];
 #pragma unroll
-        for (int c = 0; c < DC; ++c)
-            if (c == nt) xsn = xs[c];
-        Xs[nt * 64 + lane] = xsn + row_mm<DC>(p.w_out, cs, nt, oc, ld4(p.b_out + 16 * nt + 4 * g), li, g);
+    for (int s = 0; s < SF; ++s) load_wrow<DC>(w1r[s], p.w1, min(wave + 4 * s, FC - 1), lane);  // FFN1 rows, one phase ahead
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int s = 0; s < SD; ++s) {
+        const int nt = min(wave + 4 * s, DC - 1);
+        const f32x4 a = frag_mm<DC>(wo[s], oc, ld4(Ps + P_BOUT + 16 * nt + 4 * g)) + res[s];
+        if (wave + 4 * s < DC) Xs[nt * 64 + lane] = a;
     }
     __syncthreads();
     f32x4 x1[DC];
 #pragma unroll
     for (int c = 0; c < DC; ++c) x1[c] = Xs[c * 64 + lane];
-    layer_norm<DC>(x1, p.ln1_w, p.ln1_b, p.d, p.ln_eps, g);
-    __syncthreads();  // everyone has read Xs before FFN1 overwrites it
+    layer_norm<DC>(x1, Ps + P_LN1W, Ps + P_LN1B, p.d, p.ln_eps, g);
+    STAMP(4);
     // ---- FFN ----
-    for (int ft = wave; ft < FC; ft += 4) {
-        f32x4 a = row_mm<DC>(p.w1, cs, ft, x1, ld4(p.b1 + 16 * ft + 4 * g), li, g);
+    f32x4 w2r[SD][FC];
+#pragma unroll
+    for (int s = 0; s < SD; ++s) load_wrow<FC>(w2r[s], p.w2, min(wave + 4 * s, DC - 1), lane);  // FFN2 rows, one phase ahead
+    __builtin_amdgcn_sched_barrier(0);
+    __syncthreads();  // everyone has read Xs before FFN1 overwrites it
+#pragma unroll
+    for (int s = 0; s < SF; ++s) {
+        const int ft = min(wave + 4 * s, FC - 1);
+        f32x4 a = frag_mm<DC>(w1r[s], x1, ld4(Ps + P_B1 + 16 * ft + 4 * g));
 #pragma unroll
         for (int r = 0; r < 4; ++r) a[r] = fmaxf(a[r], 0.f);
-        Xs[ft * 64 + lane] = a;
+        if (wave + 4 * s < FC) Xs[ft * 64 + lane] = a;
     }
-    __syncthreads();
-    f32x4 h[FC];
+    f32x4 x1n[SD];  // the residual of FFN2 is only needed for this wave's slots
 #pragma unroll
-    for (int c = 0; c < FC; ++c) h[c] = Xs[c * 64 + lane];
-    __syncthreads();
-    for (int nt = wave; nt < DC; nt += 4) {
-        f32x4 x1n;
+    for (int s = 0; s < SD; ++s) {
+        const int nt = min(wave + 4 * s, DC - 1);
 #pragma unroll
         for (int c = 0; c < DC; ++c)
-            if (c == nt) x1n = x1[c];
-        Xs[nt * 64 + lane] = x1n + row_mm<FC>(p.w2, dff, nt, h, ld4(p.b2 + 16 * nt + 4 * g), li, g);
+            if (c == nt) x1n[s] = x1[c];
     }
     __syncthreads();
     f32x4 y[DC];
+    {
+        f32x4 h[FC];
+#pragma unroll
+        for (int c = 0; c < FC; ++c) h[c] = Xs[c * 64 + lane];
+        STAMP(5);
+        __syncthreads();
+#pragma unroll
+        for (int s = 0; s < SD; ++s) {
+            const int nt = min(wave + 4 * s, DC - 1);
+            const f32x4 a = frag_mm<FC>(w2r[s], h, ld4(Ps + P_B2 + 16 * nt + 4 * g)) + x1n[s];
+            if (wave + 4 * s < DC) Xs[nt * 64 + lane] = a;
+        }
+    }
+    // K / V rows of the next layer's in_proj for this wave's slots (fragments 0..DC-1: K rows, DC..2DC-1: V rows)
+    f32x4 wk[SK][DC], yq[DC];
+    if (p.next_w_in) {
+#pragma unroll
+        for (int s = 0; s < SK; ++s) load_wrow<DC>(wk[s], p.next_w_in + (size_t)cs * cs, min(wave + 4 * s, 2 * DC - 1), lane);
+        if (p.pos) {
+#pragma unroll
+            for (int c = 0; c < DC; ++c) yq[c] = ld4(p.pos + (size_t)prow * cs + 16 * c + 4 * g);
+        }
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    __syncthreads();
 #pragma unroll
     for (int c = 0; c < DC; ++c) y[c] = Xs[c * 64 + lane];
-    layer_norm<DC>(y, p.ln2_w, p.ln2_b, p.d, p.ln_eps, g);
+    layer_norm<DC>(y, Ps + P_LN2W, Ps + P_LN2B, p.d, p.ln_eps, g);
+    STAMP(6);
     if (qvalid) {
-        for (int nt = wave; nt < DC; nt += 4) {
-            f32x4 yn;
 #pragma unroll
-            for (int c = 0; c < DC; ++c)
-                if (c == nt) yn = y[c];
-            *reinterpret_cast<f32x4*>(p.out + (size_t)qtok * cs + 16 * nt + 4 * g) = yn;
+        for (int s = 0; s < SD; ++s) {
+            const int nt = wave + 4 * s;
+            if (nt < DC) {
+                f32x4 yn;
+#pragma unroll
+                for (int c = 0; c < DC; ++c)
+                    if (c == nt) yn = y[c];
+                *reinterpret_cast<f32x4*>(p.out + (size_t)qtok * cs + 16 * nt + 4 * g) = yn;
+            }
         }
     }
     // ---- K / V of the next layer from the layer output still in registers ----
     if (p.next_w_in) {
-        f32x4 yq[DC];
 #pragma unroll
-        for (int c = 0; c < DC; ++c) {
-            yq[c] = y[c];
-            if (p.pos) yq[c] += ld4(p.pos + (size_t)prow * cs + 16 * c + 4 * g);
-        }
-        for (int f = wave; f < 2 * DC; f += 4) {  // fragments 0..DC-1: K rows, DC..2DC-1: V rows
-            const bool isv = f >= DC;
-            const int nt = isv ? f - DC : f;
-            const int wrow = (isv ? 2 : 1) * cs;
-            const f32x4 a = row_mm<DC>(p.next_w_in + (size_t)wrow * cs, cs, nt, isv ? y : yq, ld4(p.next_b_in + wrow + 16 * nt + 4 * g), li, g);
-            if (qvalid) {
-                if (!isv) {
-                    *reinterpret_cast<f32x4*>(p.next_kbuf + (size_t)qtok * cs + 16 * nt + 4 * g) = a;
-                } else {
+        for (int c = 0; c < DC; ++c) yq[c] = p.pos ? yq[c] + y[c] : y[c];
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) p.next_vbuf[(size_t)(16 * nt + 4 * g + r) * p.n_tok_pad + qtok] = a[r];
-                }
+        for (int s = 0; s < SK; ++s) {
+            const int f = wave + 4 * s;
+            if (f < 2 * DC) {  // (wave-uniform)
+                const bool isv = f >= DC;
+                const int nt = isv ? f - DC : f;
+                const f32x4 bias = ld4(Ps + P_BKV + 16 * f + 4 * g);
+                f32x4 a = isv ? frag_mm<DC>(wk[s], y, bias) : frag_mm<DC>(wk[s], yq, bias);
+                if (isv && !qvalid) a = (f32x4){0.f, 0.f, 0.f, 0.f};  // keys past the group: V must stay finite
+                store_kv_frag(p.next_kbuf, p.next_vbuf, v, DC, nt, a, a, !isv, isv, lane);
             }
         }
     }
+    STAMP(7);
+#undef STAMP
 }
 
 // =====================================================================================================================
@@ -544,8 +534,8 @@ __global__ __launch_bounds__(64) void enc_kv_lp_k(const EncK p) {
             av[half][0] = av[half][1] = ld4(p.b_in + 2 * cs + 16 * nt + 4 * g);
 #pragma unroll
             for (int cc = 0; cc < DC; ++cc) {
-                const f32x4 wk = ld4(p.w_in + (size_t)(cs + 16 * nt + li) * cs + 16 * cc + 4 * g);
-                const f32x4 wv = ld4(p.w_in + (size_t)(2 * cs + 16 * nt + li) * cs + 16 * cc + 4 * g);
+                const f32x4 wk = ld4(p.w_in + (((size_t)(DC + nt) * DC + cc) * 64 + lane) * 4);
+                const f32x4 wv = ld4(p.w_in + (((size_t)(2 * DC + nt) * DC + cc) * 64 + lane) * 4);
 #pragma unroll
                 for (int s = 0; s < 4; ++s)
 #pragma unroll
@@ -771,10 +761,15 @@ int fill(const i2r_encoder_desc* d, EncK& k) {
     k.w_in = d->w_in; k.b_in = d->b_in; k.w_out = d->w_out; k.b_out = d->b_out; k.ln1_w = d->ln1_w; k.ln1_b = d->ln1_b;
     k.w1 = d->w1; k.b1 = d->b1; k.w2 = d->w2; k.b2 = d->b2; k.ln2_w = d->ln2_w; k.ln2_b = d->ln2_b;
     k.n_tok = d->n_tok; k.n_tok_pad = ((d->n_tok + 63) / 64) * 64 + 64; k.n_grp = d->n_grp; k.d = d->d; k.cs = d->cs;
-    k.dff_pad = d->dff_pad; k.pos_period = d->pos_period; k.ln_eps = d->ln_eps;
+    k.dff_pad = d->dff_pad; k.pos_period = d->pos_period; k.ln_eps = d->ln_eps; k.n_qtiles = d->n_qtiles16;
     k.qscale = 1.0f / sqrtf((float)d->d);
     k.w_in_lp = d->w_in_lp; k.w_out_lp = d->w_out_lp; k.w1_lp = d->w1_lp; k.w2_lp = d->w2_lp;
     k.next_w_in = d->next_w_in; k.next_b_in = d->next_b_in; k.next_kbuf = d->next_kbuf; k.next_vbuf = d->next_vbuf;
+    {   // tuning only: I2R_ENC_STAMP=<device address of 32 B x waves>, I2R_ENC_STAMP_FUSED=1 stamps the layers with a fused K/V tail
+        static const char* se = getenv("I2R_ENC_STAMP");
+        static const bool fused = getenv("I2R_ENC_STAMP_FUSED") && atoi(getenv("I2R_ENC_STAMP_FUSED"));
+        k.stamp = (se && fused == (d->next_w_in != nullptr)) ? (long long*)strtoull(se, nullptr, 0) : nullptr;
+    }
     I2R_CHECK_ARG(!d->next_w_in || (d->next_b_in && d->next_kbuf && d->next_vbuf && d->next_kbuf != d->kbuf && d->next_vbuf != d->vbuf && d->dtype == 0),
                   "i2r_encoder: fused next-layer K/V needs its own buffers (fp32 mode only)");
     I2R_CHECK_ARG(d->dtype >= 0 && d->dtype <= 2, "i2r_encoder: dtype %d", d->dtype);
@@ -795,10 +790,13 @@ extern "C" int i2r_encoder_kv(const i2r_encoder_desc* d, void* stream) {
         hipLaunchKernelGGL((enc_kv_lp_k<6, 1>), dim3(nblk), dim3(64), 0, (hipStream_t)stream, k);
     else if (d->dtype == 2)
         hipLaunchKernelGGL((enc_kv_lp_k<6, 2>), dim3(nblk), dim3(64), 0, (hipStream_t)stream, k);
-    else if (d->cs == 96)
-        hipLaunchKernelGGL(enc_kv_k<6>, dim3(nblk), dim3(64), 0, (hipStream_t)stream, k);
-    else
-        hipLaunchKernelGGL(enc_kv_k<5>, dim3(nblk), dim3(64), 0, (hipStream_t)stream, k);
+    else {
+        I2R_CHECK_ARG(d->n_qtiles16 > 0, "i2r_encoder_kv: n_qtiles16");
+        if (d->cs == 96)
+            hipLaunchKernelGGL(enc_kv_k<6>, dim3((unsigned)d->n_qtiles16), dim3(64), 0, (hipStream_t)stream, k);
+        else
+            hipLaunchKernelGGL(enc_kv_k<5>, dim3((unsigned)d->n_qtiles16), dim3(64), 0, (hipStream_t)stream, k);
+    }
     I2R_CHECK_LAUNCH("i2r_encoder_kv");
     return I2R_OK;
 }
@@ -807,7 +805,6 @@ extern "C" int i2r_encoder_layer(const i2r_encoder_desc* d, void* stream) {
     EncK k;
     int rc = fill(d, k);
     if (rc) return rc;
-    I2R_CHECK_ARG(d->n_qtiles32 > 0, "i2r_encoder_layer: n_qtiles32");
     if (d->dtype != 0) {
         // 64 queries per wave when that still gives >= 2 waves per SIMD-pair of the chip, else 16 (more, shorter waves)
         const bool big = d->n_qtiles64 >= 512;
@@ -822,20 +819,12 @@ extern "C" int i2r_encoder_layer(const i2r_encoder_desc* d, void* stream) {
         I2R_CHECK_LAUNCH("i2r_encoder_layer");
         return I2R_OK;
     }
-    static const int v2 = getenv("I2R_ENC_V2") ? atoi(getenv("I2R_ENC_V2")) : 0;  // tuning switch: the one-wave-per-fragment kernel
-    if (v2 && !d->next_w_in) {
-        constexpr int NW = 2;
-        if (d->cs == 96)
-            hipLaunchKernelGGL((enc_layer_k<6, 12, NW>), dim3((unsigned)d->n_qtiles32), dim3(NW * 64), 0, (hipStream_t)stream, k);
-        else
-            hipLaunchKernelGGL((enc_layer_k<5, 12, NW>), dim3((unsigned)d->n_qtiles32), dim3(NW * 64), 0, (hipStream_t)stream, k);
-    } else {
-        I2R_CHECK_ARG(d->n_qtiles16 > 0, "i2r_encoder_layer: n_qtiles16");
-        if (d->cs == 96)
-            hipLaunchKernelGGL((enc_layer4_k<6, 12>), dim3((unsigned)d->n_qtiles16), dim3(256), 0, (hipStream_t)stream, k);
-        else
-            hipLaunchKernelGGL((enc_layer4_k<5, 12>), dim3((unsigned)d->n_qtiles16), dim3(256), 0, (hipStream_t)stream, k);
-    }
+    I2R_CHECK_ARG(d->n_qtiles16 > 0, "i2r_encoder_layer: n_qtiles16");
+    const unsigned grid = (unsigned)((d->n_qtiles16 + 7) / 8 * 8);  // (XCD-major tile order inside the kernel)
+    if (d->cs == 96)
+        hipLaunchKernelGGL((enc_layer4_k<6, 12>), dim3(grid), dim3(256), 0, (hipStream_t)stream, k);
+    else
+        hipLaunchKernelGGL((enc_layer4_k<5, 12>), dim3(grid), dim3(256), 0, (hipStream_t)stream, k);
     I2R_CHECK_LAUNCH("i2r_encoder_layer");
     return I2R_OK;
 }

@@ -52,6 +52,15 @@ def pack_k4(w_taps, cin_pad, cout_pad):
 PRECISIONS = {"fp32": 0, "bf16": 1, "fp16": 2}
 
 
+def pack_frag(m):
+    """[rows, cols] (both multiples of 16) -> MFMA A-operand images in lane order (csrc/i2r_encoder.hip header):
+    packed[((rb*KC + c)*64 + l)*4 + r] = m[16 rb + (l & 15)][16 c + 4 (l >> 4) + r]; one 64-lane 16-byte load = 1 KB contiguous."""
+    rows, cols = m.shape
+    assert rows % 16 == 0 and cols % 16 == 0
+    v = m.reshape(rows // 16, 16, cols // 16, 4, 4)              # [rb, li, c, g, r]
+    return v.permute(0, 2, 3, 1, 4).contiguous().reshape(rows, cols)  # [rb, c, g, li, r]
+
+
 def pack_k8(w_taps, cin_pad, cout_pad, tdtype):
     """w_taps [ntaps, cin, cout] -> 16-bit [ntaps, g8_pad, cout_pad, 8] (cin zero-padded to whole 32-channel MFMA steps)."""
     nt, cin, cout = w_taps.shape
@@ -196,6 +205,8 @@ class Packer:
                 return v.permute(0, 1, 3, 2, 4).reshape(rows, cols).to(tdt).contiguous()   # [row, c, g, half, r]
             lp = dict(w_in_lp=perm(t["w_in"]), w_out_lp=perm(t["w_out"]), w1_lp=perm(t["w1"]), w2_lp=perm(t["w2"]))
             lp = {k: self._dev(v) for k, v in lp.items()}
+        for k in ("w_in", "w_out", "w1", "w2"):
+            t[k] = pack_frag(t[k])
         t = {k: self._dev(v.float()) for k, v in t.items()}
         t.update(lp)
         t.update(d=d, cs=cs, dff_pad=fs, dtype=self.dtype if lp else 0)
@@ -506,8 +517,11 @@ class Program:
         # capable stacks keep one enc_kv launch per layer (they may fall back to fp32 kernels per call, see set_groups)
         fuse_kv = all(not L.get("dtype", 0) for L in layers) and len(layers) > 1
         nbuf = 2 if fuse_kv else 1
-        kbufs = [torch.empty(n_tok * cs, dtype=torch.float32, device=self.device) for _ in range(nbuf)]
-        vbufs = [torch.zeros(cs * n_pad, dtype=torch.float32, device=self.device) for _ in range(nbuf)]
+        # K / V^T workspaces: fragment-packed per 16-token tile of a group (fp32 kernels; <= n_tok/16 + groups tiles) or the
+        # 16-bit kernels' [n_tok, cs] / [cs, n_pad] images -- sized for either
+        kv_floats = max((n_tok // 16 + x.n + 1) * 16 * cs, cs * n_pad)
+        kbufs = [torch.zeros(kv_floats, dtype=torch.float32, device=self.device) for _ in range(nbuf)]
+        vbufs = [torch.zeros(kv_floats, dtype=torch.float32, device=self.device) for _ in range(nbuf)]
         goff = torch.zeros(x.n + 1, dtype=torch.int32, device=self.device)
         self.keep += kbufs + vbufs + [goff]
         cur = x
