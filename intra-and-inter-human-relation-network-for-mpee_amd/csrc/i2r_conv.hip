@@ -58,48 +58,108 @@ struct ConvGroupK {
 // D layout: lane (li = l&15, g) holds channel n = nt*16 + li of pixels 4g + r (r = 0..3).  A 4x4 transpose inside each
 // lane quad (two DPP butterfly stages, no LDS) turns that into: lane (q = li>>2, j = li&3, g) holds channels
 // nt*16 + 4q .. +3 of pixel 4g + j, so bias / residual / store are 16-byte accesses (4x fewer VMEM instructions;
-// the scalar-store epilogue measured 24 % of the kernel).
+// the scalar-store epilogue measured 24 % of the kernel).  A second step swaps the roles of q and j across the 16 lanes of a
+// row (ds_bpermute, lane 4j+q <- lane 4q+j): then the four CONSECUTIVE lanes of a quad hold the four 16-byte pieces of ONE
+// pixel's 64 contiguous bytes.  The texture addresser retires a 64-lane 16-byte access in 16 cycles only when every quad
+// falls into one 64-byte segment, 64 cycles otherwise (tools/probe/load_pattern.hip) -- with residual loads that was
+// 2 x MT x NT slow accesses per wave.
 template <int MT, int NT>
 __device__ __forceinline__ void conv_epilogue(const ConvK& p, f32x4 (&acc)[MT][NT], int img, int oy0, int ox0, int wm, int n_base,
                                               int li, int g, int tile_px) {
     if ((p.dbg & 1) && acc[0][0][0] != 12345.678f) return;
-    const int j4 = li & 3, q4 = li >> 2;
+    const int j4 = li & 3;
+    const int pj = li >> 2, pq = li & 3;  // after the lane permutation: this lane's pixel (4g + pj) and 16-byte piece (pq)
+    const int perm_src = (g * 16 + pq * 4 + pj) * 4;  // ds_bpermute byte address of the lane holding (q = pq, j = pj)
+    auto to_pixel_major = [&](f32x4 v) {
+        v = quad_transpose(v, j4);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const float x = v[e];  // (scalar copy: __builtin_bit_cast on a vector element lvalue miscompiles)
+            v[e] = __int_as_float(__builtin_amdgcn_ds_bpermute(perm_src, __float_as_int(x)));
+        }
+        return v;
+    };
+    auto finish = [&](f32x4 t, int n, bool full, const float* res_post_at) {
+        if (p.relu == 1) {
+            t[0] = fmaxf(t[0], 0.f); t[1] = fmaxf(t[1], 0.f); t[2] = fmaxf(t[2], 0.f); t[3] = fmaxf(t[3], 0.f);
+        } else if (p.relu == 2) {  // exact-erf GELU (HRFormer MlpDWBN, hrformer.py:1197)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) t[e] = 0.5f * t[e] * (1.f + erff(t[e] * 0.70710678118654752f));
+        }
+        if (res_post_at) t += *reinterpret_cast<const f32x4*>(res_post_at);
+        if (!full) {  // channels >= cout are padding: keep them exactly zero
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+                if (n + e >= p.cout) t[e] = 0.f;
+        }
+        return t;
+    };
+    // per-lane channel piece of every N fragment: bias fetched once, up front
+    f32x4 bias[NT];
+    bool nok[NT];
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+        const int n = n_base + nt * 16 + pq * 4;
+        nok[nt] = n < p.cout_pad && (n + 4 <= p.cout || n + 4 <= p.out_cs);
+        bias[nt] = n < p.cout_pad ? *reinterpret_cast<const f32x4*>(p.bias + n) : (f32x4){0.f, 0.f, 0.f, 0.f};
+    }
+    if (p.rep == 1 && !(p.dbg & 16)) {
+        // ---- every output pixel written once: issue ALL residual loads of the tile first (one memory latency instead of
+        //      MT x NT dependent load -> add -> store round trips), then transform and store ----
+        size_t off[MT];
+        bool pv[MT];
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) {
+            const int m = (wm * MT + mt) * 16 + g * 4 + pj;
+            const int ty = m / p.tile_w, tx = m - ty * p.tile_w;
+            const int oy = oy0 + ty, ox = ox0 + tx;
+            pv[mt] = m < tile_px && oy < p.conv_h && ox < p.conv_w;
+            off[mt] = ((size_t)(img * p.out_h + oy * p.out_step + p.out_off_y) * p.out_w + ox * p.out_step + p.out_off_x) * p.out_cs;
+        }
+        f32x4 r[MT][NT];
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) {
+                const size_t o = off[mt] + n_base + nt * 16 + pq * 4;
+                r[mt][nt] = bias[nt];
+                if (pv[mt] && nok[nt]) {
+                    if (p.res1) r[mt][nt] += *reinterpret_cast<const f32x4*>(p.res1 + o);
+                    if (p.res2) r[mt][nt] += *reinterpret_cast<const f32x4*>(p.res2 + o);
+                }
+            }
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) {
+                const f32x4 v = to_pixel_major(acc[mt][nt]);
+                const int n = n_base + nt * 16 + pq * 4;
+                if (!pv[mt] || !nok[nt]) continue;
+                const size_t o = off[mt] + n;
+                *reinterpret_cast<f32x4*>(p.out + o) = finish(v + r[mt][nt], n, n + 4 <= p.cout, p.res_post ? p.res_post + o : nullptr);
+            }
+        return;
+    }
+    // ---- nearest-neighbour upsample scatter (HRNet fuse layers): rep x rep destinations per conv pixel ----
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt) {
-        const int m = (wm * MT + mt) * 16 + g * 4 + j4;
+        const int m = (wm * MT + mt) * 16 + g * 4 + pj;
         const int ty = m / p.tile_w, tx = m - ty * p.tile_w;
         const int oy = oy0 + ty, ox = ox0 + tx;
         const bool pvalid = m < tile_px && oy < p.conv_h && ox < p.conv_w;
         const int by = oy * p.out_step + p.out_off_y, bx = ox * p.out_step + p.out_off_x;
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt) {
-            f32x4 v = acc[mt][nt];
-            v = quad_transpose(v, j4);
-            const int n = n_base + nt * 16 + q4 * 4;
-            if (!pvalid || n >= p.cout_pad) continue;
-            v += *reinterpret_cast<const f32x4*>(p.bias + n);
-            const bool full = n + 4 <= p.cout;  // (cout % 4 != 0 only for padded-channel layers: scalar tail below)
+            const f32x4 v = to_pixel_major(acc[mt][nt]) + bias[nt];
+            const int n = n_base + nt * 16 + pq * 4;
+            if (!pvalid || !nok[nt]) continue;
             for (int ry = 0; ry < p.rep; ++ry)
                 for (int rx = 0; rx < p.rep; ++rx) {
                     const size_t o = ((size_t)(img * p.out_h + by + ry) * p.out_w + bx + rx) * p.out_cs + n;
                     f32x4 t = v;
-                    if (full || n + 4 <= p.out_cs) {
-                        if (p.res1) t += *reinterpret_cast<const f32x4*>(p.res1 + o);
-                        if (p.res2) t += *reinterpret_cast<const f32x4*>(p.res2 + o);
-                        if (p.relu == 1) {
-                            t[0] = fmaxf(t[0], 0.f); t[1] = fmaxf(t[1], 0.f); t[2] = fmaxf(t[2], 0.f); t[3] = fmaxf(t[3], 0.f);
-                        } else if (p.relu == 2) {  // exact-erf GELU (HRFormer MlpDWBN, hrformer.py:1197)
-#pragma unroll
-                            for (int e = 0; e < 4; ++e) t[e] = 0.5f * t[e] * (1.f + erff(t[e] * 0.70710678118654752f));
-                        }
-                        if (p.res_post) t += *reinterpret_cast<const f32x4*>(p.res_post + o);
-                        if (!full) {  // channels >= cout are padding: keep them exactly zero
-#pragma unroll
-                            for (int e = 0; e < 4; ++e)
-                                if (n + e >= p.cout) t[e] = 0.f;
-                        }
-                        *reinterpret_cast<f32x4*>(p.out + o) = t;
-                    }
+                    if (p.res1) t += *reinterpret_cast<const f32x4*>(p.res1 + o);
+                    if (p.res2) t += *reinterpret_cast<const f32x4*>(p.res2 + o);
+                    *reinterpret_cast<f32x4*>(p.out + o) = finish(t, n, n + 4 <= p.cout, p.res_post ? p.res_post + o : nullptr);
                 }
         }
     }
@@ -261,14 +321,21 @@ __device__ __forceinline__ void conv_body(const ConvK& p, int bid, f32x4* lds) {
     const int py0 = oy0 * p.stride + p.iy0, px0 = ox0 * p.stride + p.ix0;
     const int phw = p.ph * p.pw;
 
+    // Staging assignment: thread t handles the patch pixels (t >> 2) + 64 j and, of every 4 consecutive channel groups, group
+    // (t & 3) -- the four lanes of a quad fetch the 64 contiguous bytes of ONE pixel.  (With one pixel per lane every lane of
+    // a load hits a different 64-byte segment and the texture addresser needs 64 instead of 16 cycles per instruction:
+    // tools/probe/load_pattern.hip.)
     // patch pixel -> global float offset of channel 0 (clamped to 0 outside the image, with a validity bit);
     // channel independent, so computed once
-    constexpr int NPP = PF > 0 ? PF : kMaxPP;
+    // (the synchronous variant PF == 0 serves patches of up to 1280 pixels: it keeps one pixel per lane, 20 offsets per thread
+    // would cost a wave of occupancy)
+    constexpr int NPP = PF > 0 ? 4 * PF : kMaxPP;
+    const int ul = tid & 3;
     int goff[NPP];
     bool gval[NPP];
 #pragma unroll
     for (int j = 0; j < NPP; ++j) {
-        const int pp = tid + j * 256;
+        const int pp = PF > 0 ? (tid >> 2) + j * 64 : tid + j * 256;
         goff[j] = 0;
         gval[j] = false;
         if (pp < phw) {
@@ -280,7 +347,7 @@ __device__ __forceinline__ void conv_body(const ConvK& p, int bid, f32x4* lds) {
             }
         }
     }
-    const int npp = (phw + 255) >> 8;  // patch pixels per thread actually in use (wave-uniform)
+    const int npp = (phw + 255) >> 8;  // PF == 0: patch pixels per thread actually in use (wave-uniform)
 
     // A-fragment patch-pixel base of this lane's pixel in each M fragment
     const int tile_px = p.tile_h * p.tile_w;
@@ -357,33 +424,34 @@ __device__ __forceinline__ void conv_body(const ConvK& p, int bid, f32x4* lds) {
         // ---- double-buffered staging: chunks of 4*ckg channels (ckg <= CAP); the NEXT chunk's patch is loaded into
         //      registers while the MFMAs of the current chunk run, and written to the other LDS buffer afterwards
         //      (one barrier per chunk) ----
-        f32x4 v[CAP][PF];
+        constexpr int UQ = CAP / 4, PJ = 4 * PF;
+        f32x4 v[UQ][PJ];
         const int ckg = p.ck >> 2;
         auto stage_load = [&](int c0) {
 #pragma unroll
-            for (int u = 0; u < CAP; ++u)
-                if (u < ckg) {
+            for (int uq = 0; uq < UQ; ++uq)
+                if (uq * 4 < ckg) {
 #pragma unroll
-                    for (int j = 0; j < PF; ++j)
-                        if (!(p.dbg & 2)) v[u][j] = *reinterpret_cast<const f32x4*>(p.in + goff[j] + c0 + u * 4);
+                    for (int j = 0; j < PJ; ++j)
+                        if (!(p.dbg & 2)) v[uq][j] = *reinterpret_cast<const f32x4*>(p.in + goff[j] + c0 + (uq * 4 + ul) * 4);
                 }
             if (p.in2) {
 #pragma unroll
-                for (int u = 0; u < CAP; ++u)
-                    if (u < ckg) {
+                for (int uq = 0; uq < UQ; ++uq)
+                    if (uq * 4 < ckg) {
 #pragma unroll
-                        for (int j = 0; j < PF; ++j) v[u][j] += *reinterpret_cast<const f32x4*>(p.in2 + goff[j] + c0 + u * 4);
+                        for (int j = 0; j < PJ; ++j) v[uq][j] += *reinterpret_cast<const f32x4*>(p.in2 + goff[j] + c0 + (uq * 4 + ul) * 4);
                     }
             }
         };
         auto stage_store = [&](f32x4* buf) {
 #pragma unroll
-            for (int u = 0; u < CAP; ++u)
-                if (u < ckg) {
+            for (int uq = 0; uq < UQ; ++uq)
+                if (uq * 4 < ckg) {
 #pragma unroll
-                    for (int j = 0; j < PF; ++j) {
-                        const int pp = tid + j * 256;
-                        if (pp < phw) buf[u * p.plane + pp] = gval[j] ? v[u][j] : (f32x4){0.f, 0.f, 0.f, 0.f};
+                    for (int j = 0; j < PJ; ++j) {
+                        const int pp = (tid >> 2) + j * 64;
+                        if (pp < phw) buf[(uq * 4 + ul) * p.plane + pp] = gval[j] ? v[uq][j] : (f32x4){0.f, 0.f, 0.f, 0.f};
                     }
                 }
         };
@@ -614,7 +682,8 @@ static int prepare(const i2r_conv_desc* d, int force_mt, int force_cap, int forc
     k.ph = (th - 1) * d->stride + max_dy + 1;
     k.pw = (tw - 1) * d->stride + max_dx + 1;
     I2R_CHECK_ARG(k.ph * k.pw <= kMaxPP * 256, "i2r_conv: patch %dx%d too large", k.ph, k.pw);
-    k.plane = cdiv(k.ph * k.pw, 16) * 16;
+    static const int plane_pad = getenv("I2R_CONV_PLANE_PAD") ? atoi(getenv("I2R_CONV_PLANE_PAD")) : 0;  // tuning switch (LDS banks)
+    k.plane = cdiv(k.ph * k.pw, 16) * 16 + plane_pad;
     k.tap_kw = max_dx + 1;
     k.tap_kh = max_dy + 1;
     for (int t = 0; t < d->ntaps; ++t)

@@ -116,13 +116,37 @@ __device__ __forceinline__ void store_kv_frag(float* kbuf, float* vbuf, int frag
     }
 }
 
-// ---- K / V projection of one 16-token tile per wave (first layer of a stack; later layers get theirs from the fused tail) ----
+// one output fragment (16 features x 16 tokens) of  Y^T = W X^T (+bias):  acc += sum_c W[16nt+li][16c+4g..] * x[c];
+// W fragment-packed (see the header): the KC loads of a fragment are 1 KB contiguous each
+template <int KC>
+__device__ __forceinline__ void load_wrow(f32x4 (&wr)[KC], const float* W, int nt, int lane) {
+    const float* f = W + ((size_t)nt * KC * 64 + lane) * 4;
+#pragma unroll
+    for (int c = 0; c < KC; ++c) wr[c] = ld4(f + c * 256);
+}
+template <int KC>
+__device__ __forceinline__ f32x4 frag_mm(const f32x4 (&wr)[KC], const f32x4 (&x)[KC], f32x4 acc) {
+#pragma unroll
+    for (int c = 0; c < KC; ++c)
+#pragma unroll
+        for (int s = 0; s < 4; ++s) acc = mfma16(wr[c][s], x[c][s], acc);
+    return acc;
+}
+// ---- K / V projection of one 16-token tile per workgroup (first layer of a stack; later layers get theirs from the fused tail).
+//      4 waves: wave w computes the output fragments w, w+4, ... of [K | V] (2*DC fragments), weight rows fetched up front ----
 template <int DC>
-__global__ __launch_bounds__(64) void enc_kv_k(const EncK p) {
-    const int lane = threadIdx.x, li = lane & 15, g = lane >> 4;
-    const int cs = DC * 16;
+__global__ __launch_bounds__(256) void enc_kv_k(const EncK p) {
+    constexpr int cs = DC * 16, SK = (2 * DC + 3) / 4;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, li = lane & 15, g = lane >> 4;
     int s0, e0;
     load_groups(p, lane, s0, e0);
+    f32x4 wk[SK][DC], bk[SK];
+#pragma unroll
+    for (int s = 0; s < SK; ++s) {
+        const int f = min(wave + 4 * s, 2 * DC - 1);
+        load_wrow<DC>(wk[s], p.w_in + (size_t)cs * cs, f, lane);  // K rows = row blocks [DC, 2DC), V rows = [2DC, 3DC)
+        bk[s] = ld4(p.b_in + cs + 16 * f + 4 * g);
+    }
     const Tile t = locate_tile(p, blockIdx.x, lane, s0, e0);
     const int tok = t.gs + 16 * t.j + li;
     const bool valid = tok < t.ge;
@@ -135,22 +159,15 @@ __global__ __launch_bounds__(64) void enc_kv_k(const EncK p) {
         xq[c] = xs[c];
         if (p.pos) xq[c] += ld4(p.pos + (size_t)prow * cs + 16 * c + 4 * g);
     }
-    // K rows of w_in: row blocks [DC, 2DC); V rows: [2DC, 3DC)
 #pragma unroll
-    for (int nt = 0; nt < DC; ++nt) {
-        f32x4 ak = ld4(p.b_in + cs + 16 * nt + 4 * g), av = ld4(p.b_in + 2 * cs + 16 * nt + 4 * g);
-#pragma unroll
-        for (int c = 0; c < DC; ++c) {
-            const f32x4 wk = ld4(p.w_in + (((size_t)(DC + nt) * DC + c) * 64 + lane) * 4);
-            const f32x4 wv = ld4(p.w_in + (((size_t)(2 * DC + nt) * DC + c) * 64 + lane) * 4);
-#pragma unroll
-            for (int s = 0; s < 4; ++s) {
-                ak = mfma16(wk[s], xq[c][s], ak);
-                av = mfma16(wv[s], xs[c][s], av);
-            }
+    for (int s = 0; s < SK; ++s) {
+        const int f = wave + 4 * s;
+        if (f < 2 * DC) {  // (wave-uniform)
+            const bool isv = f >= DC;
+            f32x4 a = isv ? frag_mm<DC>(wk[s], xs, bk[s]) : frag_mm<DC>(wk[s], xq, bk[s]);
+            if (isv && !valid) a = (f32x4){0.f, 0.f, 0.f, 0.f};  // keys past the group: masked scores, but V must stay finite
+            store_kv_frag(p.kbuf, p.vbuf, t.base + t.j, DC, isv ? f - DC : f, a, a, !isv, isv, lane);
         }
-        if (!valid) av = (f32x4){0.f, 0.f, 0.f, 0.f};  // keys past the group: masked scores, but V must stay finite
-        store_kv_frag(p.kbuf, p.vbuf, t.base + t.j, DC, nt, ak, av, true, true, lane);
     }
 }
 
@@ -178,22 +195,6 @@ __device__ __forceinline__ void layer_norm(f32x4 (&y)[DC], const float* w, const
     }
 }
 
-// one output fragment (16 features x 16 tokens) of  Y^T = W X^T (+bias):  acc += sum_c W[16nt+li][16c+4g..] * x[c];
-// W fragment-packed (see the header): the KC loads of a fragment are 1 KB contiguous each
-template <int KC>
-__device__ __forceinline__ void load_wrow(f32x4 (&wr)[KC], const float* W, int nt, int lane) {
-    const float* f = W + ((size_t)nt * KC * 64 + lane) * 4;
-#pragma unroll
-    for (int c = 0; c < KC; ++c) wr[c] = ld4(f + c * 256);
-}
-template <int KC>
-__device__ __forceinline__ f32x4 frag_mm(const f32x4 (&wr)[KC], const f32x4 (&x)[KC], f32x4 acc) {
-#pragma unroll
-    for (int c = 0; c < KC; ++c)
-#pragma unroll
-        for (int s = 0; s < 4; ++s) acc = mfma16(wr[c][s], x[c][s], acc);
-    return acc;
-}
 // =====================================================================================================================
 // fp32 encoder layer, 4 waves per 16-query tile (enc_layer4_k) -- the default fp32 kernel
 // ---------------------------------------------------------------------------------------------------------------------
@@ -793,9 +794,9 @@ extern "C" int i2r_encoder_kv(const i2r_encoder_desc* d, void* stream) {
     else {
         I2R_CHECK_ARG(d->n_qtiles16 > 0, "i2r_encoder_kv: n_qtiles16");
         if (d->cs == 96)
-            hipLaunchKernelGGL(enc_kv_k<6>, dim3((unsigned)d->n_qtiles16), dim3(64), 0, (hipStream_t)stream, k);
+            hipLaunchKernelGGL(enc_kv_k<6>, dim3((unsigned)d->n_qtiles16), dim3(256), 0, (hipStream_t)stream, k);
         else
-            hipLaunchKernelGGL(enc_kv_k<5>, dim3((unsigned)d->n_qtiles16), dim3(64), 0, (hipStream_t)stream, k);
+            hipLaunchKernelGGL(enc_kv_k<5>, dim3((unsigned)d->n_qtiles16), dim3(256), 0, (hipStream_t)stream, k);
     }
     I2R_CHECK_LAUNCH("i2r_encoder_kv");
     return I2R_OK;

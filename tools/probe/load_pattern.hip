@@ -10,14 +10,15 @@ __global__ __launch_bounds__(256) void k(const float* __restrict__ src, float* o
     size_t off;
     if (mode == 0) off = (size_t)lane * 4;
     else if (mode == 1) off = (size_t)li * rowf + 4 * g;
+    else if (mode == 3) off = (size_t)lane * rowf;
     else off = (size_t)(lane >> 2) * rowf + 4 * (lane & 3);
-    const float* base = src + (size_t)((blockIdx.x * 4 + wave) & 63) * 16 * rowf + off;
+    const float* base = src + (size_t)((blockIdx.x * 4 + wave) & 15) * 64 * rowf + off;
     f32x4 acc = (f32x4){0.f, 0.f, 0.f, 0.f};
     long long t0 = __builtin_amdgcn_s_memtime();
     for (int it = 0; it < iters; ++it) {
-        const float* p = base + (size_t)(it & 7) * 64 * 16 * rowf;
+        const float* p = base + (size_t)(it & 7) * 16 * 64 * rowf;
 #pragma unroll
-        for (int c = 0; c < 6; ++c) acc += *reinterpret_cast<const f32x4*>(p + (mode == 0 ? 256 * c : 16 * c));
+        for (int c = 0; c < 6; ++c) acc += *reinterpret_cast<const f32x4*>(p + (mode == 0 ? 256 * c : mode == 3 ? 4 * c : 16 * c));
     }
     long long t1 = __builtin_amdgcn_s_memtime();
     out[blockIdx.x * 256 + threadIdx.x] = acc[0] + acc[1] + acc[2] + acc[3];
@@ -26,11 +27,11 @@ __global__ __launch_bounds__(256) void k(const float* __restrict__ src, float* o
 int main() {
     const int rowf = 96;  // floats per row (the encoder's K rows)
     float *src, *out; long long* cyc;
-    const size_t n = (size_t)8 * 64 * 16 * rowf + 4096;
+    const size_t n = (size_t)9 * 16 * 64 * rowf + 4096;
     hipMalloc(&src, n * 4); hipMemset(src, 0, n * 4);
     hipMalloc(&out, 1024 * 256 * 4); hipMalloc(&cyc, 1024 * 4 * 8);
     for (int blocks = 256; blocks <= 512; blocks *= 2)
-        for (int mode = 0; mode < 3; ++mode) {
+        for (int mode = 0; mode < 4; ++mode) {
             const int iters = 2000;
             hipLaunchKernelGGL(k, dim3(blocks), dim3(256), 0, 0, src, out, cyc, iters, mode, rowf);
             hipDeviceSynchronize();
