@@ -36,7 +36,7 @@ struct EncK {
     const float* w1; const float* b1;
     const float* w2; const float* b2;
     const float* ln2_w; const float* ln2_b;
-    int n_tok, n_tok_pad, n_grp, d, cs, dff_pad, pos_period, n_qtiles;
+    int n_tok, n_tok_pad, n_grp, d, cs, dff_pad, pos_period, n_qblk;
     float ln_eps, qscale;
     // 16-bit MFMA mode: weights as bf16/f16 [out][in] with the columns of every 32-block permuted to the MFMA operand order
     const void* w_in_lp; const void* w_out_lp; const void* w1_lp; const void* w2_lp;
@@ -71,33 +71,43 @@ __device__ __forceinline__ void load_groups(const EncK& p, int gi, int& s0, int&
         e0 = p.grp_off[gi + 1];
     }
 }
-// (s0, e0) = load_groups(lane), issued by the caller ahead of other loads so the table's latency overlaps them
+// (s0, e0) = load_groups(lane), issued by the caller ahead of other loads so the table's latency overlaps them.
+// Work items are runs of QT 16-token tiles of ONE group (QT = 1 or 2); Tile.j counts work items inside the group.
+template <int QT>
 __device__ __forceinline__ Tile locate_tile(const EncK& p, int v, int lane, int s0, int e0) {
     Tile t = {0, 0, 0, 0};
-    int b = v;
+    int b = v, base16 = 0;
     for (int base = 0; base < p.n_grp; base += 64) {
         if (base > 0) load_groups(p, base + lane, s0, e0);
-        const int nq = (e0 - s0 + 15) >> 4;
-        int inc = nq;
+        const int nq16 = (e0 - s0 + 15) >> 4;
+        const int nq = QT == 1 ? nq16 : (nq16 + QT - 1) / QT;
+        int inc = nq, inc16 = nq16;
 #pragma unroll
         for (int d = 1; d < 64; d <<= 1) {
             const int u = __shfl_up(inc, d);
             if (lane >= d) inc += u;
+            if (QT != 1) {
+                const int u16 = __shfl_up(inc16, d);
+                if (lane >= d) inc16 += u16;
+            }
         }
+        if (QT == 1) inc16 = inc;
         const int total = __shfl(inc, 63);
         if (b < total) {
             const int src = __ffsll((long long)__ballot(inc > b)) - 1;
             t.gs = __shfl(s0, src);
             t.ge = __shfl(e0, src);
             b -= __shfl(inc - nq, src);
+            base16 += __shfl(inc16 - nq16, src);
             break;
         }
         b -= total;
+        base16 += __shfl(inc16, 63);
     }
     t.gs = __builtin_amdgcn_readfirstlane(t.gs);
     t.ge = __builtin_amdgcn_readfirstlane(t.ge);
     t.j = __builtin_amdgcn_readfirstlane(b);
-    t.base = v - t.j;
+    t.base = __builtin_amdgcn_readfirstlane(base16);
     return t;
 }
 
@@ -147,7 +157,7 @@ __global__ __launch_bounds__(256) void enc_kv_k(const EncK p) {
         load_wrow<DC>(wk[s], p.w_in + (size_t)cs * cs, f, lane);  // K rows = row blocks [DC, 2DC), V rows = [2DC, 3DC)
         bk[s] = ld4(p.b_in + cs + 16 * f + 4 * g);
     }
-    const Tile t = locate_tile(p, blockIdx.x, lane, s0, e0);
+    const Tile t = locate_tile<1>(p, blockIdx.x, lane, s0, e0);
     const int tok = t.gs + 16 * t.j + li;
     const bool valid = tok < t.ge;
     const int row = valid ? tok : t.ge - 1;
@@ -204,14 +214,17 @@ __device__ __forceinline__ void layer_norm(f32x4 (&y)[DC], const float* w, const
 // by OUTPUT fragments (wave w computes fragments w, w+4, ...), activations exchanged through LDS (a few KB).  The K / V
 // projection of the NEXT layer is fused into the tail (the layer output is already in registers), removing the separate
 // enc_kv launch for all layers but the first.
-template <int DC, int FC>
+template <int DC, int FC, int QT>
 __global__ __launch_bounds__(256, 2) void enc_layer4_k(const EncK p) {
     constexpr int cs = DC * 16, dff = FC * 16;
     constexpr int SD = (DC + 3) / 4, SF = (FC + 3) / 4, SK = (2 * DC + 3) / 4;  // output-fragment slots per wave of each GEMM
-    // LDS (float4 units): exchange area X[max(FC,DC)][64] + partial-O area O[4][DC][64] + (m,l) area ML[4][2][16]
-    __shared__ f32x4 Xs[(FC > DC ? FC : DC) * 64];
-    __shared__ f32x4 Os[4 * DC * 64];
-    __shared__ float MLs[4 * 2 * 16];
+    constexpr int XF = FC > DC ? FC : DC;
+    // LDS (float4 units): exchange area X[XF][QT][64], partial-O area O[4][QT][DC][64] (re-used as the FFN2 exchange area
+    // Y[DC][QT][64] once the merge is over), (m, l) area ML[4][QT][2][16]
+    __shared__ f32x4 Xs[XF * QT * 64];
+    __shared__ f32x4 Os[4 * QT * DC * 64];
+    __shared__ float MLs[4 * QT * 2 * 16];
+    f32x4* const Ys = Os;
     // the small per-feature vectors of the layer tail, staged once (read back as 16-byte broadcasts; no VMEM latency in the tail)
     constexpr int P_BOUT = 0, P_LN1W = cs, P_LN1B = 2 * cs, P_B1 = 3 * cs, P_B2 = 3 * cs + dff, P_LN2W = 4 * cs + dff,
                   P_LN2B = 5 * cs + dff, P_BKV = 6 * cs + dff, P_END = 8 * cs + dff;
@@ -247,19 +260,25 @@ __global__ __launch_bounds__(256, 2) void enc_layer4_k(const EncK p) {
         if (i >= P_BKV) sp = p.next_b_in, o = cs + i - P_BKV;
         if (i < P_END && sp) pstage = ld4(sp + o);
     }
-    // ---- which (group, query tile)?  Workgroup b runs on XCD b % 8: give every XCD a contiguous run of tiles, so the K / V
+
+    // ---- which (group, query tiles)?  Workgroup b runs on XCD b % 8: give every XCD a contiguous run of tiles, so the K / V
     //      of one group are read through ONE L2 instead of all eight ----
     const int per_xcd = gridDim.x >> 3;
     const int v = (blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3);
-    if (v >= p.n_qtiles) return;
-    const Tile t = locate_tile(p, v, lane, gs0, ge0);
+    if (v >= p.n_qblk) return;
+    const Tile t = locate_tile<QT>(p, v, lane, gs0, ge0);
     if (tid * 4 < P_END) *reinterpret_cast<f32x4*>(Ps + tid * 4) = pstage;  // (visible after the barrier that follows the q projection)
-    const int gs = t.gs, ge = t.ge, b = t.j;
+    const int gs = t.gs, ge = t.ge;
     const int nfrag = (ge - gs + 15) >> 4;
-    const int qtok = gs + b * 16 + li;
-    const bool qvalid = qtok < ge;
-    const int qrow = qvalid ? qtok : ge - 1;
-    const int prow = p.pos_period > 0 ? qrow % p.pos_period : qrow;
+    int qtok[QT], qrow[QT], prow[QT];
+    bool qvalid[QT];
+#pragma unroll
+    for (int u = 0; u < QT; ++u) {
+        qtok[u] = gs + (t.j * QT + u) * 16 + li;
+        qvalid[u] = qtok[u] < ge;
+        qrow[u] = qvalid[u] ? qtok[u] : ge - 1;
+        prow[u] = p.pos_period > 0 ? qrow[u] % p.pos_period : qrow[u];
+    }
 
     // A operands of the group's jj-th 16-key fragment (fragment-packed: 2 x DC contiguous 1 KB loads)
     auto fetch_kv = [&](int jj, f32x4(&ka)[DC], f32x4(&va)[DC]) {
@@ -271,66 +290,89 @@ __global__ __launch_bounds__(256, 2) void enc_layer4_k(const EncK p) {
         }
     };
     f32x4 ka0[DC], va0[DC], ka1[DC], va1[DC];
-    f32x4 q[DC];
+    f32x4 q[QT][DC];
     {
-        f32x4 xq[DC];
+        f32x4 xq[QT][DC];
 #pragma unroll
-        for (int c = 0; c < DC; ++c) {
-            xq[c] = ld4(p.src + (size_t)qrow * cs + 16 * c + 4 * g);
-            if (p.pos) xq[c] += ld4(p.pos + (size_t)prow * cs + 16 * c + 4 * g);
-        }
+        for (int u = 0; u < QT; ++u)
+#pragma unroll
+            for (int c = 0; c < DC; ++c) {
+                xq[u][c] = ld4(p.src + (size_t)qrow[u] * cs + 16 * c + 4 * g);
+                if (p.pos) xq[u][c] += ld4(p.pos + (size_t)prow[u] * cs + 16 * c + 4 * g);
+            }
         fetch_kv(min(wave, nfrag - 1), ka0, va0);  // first key fragment of this wave: in flight under the q projection
         __builtin_amdgcn_sched_barrier(0);
         // ---- q projection (scaled by d^-1/2 * log2 e: the softmax below works in base 2), exchanged through LDS ----
 #pragma unroll
         for (int s = 0; s < SD; ++s) {
             const int nt = min(wave + 4 * s, DC - 1);
-            const f32x4 a = frag_mm<DC>(wq[s], xq, bq[s]) * (p.qscale * 1.4426950408889634f);
-            if (wave + 4 * s < DC) Xs[nt * 64 + lane] = a;
+#pragma unroll
+            for (int u = 0; u < QT; ++u) {
+                const f32x4 a = frag_mm<DC>(wq[s], xq[u], bq[s]) * (p.qscale * 1.4426950408889634f);
+                if (wave + 4 * s < DC) Xs[(nt * QT + u) * 64 + lane] = a;
+            }
         }
     }
     __syncthreads();
 #pragma unroll
-    for (int c = 0; c < DC; ++c) q[c] = Xs[c * 64 + lane];
+    for (int u = 0; u < QT; ++u)
+#pragma unroll
+        for (int c = 0; c < DC; ++c) q[u][c] = Xs[(c * QT + u) * 64 + lane];
     STAMP(1);
 
     // ---- attention over this wave's key fragments (wave, wave+4, ...), each prefetched a whole fragment ahead.
     //      Online softmax with a LAZY reference: the running reference m (per query, base-2 units) is only raised -- and O, l
     //      rescaled -- when some score exceeds it by more than 2^10; otherwise p = 2^(s-m) <= 1024 is accumulated as is.
     //      The normalisation O / l at the end is exact either way (same reference in numerator and denominator). ----
-    f32x4 o[DC];
+    f32x4 o[QT][DC];
+    float m_run[QT], l_run[QT];  // l_run: this lane's keys only (summed over the 4 lanes of a query at the end)
 #pragma unroll
-    for (int nt = 0; nt < DC; ++nt) o[nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    float m_run = -__builtin_inff(), l_run = 0.f;  // l_run: this lane's keys only (summed over the 4 lanes of a query at the end)
+    for (int u = 0; u < QT; ++u) {
+        m_run[u] = -__builtin_inff();
+        l_run[u] = 0.f;
+#pragma unroll
+        for (int nt = 0; nt < DC; ++nt) o[u][nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    }
     auto attend = [&](int k0, const f32x4(&ka)[DC], const f32x4(&va)[DC]) {
-        f32x4 st = (f32x4){0.f, 0.f, 0.f, 0.f};
+        f32x4 st[QT];
+#pragma unroll
+        for (int u = 0; u < QT; ++u) st[u] = (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int c = 0; c < DC; ++c)
 #pragma unroll
-            for (int s = 0; s < 4; ++s) st = mfma16(ka[c][s], q[c][s], st);  // S^T[key 4g+r][query li]
+            for (int s = 0; s < 4; ++s)
+#pragma unroll
+                for (int u = 0; u < QT; ++u) st[u] = mfma16(ka[c][s], q[u][c][s], st[u]);  // S^T[key 4g+r][query li]
         if (k0 + 16 > ge) {  // (wave-uniform) ragged last fragment of the group
 #pragma unroll
-            for (int r = 0; r < 4; ++r)
-                if (k0 + 4 * g + r >= ge) st[r] = -__builtin_inff();
-        }
-        const float mx = fmaxf(fmaxf(st[0], st[1]), fmaxf(st[2], st[3]));
-        if (__any(mx > m_run + 10.f)) {  // (wave-uniform, rare after the first fragment)
-            const float m_new = fmaxf(m_run, xmax(mx));
-            const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);  // first time: 2^-inf = 0
-            l_run *= alpha;
+            for (int u = 0; u < QT; ++u)
 #pragma unroll
-            for (int nt = 0; nt < DC; ++nt) o[nt] *= alpha;
-            m_run = m_new;
+                for (int r = 0; r < 4; ++r)
+                    if (k0 + 4 * g + r >= ge) st[u][r] = -__builtin_inff();
         }
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            st[r] = __builtin_amdgcn_exp2f(st[r] - m_run);
-            l_run += st[r];
+        for (int u = 0; u < QT; ++u) {
+            const float mx = fmaxf(fmaxf(st[u][0], st[u][1]), fmaxf(st[u][2], st[u][3]));
+            if (__any(mx > m_run[u] + 10.f)) {  // (wave-uniform, rare after the first fragment)
+                const float m_new = fmaxf(m_run[u], xmax(mx));
+                const float alpha = __builtin_amdgcn_exp2f(m_run[u] - m_new);  // first time: 2^-inf = 0
+                l_run[u] *= alpha;
+#pragma unroll
+                for (int nt = 0; nt < DC; ++nt) o[u][nt] *= alpha;
+                m_run[u] = m_new;
+            }
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                st[u][r] = __builtin_amdgcn_exp2f(st[u][r] - m_run[u]);
+                l_run[u] += st[u][r];
+            }
         }
 #pragma unroll
         for (int s = 0; s < 4; ++s)
 #pragma unroll
-            for (int nt = 0; nt < DC; ++nt) o[nt] = mfma16(va[nt][s], st[s], o[nt]);  // O^T[dim][query] += V^T[dim][key] P^T
+            for (int nt = 0; nt < DC; ++nt)
+#pragma unroll
+                for (int u = 0; u < QT; ++u) o[u][nt] = mfma16(va[nt][s], st[u][s], o[u][nt]);  // O^T[dim][query] += V^T[dim][key] P^T
     };
     {
         int jj = wave;
@@ -345,44 +387,49 @@ __global__ __launch_bounds__(256, 2) void enc_layer4_k(const EncK p) {
         if (jj < nfrag) attend(gs + 16 * jj, ka0, va0);
     }
     STAMP(2);
-    // out-proj rows of this wave's slots: in flight under the merge
-    f32x4 wo[SD][DC], res[SD];
+    // out-proj rows of this wave's slots + the residual pieces they need: in flight under the merge
+    f32x4 wo[SD][DC], res[SD][QT];
 #pragma unroll
     for (int s = 0; s < SD; ++s) {
         load_wrow<DC>(wo[s], p.w_out, min(wave + 4 * s, DC - 1), lane);
-        res[s] = ld4(p.src + (size_t)qrow * cs + 16 * min(wave + 4 * s, DC - 1) + 4 * g);
+#pragma unroll
+        for (int u = 0; u < QT; ++u) res[s][u] = ld4(p.src + (size_t)qrow[u] * cs + 16 * min(wave + 4 * s, DC - 1) + 4 * g);
     }
     __builtin_amdgcn_sched_barrier(0);
     // ---- merge the four partial softmax states ----
-    l_run = xsum(l_run);
-    if (g == 0) {
-        MLs[(wave * 2 + 0) * 16 + li] = m_run;
-        MLs[(wave * 2 + 1) * 16 + li] = l_run;
-    }
 #pragma unroll
-    for (int nt = 0; nt < DC; ++nt) Os[(wave * DC + nt) * 64 + lane] = o[nt];
+    for (int u = 0; u < QT; ++u) {
+        const float l = xsum(l_run[u]);
+        if (g == 0) {
+            MLs[((wave * QT + u) * 2 + 0) * 16 + li] = m_run[u];
+            MLs[((wave * QT + u) * 2 + 1) * 16 + li] = l;
+        }
+#pragma unroll
+        for (int nt = 0; nt < DC; ++nt) Os[((wave * QT + u) * DC + nt) * 64 + lane] = o[u][nt];
+    }
     __syncthreads();
-    f32x4 oc[DC];
-    {
+    f32x4 oc[QT][DC];
+#pragma unroll
+    for (int u = 0; u < QT; ++u) {
         float mw[4], m = -__builtin_inff();
 #pragma unroll
         for (int w = 0; w < 4; ++w) {
-            mw[w] = MLs[(w * 2) * 16 + li];
+            mw[w] = MLs[((w * QT + u) * 2) * 16 + li];
             m = fmaxf(m, mw[w]);
         }
         float l = 0.f, sc[4];
 #pragma unroll
         for (int w = 0; w < 4; ++w) {
             sc[w] = __builtin_amdgcn_exp2f(mw[w] - m);  // a wave without keys has m = -inf, l = 0, O = 0 -> scale 0
-            l += MLs[(w * 2 + 1) * 16 + li] * sc[w];
+            l += MLs[((w * QT + u) * 2 + 1) * 16 + li] * sc[w];
         }
         const float inv = 1.f / l;
 #pragma unroll
         for (int nt = 0; nt < DC; ++nt) {
             f32x4 a = (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-            for (int w = 0; w < 4; ++w) a += Os[(w * DC + nt) * 64 + lane] * sc[w];
-            oc[nt] = a * inv;
+            for (int w = 0; w < 4; ++w) a += Os[((w * QT + u) * DC + nt) * 64 + lane] * sc[w];
+            oc[u][nt] = a * inv;
         }
     }
     STAMP(3);
@@ -394,85 +441,111 @@ __global__ __launch_bounds__(256, 2) void enc_layer4_k(const EncK p) {
 #pragma unroll
     for (int s = 0; s < SD; ++s) {
         const int nt = min(wave + 4 * s, DC - 1);
-        const f32x4 a = frag_mm<DC>(wo[s], oc, ld4(Ps + P_BOUT + 16 * nt + 4 * g)) + res[s];
-        if (wave + 4 * s < DC) Xs[nt * 64 + lane] = a;
+#pragma unroll
+        for (int u = 0; u < QT; ++u) {
+            const f32x4 a = frag_mm<DC>(wo[s], oc[u], ld4(Ps + P_BOUT + 16 * nt + 4 * g)) + res[s][u];
+            if (wave + 4 * s < DC) Xs[(nt * QT + u) * 64 + lane] = a;
+        }
     }
     __syncthreads();
-    f32x4 x1[DC];
+    f32x4 x1[QT][DC];
 #pragma unroll
-    for (int c = 0; c < DC; ++c) x1[c] = Xs[c * 64 + lane];
-    layer_norm<DC>(x1, Ps + P_LN1W, Ps + P_LN1B, p.d, p.ln_eps, g);
+    for (int u = 0; u < QT; ++u) {
+#pragma unroll
+        for (int c = 0; c < DC; ++c) x1[u][c] = Xs[(c * QT + u) * 64 + lane];
+        layer_norm<DC>(x1[u], Ps + P_LN1W, Ps + P_LN1B, p.d, p.ln_eps, g);
+    }
     STAMP(4);
     // ---- FFN ----
     f32x4 w2r[SD][FC];
+    if constexpr (QT == 1) {  // FFN2 rows one phase ahead (with two tiles in flight the registers are not there: fetched after FFN1)
 #pragma unroll
-    for (int s = 0; s < SD; ++s) load_wrow<FC>(w2r[s], p.w2, min(wave + 4 * s, DC - 1), lane);  // FFN2 rows, one phase ahead
-    __builtin_amdgcn_sched_barrier(0);
+        for (int s = 0; s < SD; ++s) load_wrow<FC>(w2r[s], p.w2, min(wave + 4 * s, DC - 1), lane);
+        __builtin_amdgcn_sched_barrier(0);
+    }
     __syncthreads();  // everyone has read Xs before FFN1 overwrites it
 #pragma unroll
     for (int s = 0; s < SF; ++s) {
         const int ft = min(wave + 4 * s, FC - 1);
-        f32x4 a = frag_mm<DC>(w1r[s], x1, ld4(Ps + P_B1 + 16 * ft + 4 * g));
 #pragma unroll
-        for (int r = 0; r < 4; ++r) a[r] = fmaxf(a[r], 0.f);
-        if (wave + 4 * s < FC) Xs[ft * 64 + lane] = a;
+        for (int u = 0; u < QT; ++u) {
+            f32x4 a = frag_mm<DC>(w1r[s], x1[u], ld4(Ps + P_B1 + 16 * ft + 4 * g));
+#pragma unroll
+            for (int r = 0; r < 4; ++r) a[r] = fmaxf(a[r], 0.f);
+            if (wave + 4 * s < FC) Xs[(ft * QT + u) * 64 + lane] = a;
+        }
     }
-    f32x4 x1n[SD];  // the residual of FFN2 is only needed for this wave's slots
+    if constexpr (QT != 1) {
+#pragma unroll
+        for (int s = 0; s < SD; ++s) load_wrow<FC>(w2r[s], p.w2, min(wave + 4 * s, DC - 1), lane);
+    }
+    f32x4 x1n[SD][QT];  // the residual of FFN2 is only needed for this wave's slots
 #pragma unroll
     for (int s = 0; s < SD; ++s) {
         const int nt = min(wave + 4 * s, DC - 1);
 #pragma unroll
-        for (int c = 0; c < DC; ++c)
-            if (c == nt) x1n[s] = x1[c];
+        for (int u = 0; u < QT; ++u)
+#pragma unroll
+            for (int c = 0; c < DC; ++c)
+                if (c == nt) x1n[s][u] = x1[u][c];
     }
     __syncthreads();
-    f32x4 y[DC];
-    {
+    STAMP(5);
+#pragma unroll
+    for (int u = 0; u < QT; ++u) {  // (one tile at a time: h is FC fragments)
         f32x4 h[FC];
 #pragma unroll
-        for (int c = 0; c < FC; ++c) h[c] = Xs[c * 64 + lane];
-        STAMP(5);
-        __syncthreads();
+        for (int c = 0; c < FC; ++c) h[c] = Xs[(c * QT + u) * 64 + lane];
 #pragma unroll
         for (int s = 0; s < SD; ++s) {
             const int nt = min(wave + 4 * s, DC - 1);
-            const f32x4 a = frag_mm<FC>(w2r[s], h, ld4(Ps + P_B2 + 16 * nt + 4 * g)) + x1n[s];
-            if (wave + 4 * s < DC) Xs[nt * 64 + lane] = a;
+            const f32x4 a = frag_mm<FC>(w2r[s], h, ld4(Ps + P_B2 + 16 * nt + 4 * g)) + x1n[s][u];
+            if (wave + 4 * s < DC) Ys[(nt * QT + u) * 64 + lane] = a;
         }
     }
     // K / V rows of the next layer's in_proj for this wave's slots (fragments 0..DC-1: K rows, DC..2DC-1: V rows)
-    f32x4 wk[SK][DC], yq[DC];
+    f32x4 wk[SK][DC], yq[QT][DC];
     if (p.next_w_in) {
 #pragma unroll
         for (int s = 0; s < SK; ++s) load_wrow<DC>(wk[s], p.next_w_in + (size_t)cs * cs, min(wave + 4 * s, 2 * DC - 1), lane);
         if (p.pos) {
 #pragma unroll
-            for (int c = 0; c < DC; ++c) yq[c] = ld4(p.pos + (size_t)prow * cs + 16 * c + 4 * g);
+            for (int u = 0; u < QT; ++u)
+#pragma unroll
+                for (int c = 0; c < DC; ++c) yq[u][c] = ld4(p.pos + (size_t)prow[u] * cs + 16 * c + 4 * g);
         }
     }
     __builtin_amdgcn_sched_barrier(0);
     __syncthreads();
+    f32x4 y[QT][DC];
 #pragma unroll
-    for (int c = 0; c < DC; ++c) y[c] = Xs[c * 64 + lane];
-    layer_norm<DC>(y, Ps + P_LN2W, Ps + P_LN2B, p.d, p.ln_eps, g);
+    for (int u = 0; u < QT; ++u) {
+#pragma unroll
+        for (int c = 0; c < DC; ++c) y[u][c] = Ys[(c * QT + u) * 64 + lane];
+        layer_norm<DC>(y[u], Ps + P_LN2W, Ps + P_LN2B, p.d, p.ln_eps, g);
+    }
     STAMP(6);
-    if (qvalid) {
 #pragma unroll
-        for (int s = 0; s < SD; ++s) {
-            const int nt = wave + 4 * s;
-            if (nt < DC) {
-                f32x4 yn;
+    for (int u = 0; u < QT; ++u)
+        if (qvalid[u]) {
 #pragma unroll
-                for (int c = 0; c < DC; ++c)
-                    if (c == nt) yn = y[c];
-                *reinterpret_cast<f32x4*>(p.out + (size_t)qtok * cs + 16 * nt + 4 * g) = yn;
+            for (int s = 0; s < SD; ++s) {
+                const int nt = wave + 4 * s;
+                if (nt < DC) {
+                    f32x4 yn;
+#pragma unroll
+                    for (int c = 0; c < DC; ++c)
+                        if (c == nt) yn = y[u][c];
+                    *reinterpret_cast<f32x4*>(p.out + (size_t)qtok[u] * cs + 16 * nt + 4 * g) = yn;
+                }
             }
         }
-    }
     // ---- K / V of the next layer from the layer output still in registers ----
     if (p.next_w_in) {
 #pragma unroll
-        for (int c = 0; c < DC; ++c) yq[c] = p.pos ? yq[c] + y[c] : y[c];
+        for (int u = 0; u < QT; ++u)
+#pragma unroll
+            for (int c = 0; c < DC; ++c) yq[u][c] = p.pos ? yq[u][c] + y[u][c] : y[u][c];
 #pragma unroll
         for (int s = 0; s < SK; ++s) {
             const int f = wave + 4 * s;
@@ -480,9 +553,13 @@ __global__ __launch_bounds__(256, 2) void enc_layer4_k(const EncK p) {
                 const bool isv = f >= DC;
                 const int nt = isv ? f - DC : f;
                 const f32x4 bias = ld4(Ps + P_BKV + 16 * f + 4 * g);
-                f32x4 a = isv ? frag_mm<DC>(wk[s], y, bias) : frag_mm<DC>(wk[s], yq, bias);
-                if (isv && !qvalid) a = (f32x4){0.f, 0.f, 0.f, 0.f};  // keys past the group: V must stay finite
-                store_kv_frag(p.next_kbuf, p.next_vbuf, v, DC, nt, a, a, !isv, isv, lane);
+#pragma unroll
+                for (int u = 0; u < QT; ++u) {
+                    if (t.j * QT + u >= nfrag) continue;  // (wave-uniform) the odd last tile of a group has no second half
+                    f32x4 a = isv ? frag_mm<DC>(wk[s], y[u], bias) : frag_mm<DC>(wk[s], yq[u], bias);
+                    if (isv && !qvalid[u]) a = (f32x4){0.f, 0.f, 0.f, 0.f};  // keys past the group: V must stay finite
+                    store_kv_frag(p.next_kbuf, p.next_vbuf, t.base + t.j * QT + u, DC, nt, a, a, !isv, isv, lane);
+                }
             }
         }
     }
@@ -762,7 +839,7 @@ int fill(const i2r_encoder_desc* d, EncK& k) {
     k.w_in = d->w_in; k.b_in = d->b_in; k.w_out = d->w_out; k.b_out = d->b_out; k.ln1_w = d->ln1_w; k.ln1_b = d->ln1_b;
     k.w1 = d->w1; k.b1 = d->b1; k.w2 = d->w2; k.b2 = d->b2; k.ln2_w = d->ln2_w; k.ln2_b = d->ln2_b;
     k.n_tok = d->n_tok; k.n_tok_pad = ((d->n_tok + 63) / 64) * 64 + 64; k.n_grp = d->n_grp; k.d = d->d; k.cs = d->cs;
-    k.dff_pad = d->dff_pad; k.pos_period = d->pos_period; k.ln_eps = d->ln_eps; k.n_qtiles = d->n_qtiles16;
+    k.dff_pad = d->dff_pad; k.pos_period = d->pos_period; k.ln_eps = d->ln_eps; k.n_qblk = d->n_qtiles16;
     k.qscale = 1.0f / sqrtf((float)d->d);
     k.w_in_lp = d->w_in_lp; k.w_out_lp = d->w_out_lp; k.w1_lp = d->w1_lp; k.w2_lp = d->w2_lp;
     k.next_w_in = d->next_w_in; k.next_b_in = d->next_b_in; k.next_kbuf = d->next_kbuf; k.next_vbuf = d->next_vbuf;
@@ -820,12 +897,19 @@ extern "C" int i2r_encoder_layer(const i2r_encoder_desc* d, void* stream) {
         I2R_CHECK_LAUNCH("i2r_encoder_layer");
         return I2R_OK;
     }
-    I2R_CHECK_ARG(d->n_qtiles16 > 0, "i2r_encoder_layer: n_qtiles16");
-    const unsigned grid = (unsigned)((d->n_qtiles16 + 7) / 8 * 8);  // (XCD-major tile order inside the kernel)
-    if (d->cs == 96)
-        hipLaunchKernelGGL((enc_layer4_k<6, 12>), dim3(grid), dim3(256), 0, (hipStream_t)stream, k);
-    else
-        hipLaunchKernelGGL((enc_layer4_k<5, 12>), dim3(grid), dim3(256), 0, (hipStream_t)stream, k);
+    I2R_CHECK_ARG(d->n_qtiles16 > 0 && d->n_qtiles32 > 0, "i2r_encoder_layer: n_qtiles16 / n_qtiles32");
+    // two 16-query tiles per workgroup halve the K / V traffic per MFMA; worth it once there are enough workgroups for the chip
+    static const int qt_env = getenv("I2R_ENC_QT") ? atoi(getenv("I2R_ENC_QT")) : 0;  // tuning switch: force 1 or 2
+    const int qt = qt_env ? qt_env : (d->n_qtiles32 >= 512 ? 2 : 1);
+    k.n_qblk = qt == 2 ? d->n_qtiles32 : d->n_qtiles16;
+    const unsigned grid = (unsigned)((k.n_qblk + 7) / 8 * 8);  // (XCD-major tile order inside the kernel)
+    if (d->cs == 96) {
+        if (qt == 2) hipLaunchKernelGGL((enc_layer4_k<6, 12, 2>), dim3(grid), dim3(256), 0, (hipStream_t)stream, k);
+        else hipLaunchKernelGGL((enc_layer4_k<6, 12, 1>), dim3(grid), dim3(256), 0, (hipStream_t)stream, k);
+    } else {
+        if (qt == 2) hipLaunchKernelGGL((enc_layer4_k<5, 12, 2>), dim3(grid), dim3(256), 0, (hipStream_t)stream, k);
+        else hipLaunchKernelGGL((enc_layer4_k<5, 12, 1>), dim3(grid), dim3(256), 0, (hipStream_t)stream, k);
+    }
     I2R_CHECK_LAUNCH("i2r_encoder_layer");
     return I2R_OK;
 }
