@@ -84,7 +84,7 @@ def per_launch_timing(program, reps=3):
                 name, flop = conv_kernel_name(members), sum(conv_flop(m) for m in members)
             else:
                 name = {cabi.OP_STEM: "stem_conv_k", cabi.OP_MAXPOOL: "maxpool_k", cabi.OP_HEAD: "head_k",
-                        cabi.OP_ENC_KV: "enc_kv_k", cabi.OP_ENC_LAYER: "enc_layer_k", cabi.OP_LAYERNORM: "layernorm_k",
+                        cabi.OP_ENC_KV: "enc_kv_k", cabi.OP_ENC_LAYER: "enc_layer4_k", cabi.OP_LAYERNORM: "layernorm_k",
                         cabi.OP_WINATTN: "window_attn_k", cabi.OP_DWCONV: "dwconv3x3_k", cabi.OP_UPSAMPLE: "upsample_add_k"}[kind]
                 flop = 0.0
             s = stats.setdefault(name, [0, 0.0, 0.0])
@@ -257,7 +257,7 @@ def main():
                 att_flop = per_tok * sum(length) * tok * cfg.MODEL.ENCODER_LAYERS
                 att_ms = sum(s[1] for k, s in stats.items() if k.startswith("enc_")) / reps
                 att = att_flop / (att_ms * 1e-3) / 1e12
-                out["roofline"]["attention_blocks"] = {"kernels": "enc_kv_k + enc_layer_k", "gflop_per_step": round(att_flop / 1e9, 3),
+                out["roofline"]["attention_blocks"] = {"kernels": "enc_kv_k + enc_layer4_k", "gflop_per_step": round(att_flop / 1e9, 3),
                                                        "ms_per_step": round(att_ms, 3), "achieved": round(att, 2),
                                                        "peak": FP32_MFMA_PEAK_TFLOPS, "frac": round(att / FP32_MFMA_PEAK_TFLOPS, 4)}
         if not args.no_cpu_baseline:

@@ -176,17 +176,22 @@ int i2r_upsample_bilinear_add(const float* low, const float* res, float* out, in
  * Token matrix layout: [n_tok, cs] fp32 (cs = padded d, multiple of 16).  Group g owns the contiguous
  * token rows [grp_off[g], grp_off[g+1]).  `pos` has per-token rows when pos_stride_tok = cs, or is a
  * table indexed by (token % pos_period) when pos_period > 0 (TransPose-H sine table).
- * Weights are the reference's own row-major [out][in] matrices, zero-padded to cs / dff_pad.
- * i2r_encoder_kv fills the K,V rows; i2r_encoder_layer consumes them.
+ * Matrices are the reference's [out][in] nn.Linear weights, zero-padded to cs / dff_pad and FRAGMENT-PACKED: every
+ * 16 x 16 block is stored as the MFMA A-operand image in lane order,
+ *     packed[((rb*KC + c)*64 + l)*4 + r] = W[16*rb + (l & 15)][16*c + 4*(l >> 4) + r],   KC = cols / 16,
+ * so that one 64-lane 16-byte load is 1 KB contiguous (a row-major matrix read in operand order costs 4x the
+ * texture-addresser time on gfx950).  i2r_encoder_kv fills K / V^T for the first layer of a stack (fp32 mode: one
+ * fragment-packed image per 16-token tile of each group, tiles numbered group by group: <= n_tok/16 + n_grp tiles of
+ * 16*cs floats each in kbuf and in vbuf); i2r_encoder_layer consumes them.
  * ------------------------------------------------------------------------------------------------ */
 typedef struct i2r_encoder_desc {
     const float* src;      /* [n_tok, cs] */
     const float* pos;      /* optional */
-    float* kbuf;           /* [n_tok, cs] workspace */
-    float* vbuf;           /* [cs, n_tok_pad] workspace, FEATURE-major; n_tok_pad = roundup(n_tok, 64) + 64 */
+    float* kbuf;           /* workspace, max((n_tok/16 + n_grp) * 16 * cs, cs * n_tok_pad) floats (fp32 / 16-bit mode images) */
+    float* vbuf;           /* workspace, same size; n_tok_pad = roundup(n_tok, 64) + 64 */
     float* out;            /* [n_tok, cs] (may not alias src) */
     const int32_t* grp_off;/* device int32 [n_grp + 1] */
-    const float* w_in;     /* [3*cs, cs]  (q rows, k rows, v rows; padded) */
+    const float* w_in;     /* [3*cs, cs]  (q rows, k rows, v rows; padded), fragment-packed like all four matrices */
     const float* b_in;     /* [3*cs] */
     const float* w_out;    /* [cs, cs] */
     const float* b_out;    /* [cs] */
@@ -201,14 +206,14 @@ typedef struct i2r_encoder_desc {
     int32_t cs;            /* padded dim: 96 or 80 */
     int32_t dff_pad;       /* padded feed-forward dim: 192 */
     int32_t pos_period;    /* 0: pos row = token; >0: pos row = token % pos_period */
-    int32_t n_qtiles32;    /* sum over groups of ceil(group_len / 32): the query-tile count (host knows lengths) */
+    int32_t n_qtiles32;    /* sum over groups of ceil(group_len / 32) (host knows the lengths): work items of the two-tile kernel */
     float ln_eps;
     /* 16-bit MFMA mode (dtype 1 bf16 / 2 f16; cs == 96, group offsets multiples of 32): q-proj, QK^T, PV, out-proj and FFN run
      * on v_mfma_f32_16x16x32 with fp32 accumulation; kbuf / vbuf then hold 16-bit data (same byte budget is enough).
      * w_*_lp: the matrices above as 16-bit [out][in] with the columns of every 32-block permuted to
      * new position 8g + 4*half + r  <-  column 32c + 16*half + 4g + r  (g < 4, half < 2, r < 4). */
     int32_t dtype;
-    int32_t n_qtiles16, n_qtiles64;   /* like n_qtiles32 for 16- and 64-query tiles */
+    int32_t n_qtiles16, n_qtiles64;   /* like n_qtiles32 for 16- and 64-query tiles (n_qtiles16 = number of K / V fragments) */
     const void* w_in_lp; const void* w_out_lp; const void* w1_lp; const void* w2_lp;
     /* fp32 mode: fuse the K / V projection of the NEXT layer into this launch (the layer output is still in registers):
      * next_w_in / next_b_in = the next layer's padded in_proj (its k and v rows are used), written to next_kbuf / next_vbuf

@@ -1,4 +1,5 @@
 """-m gpu: each HIP entry point of include/i2r_hip.h against the plain fp32 torch CPU op it replaces."""
+import os
 import pytest
 import torch
 import torch.nn.functional as F
@@ -191,6 +192,52 @@ def test_encoder_layer_matches_oracle(d, length, hw, use_pos):
     assert err < 2e-4, "encoder d=%d max-abs %.3e" % (d, err)
     if d == 78:
         assert out.t.view(-1, out.cs)[:, 78:].abs().max().item() == 0.0
+
+
+def _encoder_stack_case(n_layers, length, hw, d=96):
+    """multi-layer stack: layers > 0 take K / V from the fused tail of the previous layer (ping-pong fragment buffers)"""
+    h, w = hw
+    S = sum(length)
+    sd, sd2, layers = {}, {}, []
+    pk = None
+    for i in range(n_layers):
+        one = _encoder_sd(d, 192, "st%d_%d_%d" % (i, S, h))
+        sd2.update({k.replace("L.", "E.layers.%d." % i): v for k, v in one.items()})
+        layers.append(engine.Packer(one, torch.device(DEV)).encoder_layer("L", d, 192))
+    feat = _rand((S, d, h, w), "sf%d%d" % (S, h))
+    pos = _rand((S, d, h, w), "sp%d%d" % (S, h), 0.5)
+    ref = i2r_cpu.inter_human_encoder(sd2, "E", n_layers, feat, pos, length)
+    P = engine.Program(torch.device(DEV))
+    fa, pa = to_act(P, feat), to_act(P, pos)
+    offs = [0]
+    for n in length:
+        offs.append(offs[-1] + n * h * w)
+    out = P.encoder(fa, layers, offs, pos=pa.ptr)
+    run(P)
+    run(P)  # replay: the workspaces hold the previous run's fragments
+    return (from_act(out) - ref).abs().max().item()
+
+
+@pytest.mark.parametrize("length,hw", [
+    ([2, 1, 3], (6, 6)),     # 72 / 36 / 108 tokens: 5, 3 and 7 tiles -- ragged last fragments, odd tile counts
+    ([1, 4], (16, 12)),      # aligned groups of different size
+    ([3], (5, 4)),           # 60 tokens: one group, last tile a quarter full
+])
+def test_encoder_stack_fused_kv(length, hw):
+    err = _encoder_stack_case(3, length, hw)
+    assert err < 3e-4, "3-layer stack max-abs %.3e" % err
+
+
+def test_encoder_stack_two_tiles_per_workgroup():
+    """the two-tile variant of the layer kernel (chosen for >= 512 work items, forced here through I2R_ENC_QT=2, which the
+    library reads once per process -> subprocess) on the ragged cases above"""
+    import subprocess, sys
+    env = dict(os.environ, I2R_ENC_QT="2")
+    code = ("import sys; sys.path.insert(0, %r); import conftest; import test_kernels_gpu as t; "
+            "errs = [t._encoder_stack_case(3, l, hw) for l, hw in (([2, 1, 3], (6, 6)), ([1, 4], (16, 12)), ([3], (5, 4)), ([5], (24, 18)))]; "
+            "print('ERRS', errs); assert max(errs) < 3e-4" % os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
 
 
 def test_encoder_sine_table_period():
