@@ -8,7 +8,8 @@ Weight packing (done once per load_state_dict / device move):
     float64 and rounded once to fp32.
   * conv weights go to the "k4" layout  [tap][cin/4][cout_pad][4]  consumed by i2r_conv (include/i2r_hip.h).
   * ConvTranspose2d(k4,s2,p1) is split into its four output-parity 2x2 convolutions.
-  * encoder matrices stay in the reference's row-major [out][in] form, zero-padded to multiples of 16.
+  * encoder matrices ([out][in], zero-padded to multiples of 16) are stored fragment-packed: every 16x16 block as the MFMA
+    A-operand image in lane order (pack_frag), so one 64-lane 16-byte load is 1 KB contiguous.
 
 A Program is the static list of launches for one (S, H, W, length) signature: all intermediate NHWC buffers
 are pre-allocated (arena with reuse), so a forward is ONE call into i2r_run_program.

@@ -1,0 +1,18 @@
+#!/bin/bash
+# GPU box: regenerate the artefacts under profiles/ (run from the repo root through gpurun; outputs land in gpurun_out/prof_*).
+# 1. bench line (default command), 2. the same command under rocprofv3 --kernel-trace --stats, 3. PMC passes (separate runs,
+# --kernel-trace only) on the dominant grouped conv launch and on the encoder layer kernel.
+set -x
+cd /tmp && export TMPDIR=/tmp
+R=${GRAFT_REPO_ROOT:-/root/repo}
+O=$R/gpurun_out
+mkdir -p $O
+cd $R
+python bench.py > $O/bench.json 2> $O/bench.err
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_stats -- python bench.py --no-cpu-baseline > $O/bench_under_rocprof.json 2> $O/rocprof_stats.err
+for c in FETCH_SIZE WRITE_SIZE; do
+  rocprofv3 --pmc $c --kernel-trace --output-format csv -d $O/prof_pmc_$c -- python tools/one_conv.py 32 5 group > $O/pmc_$c.log 2>&1
+done
+rocprofv3 --pmc SQ_INSTS_MFMA SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES --kernel-trace --output-format csv -d $O/prof_pmc_sq -- python tools/one_conv.py 32 5 group > $O/pmc_sq.log 2>&1
+rocprofv3 --pmc GRBM_GUI_ACTIVE SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY --kernel-trace --output-format csv -d $O/prof_pmc_sq2 -- python tools/one_conv.py 32 5 group > $O/pmc_sq2.log 2>&1
+find $O -name "*.csv" | head -40

@@ -1,0 +1,76 @@
+"""Condense gpurun_out/prof_* (written by tools/collect_profiles.sh on the GPU box) into the small files kept under profiles/."""
+import csv
+import glob
+import json
+import os
+import shutil
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+O = os.path.join(ROOT, "gpurun_out")
+P = os.path.join(ROOT, "profiles")
+tag = sys.argv[1] if len(sys.argv) > 1 else "round1"
+DOM = "conv_igemm_f32<3, 3, 12, 1>"
+
+
+def counters(d):
+    f = glob.glob(os.path.join(O, d, "*", "*_counter_collection.csv"))[0]
+    acc = {}
+    with open(f) as fh:
+        for r in csv.DictReader(fh):
+            if DOM in r["Kernel_Name"]:
+                acc.setdefault(r["Counter_Name"], []).append(float(r["Counter_Value"]))
+    return {k: sum(v) / len(v) for k, v in acc.items()}, {k: len(v) for k, v in acc.items()}
+
+
+shutil.copy(os.path.join(O, "bench.json"), os.path.join(P, tag + "_bench.json"))
+shutil.copy(os.path.join(O, "bench_under_rocprof.json"), os.path.join(P, tag + "_bench_under_rocprof.json"))
+ks = glob.glob(os.path.join(O, "prof_stats", "*", "*_kernel_stats.csv"))[0]
+rows = list(csv.reader(open(ks)))
+with open(os.path.join(P, tag + "_bench_kernel_stats.csv"), "w", newline="") as fh:
+    w = csv.writer(fh, quoting=csv.QUOTE_ALL)
+    w.writerow(rows[0])
+    for r in rows[1:]:
+        if float(r[4]) >= 0.05:  # kernels with >= 0.05 % of the GPU time (drops torch's one-off init kernels)
+            w.writerow(r)
+fetch, n = counters("prof_pmc_FETCH_SIZE")
+write, _ = counters("prof_pmc_WRITE_SIZE")
+S = 32
+alg = {"read_inputs": 0, "read_residual": 0, "read_weights": 0, "write": 0}
+for c, h, w_ in ((48, 64, 48), (96, 32, 24), (192, 16, 12)):
+    a = S * h * w_ * c * 4
+    alg["read_inputs"] += a
+    alg["read_residual"] += a
+    alg["write"] += a
+    alg["read_weights"] += c * c * 9 * 4
+hbm = {
+    "FETCH_SIZE_KB_per_launch": fetch["FETCH_SIZE"], "WRITE_SIZE_KB_per_launch": write["WRITE_SIZE"],
+    "launches_averaged": n["FETCH_SIZE"],
+    "launch": "grouped stage-3 conv: 48@64x48 + 96@32x24 + 192@16x12, 3x3, S=32, +residual +ReLU (tools/one_conv.py 32 5 group)",
+    "algorithmic_bytes": alg,
+    "hbm_bytes_per_launch": (2 * fetch["FETCH_SIZE"] + write["WRITE_SIZE"]) * 1024,
+    "note": "separate rocprofv3 --pmc passes; FETCH_SIZE doubled per MI355X_MICROARCH.md (gfx950 reports half the bytes of 16 B/lane reads); "
+            "WRITE_SIZE uncalibrated. Reads are 1.3x the algorithmic input+residual bytes: every 8x24-pixel tile stages a 10x26 patch "
+            "(halo, 1.35x); writes match.  At the measured launch time this is ~1.2 TB/s of the ~8 TB/s HBM roof: the kernel is MFMA-bound.",
+}
+json.dump(hbm, open(os.path.join(P, tag + "_hbm_traffic.json"), "w"), indent=1)
+sq, _ = counters("prof_pmc_sq")
+sq2, _ = counters("prof_pmc_sq2")
+sq.update(sq2)
+cyc = sq["GRBM_GUI_ACTIVE"] / 8.0
+sq["derived"] = {"kernel_cycles_per_xcd": cyc, "mfma_busy_frac": sq["SQ_VALU_MFMA_BUSY_CYCLES"] / (cyc * 1024.0),
+                 "avg_waves_per_simd": sq["SQ_WAVE_CYCLES"] / (cyc * 256.0),
+                 "wait_any_frac_of_wave_cycles": sq["SQ_WAIT_ANY"] / sq["SQ_WAVE_CYCLES"]}
+sq["_note"] = ("per-dispatch averages over the grouped stage-3 conv launch (%s); profiled runs clock lower than un-profiled ones" % DOM)
+json.dump(sq, open(os.path.join(P, tag + "_pmc_sq_grouped_conv.json"), "w"), indent=1)
+for c in ("FETCH_SIZE", "WRITE_SIZE"):
+    f = glob.glob(os.path.join(O, "prof_pmc_" + c, "*", "*_counter_collection.csv"))[0]
+    with open(f) as fh, open(os.path.join(P, "%s_pmc_%s_grouped_conv.csv" % (tag, c.lower())), "w", newline="") as out:
+        w = csv.writer(out)
+        w.writerow(["Kernel_Name", "Grid_Size", "LDS_Block_Size", "VGPR_Count", "Accum_VGPR_Count", "Counter_Name", "Counter_Value"])
+        for r in csv.DictReader(fh):
+            if DOM in r["Kernel_Name"]:
+                w.writerow([r["Kernel_Name"][:70], r["Grid_Size"], r["LDS_Block_Size"], r["VGPR_Count"], r["Accum_VGPR_Count"],
+                            r["Counter_Name"], r["Counter_Value"]])
+print(json.dumps(hbm, indent=1))
+print(json.dumps(sq, indent=1))
