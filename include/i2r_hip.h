@@ -145,11 +145,14 @@ int i2r_layernorm(const float* in, const float* w, const float* b, float* out, i
 /* i2r_window_attn -- the softmax(q k^T) v core of InterlacedPoolAttention / MHA_ over 7x7 windows
  * (hrformer.py:1164-1180, 692-935): centre zero-padding to multiples of 7 (:947-956), window gather (:978-987),
  * heads = c / head_dim, q scaled by head_dim^-0.5 (:780), NO relative-position bias (:883-885), de-pad (:958-964).
- * qkv: [n, h, w, 3*cs] holding q | k | v projections of the LayerNorm-ed tokens (a 1x1 i2r_conv with the stacked
- * q/k/v_proj weights); bias_qkv: [3*cs] = the projections of a zero token (what padded tokens contribute).
- * out: [n, h, w, cs] attention output BEFORE out_proj. head_dim <= 40. */
+ * qkv: [n, h, w, 3*hs] holding the q | k | v projections of the LayerNorm-ed tokens (a 1x1 i2r_conv with the stacked
+ * q/k/v_proj weights), each part hs = heads*40 wide: head hh's dim d at channel hh*40 + d, the pad channel(s) of a head
+ * exactly zero (zero weight rows), q ALREADY scaled by head_dim^-0.5 (folded into q_proj by the host).
+ * bias_qkv: [3*hs] = the projections of a zero token in the same layout (what padded tokens contribute).
+ * out: [n, h, w, hs] attention output BEFORE out_proj, same head-padded channel order (out_proj gets zero columns there).
+ * 36 < head_dim <= 40 (HRFormer-B: 39).  Runs on the fp32 matrix pipe: one workgroup per (crop, window, head). */
 int i2r_window_attn(const float* qkv, const float* bias_qkv, float* out, int32_t n_img, int32_t h, int32_t w, int32_t c,
-                    int32_t cs, int32_t heads, void* stream);
+                    int32_t hs, int32_t heads, void* stream);
 
 /* i2r_dwconv3x3 -- depth-wise 3x3 conv, pad 1, stride 1|2, + bias (eval BN folded) + activation (0 none, 1 ReLU,
  * 2 GELU): MlpDWBN.dw3x3+norm2+act2 (hrformer.py:1070-1080,1106-1108) and the DW down-sampling hops of the fuse

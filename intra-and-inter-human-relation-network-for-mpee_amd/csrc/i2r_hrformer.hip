@@ -63,80 +63,111 @@ __global__ __launch_bounds__(256) void layernorm_k(const float* __restrict__ in,
     }
 }
 
-// ---- 7x7 window attention: one wave per (crop, window, head); lane t < 49 owns query token t ----
-// qkv: [n, h, w, 3*cs] (q | k | v, each cs wide, head hh at channels hh*hd..); tokens of the zero-padded border are
-// not stored: their projections equal the bias vector (LayerNorm output is padded with zeros BEFORE q/k/v_proj).
-template <int HDP>  // head_dim padded to a multiple of 4 (39 -> 40)
-__global__ __launch_bounds__(64, 4) void window_attn_k(const float* __restrict__ qkv, const float* __restrict__ bias,
-                                                    float* __restrict__ out, int n_img, int h, int w, int cs, int heads,
-                                                    int hd, int nwy, int nwx, int pad_top, int pad_left, float scale) {
-    __shared__ __attribute__((aligned(16))) float Ks[49 * HDP];
-    __shared__ __attribute__((aligned(16))) float Vs[49 * HDP];
-    __shared__ float Ps[49 * 64];
-    const int t = threadIdx.x;
+// ---- 7x7 window attention on the fp32 matrix pipe: one workgroup (4 waves) per (crop, window, head) ----
+// qkv: [n, h, w, 3*hs] (q | k | v, each hs = heads*HP wide; head hh owns channels hh*HP .. hh*HP+hd-1, HP = head_dim padded
+// to a multiple of 4 with exactly-zero pad channels; q already carries the hd^-1/2 scale: the host folds it into q_proj).
+// Tokens of the zero-padded window border are not stored: their projections equal the bias vector (the LayerNorm output is
+// padded with zeros BEFORE q/k/v_proj, hrformer.py:947-956).
+// Transposed formulation as in the encoder kernel: S^T[key][query] = K Q^T and O^T[dim][query] = V^T P^T, so the softmax
+// output fragment (D layout) is the B operand of the second product without leaving the registers.  The 49 tokens are padded
+// to 4 fragments of 16 (keys >= 49 masked to -inf; V^T columns >= 49 zero), head_dim 39 -> 3 k-blocks of 16 (dims >= 40 zero).
+// Q / K rows and V^T go through LDS once per workgroup (coalesced 16-byte gathers; row strides 44 / 68 floats keep the
+// ds_read_b128 operand fetches bank-conflict free); wave w owns query fragment w.
+template <int HP>
+__global__ __launch_bounds__(256) void window_attn_k(const float* __restrict__ qkv, const float* __restrict__ bias,
+                                                     float* __restrict__ out, int n_img, int h, int w, int hs, int heads,
+                                                     int hd, int nwy, int nwx, int pad_top, int pad_left) {
+    static_assert(HP == 40, "3 k-blocks of 16 with the upper half of the last one zero");
+    constexpr int QS = 44, VS = 68, J4 = HP / 4;
+    __shared__ __attribute__((aligned(16))) float Qs[64 * QS];
+    __shared__ __attribute__((aligned(16))) float Ks[64 * QS];
+    __shared__ __attribute__((aligned(16))) float Vt[48 * VS];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, li = lane & 15, g = lane >> 4;
     int bid = blockIdx.x;
     const int hh = bid % heads; bid /= heads;
     const int wx = bid % nwx; bid /= nwx;
     const int wy = bid % nwy;
     const int img = bid / nwy;
-    const int ty = t / 7, tx = t - ty * 7;
-    const int y = wy * 7 + ty - pad_top, x = wx * 7 + tx - pad_left;
-    const bool live = t < 49;
-    const bool inside = live && y >= 0 && y < h && x >= 0 && x < w;
-    const size_t pix = ((size_t)img * h + (inside ? y : 0)) * w + (inside ? x : 0);
-    const float* qp = inside ? qkv + pix * 3 * cs + hh * hd : bias + hh * hd;
-    const int kstep = inside ? cs : cs;  // k at +cs, v at +2cs in both the tensor row and the bias vector
-    float q[HDP];
+    const f32x4 z4 = (f32x4){0.f, 0.f, 0.f, 0.f};
+    // rows 49..63 of Q / K and the key columns 49..63 of V^T: zero (Q, V^T) or anything finite (K: masked)
+    for (int i = tid; i < 15 * QS / 4; i += 256) {
+        reinterpret_cast<f32x4*>(Qs + 49 * QS)[i] = z4;
+        reinterpret_cast<f32x4*>(Ks + 49 * QS)[i] = z4;
+    }
+    for (int i = tid; i < 48 * 5; i += 256) {  // V^T[dim][48..67]: the column of token 48 is rewritten below
+        const int d = i / 5, c4 = i - d * 5;
+        *reinterpret_cast<f32x4*>(Vt + d * VS + 48 + c4 * 4) = z4;
+    }
+    for (int i = tid; i < 8 * VS / 4; i += 256) reinterpret_cast<f32x4*>(Vt + 40 * VS)[i] = z4;  // dims 40..47
+    __syncthreads();
+    // ---- gather: 49 tokens x (q, k, v) x HP/4 pieces of 16 bytes ----
+    for (int e = tid; e < 3 * 49 * J4; e += 256) {
+        const int part = e / (49 * J4), r = e - part * 49 * J4;
+        const int t = r / J4, j4 = r - t * J4;
+        const int ty = t / 7, tx = t - ty * 7;
+        const int y = wy * 7 + ty - pad_top, x = wx * 7 + tx - pad_left;
+        const bool inside = y >= 0 && y < h && x >= 0 && x < w;
+        const float* src = inside ? qkv + (((size_t)img * h + y) * w + x) * 3 * hs : bias;
+        const f32x4 v = *reinterpret_cast<const f32x4*>(src + part * hs + hh * HP + j4 * 4);
+        if (part == 0) *reinterpret_cast<f32x4*>(Qs + t * QS + j4 * 4) = v;
+        else if (part == 1) *reinterpret_cast<f32x4*>(Ks + t * QS + j4 * 4) = v;
+        else {
 #pragma unroll
-    for (int d = 0; d < HDP; ++d) {
-        q[d] = 0.f;
-        if (live && d < hd) {
-            q[d] = qp[d] * scale;
-            Ks[t * HDP + d] = qp[kstep + d];
-            Vs[t * HDP + d] = qp[2 * kstep + d];
-        } else if (live) {
-            Ks[t * HDP + d] = 0.f;
-            Vs[t * HDP + d] = 0.f;
+            for (int i = 0; i < 4; ++i) Vt[(j4 * 4 + i) * VS + t] = v[i];
         }
     }
     __syncthreads();
-    // scores go through a lane-private LDS column (Ps[j][t]) instead of 49 registers: q[] and o[] already take 80
+    // ---- S^T = K Q^T for this wave's 16 queries ----
+    f32x4 bq[3];
+#pragma unroll
+    for (int c = 0; c < 3; ++c) bq[c] = (c < 2 || g < 2) ? *reinterpret_cast<const f32x4*>(Qs + (wave * 16 + li) * QS + 16 * c + 4 * g) : z4;
+    f32x4 st[4];
+#pragma unroll
+    for (int kf = 0; kf < 4; ++kf) {
+        st[kf] = z4;
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            const f32x4 ka = (c < 2 || g < 2) ? *reinterpret_cast<const f32x4*>(Ks + (kf * 16 + li) * QS + 16 * c + 4 * g) : z4;
+#pragma unroll
+            for (int s4 = 0; s4 < 4; ++s4) st[kf] = mfma16(ka[s4], bq[c][s4], st[kf]);
+        }
+    }
+    // keys 49..63 do not exist (row 4g + r of fragment 3)
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+        if (4 * g + r >= 1) st[3][r] = -__builtin_inff();
     float mx = -__builtin_inff();
-#pragma unroll 2
-    for (int j = 0; j < 49; ++j) {
-        float s = 0.f;
 #pragma unroll
-        for (int d4 = 0; d4 < HDP / 4; ++d4) {
-            const f32x4 kv = *reinterpret_cast<const f32x4*>(Ks + j * HDP + d4 * 4);
-            s = fmaf(q[d4 * 4], kv[0], s); s = fmaf(q[d4 * 4 + 1], kv[1], s);
-            s = fmaf(q[d4 * 4 + 2], kv[2], s); s = fmaf(q[d4 * 4 + 3], kv[3], s);
-        }
-        Ps[j * 64 + t] = s;
-        mx = fmaxf(mx, s);
-    }
+    for (int kf = 0; kf < 4; ++kf) mx = fmaxf(mx, fmaxf(fmaxf(st[kf][0], st[kf][1]), fmaxf(st[kf][2], st[kf][3])));
+    mx = fmaxf(mx, __shfl_xor(mx, 16));
+    mx = fmaxf(mx, __shfl_xor(mx, 32));
     float sum = 0.f;
-    float o[HDP];
 #pragma unroll
-    for (int d = 0; d < HDP; ++d) o[d] = 0.f;
-#pragma unroll 2
-    for (int j = 0; j < 49; ++j) {
-        const float pj = __expf(Ps[j * 64 + t] - mx);
-        sum += pj;
+    for (int kf = 0; kf < 4; ++kf)
 #pragma unroll
-        for (int d4 = 0; d4 < HDP / 4; ++d4) {
-            const f32x4 vv = *reinterpret_cast<const f32x4*>(Vs + j * HDP + d4 * 4);
-            o[d4 * 4] = fmaf(pj, vv[0], o[d4 * 4]); o[d4 * 4 + 1] = fmaf(pj, vv[1], o[d4 * 4 + 1]);
-            o[d4 * 4 + 2] = fmaf(pj, vv[2], o[d4 * 4 + 2]); o[d4 * 4 + 3] = fmaf(pj, vv[3], o[d4 * 4 + 3]);
+        for (int r = 0; r < 4; ++r) {
+            st[kf][r] = __expf(st[kf][r] - mx);
+            sum += st[kf][r];
         }
-    }
+    sum += __shfl_xor(sum, 16);
+    sum += __shfl_xor(sum, 32);
     const float inv = 1.f / sum;
-    if (inside) {
-        float* op = out + pix * cs + hh * hd;
+    // ---- O^T = V^T P^T ----
+    const int t = wave * 16 + li;  // this lane's query token
+    const int ty = t / 7, tx = t - ty * 7;
+    const int y = wy * 7 + ty - pad_top, x = wx * 7 + tx - pad_left;
+    const bool store = t < 49 && y >= 0 && y < h && x >= 0 && x < w;
+    float* orow = out + (((size_t)img * h + (store ? y : 0)) * w + (store ? x : 0)) * hs + hh * HP;
 #pragma unroll
-        for (int d = 0; d < HDP; ++d)
-            if (d < hd) op[d] = o[d] * inv;
-        if (hh == heads - 1)  // keep the padded channels (c .. cs-1) of the row exactly zero
-            for (int ch = heads * hd; ch < cs; ++ch) out[pix * cs + ch] = 0.f;
+    for (int df = 0; df < 3; ++df) {
+        f32x4 o = z4;
+#pragma unroll
+        for (int kf = 0; kf < 4; ++kf) {
+            const f32x4 va = *reinterpret_cast<const f32x4*>(Vt + (df * 16 + li) * VS + kf * 16 + 4 * g);
+#pragma unroll
+            for (int s4 = 0; s4 < 4; ++s4) o = mfma16(va[s4], st[kf][s4], o);
+        }
+        if (store && 16 * df + 4 * g < HP) *reinterpret_cast<f32x4*>(orow + 16 * df + 4 * g) = o * inv;
     }
 }
 
@@ -212,18 +243,17 @@ extern "C" int i2r_layernorm(const float* in, const float* w, const float* b, fl
 }
 
 extern "C" int i2r_window_attn(const float* qkv, const float* bias_qkv, float* out, int32_t n_img, int32_t h, int32_t w, int32_t c,
-                               int32_t cs, int32_t heads, void* stream) {
+                               int32_t hs, int32_t heads, void* stream) {
     I2R_CHECK_ARG(qkv && bias_qkv && out, "i2r_window_attn: null pointer");
-    I2R_CHECK_ARG(heads > 0 && c % heads == 0 && c <= cs, "i2r_window_attn: c=%d heads=%d", c, heads);
+    I2R_CHECK_ARG(heads > 0 && c % heads == 0, "i2r_window_attn: c=%d heads=%d", c, heads);
     const int hd = c / heads;
-    I2R_CHECK_ARG(hd <= 40, "i2r_window_attn: head_dim %d > 40 unsupported", hd);
+    I2R_CHECK_ARG(hd > 36 && hd <= 40 && hs == heads * 40, "i2r_window_attn: head_dim %d / part width %d (need 37..40 and heads*40)", hd, hs);
     const int nwy = (h + 6) / 7, nwx = (w + 6) / 7;
     const int pad_top = (nwy * 7 - h) / 2, pad_left = (nwx * 7 - w) / 2;
-    const float scale = 1.0f / sqrtf((float)hd);
     const long long nblk = (long long)n_img * nwy * nwx * heads;
     I2R_CHECK_ARG(nblk < (1ll << 31), "i2r_window_attn: grid");
-    hipLaunchKernelGGL(window_attn_k<40>, dim3((unsigned)nblk), dim3(64), 0, (hipStream_t)stream, qkv, bias_qkv, out, n_img, h, w,
-                       cs, heads, hd, nwy, nwx, pad_top, pad_left, scale);
+    hipLaunchKernelGGL(window_attn_k<40>, dim3((unsigned)nblk), dim3(256), 0, (hipStream_t)stream, qkv, bias_qkv, out, n_img, h, w,
+                       hs, heads, hd, nwy, nwx, pad_top, pad_left);
     I2R_CHECK_LAUNCH("i2r_window_attn");
     return I2R_OK;
 }

@@ -232,15 +232,31 @@ class Packer:
         w[:c], b[:c] = self.sd[key + ".weight"], self.sd[key + ".bias"]
         return dict(w=self._dev(w), b=self._dev(b), c=c, cs=cs)
 
-    def qkv(self, p, c):
-        """stacked q/k/v_proj as one 1x1 conv with 3*cs outputs (q | k | v, each cs wide, zero rows for the padding)."""
-        cs = _r16(c)
-        W = torch.zeros(3 * cs, c, dtype=torch.float64)
-        b = torch.zeros(3 * cs, dtype=torch.float64)
+    HEAD_PAD = 40  # window attention: every head's channels padded to a 16-byte multiple (head_dim 39 -> 40)
+
+    def qkv(self, p, c, heads):
+        """stacked q/k/v_proj as one 1x1 conv with 3*hs outputs (q | k | v, each hs = heads*HEAD_PAD wide): head hh's dim d sits at
+        channel hh*HEAD_PAD + d, pad channels have zero weights and bias (they come out exactly 0).  The hd^-0.5 scale of the
+        queries (hrformer.py:780) is folded into the q rows."""
+        hd, hp = c // heads, self.HEAD_PAD
+        assert hd * heads == c and hp - 4 < hd <= hp
+        hs = heads * hp
+        W = torch.zeros(3 * hs, c, dtype=torch.float64)
+        b = torch.zeros(3 * hs, dtype=torch.float64)
+        rows = torch.tensor([hh * hp + d for hh in range(heads) for d in range(hd)])
         for i, n in enumerate(("q_proj", "k_proj", "v_proj")):
-            W[i * cs:i * cs + c] = self.sd["%s.%s.weight" % (p, n)].double()
-            b[i * cs:i * cs + c] = self.sd["%s.%s.bias" % (p, n)].double()
+            sc = float(hd) ** -0.5 if i == 0 else 1.0
+            W[i * hs + rows] = self.sd["%s.%s.weight" % (p, n)].double() * sc
+            b[i * hs + rows] = self.sd["%s.%s.bias" % (p, n)].double() * sc
         return self.linear_as_conv(W, b)
+
+    def attn_out(self, p, c, heads):
+        """out_proj as a 1x1 conv reading the head-padded attention output (cin = heads*HEAD_PAD, zero columns for the pads)."""
+        hd, hp = c // heads, self.HEAD_PAD
+        cols = torch.tensor([hh * hp + d for hh in range(heads) for d in range(hd)])
+        W = torch.zeros(c, heads * hp, dtype=torch.float64)
+        W[:, cols] = self.sd[p + ".out_proj.weight"].double()
+        return self.linear_as_conv(W, self.sd[p + ".out_proj.bias"])
 
     def table(self, key, rows, d):
         """[rows, 1, d] parameter (TransPose-H pos_embedding) -> [rows, cs] device table."""
@@ -478,11 +494,11 @@ class Program:
         return out
 
     def winattn(self, qkv, bias, c, heads, lane=0):
-        cs = _r16(c)
-        assert qkv.cs == 3 * cs
-        out = self.alloc(qkv.n, qkv.h, qkv.w, c)
+        hs = heads * Packer.HEAD_PAD
+        assert qkv.cs == 3 * hs, (qkv.cs, hs)
+        out = self.alloc(qkv.n, qkv.h, qkv.w, hs)  # head-padded channels (consumed by Packer.attn_out)
         self.keep.append(bias)
-        a = cabi.WinAttnArgs(qkv.ptr, bias.data_ptr(), out.ptr, qkv.n, qkv.h, qkv.w, c, cs, heads)
+        a = cabi.WinAttnArgs(qkv.ptr, bias.data_ptr(), out.ptr, qkv.n, qkv.h, qkv.w, c, hs, heads)
         self.ops.append((cabi.OP_WINATTN, lane, a))
         return out
 
@@ -800,8 +816,8 @@ class HRFormerB:
             for k in range(st["num_blocks"][i]):
                 r = "%s.branches.%d.%d" % (q, i, k)
                 blks.append(dict(c=ch[i], heads=st["num_heads"][i], ln1=pk.ln(r + ".norm1", ch[i]), ln2=pk.ln(r + ".norm2", ch[i]),
-                                 qkv=pk.qkv(r + ".attn.attn", ch[i]),
-                                 out=pk.linear_as_conv(pk.sd[r + ".attn.attn.out_proj.weight"], pk.sd[r + ".attn.attn.out_proj.bias"]),
+                                 qkv=pk.qkv(r + ".attn.attn", ch[i], st["num_heads"][i]),
+                                 out=pk.attn_out(r + ".attn.attn", ch[i], st["num_heads"][i]),
                                  fc1=pk.conv(r + ".mlp.fc1", r + ".mlp.norm1"), dw=pk.dw(r + ".mlp.dw3x3", r + ".mlp.norm2"),
                                  fc2=pk.conv(r + ".mlp.fc2", r + ".mlp.norm3")))
             mod["blocks"].append(blks)

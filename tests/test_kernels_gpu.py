@@ -290,10 +290,10 @@ def test_window_attention_block_matches_oracle(c, heads, h, w):
     pk = engine.Packer(sd, torch.device(DEV))
     xa = to_act(P, x)
     n1a = P.layernorm(xa, pk.ln("b.norm1", c))
-    qkvw = pk.qkv(p, c)
+    qkvw = pk.qkv(p, c, heads)
     qkv = P.conv(n1a, qkvw)
     a = P.winattn(qkv, qkvw.bias, c, heads)
-    out = P.conv(a, pk.linear_as_conv(sd[p + ".out_proj.weight"], sd[p + ".out_proj.bias"]), res1=xa)
+    out = P.conv(a, pk.attn_out(p, c, heads), res1=xa)
     run(P)
     err = (from_act(out) - ref).abs().max().item()
     assert err < 2e-4, "window attention c=%d max-abs %.3e" % (c, err)
