@@ -200,6 +200,49 @@ __global__ __launch_bounds__(256) void dwconv3x3_k(const float* __restrict__ in,
     *reinterpret_cast<f32x4*>(out + (size_t)pix * cs + cg * 4) = act4(acc, act);
 }
 
+// stride-1 variant: one thread = 4 vertically adjacent output pixels x 4 channels -- 18 input loads and 9 weight loads
+// for 4 outputs instead of 36 + 36 (the kernel is L1 / addresser bound, not HBM bound, with one output per thread)
+__global__ __launch_bounds__(256) void dwconv3x3_s1_k(const float* __restrict__ in, const float* __restrict__ w,
+                                                      const float* __restrict__ bias, float* __restrict__ out, int n_img, int h,
+                                                      int wd, int c4, int cs, int act) {
+    const long long gid = (long long)blockIdx.x * 256 + threadIdx.x;
+    const int cg = (int)(gid % c4);
+    const long long col = gid / c4;
+    const int hs = (h + 3) >> 2;  // strips per column
+    if (col >= (long long)n_img * hs * wd) return;
+    const int ox = (int)(col % wd);
+    const int oy0 = (int)((col / wd) % hs) * 4;
+    const int img = (int)(col / ((long long)wd * hs));
+    f32x4 wv[9];
+#pragma unroll
+    for (int t = 0; t < 9; ++t) wv[t] = *reinterpret_cast<const f32x4*>(w + t * cs + cg * 4);
+    const f32x4 b = *reinterpret_cast<const f32x4*>(bias + cg * 4);
+    f32x4 acc[4] = {b, b, b, b};
+#pragma unroll
+    for (int r = 0; r < 6; ++r) {  // input rows oy0-1 .. oy0+4
+        const int iy = oy0 - 1 + r;
+        if (iy < 0 || iy >= h) continue;
+#pragma unroll
+        for (int kx = 0; kx < 3; ++kx) {
+            const int ix = ox - 1 + kx;
+            if (ix < 0 || ix >= wd) continue;
+            const f32x4 v = *reinterpret_cast<const f32x4*>(in + ((size_t)(img * h + iy) * wd + ix) * cs + cg * 4);
+#pragma unroll
+            for (int o = 0; o < 4; ++o) {
+                const int ky = r - o;  // output row oy0 + o takes input row oy0 + o - 1 + ky
+                if (ky >= 0 && ky < 3) {
+                    const f32x4 ww = wv[ky * 3 + kx];
+                    acc[o][0] = fmaf(v[0], ww[0], acc[o][0]); acc[o][1] = fmaf(v[1], ww[1], acc[o][1]);
+                    acc[o][2] = fmaf(v[2], ww[2], acc[o][2]); acc[o][3] = fmaf(v[3], ww[3], acc[o][3]);
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int o = 0; o < 4; ++o)
+        if (oy0 + o < h) *reinterpret_cast<f32x4*>(out + ((size_t)(img * h + oy0 + o) * wd + ox) * cs + cg * 4) = act4(acc[o], act);
+}
+
 // ---- out = act(res + bilinear_upsample(low)), align_corners = False, integer scale ----
 __global__ __launch_bounds__(256) void upsample_add_k(const float* __restrict__ low, const float* __restrict__ res,
                                                       float* __restrict__ out, int n_img, int lh, int lw, int scale, int c4, int cs,
@@ -263,9 +306,15 @@ extern "C" int i2r_dwconv3x3(const float* in, const float* w, const float* bias,
     I2R_CHECK_ARG(in && w && bias && out && in != out, "i2r_dwconv3x3: bad pointers");
     I2R_CHECK_ARG(c > 0 && c <= cs && cs % 4 == 0 && (stride == 1 || stride == 2) && act >= 0 && act <= 2, "i2r_dwconv3x3: args");
     const int out_h = (in_h - 1) / stride + 1, out_w = (in_w - 1) / stride + 1;
-    const long long nthr = (long long)n_img * out_h * out_w * (cs / 4);
-    hipLaunchKernelGGL(dwconv3x3_k, dim3((unsigned)((nthr + 255) / 256)), dim3(256), 0, (hipStream_t)stream, in, w, bias, out, n_img,
-                       in_h, in_w, out_h, out_w, cs / 4, cs, stride, act);
+    if (stride == 1) {
+        const long long nthr = (long long)n_img * ((in_h + 3) / 4) * in_w * (cs / 4);
+        hipLaunchKernelGGL(dwconv3x3_s1_k, dim3((unsigned)((nthr + 255) / 256)), dim3(256), 0, (hipStream_t)stream, in, w, bias, out,
+                           n_img, in_h, in_w, cs / 4, cs, act);
+    } else {
+        const long long nthr = (long long)n_img * out_h * out_w * (cs / 4);
+        hipLaunchKernelGGL(dwconv3x3_k, dim3((unsigned)((nthr + 255) / 256)), dim3(256), 0, (hipStream_t)stream, in, w, bias, out, n_img,
+                           in_h, in_w, out_h, out_w, cs / 4, cs, stride, act);
+    }
     I2R_CHECK_LAUNCH("i2r_dwconv3x3");
     return I2R_OK;
 }
