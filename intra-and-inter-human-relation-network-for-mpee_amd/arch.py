@@ -159,6 +159,18 @@ def vanilla_spec(cfg):
     return spec
 
 
+def hrnet_spec(cfg, p=""):
+    """hrnet.HRNet (:275-325): the W48 tower, `reduce` (1x1, no bias) on the lowest-resolution branch and a `final_layer` that
+    forward() (:419-446) never applies."""
+    M = cfg["MODEL"]
+    extra = M["EXTRA"]
+    spec = Spec()
+    ch = hrnet_w48_tower(spec, p, extra)
+    spec.conv(p + "reduce", M["DIM_MODEL"], ch[-1], 1)
+    spec.conv(p + "final_layer", M["NUM_JOINTS"], M["DIM_MODEL"], extra["FINAL_CONV_KERNEL"], bias=True)
+    return spec
+
+
 def transpose_h_spec(cfg, p=""):
     """transpose_h.TransPoseH (:418-480)."""
     M = cfg["MODEL"]
@@ -190,8 +202,10 @@ def interformer_spec(cfg):
     elif sf == "hrformer":
         from . import arch_hrformer
         spec.extend(arch_hrformer.hrformer_spec(cfg, "singleformer."))
+    elif not sf:  # bare HRNet backbone (interformer.py:143-144 -> backbone.build_backbone -> hrnet.HRNet); no shipped yaml
+        spec.extend(hrnet_spec(cfg, "backbone.body."))
     else:
-        raise NotImplementedError("MODEL.SINGLEFORMER=%r (reference builds lib/models/hrnet.py here; no shipped yaml)" % (sf,))
+        raise NotImplementedError("MODEL.SINGLEFORMER=%r" % (sf,))
     multi_position_embedding(spec, "multi_position_embedding", M["MULTI_POS_EMBEDDING"], d, M["TRANS_SIZE"],
                              M["MULTI_POS_EMBEDDING_DIM"])
     assert not (M["MULTI_POS_EMBEDDING"] == "cat_vec" and M["USE_MULTI_POS"]), "cat_vec fusion not supported"

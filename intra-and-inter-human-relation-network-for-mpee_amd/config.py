@@ -183,6 +183,7 @@ NAMED = {
     "hrt_192_p4_b4": "crowdpose_hrt_192_p4_b4.yaml",
     "coco_hrt_288_p2_b4": "coco_hrt_288_p2_b4.yaml",
     "coco_tph_192_p4_b4": "coco_tph_192_p4_b4.yaml",
+    "w48_bare_p6": "crowdpose_w48_bare_p6.yaml",   # interformer without a first stage (bare HRNet backbone)
 }
 
 

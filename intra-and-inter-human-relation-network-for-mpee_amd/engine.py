@@ -929,7 +929,7 @@ class HRFormerB:
 class Engine:
     """Packed model + program cache for one device. Built by models/_base.I2RModule."""
 
-    def __init__(self, cfg, state_dict, device, precision="fp32"):
+    def __init__(self, cfg, state_dict, device, precision="fp32", name=None):
         cabi.lib()  # fail loudly here when the HIP library is absent
         self.precision = precision
         self.cfg = cfg
@@ -940,12 +940,16 @@ class Engine:
         self.multi_lane = False  # (grouped launches replaced per-branch stream lanes)
         self.side_streams = [torch.cuda.Stream(device=self.device) for _ in range(3)]
         M = cfg["MODEL"]
-        self.name = M["NAME"]
+        self.name = name or M["NAME"]
         pk = Packer(state_dict, self.device, precision)
         d, dff = M["DIM_MODEL"], M["DIM_FEEDFORWARD"]
         assert M["N_HEAD"] == 1, "the shipped configs use single-head attention (N_HEAD=1)"
         assert not M["NORMALIZE_BEFORE"], "NORMALIZE_BEFORE is false in every shipped config (post-norm only)"
-        if self.name == "interformer_pureMulti":
+        self.singleformer = None
+        if self.name == "hrnet":  # stand-alone backbone (models/hrnet.py): tower + reduce, see forward_backbone()
+            self.tower = HRNetW48(pk, "", M["EXTRA"])
+            self.reduce = pk.conv("reduce")
+        elif self.name == "interformer_pureMulti":
             self.tower = HRNetW48(pk, "", M["EXTRA"])
             self.reduce = pk.conv("reduce")
             self.use_pos = bool(M["USE_MULTI_POS"])
@@ -974,6 +978,10 @@ class Engine:
                 assert d == 78, "HRFormer-B emits 78 channels (hrformer.py:2527)"
                 self.tower = HRFormerB(pk, p)
                 self.single_head = pk.head(p + "keypoint_head.final_layer")
+            elif not sf:  # bare backbone: hrnet.HRNet.forward = reduce(lowest branch) (hrnet.py:419-446), no first-stage head
+                assert self.name == "interformer", "interformer_2stage always has a first stage"
+                self.tower = HRNetW48(pk, "backbone.body.", M["EXTRA"])
+                self.reduce = pk.conv("backbone.body.reduce")
             else:
                 raise NotImplementedError("MODEL.SINGLEFORMER=%r" % (sf,))
             self.use_pos = bool(M["USE_MULTI_POS"])
@@ -997,7 +1005,7 @@ class Engine:
             else:
                 raise NotImplementedError("UPSAMPLE_TYPE=%r" % up)
             self.head = pk.head("final_layer")
-            self.return_dict = bool(M["INTER_SUPERVISION"]) and not M["SINGLEFORMER_FIX"]
+            self.return_dict = bool(M["INTER_SUPERVISION"]) and not M["SINGLEFORMER_FIX"] and bool(sf)
         else:
             raise NotImplementedError("MODEL.NAME=%r" % self.name)
 
@@ -1022,7 +1030,7 @@ class Engine:
         if flip:
             S, length = 2 * S, list(length) + list(length)
         xs, patch["x"] = self.tower.emit(P, S, H, W, n_src=n_src)
-        if self.name == "interformer_pureMulti":
+        if self.name == "interformer_pureMulti" or not self.singleformer:
             f = P.conv(xs[-1], self.reduce)
             P.release(*xs)
             single_feat = None
@@ -1065,6 +1073,25 @@ class Engine:
         patch["multi"] = P.head(e, self.head)
         P.finalize()
         return P, patch
+
+    def forward_backbone(self, x):
+        """hrnet.HRNet.forward (hrnet.py:419-446): x [S,3,H,W] -> reduce(lowest branch) as an NCHW tensor [S, d, H/16, W/16]."""
+        assert self.name == "hrnet" and x.dim() == 4 and x.shape[1] == 3 and x.dtype == torch.float32
+        S, _, H, W = x.shape
+        x = x.to(self.device).contiguous()
+        key = (S, H, W, "backbone")
+        if key not in self.programs:
+            P = Program(self.device)
+            xs, px = self.tower.emit(P, S, H, W, n_src=S)
+            f = P.conv(xs[-1], self.reduce)
+            P.release(*xs)
+            P.finalize()
+            self.programs[key] = (P, px, f)
+        P, px, f = self.programs[key]
+        px.in_ = x.data_ptr()
+        P.run()
+        # (NHWC arena buffer -> the reference's NCHW tensor: a torch view + copy, boundary plumbing only)
+        return f.t.view(S, f.h, f.w, f.cs)[..., :f.c].permute(0, 3, 1, 2).contiguous()
 
     def forward(self, x, pos_mask, length, flip_joint_map=None):
         """flip_joint_map (device int32 [J], see caller.joint_map): run the flip test in the same forward and return the merged

@@ -94,9 +94,12 @@ class I2RModule(nn.Module):
                 "(model.cuda()) -- there is no CPU execution path in the product (the CPU oracle lives in oracle/).")
         if self._engine is None or self._engine_key != dev:
             from ..engine import Engine
-            self._engine = Engine(self.cfg, self.state_dict(), dev, self.precision)
+            self._engine = Engine(self.cfg, self.state_dict(), dev, self.precision, name=self._engine_name())
             self._engine_key = dev
         return self._engine
+
+    def _engine_name(self):
+        return None  # MODEL.NAME
 
     def forward_flip(self, x, pos_mask, length, flip_pairs):
         """Flip test of validate() (lib/core/function.py:142-162) in ONE batched forward: returns

@@ -287,13 +287,22 @@ def forward_two_stage(sd, cfg, x, pos_mask, length, collect=None):
     elif M["SINGLEFORMER"] == "hrformer":
         from i2r_cpu_hrformer import forward_hrformer
         feat, single = forward_hrformer(sd, "singleformer.", cfg, x, collect)
+    elif not M["SINGLEFORMER"]:
+        # bare backbone (interformer.py:291-292 -> backbone.HRNetBackbone -> hrnet.HRNet.forward :419-446): reduce(lowest branch),
+        # no first-stage head, no pooling, no residual
+        ys = hrnet_w48_stages(sd, "backbone.body.", x, M["EXTRA"], collect)
+        feat, single = None, None
+        f = F.conv2d(ys[-1], sd["backbone.body.reduce.weight"])
+        if collect is not None:
+            collect["reduce"] = f
     else:
         raise NotImplementedError("SINGLEFORMER=%r" % (M["SINGLEFORMER"],))
-    if collect is not None:
-        collect["single_feat"] = feat
-    f = feat
-    for _ in range(int(math.log(f.shape[-1] // M["TRANS_SIZE"][-1], 2))):  # max_pool, :260-264,:290
-        f = _maxpool(f)
+    if feat is not None:
+        if collect is not None:
+            collect["single_feat"] = feat
+        f = feat
+        for _ in range(int(math.log(f.shape[-1] // M["TRANS_SIZE"][-1], 2))):  # max_pool, :260-264,:290
+            f = _maxpool(f)
     pos = None
     if M["USE_MULTI_POS"]:
         assert M["MULTI_POS_EMBEDDING"] == "conv", "only the 'conv' multi-position mode is restated"
@@ -319,9 +328,10 @@ def forward_two_stage(sd, cfg, x, pos_mask, length, collect=None):
         f = _deconv_bn_relu(sd, "deconv_layers.0", "deconv_layers.1", f)
     else:
         raise NotImplementedError("UPSAMPLE_TYPE=%r" % up)
-    f = feat + f  # residual (:315)
+    if feat is not None:
+        f = feat + f  # residual (:315)
     multi = F.conv2d(f, sd["final_layer.weight"], sd["final_layer.bias"])
-    if M["INTER_SUPERVISION"] and not M["SINGLEFORMER_FIX"]:
+    if M["INTER_SUPERVISION"] and not M["SINGLEFORMER_FIX"] and feat is not None:
         return {"single": single, "multi": multi}
     return multi
 

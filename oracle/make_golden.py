@@ -39,6 +39,7 @@ CASES = [
     ("hrt_l21", "hrt_192_p4_b4", [2, 1], (256, 192), True),
     ("hrt288_l2", "coco_hrt_288_p2_b4", [2], (384, 288), False),     # 96x72 maps, 24x18 inter-human tokens
     ("tph2s_l12", "coco_tph_192_p4_b4", [1, 2], (256, 192), False),  # interformer_2stage wiring (multiplex deconv, multi-pos)
+    ("bare_l21", "w48_bare_p6", [2, 1], (256, 192), False),          # interformer with MODEL.SINGLEFORMER unset (models/hrnet.py)
 ]
 
 
@@ -63,7 +64,10 @@ def main():
     torch.set_num_threads(8)
     os.makedirs(OUT, exist_ok=True)
     nets = {}
+    only = set(sys.argv[1:])  # optional: regenerate just these tags
     for tag, cname, length, (H, W), full in CASES:
+        if only and tag not in only:
+            continue
         cfg = config.load_config(cname)
         if cname not in nets:
             net = ref_shim.build_reference_model(cfg)

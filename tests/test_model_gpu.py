@@ -48,6 +48,23 @@ def test_heatmaps_match_reference_golden(tag):
             assert err_ref < TOL, "%s/%s vs reference golden max-abs %.3e" % (tag, k, err_ref)
 
 
+def test_standalone_hrnet_backbone_module():
+    """models.hrnet.get_pose_net / models.backbone.build_backbone (reference lib/models/hrnet.py:419-446, backbone.py:9-20): the bare
+    tower + reduce, fed with the `backbone.body.*` weights of the bare-backbone interformer case."""
+    cfg, sd, x, m, length, g = setup("bare_l21")
+    body = {k[len("backbone.body."):]: v for k, v in sd.items() if k.startswith("backbone.body.")}
+    net = models.hrnet.get_pose_net(cfg, is_train=False)
+    net.load_state_dict(body, strict=True)
+    y = net.cuda()(x.cuda()).cpu()
+    ys = i2r_cpu.hrnet_w48_stages(sd, "backbone.body.", x, cfg.MODEL.EXTRA)
+    ref = torch.nn.functional.conv2d(ys[-1], sd["backbone.body.reduce.weight"])
+    assert y.shape == ref.shape == (3, 96, 16, 12)
+    assert (y - ref).abs().max().item() < TOL
+    bb = models.backbone.build_backbone(cfg)
+    bb.body.load_state_dict(body, strict=True)
+    assert torch.equal(bb.cuda()(x.cuda()).cpu(), y)
+
+
 def test_ragged_batches_and_program_cache():
     """var-len groups: a crop's heatmaps depend only on its own image; different `length` signatures coexist."""
     cfg, sd, x, m, length, g = setup("w48_l213")
