@@ -136,6 +136,21 @@ int i2r_flip_merge(const float* y, const float* y_flipped, const int32_t* joint_
 int i2r_decode(const float* heatmaps, const float* center, const float* scale, float* preds, float* maxvals, int32_t n,
                int32_t joints, int32_t h, int32_t w, int32_t blur_kernel, int32_t transform_back, void* stream);
 
+/* ---- input side (reference lib/dataset/JointsDataset.py:296-333) ------------------------
+ * i2r_crop_affine -- cv2.warpAffine(image, trans, IMAGE_SIZE, INTER_LINEAR) + ToTensor + Normalize for the n persons of ONE
+ * image: out[p][c][y][x] = (bilinear(img, M_p (x, y, 1)^T) / 255 - mean[c]) * inv_std[c], taps outside the image = 0.
+ * img: device uint8 [ih, iw, 3] with row pitch row_bytes (HWC as cv2.imread delivers it; swap_rb = DATASET.COLOR_RGB);
+ * inv_trans: device float [n, 6] = the INVERSE (input pixel -> image pixel) of get_affine_transform(center, scale, 0, size)
+ * (lib/utils/transforms.py:61-96); out: [n, 3, oh, ow] fp32.  fp32 interpolation, NOT cv2's fixed-point one (parity unpinned:
+ * cv2 is not available to pin it; deviation bounded by cv2's 1/32-pixel / 8-bit quantisation). */
+int i2r_crop_affine(const unsigned char* img, int32_t ih, int32_t iw, int32_t row_bytes, int32_t swap_rb, const float* inv_trans,
+                    const float* mean, const float* inv_std, float* out, int32_t n, int32_t oh, int32_t ow, void* stream);
+
+/* i2r_box_mask -- get_position(shape, box, 'single') + rotate_bound(., 0) + cv2.resize(., IMAGE_SIZE) + ToTensor
+ * (JointsDataset.py:165-177,323-331): the filled inclusive rectangle boxes[p] = (int(x), int(y), int(x+w), int(y+h)) at image
+ * resolution, resized bilinearly (half-pixel centres) to [n, 1, oh, ow], values in [0, 1].  Same parity note as above. */
+int i2r_box_mask(const int32_t* boxes, int32_t ih, int32_t iw, float* out, int32_t n, int32_t oh, int32_t ow, void* stream);
+
 /* ---- HRFormer-B glue (reference lib/models/hrformer.py) ---------------------------------------------------- */
 /* i2r_layernorm -- nn.LayerNorm(c, eps) over the channels of every pixel/token of an NHWC tensor
  * (GeneralTransformerBlock.norm1/norm2, hrformer.py:1198,1235-1237). w, b: [cs] zero-padded. */

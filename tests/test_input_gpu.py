@@ -1,0 +1,63 @@
+"""-m gpu: the input-side kernels (csrc/i2r_input.hip) through the C-ABI against the CPU restatement of the same definition, and the
+whole chain image -> crops -> forward."""
+import numpy as np
+import pytest
+import torch
+
+import input_cpu
+from _golden import setup
+from i2r_amd import input as inp
+from i2r_amd import models
+
+pytestmark = pytest.mark.gpu
+
+
+def _scene(seed, ih, iw, n):
+    rng = np.random.RandomState(seed)
+    img = rng.randint(0, 256, size=(ih, iw, 3)).astype(np.uint8)
+    boxes = []
+    for _ in range(n):
+        w, h = rng.uniform(0.15, 0.6) * iw, rng.uniform(0.2, 0.8) * ih
+        x, y = rng.uniform(-0.1 * iw, iw - 0.5 * w), rng.uniform(-0.1 * ih, ih - 0.5 * h)   # some boxes stick out of the image
+        boxes.append((x, y, w, h))
+    centers = [np.array([b[0] + b[2] * 0.5, b[1] + b[3] * 0.5]) for b in boxes]
+    scales = []
+    for b in boxes:   # _box2cs convention of the datasets: aspect-corrected box / 200 * 1.25
+        w, h = b[2], b[3]
+        if w > 0.75 * h:
+            h = w / 0.75
+        else:
+            w = h * 0.75
+        scales.append(np.array([w / 200.0, h / 200.0]) * 1.25)
+    return img, centers, scales, boxes
+
+
+@pytest.mark.parametrize("ih,iw,n,rgb", [(480, 640, 3, False), (333, 517, 2, True), (64, 48, 1, False)])
+def test_crops_and_masks_match_cpu_restatement(ih, iw, n, rgb):
+    img, centers, scales, boxes = _scene(ih + n, ih, iw, n)
+    x, m = inp.person_inputs(img, centers, scales, boxes, (192, 256), color_rgb=rgb)
+    torch.cuda.synchronize()
+    inv = np.stack([inp.invert_affine(inp.get_affine_transform(centers[i], scales[i], 0, (192, 256))) for i in range(n)]).astype(np.float32)
+    ref_x = input_cpu.crop_affine(img, inv, inp.IMAGENET_MEAN, inp.IMAGENET_STD, 256, 192, swap_rb=rgb)
+    bx = [(int(b[0]), int(b[1]), int(b[0] + b[2]), int(b[1] + b[3])) for b in boxes]
+    ref_m = input_cpu.box_mask(bx, ih, iw, 256, 192)
+    assert x.shape == (n, 3, 256, 192) and m.shape == (n, 1, 256, 192)
+    # fp32 bilinear on both sides; contraction order of the four taps may differ by an ulp of a 0..255 value
+    assert np.abs(x.cpu().numpy() - ref_x).max() < 2e-4
+    assert np.abs(m.cpu().numpy() - ref_m).max() < 1e-6
+
+
+def test_image_to_heatmaps_chain():
+    """image bytes -> device crops / masks -> collate -> model: the crops of one image, collated with a second image's, give the same
+    heat maps as running that image alone (and the forward accepts what the input side produces)."""
+    cfg, sd, _, _, _, _ = setup("w48_l1")
+    net = models.interformer_pureMulti.get_pose_net(cfg, is_train=False)
+    net.load_state_dict(sd, strict=True)
+    net = net.cuda()
+    a = inp.person_inputs(*_scene(1, 240, 320, 2), cfg.MODEL.IMAGE_SIZE)
+    b = inp.person_inputs(*_scene(2, 200, 300, 1), cfg.MODEL.IMAGE_SIZE)
+    x, m, length = inp.collate([a, b])
+    assert length == [2, 1] and x.shape == (3, 3, 256, 192)
+    y = net(x, m, length)
+    ya = net(a[0], a[1], [2])
+    assert torch.isfinite(y).all() and (y[:2] - ya).abs().max().item() < 1e-4
