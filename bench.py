@@ -53,43 +53,51 @@ def conv_flop(d):
     return 2.0 * d.n_img * d.conv_h * d.conv_w * d.cout * d.cin * d.ntaps
 
 
+def _op_name_flop(kind, st):
+    if kind == cabi.OP_CONV:
+        return conv_kernel_name([st]), conv_flop(st)
+    if kind == cabi.OP_CONV_GROUP:
+        members = [st.d[i].contents for i in range(st.n)]
+        return conv_kernel_name(members), sum(conv_flop(m) for m in members)
+    name = {cabi.OP_STEM: "stem_conv_k", cabi.OP_MAXPOOL: "maxpool_k", cabi.OP_HEAD: "head_k",
+            cabi.OP_ENC_KV: "enc_kv_k", cabi.OP_ENC_LAYER: "enc_layer4_k", cabi.OP_LAYERNORM: "layernorm_k",
+            cabi.OP_WINATTN: "window_attn_k", cabi.OP_DWCONV: "dwconv3x3_k", cabi.OP_UPSAMPLE: "upsample_add_k"}[kind]
+    return name, 0.0
+
+
 def per_launch_timing(program, reps=3):
-    """Run the program op by op with HIP events on the launch stream -> per-kernel (count, total ms, total flop)."""
+    """Replay the program with HIP events on the launch stream between RUNS of consecutive launches of the same kernel (e.g. the six
+    encoder layers, the 8 convs of a branch block) -> per-kernel (launch count, total ms, total flop).  Timing a run as a whole
+    keeps the kernels back to back as in the real step; one event pair per launch would add its own few microseconds to each."""
     import ctypes as C
     L = cabi.lib()
     cur = torch.cuda.current_stream().cuda_stream
     streams = (C.c_void_p * 4)(cur, cur, cur, cur)
+    ops = [(i, kind, st) for i, (kind, lane, st) in enumerate(program.ops) if kind not in (cabi.OP_FORK, cabi.OP_JOIN)]
+    named = [(i,) + _op_name_flop(kind, st) for i, kind, st in ops]  # single-stream pass: lanes collapse onto the current stream
+    runs = []  # [name, [op indices], flop]
+    for i, name, flop in named:
+        if runs and runs[-1][0] == name:
+            runs[-1][1].append(i)
+            runs[-1][2] += flop
+        else:
+            runs.append([name, [i], flop])
     stats = {}
     for rep in range(reps + 1):
-        evs = [torch.cuda.Event(enable_timing=True) for _ in range(len(program.ops) + 1)]
+        evs = [torch.cuda.Event(enable_timing=True) for _ in range(len(runs) + 1)]
         evs[0].record()
-        for i in range(len(program.ops)):
-            if program.ops[i][0] in (cabi.OP_FORK, cabi.OP_JOIN):
-                evs[i + 1].record()
-                continue  # single-stream timing pass: lanes collapse onto the current stream
-            cabi.check(L.i2r_run_program(C.cast(C.byref(program._c_ops, i * C.sizeof(cabi.Op)), C.POINTER(cabi.Op)), 1,
-                                         streams, None), "op %d" % i)
-            evs[i + 1].record()
+        for r, (name, idx, flop) in enumerate(runs):
+            for i in idx:
+                cabi.check(L.i2r_run_program(C.cast(C.byref(program._c_ops, i * C.sizeof(cabi.Op)), C.POINTER(cabi.Op)), 1,
+                                             streams, None), "op %d" % i)
+            evs[r + 1].record()
         torch.cuda.synchronize()
         if rep == 0:
             continue  # warm-up pass
-        for i, (kind, lane, st) in enumerate(program.ops):
-            if kind in (cabi.OP_FORK, cabi.OP_JOIN):
-                continue
-            ms = evs[i].elapsed_time(evs[i + 1])
-            if kind == cabi.OP_CONV:
-                name, flop = conv_kernel_name([st]), conv_flop(st)
-            elif kind == cabi.OP_CONV_GROUP:
-                members = [st.d[i].contents for i in range(st.n)]
-                name, flop = conv_kernel_name(members), sum(conv_flop(m) for m in members)
-            else:
-                name = {cabi.OP_STEM: "stem_conv_k", cabi.OP_MAXPOOL: "maxpool_k", cabi.OP_HEAD: "head_k",
-                        cabi.OP_ENC_KV: "enc_kv_k", cabi.OP_ENC_LAYER: "enc_layer4_k", cabi.OP_LAYERNORM: "layernorm_k",
-                        cabi.OP_WINATTN: "window_attn_k", cabi.OP_DWCONV: "dwconv3x3_k", cabi.OP_UPSAMPLE: "upsample_add_k"}[kind]
-                flop = 0.0
+        for r, (name, idx, flop) in enumerate(runs):
             s = stats.setdefault(name, [0, 0.0, 0.0])
-            s[0] += 1
-            s[1] += ms
+            s[0] += len(idx)
+            s[1] += evs[r].elapsed_time(evs[r + 1])
             s[2] += flop
     return stats, reps
 
