@@ -59,6 +59,9 @@ def _op_name_flop(kind, st):
     if kind == cabi.OP_CONV_GROUP:
         members = [st.d[i].contents for i in range(st.n)]
         return conv_kernel_name(members), sum(conv_flop(m) for m in members)
+    if kind == cabi.OP_CONV_CHAIN:
+        members = [st.descs[i].contents for i in range(st.n_layers * st.n_members)]
+        return "conv_chain_f32<%d, %d, %d, %d>" % (st.mt, st.nt, st.cap, st.pf), sum(conv_flop(m) for m in members)
     name = {cabi.OP_STEM: "stem_conv_k", cabi.OP_MAXPOOL: "maxpool_k", cabi.OP_HEAD: "head_k",
             cabi.OP_ENC_KV: "enc_kv_k", cabi.OP_ENC_LAYER: "enc_layer4_k", cabi.OP_LAYERNORM: "layernorm_k",
             cabi.OP_WINATTN: "window_attn_k", cabi.OP_DWCONV: "dwconv3x3_k", cabi.OP_UPSAMPLE: "upsample_add_k"}[kind]
@@ -244,11 +247,11 @@ def main():
             prog = next(iter(net.engine().programs.values()))[0]
             stats, reps = per_launch_timing(prog)
             total_ms = sum(s[1] for s in stats.values())
-            dom = max((k for k in stats if k.startswith("conv_igemm")), key=lambda k: stats[k][1])
+            dom = max((k for k in stats if k.startswith("conv_")), key=lambda k: stats[k][1])
             cnt, ms, flop = stats[dom]
             ach = flop / (ms * 1e-3) / 1e12
-            conv_ms = sum(s[1] for k, s in stats.items() if k.startswith("conv_igemm"))
-            conv_flop = sum(s[2] for k, s in stats.items() if k.startswith("conv_igemm"))
+            conv_ms = sum(s[1] for k, s in stats.items() if k.startswith("conv_"))
+            conv_flop = sum(s[2] for k, s in stats.items() if k.startswith("conv_"))
             out["roofline"] = {
                 "bound": "mfma", "kernel": dom, "achieved": round(ach, 2), "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
                 "frac": round(ach / FP32_MFMA_PEAK_TFLOPS, 4), "traffic": hbm_traffic(),

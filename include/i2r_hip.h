@@ -95,6 +95,36 @@ int i2r_conv(const i2r_conv_desc* d, void* stream);
 int i2r_conv_grouped(const i2r_conv_desc* const* descs, int32_t n, const int32_t* block_map, int32_t map_len,
                      void* stream);
 
+/* i2r_conv_chain (EXPERIMENTAL: correct and tested, but measured slower than one i2r_conv_grouped per layer on MI355X at 32 crops;
+ * the host side keeps it behind I2R_CONV_CHAIN=1) -- n_layers DEPENDENT stride-1 convolutions (layer l of member g reads layer l-1's output of member g) for up to
+ * I2R_MAX_GROUP independent members in ONE persistent launch: the 8 convs of the 4 BasicBlocks of every branch of a
+ * HighResolutionModule (interformer_pureMulti.py:392-397).  Instead of a chip-wide barrier per layer, a tile starts as soon as the
+ * 3x3 tile neighbourhood of the previous layer has finished (completion counters in `flags`), which removes the per-launch
+ * fill / drain and round quantisation.  descs: host array [n_layers * n_members], layer-major; every layer of a member must resolve
+ * to the same tiling.  Workspaces are the caller's:
+ *   i2r_conv_chain_pack(a, host_buf, bytes)  validates, fills the outputs below and (host_buf != NULL) writes the kernel-side
+ *       descriptors into host_buf (a->kdesc_bytes bytes) for the caller to copy to the device (a->kdesc);
+ *   items / item_ofs: eight work queues, one per XCD -- the persistent workgroups with (index % 8) == x pop
+ *       items[item_ofs[x] .. item_ofs[x+1]) in order; each item = (layer << 26) | (member << 24) | workgroup index within the member
+ *       (numbered as i2r_conv_grouped numbers them: cout block fastest, then tile x, tile y, image); every queue must be sorted
+ *       by layer and hold ALL items of its images (producers and consumers then share one L2); n_blocks <= a->capacity;
+ *   flags: n_flags + 17 int32 (zeroed by i2r_conv_chain itself; word [n_flags] afterwards: 0 ok, 1 = a dependency wait timed out,
+ *       2 = workgroups of one residue class (index % 8) ran on different XCDs, i.e. the same-L2 assumption of the schedule is void). */
+typedef struct i2r_conv_chain_args {
+    const i2r_conv_desc* const* descs;
+    int32_t n_layers, n_members;
+    const void* kdesc;
+    const int32_t* item_ofs;
+    const int32_t* items;
+    int32_t* flags;
+    int32_t n_blocks;
+    /* outputs of i2r_conv_chain_pack */
+    int32_t n_flags, kdesc_bytes, capacity, nt, mt, cap, pf, lds_bytes;
+    int32_t tiles[I2R_MAX_GROUP][4];  /* per member: tiles_y, tiles_x, cout blocks, workgroups per layer */
+} i2r_conv_chain_args;
+int i2r_conv_chain_pack(i2r_conv_chain_args* a, void* host_buf, int64_t host_bytes);
+int i2r_conv_chain(const i2r_conv_chain_args* a, void* stream);
+
 /* ------------------------------------------------------------------------------------------------
  * i2r_stem_conv -- first 3x3 stride-2 pad-1 conv of a tower (cin = 1..4) + folded BN + ReLU, reading the
  * boundary NCHW fp32 tensor and writing NHWC.
@@ -250,7 +280,7 @@ int i2r_encoder_layer(const i2r_encoder_desc* d, void* stream);
 enum {
     I2R_OP_CONV = 1, I2R_OP_STEM = 2, I2R_OP_MAXPOOL = 3, I2R_OP_HEAD = 4,
     I2R_OP_ENC_KV = 5, I2R_OP_ENC_LAYER = 6, I2R_OP_FORK = 7, I2R_OP_JOIN = 8, I2R_OP_CONV_GROUP = 9,
-    I2R_OP_LAYERNORM = 10, I2R_OP_WINATTN = 11, I2R_OP_DWCONV = 12, I2R_OP_UPSAMPLE = 13
+    I2R_OP_LAYERNORM = 10, I2R_OP_WINATTN = 11, I2R_OP_DWCONV = 12, I2R_OP_UPSAMPLE = 13, I2R_OP_CONV_CHAIN = 14
 };
 
 typedef struct i2r_stem_args {

@@ -17,6 +17,7 @@ MAX_TAPS = 9
 OP_CONV, OP_STEM, OP_MAXPOOL, OP_HEAD, OP_ENC_KV, OP_ENC_LAYER, OP_FORK, OP_JOIN, OP_CONV_GROUP = 1, 2, 3, 4, 5, 6, 7, 8, 9
 MAX_GROUP = 4
 OP_LAYERNORM, OP_WINATTN, OP_DWCONV, OP_UPSAMPLE = 10, 11, 12, 13
+OP_CONV_CHAIN = 14
 
 _fp = C.c_void_p  # device pointers travel as integers
 _i32 = C.c_int32
@@ -84,13 +85,20 @@ class ConvGroupArgs(C.Structure):
     _fields_ = [("d", C.POINTER(ConvDesc) * MAX_GROUP), ("block_map", _fp), ("n", _i32), ("map_len", _i32)]
 
 
+class ConvChainArgs(C.Structure):
+    _fields_ = [("descs", C.POINTER(C.POINTER(ConvDesc))), ("n_layers", _i32), ("n_members", _i32),
+                ("kdesc", _fp), ("item_ofs", _fp), ("items", _fp), ("flags", _fp), ("n_blocks", _i32),
+                ("n_flags", _i32), ("kdesc_bytes", _i32), ("capacity", _i32), ("nt", _i32), ("mt", _i32), ("cap", _i32), ("pf", _i32),
+                ("lds_bytes", _i32), ("tiles", (_i32 * 4) * MAX_GROUP)]
+
+
 class Op(C.Structure):
     _fields_ = [("kind", _i32), ("lane", _i32), ("args", C.c_void_p)]
 
 
 # every symbol include/i2r_hip.h declares (tests/test_cabi.py checks the built library exports them all)
 EXPORTS = ("i2r_conv", "i2r_conv_grouped", "i2r_conv_kernel_name", "i2r_stem_conv", "i2r_maxpool3x3s2", "i2r_head", "i2r_layernorm", "i2r_window_attn", "i2r_dwconv3x3",
-           "i2r_upsample_bilinear_add", "i2r_flip_merge", "i2r_decode", "i2r_crop_affine", "i2r_box_mask", "i2r_encoder_kv", "i2r_encoder_layer",
+           "i2r_upsample_bilinear_add", "i2r_flip_merge", "i2r_decode", "i2r_crop_affine", "i2r_box_mask", "i2r_conv_chain_pack", "i2r_conv_chain", "i2r_encoder_kv", "i2r_encoder_layer",
            "i2r_run_program", "i2r_abi_version", "i2r_last_error", "i2r_device_check")
 
 _LIB = None
@@ -109,6 +117,8 @@ def load_library(path=LIB_PATH):
     L = C.CDLL(path)
     L.i2r_conv.argtypes = [C.POINTER(ConvDesc), C.c_void_p]
     L.i2r_conv_grouped.argtypes = [C.POINTER(C.POINTER(ConvDesc)), _i32, _fp, _i32, C.c_void_p]
+    L.i2r_conv_chain_pack.argtypes = [C.POINTER(ConvChainArgs), C.c_void_p, C.c_int64]
+    L.i2r_conv_chain.argtypes = [C.POINTER(ConvChainArgs), C.c_void_p]
     L.i2r_conv_kernel_name.argtypes = [C.POINTER(C.POINTER(ConvDesc)), _i32, C.c_char_p, _i32]
     L.i2r_stem_conv.argtypes = [_fp, _fp, _fp, _fp, _i32, _i32, _i32, _i32, _i32, _i32, _i32, C.c_void_p]
     L.i2r_flip_merge.argtypes = [_fp, _fp, _fp, _fp, _i32, _i32, _i32, _i32, C.c_void_p]

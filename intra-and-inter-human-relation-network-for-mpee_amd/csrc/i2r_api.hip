@@ -90,6 +90,9 @@ extern "C" int i2r_run_program(const i2r_op* ops, int32_t n_ops, void* const* st
                 rc = i2r_layernorm(a->in, a->w, a->b, a->out, a->npix, a->c, a->cs, a->eps, st);
                 break;
             }
+            case I2R_OP_CONV_CHAIN:
+                rc = i2r_conv_chain((const i2r_conv_chain_args*)op.args, st);
+                break;
             case I2R_OP_WINATTN: {
                 const i2r_winattn_args* a = (const i2r_winattn_args*)op.args;
                 rc = i2r_window_attn(a->qkv, a->bias, a->out, a->n_img, a->h, a->w_, a->c, a->cs, a->heads, st);

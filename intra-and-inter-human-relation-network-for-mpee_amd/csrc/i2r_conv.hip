@@ -539,6 +539,82 @@ __global__ __launch_bounds__(256) void conv_igemm_f32(const ConvGroupK grp) {
     conv_body<MT, NT, CAP, PF>(grp.g[gi], bid - start, lds);
 }
 
+// ---- persistent "chain" kernel: L dependent layers x G independent members in ONE launch, tile-level dataflow instead of a
+//      chip-wide barrier (kernel boundary) per layer.  The persistent workgroups of an XCD (index % 8) pop work items
+//      (layer, member, tile workgroup) from that XCD's queue, which the host sorted by layer; an item waits until the tiles of
+//      the previous layer that its input patch touches (the 3x3 tile neighbourhood, all cout blocks) have signalled completion.
+//      All items of one image sit in one queue, so producer and consumer meet in the same L2.  A waited-for item precedes the
+//      waiter in the queue, i.e. it has been popped by a RUNNING workgroup (the grid never exceeds the resident capacity
+//      i2r_conv_chain_pack reports): no deadlock. ----
+struct ChainK {
+    const ConvK* k;        // device [n_layers * n_members], layer-major
+    const int* fbase;      // device [n_layers * n_members]: first completion counter of (layer, member)
+    const int* item_ofs;   // device [9]: the item range of each XCD's queue
+    const int* items;      // device: (layer << 26) | (member << 24) | workgroup index within the member
+    int* flags;            // device completion counters (zeroed before the launch) + error word at [n_flags] + 8 XCC check words + 8 queue heads
+    int n_layers, n_members, n_flags;
+};
+
+template <int MT, int NT, int CAP, int PF>
+__global__ __launch_bounds__(256) void conv_chain_f32(const ChainK c) {
+    extern __shared__ __attribute__((aligned(16))) f32x4 lds[];
+    const int tid = threadIdx.x;
+    __shared__ int s_next;
+    const int xq = blockIdx.x & 7;  // one work queue per XCD (all items of an image live in one queue), popped with an atomic counter
+    const int it0 = c.item_ofs[xq], it1 = c.item_ofs[xq + 1];
+    int* const qctr = c.flags + c.n_flags + 9 + xq;
+    // the schedule relies on workgroup b running on XCD b % 8 (round-robin dispatch): verify, flag a violation in the error word
+    if (tid == 0) {  // (words [n_flags + 1 .. + 8]: XCC id + 1 seen by residue class b % 8; all members of a class must agree)
+        const int xcc = (__builtin_amdgcn_s_getreg((20 /*HW_REG_XCC_ID*/) | (0 << 6) | ((4 - 1) << 11)) & 15) + 1;
+        const int old = atomicCAS(c.flags + c.n_flags + 1 + (blockIdx.x & 7), 0, xcc);
+        if (old != 0 && old != xcc) c.flags[c.n_flags] = 2;
+    }
+    for (;;) {
+        __syncthreads();  // the previous item's LDS reads (and s_next) are over
+        if (tid == 0) s_next = it0 + atomicAdd(qctr, 1);
+        __syncthreads();
+        const int it = s_next;
+        if (it >= it1) break;
+        const int v = c.items[it];
+        const int l = v >> 26, g = (v >> 24) & 3, bid = v & 0xFFFFFF;
+        const ConvK k = c.k[l * c.n_members + g];
+        // tile coordinates exactly as conv_body decodes them
+        int b = bid / k.n_cblk;
+        const int tile_x = b % k.tiles_x;
+        b /= k.tiles_x;
+        const int tile_y = b % k.tiles_y;
+        const int img = b / k.tiles_y;
+        if (l > 0) {
+            if (tid < 9) {
+                const int ny = tile_y + tid / 3 - 1, nx = tile_x + tid % 3 - 1;
+                if (ny >= 0 && ny < k.tiles_y && nx >= 0 && nx < k.tiles_x) {
+                    int* f = c.flags + c.fbase[(l - 1) * c.n_members + g] + (img * k.tiles_y + ny) * k.tiles_x + nx;
+                    int spins = 0;
+                    while (__hip_atomic_load(f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < k.n_cblk) {  // (served by the L2)
+                        __builtin_amdgcn_s_sleep(2);
+                        if (++spins > (1 << 24)) {  // (~seconds: a scheduling bug, not a slow producer) give up loudly, do not hang the GPU
+                            c.flags[c.n_flags] = 1;
+                            break;
+                        }
+                    }
+                }
+            }
+            __syncthreads();
+            // Producer and consumer share one XCD, hence one L2: the data is coherent there and no L2 write-back is needed (a full
+            // agent-scope release + acquire per item made the chain 2x slower than per-layer launches).  This CU's L1 may still
+            // hold lines of the recycled activation buffers, though, and only the agent-scope invalidate drops them:
+            // "buffer_inv sc0" is a no-op outside threadgroup-split mode (measured: intermittently stale patches with it).
+            asm volatile("buffer_inv sc1" ::: "memory");
+        }
+        conv_body<MT, NT, CAP, PF>(k, bid, lds);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's stores have reached the L2 (the L1 is write-through)
+        __syncthreads();
+        if (tid == 0)
+            __hip_atomic_fetch_add(c.flags + c.fbase[l * c.n_members + g] + (img * k.tiles_y + tile_y) * k.tiles_x + tile_x, 1,
+                                   __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+}
+
 template <int MT, int NT, int DT>
 __global__ __launch_bounds__(256) void conv_igemm_lp(const ConvGroupK grp) {
     extern __shared__ __attribute__((aligned(16))) f32x4 lds[];
@@ -811,6 +887,98 @@ extern "C" int i2r_conv_grouped(const i2r_conv_desc* const* descs, int32_t n, co
 }
 
 extern "C" int i2r_conv(const i2r_conv_desc* d, void* stream) { return i2r_conv_grouped(&d, 1, nullptr, 0, stream); }
+
+// ---- chain launches (see conv_chain_f32) ----
+namespace {
+typedef void (*chain_fn)(const ChainK);
+chain_fn pick_chain(int nt, int mt, int cap, int pf) {
+    // instantiated for the blockings the HRNet branch chains resolve to; anything else keeps the per-layer grouped launches
+    if (nt == 3 && cap == 12 && pf == 1) {
+        if (mt == 1) return conv_chain_f32<1, 3, 12, 1>;
+        if (mt == 2) return conv_chain_f32<2, 3, 12, 1>;
+        if (mt == 3) return conv_chain_f32<3, 3, 12, 1>;
+        if (mt == 4) return conv_chain_f32<4, 3, 12, 1>;
+    }
+    return nullptr;
+}
+}  // namespace
+
+extern "C" int i2r_conv_chain_pack(i2r_conv_chain_args* a, void* host_buf, int64_t host_bytes) {
+    I2R_CHECK_ARG(a && a->descs && a->n_layers >= 1 && a->n_layers <= 32 && a->n_members >= 1 && a->n_members <= kMaxGroups,
+                  "i2r_conv_chain: 1..32 layers x 1..%d members", kMaxGroups);
+    const int L = a->n_layers, G = a->n_members;
+    int nt0 = 0, mt0 = 0, cap0 = 0, pf0 = 0;
+    size_t lds0 = 0;
+    const int64_t need = (int64_t)L * G * (sizeof(ConvK) + sizeof(int));
+    a->kdesc_bytes = (int32_t)need;
+    ConvK* kd = reinterpret_cast<ConvK*>(host_buf);
+    int* fb = host_buf ? reinterpret_cast<int*>(reinterpret_cast<char*>(host_buf) + (size_t)L * G * sizeof(ConvK)) : nullptr;
+    I2R_CHECK_ARG(host_buf == nullptr || host_bytes >= need, "i2r_conv_chain_pack: buffer of %lld bytes, need %lld", (long long)host_bytes, (long long)need);
+    int nflags = 0;
+    for (int l = 0; l < L; ++l) {
+        ConvGroupK grp;
+        int nt, mt, cap, pf;
+        size_t lds;
+        long long total;
+        int rc = resolve(a->descs + (size_t)l * G, G, grp, &nt, &mt, &cap, &pf, &lds, &total);
+        if (rc) return rc;
+        if (l == 0) { nt0 = nt; mt0 = mt; cap0 = cap; pf0 = pf; lds0 = lds; }
+        I2R_CHECK_ARG(nt == nt0 && mt == mt0 && cap == cap0 && pf == pf0 && lds == lds0, "i2r_conv_chain: layer %d resolves to a different kernel variant", l);
+        for (int g = 0; g < G; ++g) {
+            const ConvK& k = grp.g[g];
+            const i2r_conv_desc* d = a->descs[(size_t)l * G + g];
+            I2R_CHECK_ARG(d->stride == 1 && d->rep == 1 && d->out_step == 1 && d->dtype == 0, "i2r_conv_chain: stride-1 fp32 layers only");
+            I2R_CHECK_ARG(k.tap_kh <= 3 && k.tap_kw <= 3, "i2r_conv_chain: the dependency window is the 3x3 tile neighbourhood");
+            if (l == 0) {
+                a->tiles[g][0] = k.tiles_y; a->tiles[g][1] = k.tiles_x; a->tiles[g][2] = k.n_cblk;
+                a->tiles[g][3] = k.n_img * k.tiles_y * k.tiles_x * k.n_cblk;
+                I2R_CHECK_ARG(k.tile_h >= 1 && k.tile_w >= 1, "i2r_conv_chain: tile");
+            } else {
+                I2R_CHECK_ARG(a->tiles[g][0] == k.tiles_y && a->tiles[g][1] == k.tiles_x && a->tiles[g][2] == k.n_cblk,
+                              "i2r_conv_chain: member %d changes its tiling at layer %d", g, l);
+                I2R_CHECK_ARG(d->in == a->descs[(size_t)(l - 1) * G + g]->out, "i2r_conv_chain: layer %d of member %d does not read layer %d's output", l, g, l - 1);
+            }
+            if (kd) { kd[l * G + g] = k; fb[l * G + g] = nflags; }
+            nflags += k.n_img * k.tiles_y * k.tiles_x;
+        }
+    }
+    chain_fn fn = pick_chain(nt0, mt0, cap0, pf0);
+    I2R_CHECK_ARG(fn != nullptr, "i2r_conv_chain: no chain kernel for nt=%d mt=%d cap=%d pf=%d", nt0, mt0, cap0, pf0);
+    a->n_flags = nflags;
+    a->nt = nt0; a->mt = mt0; a->cap = cap0; a->pf = pf0; a->lds_bytes = (int32_t)lds0;
+    if (lds0 > 64 * 1024)
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds0);
+    int per_cu = 0, dev = 0;
+    hipDeviceProp_t prop;
+    if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess ||
+        hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, reinterpret_cast<const void*>(fn), 256, lds0) != hipSuccess) {
+        (void)hipGetLastError();
+        a->capacity = 0;  // (no device: sizes only)
+    } else {
+        a->capacity = per_cu * prop.multiProcessorCount;
+    }
+    return I2R_OK;
+}
+
+extern "C" int i2r_conv_chain(const i2r_conv_chain_args* a, void* stream) {
+    I2R_CHECK_ARG(a && a->kdesc && a->item_ofs && a->items && a->flags && a->n_blocks >= 1, "i2r_conv_chain: null workspace");
+    I2R_CHECK_ARG(a->capacity > 0 && a->n_blocks <= a->capacity, "i2r_conv_chain: %d workgroups exceed the resident capacity %d", a->n_blocks, a->capacity);
+    chain_fn fn = pick_chain(a->nt, a->mt, a->cap, a->pf);
+    I2R_CHECK_ARG(fn != nullptr, "i2r_conv_chain: run i2r_conv_chain_pack first");
+    ChainK c;
+    const int LG = a->n_layers * a->n_members;
+    c.k = reinterpret_cast<const ConvK*>(a->kdesc);
+    c.fbase = reinterpret_cast<const int*>(reinterpret_cast<const char*>(a->kdesc) + (size_t)LG * sizeof(ConvK));
+    c.item_ofs = a->item_ofs; c.items = a->items; c.flags = a->flags;
+    c.n_layers = a->n_layers; c.n_members = a->n_members; c.n_flags = a->n_flags;
+    if (hipMemsetAsync(a->flags, 0, (size_t)(a->n_flags + 17) * sizeof(int), (hipStream_t)stream) != hipSuccess) {
+        i2r_set_error("i2r_conv_chain: hipMemsetAsync failed");
+        return I2R_E_LAUNCH;
+    }
+    hipLaunchKernelGGL(fn, dim3((unsigned)a->n_blocks), dim3(256), (size_t)a->lds_bytes, (hipStream_t)stream, c);
+    I2R_CHECK_LAUNCH("i2r_conv_chain");
+    return I2R_OK;
+}
 
 extern "C" int i2r_conv_kernel_name(const i2r_conv_desc* const* descs, int32_t n, char* buf, int32_t buflen) {
     ConvGroupK grp;

@@ -16,6 +16,7 @@ are pre-allocated (arena with reuse), so a forward is ONE call into i2r_run_prog
 """
 import ctypes as C
 import math
+import os
 
 import torch
 
@@ -425,17 +426,9 @@ class Program:
             self.ops.append((cabi.OP_CONV, lane, d))
         return out
 
-    def flush_group(self, group, lane=0):
-        """Emit the convs collected in `group` as ONE grouped launch (same NT required; a common mt is chosen by the
-        cost model; heaviest-K members first so the long workgroups start early)."""
-        if not group:
-            return
-        nts = {g[2] for g in group}
-        if len(group) == 1 or len(nts) != 1 or len(group) > cabi.MAX_GROUP:
-            for d, _, _ in group:
-                self.ops.append((cabi.OP_CONV, lane, d))
-            del group[:]
-            return
+    @staticmethod
+    def _group_tiles(group):
+        """common mt + per-member tiles of a grouped launch (cost model: workgroups of all members share the chip)"""
         best = None
         for mt in (2, 3, 4, 1):
             try:
@@ -454,6 +447,87 @@ class Program:
             if best is None or cost < best[0]:
                 best = (cost, mt, tiles)
         _, mt, tiles = best
+        return mt, tiles
+
+    def conv_chain(self, layers, lane=0):
+        """layers: list of groups (as collected by conv(group=...)), layer l of member g reading layer l-1's output of member g.
+        EXPERIMENTAL, off by default (I2R_CONV_CHAIN=1 enables): ONE persistent chain launch (i2r_conv_chain: tile-level dataflow
+        between the layers) instead of one grouped launch per layer.  Measured on MI355X at 32 crops: bit-identical results, but
+        7.9 ms/step against 7.2 ms with per-layer launches -- the per-item cache invalidation that makes the
+        producer's data visible costs more than the layer barriers it removes.  Returns True if the chain launch was used."""
+        G = len(layers[0])
+        ok = G <= cabi.MAX_GROUP and all(len(g) == G for g in layers) and len({m[2] for g in layers for m in g}) == 1
+        if not ok or os.environ.get("I2R_CONV_CHAIN", "0") != "1":
+            for g in layers:
+                self.flush_group(g, lane)
+            return False
+        mt, tiles = self._group_tiles(layers[0])
+        order = sorted(range(G), key=lambda i: -(layers[0][i][0].cin * layers[0][i][0].ntaps))
+        L = len(layers)
+        ptrs = (C.POINTER(cabi.ConvDesc) * (L * G))()
+        for l, g in enumerate(layers):
+            for slot, i in enumerate(order):
+                d = g[i][0]
+                d.tile_h, d.tile_w, d.mt = tiles[i][1], tiles[i][2], mt
+                ptrs[l * G + slot] = C.pointer(d)
+                self.keep.append(d)
+        a = cabi.ConvChainArgs()
+        a.descs, a.n_layers, a.n_members = ptrs, L, G
+        lib = cabi.lib()
+        if lib.i2r_conv_chain_pack(C.byref(a), None, 0) != 0 or a.capacity < 8:
+            if os.environ.get("I2R_CONV_CHAIN_VERBOSE"):
+                print("conv_chain fallback:", lib.i2r_last_error(), "capacity", a.capacity)
+            for g in layers:  # (no chain kernel for this blocking)
+                self.flush_group(g, lane)
+            return False
+        host = (C.c_char * a.kdesc_bytes)()
+        cabi.check(lib.i2r_conv_chain_pack(C.byref(a), host, a.kdesc_bytes), "i2r_conv_chain_pack")
+        kdesc = torch.frombuffer(host, dtype=torch.uint8).clone().to(self.device)
+        # ---- schedule: one work queue per XCD (workgroup index % 8) holding all items of its images, layer by layer, heaviest first
+        n_blocks = a.capacity // 8 * 8
+        n_img = layers[0][order[0]][1][5]
+        queues = []
+        for x in range(8):
+            q = []
+            imgs = [i for i in range(n_img) if i % 8 == x]
+            for l in range(L):
+                items = []
+                for slot in range(G):
+                    ty, tx, ncb, _ = [int(v) for v in a.tiles[slot]]
+                    cost = layers[0][order[slot]][0].cin * layers[0][order[slot]][0].ntaps
+                    for img in imgs:
+                        for t in range(ty * tx):
+                            for cb in range(ncb):
+                                items.append((-cost, (l << 26) | (slot << 24) | ((img * ty * tx + t) * ncb + cb)))
+                items.sort()
+                q += [code for _, code in items]
+            queues.append(q)
+        ofs = [0]
+        for q in queues:
+            ofs.append(ofs[-1] + len(q))
+        item_ofs = torch.tensor(ofs, dtype=torch.int32, device=self.device)
+        items = torch.tensor([c for q in queues for c in q], dtype=torch.int32, device=self.device)
+        flags = torch.zeros(a.n_flags + 17, dtype=torch.int32, device=self.device)
+        a.kdesc, a.item_ofs, a.items, a.flags, a.n_blocks = kdesc.data_ptr(), item_ofs.data_ptr(), items.data_ptr(), flags.data_ptr(), n_blocks
+        self.keep += [ptrs, kdesc, item_ofs, items, flags, host]
+        self.chain_flags = getattr(self, "chain_flags", []) + [(flags, a.n_flags)]
+        self.ops.append((cabi.OP_CONV_CHAIN, lane, a))
+        for g in layers:
+            del g[:]
+        return True
+
+    def flush_group(self, group, lane=0):
+        """Emit the convs collected in `group` as ONE grouped launch (same NT required; a common mt is chosen by the
+        cost model; heaviest-K members first so the long workgroups start early)."""
+        if not group:
+            return
+        nts = {g[2] for g in group}
+        if len(group) == 1 or len(nts) != 1 or len(group) > cabi.MAX_GROUP:
+            for d, _, _ in group:
+                self.ops.append((cabi.OP_CONV, lane, d))
+            del group[:]
+            return
+        mt, tiles = self._group_tiles(group)
         order = sorted(range(len(group)), key=lambda i: -(group[i][0].cin * group[i][0].ntaps))
         a = cabi.ConvGroupArgs()
         counts, works = [], []
@@ -684,17 +758,28 @@ class HRNetW48:
         nb = mod["nb"]
         xs = list(xs)
         nblk = max(len(b) for b in mod["blocks"])
+        uniform = all(len(b) == nblk for b in mod["blocks"])  # every branch has the same depth -> one persistent chain launch
+        layers = []
         for k in range(nblk):
             grp, ts = [], {}
             for i in range(nb):
                 if k < len(mod["blocks"][i]):
                     ts[i] = P.conv(xs[i], mod["blocks"][i][k][0], relu=True, group=grp)
-            P.flush_group(grp)
+            if uniform:
+                layers.append(grp)
+                grp = []
+            else:
+                P.flush_group(grp)
             for i, t in ts.items():
                 y = P.conv(t, mod["blocks"][i][k][1], relu=True, res1=xs[i], group=grp)
                 P.release(t, xs[i])
                 xs[i] = y
-            P.flush_group(grp)
+            if uniform:
+                layers.append(grp)
+            else:
+                P.flush_group(grp)
+        if uniform:
+            P.conv_chain(layers)
         # fuse: per output i an ordered chain of launches ((src, pc, kwargs) steps); y = ((t_0 + t_1) + ...) in the
         # reference's order, identity terms folded into a neighbouring conv's residual inputs, running sum in place in y
         chains = []
