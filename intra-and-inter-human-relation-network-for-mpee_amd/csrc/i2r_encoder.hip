@@ -623,21 +623,19 @@ __global__ __launch_bounds__(64) void enc_kv_lp_k(const EncK p) {
                     }
             }
         }
+        // fragment-packed 16-bit operand images of this 32-token block (blockIdx.x), one 16-byte store per lane:
+        //   K:   [(blk*2 + tf)*KC + c][lane][8]      lane (li, g): key 16tf + li, the 8 permuted features g*8.. of 32-block c
+        //   V^T: [blk*DC + nt][lane'][8]              lane' (li' = feature in fragment nt, g' = key quad): 8 keys in the block's
+        //        permuted order (position 8*((k%16)/4) + 4*(k/16) + k%4); a 4x4 quad transpose turns (key li, features 4g+r) into
+        //        (feature 4g + (li&3), keys 4(li>>2) + r') so both 16-key halves pack into the destination lane's 16 bytes
+        const size_t blk = blockIdx.x;
 #pragma unroll
-        for (int tf = 0; tf < 2; ++tf) {
-            if (tok[tf] >= p.n_tok) continue;
-            // K row: 8 consecutive 16-bit elements = this lane's slice of 32-block c
-            *reinterpret_cast<f32x4*>(k16 + (size_t)tok[tf] * cs + c * 32 + g * 8) = pack8<DT>(ak[0][tf], ak[1][tf]);
-            // V^T: element (feature, key) lives at  feature * n_tok_pad + 32*(key/32) + 8*((key%16)/4) + 4*((key%32)/16) + key%4
-            const int t = tok[tf];
-            const size_t kpos = (size_t)(t & ~31) + 8 * ((t & 15) >> 2) + 4 * ((t & 31) >> 4) + (t & 3);
-            const f32x4 pv = pack8<DT>(av[0][tf], av[1][tf]);  // elements 0-3: features 32c+4g+r, 4-7: 32c+16+4g+r
-            const unsigned short* e = reinterpret_cast<const unsigned short*>(&pv);
+        for (int tf = 0; tf < 2; ++tf)
+            *reinterpret_cast<f32x4*>(k16 + ((((blk * 2 + tf) * (DC / 2) + c) * 64 + lane) * 8)) = pack8<DT>(ak[0][tf], ak[1][tf]);
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                v16[(size_t)(32 * c + 4 * g + r) * p.n_tok_pad + kpos] = e[r];
-                v16[(size_t)(32 * c + 16 + 4 * g + r) * p.n_tok_pad + kpos] = e[4 + r];
-            }
+        for (int half = 0; half < 2; ++half) {
+            const f32x4 pv = pack8<DT>(quad_transpose(av[half][0], li & 3), quad_transpose(av[half][1], li & 3));
+            *reinterpret_cast<f32x4*>(v16 + (((blk * DC + 2 * c + half) * 64 + 4 * g + (li & 3) + 16 * (li >> 2)) * 8)) = pv;
         }
     }
 }
@@ -648,7 +646,7 @@ __device__ __forceinline__ void gemm_T_lp(const void* W, const float* bias, int 
     f32x4 w0[KC], w1[KC];
     auto loadw = [&](f32x4(&w)[KC], int nt) {
 #pragma unroll
-        for (int c = 0; c < KC; ++c) w[c] = ld16(W, (size_t)(16 * nt + li) * ld + c * 32 + g * 8);
+        for (int c = 0; c < KC; ++c) w[c] = ld16(W, (((size_t)nt * KC + c) * 64 + (li + 16 * g)) * 8);  // fragment-packed, 1 KB per load
     };
     auto mm = [&](const f32x4(&w)[KC], int nt) {
         const f32x4 b = ld4(bias + 16 * nt + 4 * g);
@@ -708,7 +706,7 @@ __global__ __launch_bounds__(64) void enc_layer_lp_k(const EncK p) {
             }
         }
         f32x4 q32[QF][DC];
-        gemm_T_lp<DC, KC, QF, DT>(p.w_in_lp, p.b_in, cs, xB, li, g, [&](int nt, int qf, f32x4 a) { q32[qf][nt] = a * p.qscale; });
+        gemm_T_lp<DC, KC, QF, DT>(p.w_in_lp, p.b_in, cs, xB, li, g, [&](int nt, int qf, f32x4 a) { q32[qf][nt] = a * (p.qscale * 1.4426950408889634f); });
 #pragma unroll
         for (int qf = 0; qf < QF; ++qf)
 #pragma unroll
@@ -725,49 +723,55 @@ __global__ __launch_bounds__(64) void enc_layer_lp_k(const EncK p) {
 #pragma unroll
         for (int nt = 0; nt < DC; ++nt) o[qf][nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
     }
-    auto fetch_kv = [&](int k0, f32x4(&ka)[2][KC], f32x4(&va)[DC]) {
+    auto fetch_kv = [&](int k0, f32x4(&ka)[2][KC], f32x4(&va)[DC]) {  // fragment-packed images of the 32-key block k0 / 32
+        const size_t blk = (size_t)(k0 >> 5);
 #pragma unroll
-        for (int kf = 0; kf < 2; ++kf) {
-            const int krow = min(k0 + 16 * kf + li, ge - 1);
+        for (int kf = 0; kf < 2; ++kf)
 #pragma unroll
-            for (int c = 0; c < KC; ++c) ka[kf][c] = ld16(p.kbuf, (size_t)krow * cs + c * 32 + g * 8);
-        }
+            for (int c = 0; c < KC; ++c) ka[kf][c] = ld16(p.kbuf, (((blk * 2 + kf) * KC + c) * 64 + lane) * 8);
 #pragma unroll
-        for (int nt = 0; nt < DC; ++nt) va[nt] = ld16(p.vbuf, (size_t)(16 * nt + li) * p.n_tok_pad + k0 + g * 8);
+        for (int nt = 0; nt < DC; ++nt) va[nt] = ld16(p.vbuf, ((blk * DC + nt) * 64 + lane) * 8);
     };
+    // online softmax in base 2 with the lazy reference of the fp32 kernel: m is raised (and O, l rescaled) only when a score
+    // exceeds it by more than 2^10 -- the common path has no cross-lane max and no O rescale, which is what bounds this kernel
+    // (the 12 MFMAs of a 32-key block take ~200 cycles, the eager softmax took more)
     auto attend = [&](int k0, const f32x4(&ka)[2][KC], const f32x4(&va)[DC]) {
+        const bool ragged = k0 + 32 > ge;  // (wave-uniform)
 #pragma unroll
         for (int qf = 0; qf < QF; ++qf) {
             f32x4 st[2];
-            float mx = -__builtin_inff();
 #pragma unroll
             for (int kf = 0; kf < 2; ++kf) {
                 f32x4 a = (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
                 for (int c = 0; c < KC; ++c) a = mfma32_lp<DT>(ka[kf][c], qB[qf][c], a);  // S^T[key 16kf+4g+r][query li]
+                if (ragged) {
 #pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    if (k0 + 16 * kf + 4 * g + r >= ge) a[r] = -__builtin_inff();
-                    mx = fmaxf(mx, a[r]);
+                    for (int r = 0; r < 4; ++r)
+                        if (k0 + 16 * kf + 4 * g + r >= ge) a[r] = -__builtin_inff();
                 }
                 st[kf] = a;
             }
-            mx = xmax(mx);
-            const float m_new = fmaxf(m_run[qf], mx);
-            const float alpha = __expf(m_run[qf] - m_new);
-            float ls = 0.f;
+            const float mx = fmaxf(fmaxf(fmaxf(st[0][0], st[0][1]), fmaxf(st[0][2], st[0][3])),
+                                   fmaxf(fmaxf(st[1][0], st[1][1]), fmaxf(st[1][2], st[1][3])));
+            if (__any(mx > m_run[qf] + 10.f)) {
+                const float m_new = fmaxf(m_run[qf], xmax(mx));
+                const float alpha = __builtin_amdgcn_exp2f(m_run[qf] - m_new);
+                l_run[qf] *= alpha;
+#pragma unroll
+                for (int nt = 0; nt < DC; ++nt) o[qf][nt] *= alpha;
+                m_run[qf] = m_new;
+            }
 #pragma unroll
             for (int kf = 0; kf < 2; ++kf)
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    st[kf][r] = __expf(st[kf][r] - m_new);
-                    ls += st[kf][r];
+                    st[kf][r] = __builtin_amdgcn_exp2f(st[kf][r] - m_run[qf]);
+                    l_run[qf] += st[kf][r];
                 }
-            l_run[qf] = l_run[qf] * alpha + ls;
-            m_run[qf] = m_new;
             const f32x4 pB = pack8<DT>(st[0], st[1]);  // keys {4g+r} U {16+4g+r} of the block: the order V^T blocks are stored in
 #pragma unroll
-            for (int nt = 0; nt < DC; ++nt) o[qf][nt] = mfma32_lp<DT>(va[nt], pB, o[qf][nt] * alpha);
+            for (int nt = 0; nt < DC; ++nt) o[qf][nt] = mfma32_lp<DT>(va[nt], pB, o[qf][nt]);
         }
     };
     {

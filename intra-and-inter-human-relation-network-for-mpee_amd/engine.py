@@ -204,7 +204,9 @@ class Packer:
             def perm(m):
                 rows, cols = m.shape
                 v = m.view(rows, cols // 32, 2, 4, 4)          # [row, c, half, g, r]
-                return v.permute(0, 1, 3, 2, 4).reshape(rows, cols).to(tdt).contiguous()   # [row, c, g, half, r]
+                v = v.permute(0, 1, 3, 2, 4).reshape(rows // 16, 16, cols // 32, 4, 8)   # [rb, li, c, g, (half, r)]
+                # ... and fragment-packed like the fp32 matrices: [rb][c][g][li][8] = one 1 KB contiguous load per fragment
+                return v.permute(0, 2, 3, 1, 4).reshape(rows, cols).to(tdt).contiguous()
             lp = dict(w_in_lp=perm(t["w_in"]), w_out_lp=perm(t["w_out"]), w1_lp=perm(t["w1"]), w2_lp=perm(t["w2"]))
             lp = {k: self._dev(v) for k, v in lp.items()}
         for k in ("w_in", "w_out", "w1", "w2"):
