@@ -580,66 +580,7 @@ __device__ __forceinline__ f32x4 ld16(const void* base, size_t elem_off) {  // 1
     return *reinterpret_cast<const f32x4*>(reinterpret_cast<const unsigned short*>(base) + elem_off);
 }
 
-// K (permuted rows, 16-bit) and V^T (permuted 32-key blocks, 16-bit); projections themselves stay on the exact-fp32 MFMA
-template <int DC, int DT>
-__global__ __launch_bounds__(64) void enc_kv_lp_k(const EncK p) {
-    const int lane = threadIdx.x, li = lane & 15, g = lane >> 4;
-    const int cs = DC * 16;
-    const int t0 = blockIdx.x * 32;
-    f32x4 xs[2][DC], xq[2][DC];
-    int tok[2];
-#pragma unroll
-    for (int tf = 0; tf < 2; ++tf) {
-        tok[tf] = t0 + tf * 16 + li;
-        const int row = min(tok[tf], p.n_tok - 1);
-        const int prow = p.pos_period > 0 ? row % p.pos_period : row;
-#pragma unroll
-        for (int c = 0; c < DC; ++c) {
-            xs[tf][c] = ld4(p.src + (size_t)row * cs + 16 * c + 4 * g);
-            xq[tf][c] = xs[tf][c];
-            if (p.pos) xq[tf][c] += ld4(p.pos + (size_t)prow * cs + 16 * c + 4 * g);
-        }
-    }
-    unsigned short* k16 = reinterpret_cast<unsigned short*>(p.kbuf);
-    unsigned short* v16 = reinterpret_cast<unsigned short*>(p.vbuf);
-#pragma unroll
-    for (int c = 0; c < DC / 2; ++c) {
-        f32x4 ak[2][2], av[2][2];  // [half][tf]
-#pragma unroll
-        for (int half = 0; half < 2; ++half) {
-            const int nt = 2 * c + half;
-            ak[half][0] = ak[half][1] = ld4(p.b_in + cs + 16 * nt + 4 * g);
-            av[half][0] = av[half][1] = ld4(p.b_in + 2 * cs + 16 * nt + 4 * g);
-#pragma unroll
-            for (int cc = 0; cc < DC; ++cc) {
-                const f32x4 wk = ld4(p.w_in + (((size_t)(DC + nt) * DC + cc) * 64 + lane) * 4);
-                const f32x4 wv = ld4(p.w_in + (((size_t)(2 * DC + nt) * DC + cc) * 64 + lane) * 4);
-#pragma unroll
-                for (int s = 0; s < 4; ++s)
-#pragma unroll
-                    for (int tf = 0; tf < 2; ++tf) {
-                        ak[half][tf] = mfma16(wk[s], xq[tf][cc][s], ak[half][tf]);
-                        av[half][tf] = mfma16(wv[s], xs[tf][cc][s], av[half][tf]);
-                    }
-            }
-        }
-        // fragment-packed 16-bit operand images of this 32-token block (blockIdx.x), one 16-byte store per lane:
-        //   K:   [(blk*2 + tf)*KC + c][lane][8]      lane (li, g): key 16tf + li, the 8 permuted features g*8.. of 32-block c
-        //   V^T: [blk*DC + nt][lane'][8]              lane' (li' = feature in fragment nt, g' = key quad): 8 keys in the block's
-        //        permuted order (position 8*((k%16)/4) + 4*(k/16) + k%4); a 4x4 quad transpose turns (key li, features 4g+r) into
-        //        (feature 4g + (li&3), keys 4(li>>2) + r') so both 16-key halves pack into the destination lane's 16 bytes
-        const size_t blk = blockIdx.x;
-#pragma unroll
-        for (int tf = 0; tf < 2; ++tf)
-            *reinterpret_cast<f32x4*>(k16 + ((((blk * 2 + tf) * (DC / 2) + c) * 64 + lane) * 8)) = pack8<DT>(ak[0][tf], ak[1][tf]);
-#pragma unroll
-        for (int half = 0; half < 2; ++half) {
-            const f32x4 pv = pack8<DT>(quad_transpose(av[half][0], li & 3), quad_transpose(av[half][1], li & 3));
-            *reinterpret_cast<f32x4*>(v16 + (((blk * DC + 2 * c + half) * 64 + 4 * g + (li & 3) + 16 * (li >> 2)) * 8)) = pv;
-        }
-    }
-}
-
+// K (permuted rows, 16-bit) and V^T (permuted 32-key blocks, 16-bit), projected on the 16-bit pipe like every other GEMM of the layer
 // Y^T[NF frags] = W16[NF*16, KC*32] X^T + b for QF token fragments at once (the weight rows are fetched once per fragment row)
 template <int NF, int KC, int QF, int DT, typename Epi>
 __device__ __forceinline__ void gemm_T_lp(const void* W, const float* bias, int ld, const f32x4 (&x)[QF][KC], int li, int g, Epi epi) {
@@ -667,6 +608,51 @@ __device__ __forceinline__ void gemm_T_lp(const void* W, const float* bias, int 
             if (nt + 2 < NF) loadw(w0, nt + 2);
             mm(w1, nt + 1);
         }
+    }
+}
+
+template <int DC, int DT>
+__global__ __launch_bounds__(64) void enc_kv_lp_k(const EncK p) {
+    constexpr int cs = DC * 16, KC = DC / 2;
+    const int lane = threadIdx.x, li = lane & 15, g = lane >> 4;
+    const int t0 = blockIdx.x * 32;
+    // B operands of the two 16-token fragments: src + pos (keys) and src (values), packed to 16 bit like every GEMM input here
+    f32x4 xq[2][KC], xs[2][KC];
+#pragma unroll
+    for (int tf = 0; tf < 2; ++tf) {
+        const int row = min(t0 + tf * 16 + li, p.n_tok - 1);  // (rows past the end: finite duplicates, masked as keys)
+        const int prow = p.pos_period > 0 ? row % p.pos_period : row;
+#pragma unroll
+        for (int c = 0; c < KC; ++c) {
+            const f32x4 a0 = ld4(p.src + (size_t)row * cs + 32 * c + 4 * g), a1 = ld4(p.src + (size_t)row * cs + 32 * c + 16 + 4 * g);
+            xs[tf][c] = pack8<DT>(a0, a1);
+            xq[tf][c] = xs[tf][c];
+            if (p.pos)
+                xq[tf][c] = pack8<DT>(a0 + ld4(p.pos + (size_t)prow * cs + 32 * c + 4 * g), a1 + ld4(p.pos + (size_t)prow * cs + 32 * c + 16 + 4 * g));
+        }
+    }
+    // K rows of the in_proj: row blocks [DC, 2DC) of the fragment-packed 16-bit matrix, V rows: [2DC, 3DC)
+    const unsigned short* w16 = reinterpret_cast<const unsigned short*>(p.w_in_lp);
+    f32x4 ak[2][DC], av[2][DC];
+    gemm_T_lp<DC, KC, 2, DT>(w16 + (size_t)DC * KC * 512, p.b_in + cs, cs, xq, li, g, [&](int nt, int tf, f32x4 a) { ak[tf][nt] = a; });
+    gemm_T_lp<DC, KC, 2, DT>(w16 + (size_t)2 * DC * KC * 512, p.b_in + 2 * cs, cs, xs, li, g, [&](int nt, int tf, f32x4 a) { av[tf][nt] = a; });
+    // fragment-packed 16-bit operand images of this 32-token block (blockIdx.x), one 16-byte store per lane:
+    //   K:   [(blk*2 + tf)*KC + c][lane][8]      lane (li, g): key 16tf + li, the 8 permuted features g*8.. of 32-block c
+    //   V^T: [blk*DC + nt][lane'][8]              lane' (li' = feature in fragment nt, g' = key quad): 8 keys in the block's
+    //        permuted order (position 8*((k%16)/4) + 4*(k/16) + k%4); a 4x4 quad transpose turns (key li, features 4g+r) into
+    //        (feature 4g + (li&3), keys 4(li>>2) + r') so both 16-key halves pack into the destination lane's 16 bytes
+    unsigned short* k16 = reinterpret_cast<unsigned short*>(p.kbuf);
+    unsigned short* v16 = reinterpret_cast<unsigned short*>(p.vbuf);
+    const size_t blk = blockIdx.x;
+#pragma unroll
+    for (int c = 0; c < KC; ++c)
+#pragma unroll
+        for (int tf = 0; tf < 2; ++tf)
+            *reinterpret_cast<f32x4*>(k16 + ((((blk * 2 + tf) * KC + c) * 64 + lane) * 8)) = pack8<DT>(ak[tf][2 * c], ak[tf][2 * c + 1]);
+#pragma unroll
+    for (int nt = 0; nt < DC; ++nt) {
+        const f32x4 pv = pack8<DT>(quad_transpose(av[0][nt], li & 3), quad_transpose(av[1][nt], li & 3));
+        *reinterpret_cast<f32x4*>(v16 + (((blk * DC + nt) * 64 + 4 * g + (li & 3) + 16 * (li >> 2)) * 8)) = pv;
     }
 }
 
