@@ -352,6 +352,8 @@ class Program:
         self.keep = []       # everything the structs point to
         self.pool = {}       # numel -> [tensor]
         self.pending = []    # buffers released inside a fork region: reusable only after the join
+        self.lane_pool = {}  # (lane, numel) -> buffers released by that lane inside the current fork region
+        self.lane_ctx = 0    # lane whose ops are being emitted (set by the emitters inside a fork region)
         self.groupings = []  # (grouping, tokens per crop) of encoders whose groups follow `length` (set_groups)
         self.in_fork = False
         self.nbytes = 0
@@ -361,7 +363,8 @@ class Program:
     def alloc(self, n, h, w, c):
         cs = _r16(c)
         numel = n * h * w * cs
-        lst = self.pool.get(numel)
+        # inside a fork region a lane first re-uses what IT released (same stream: ordered), then buffers freed before the fork
+        lst = (self.lane_pool.get((self.lane_ctx, numel)) if self.in_fork else None) or self.pool.get(numel)
         if lst:
             t = lst.pop()
         else:
@@ -373,7 +376,7 @@ class Program:
     def release(self, *acts):
         for a in acts:
             if self.in_fork:
-                self.pending.append(a.t)
+                self.lane_pool.setdefault((self.lane_ctx, a.t.numel()), []).append(a.t)
             else:
                 self.pool.setdefault(a.t.numel(), []).append(a.t)
 
@@ -677,6 +680,10 @@ class Program:
         for t in self.pending:
             self.pool.setdefault(t.numel(), []).append(t)
         self.pending = []
+        for (_, numel), lst in self.lane_pool.items():
+            self.pool.setdefault(numel, []).extend(lst)
+        self.lane_pool = {}
+        self.lane_ctx = 0
 
     # ---- run ----
     def finalize(self):
@@ -919,21 +926,22 @@ class HRFormerB:
         return mod
 
     @staticmethod
-    def _emit_block(P, blk, x):
+    def _emit_block(P, blk, x, lane=0):
         """GeneralTransformerBlock.forward (hrformer.py:1230-1240): x += attn(LN1 x); x += mlp(LN2 x)."""
-        n1 = P.layernorm(x, blk["ln1"])
-        qkv = P.conv(n1, blk["qkv"])
+        P.lane_ctx = lane
+        n1 = P.layernorm(x, blk["ln1"], lane=lane)
+        qkv = P.conv(n1, blk["qkv"], lane=lane)
         P.release(n1)
-        a = P.winattn(qkv, blk["qkv"].bias, blk["c"], blk["heads"])
+        a = P.winattn(qkv, blk["qkv"].bias, blk["c"], blk["heads"], lane=lane)
         P.release(qkv)
-        x1 = P.conv(a, blk["out"], res1=x)
+        x1 = P.conv(a, blk["out"], res1=x, lane=lane)
         P.release(a, x)
-        n2 = P.layernorm(x1, blk["ln2"])
-        h1 = P.conv(n2, blk["fc1"], act=2)
+        n2 = P.layernorm(x1, blk["ln2"], lane=lane)
+        h1 = P.conv(n2, blk["fc1"], act=2, lane=lane)
         P.release(n2)
-        h2 = P.dwconv(h1, blk["dw"], 1, act=2)
+        h2 = P.dwconv(h1, blk["dw"], 1, act=2, lane=lane)
         P.release(h1)
-        x2 = P.conv(h2, blk["fc2"], act=2, res_post=x1)
+        x2 = P.conv(h2, blk["fc2"], act=2, res_post=x1, lane=lane)
         P.release(h2, x1)
         return x2
 
@@ -941,9 +949,19 @@ class HRFormerB:
     def _emit_module(cls, P, mod, xs):
         nb = mod["nb"]
         xs = list(xs)
-        for i in range(nb):
-            for blk in mod["blocks"][i]:
-                xs[i] = cls._emit_block(P, blk, xs[i])
+        # The branches of a module are independent until the fuse layers (hrformer.py:1708-1715) and the low-resolution ones are far
+        # too small to fill 256 CUs on their own (16x12: 160 workgroups): branch i runs on stream lane i, forked / joined around the
+        # block loops; launches are emitted round-robin over the branches so every lane's queue fills from the start.
+        lanes = nb > 1 and os.environ.get("I2R_BRANCH_LANES", "1") != "0"
+        mask = sum(1 << i for i in range(1, min(nb, 4))) if lanes else 0
+        if lanes:
+            P.fork(mask)
+        for k in range(max(len(b) for b in mod["blocks"])):
+            for i in range(nb):
+                if k < len(mod["blocks"][i]):
+                    xs[i] = cls._emit_block(P, mod["blocks"][i][k], xs[i], lane=min(i, 3) if lanes else 0)
+        if lanes:
+            P.join(mask)
         outs = []
         for i in range(mod["n_out"]):
             # y = ((t_0 + t_1) + ...) then ReLU (hrformer.py:1716-1731); identity terms ride as residual inputs
