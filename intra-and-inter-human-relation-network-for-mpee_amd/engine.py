@@ -963,7 +963,13 @@ class HRFormerB:
         if lanes:
             P.join(mask)
         outs = []
+        flanes = lanes and mod["n_out"] > 1  # the fuse sums of the outputs are independent of each other as well
+        fmask = sum(1 << i for i in range(1, min(mod["n_out"], 4))) if flanes else 0
+        if flanes:
+            P.fork(fmask)
         for i in range(mod["n_out"]):
+            ln = min(i, 3) if flanes else 0
+            P.lane_ctx = ln
             # y = ((t_0 + t_1) + ...) then ReLU (hrformer.py:1716-1731); identity terms ride as residual inputs
             acc, y, j = None, None, 0
             while j < nb:
@@ -975,29 +981,32 @@ class HRFormerB:
                 if y is None:
                     y = P.alloc(xs[i].n, xs[i].h, xs[i].w, xs[i].c)
                 if j > i:  # 1x1 conv + BN at low resolution, then bilinear up-sample and accumulate
-                    t = P.conv(xs[j], mod["fuse"][(i, j)])
-                    P.upsample_add(t, acc, y, act=1 if j + 1 >= nb else 0)
+                    t = P.conv(xs[j], mod["fuse"][(i, j)], lane=ln)
+                    P.upsample_add(t, acc, y, act=1 if j + 1 >= nb else 0, lane=ln)
                     P.release(t)
                     jn = j + 1
                 else:
                     cur = xs[j]
                     hops = mod["fuse"][(i, j)]
                     for k, (dw, pc) in enumerate(hops):
-                        d = P.dwconv(cur, dw, 2, act=0)
+                        d = P.dwconv(cur, dw, 2, act=0, lane=ln)
                         if cur is not xs[j]:
                             P.release(cur)
                         if k < len(hops) - 1:
-                            cur = P.conv(d, pc, relu=True)
+                            cur = P.conv(d, pc, relu=True, lane=ln)
                             P.release(d)
                         else:
                             res = [acc] if acc is not None else []
                             if j + 1 == i:
                                 res.append(xs[i])
                             jn = j + 2 if j + 1 == i else j + 1
-                            P.conv(d, pc, relu=(jn >= nb), res1=res[0] if res else None, res2=res[1] if len(res) > 1 else None, out=y)
+                            P.conv(d, pc, relu=(jn >= nb), res1=res[0] if res else None, res2=res[1] if len(res) > 1 else None, out=y,
+                                   lane=ln)
                             P.release(d)
                 acc, j = y, jn
             outs.append(y)
+        if flanes:
+            P.join(fmask)
         P.release(*xs)
         return outs
 
