@@ -81,6 +81,22 @@ def test_ragged_batches_and_program_cache():
         net(x.cuda(), m.cuda(), [1, 1])
 
 
+def test_many_token_groups():
+    """more than 64 images in one batch: the encoder's lane-parallel group search takes a second trip; rows of an image equal the
+    rows it gets when run alone"""
+    cfg, sd, _, _, _, _ = setup("w48_l1")
+    from i2r_amd import synth
+    net = _net(cfg, sd, "w48_pure_en6")
+    length = [1] * 66 + [3, 2]
+    x, m, length = synth.make_inputs(length, 256, 192, seed=5)
+    y = net(x.cuda(), m.cuda(), length).cpu()
+    assert y.shape[0] == 71 and torch.isfinite(y).all()
+    for i in (0, 65, 66, 67):
+        o, n = sum(length[:i]), length[i]
+        alone = net(x[o:o + n].cuda(), m[o:o + n].cuda(), [n]).cpu()
+        assert (alone - y[o:o + n]).abs().max().item() < 1e-4
+
+
 def test_full_size_batch_properties():
     """BASELINE config 2 size (S=32, length=[4]*8): the oracle is too slow to run densely in the suite, so check
     size-independent properties: permuting IMAGES permutes outputs; one image re-run alone reproduces its rows."""
