@@ -15,4 +15,7 @@ for c in FETCH_SIZE WRITE_SIZE; do
 done
 rocprofv3 --pmc SQ_INSTS_MFMA SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES --kernel-trace --output-format csv -d $O/prof_pmc_sq -- python tools/one_conv.py 32 5 group > $O/pmc_sq.log 2>&1
 rocprofv3 --pmc GRBM_GUI_ACTIVE SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY --kernel-trace --output-format csv -d $O/prof_pmc_sq2 -- python tools/one_conv.py 32 5 group > $O/pmc_sq2.log 2>&1
+# encoder layer kernel: MFMA busy inside the real forward (short bench run, counters only; a counter pass over the whole
+# forward is slow -- several minutes -- so only one is made)
+rocprofv3 --pmc SQ_INSTS_MFMA SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d $O/prof_pmc_enc -- python bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-roofline > $O/pmc_enc.log 2>&1
 find $O -name "*.csv" | head -40

@@ -72,5 +72,32 @@ for c in ("FETCH_SIZE", "WRITE_SIZE"):
             if DOM in r["Kernel_Name"]:
                 w.writerow([r["Kernel_Name"][:70], r["Grid_Size"], r["LDS_Block_Size"], r["VGPR_Count"], r["Accum_VGPR_Count"],
                             r["Counter_Name"], r["Counter_Value"]])
+
+
+def counters_of(d, kernel):
+    f = glob.glob(os.path.join(O, d, "*", "*_counter_collection.csv"))
+    if not f:
+        return None
+    acc = {}
+    with open(f[0]) as fh:
+        for r in csv.DictReader(fh):
+            if kernel in r["Kernel_Name"]:
+                acc.setdefault(r["Counter_Name"], []).append(float(r["Counter_Value"]))
+    return {k: sum(v) / len(v) for k, v in acc.items()} if acc else None
+
+
+enc = counters_of("prof_pmc_enc", "enc_layer4_k")
+if enc:
+    mem = counters_of("prof_pmc_enc_mem", "enc_layer4_k") or {}
+    enc.update(mem)
+    cyc = enc["GRBM_GUI_ACTIVE"] / 8.0
+    enc["derived"] = {"kernel_cycles_per_xcd": cyc, "mfma_busy_frac": enc["SQ_VALU_MFMA_BUSY_CYCLES"] / (cyc * 1024.0)}
+    if "FETCH_SIZE" in enc:
+        enc["derived"]["hbm_bytes_per_launch"] = (2 * enc["FETCH_SIZE"] + enc["WRITE_SIZE"]) * 1024
+        enc["derived"]["algorithmic_bytes_per_launch"] = 6144 * 96 * 4 * (2 + 2 + 2)  # src, pos, out + K, V read + next K, V written
+    enc["_note"] = ("per-dispatch averages of enc_layer4_k<6, 12, 1> (vanilla, 384 query tiles, 6144 tokens) inside the bench forward; "
+                    "2.72 GFLOP per launch; FETCH_SIZE doubled as for the conv")
+    json.dump(enc, open(os.path.join(P, tag + "_pmc_encoder_layer.json"), "w"), indent=1)
+    print(json.dumps(enc, indent=1))
 print(json.dumps(hbm, indent=1))
 print(json.dumps(sq, indent=1))
