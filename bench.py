@@ -236,7 +236,8 @@ def main():
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 4),
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": {"fp32": "f32", "bf16": "bf16", "fp16": "f16"}[args.precision], "data": "synthetic",
         "config": {"workload": "vanilla I2R-Net HRNet-W48-S 256x192, 6 encoder layers, fp32, random weights "
-                               "(BASELINE configs[1]: w48_pure_en6)" if args.config == "w48_pure_en6" else args.config + " (exploratory, fp32)",
+                               "(BASELINE configs[1]: w48_pure_en6)" if (args.config == "w48_pure_en6" and args.precision == "fp32")
+                               else "%s (exploratory, %s MFMA operands)" % (args.config, args.precision),
                    "images_per_gpu": IMAGES_PER_GPU, "persons_per_image": PERSONS, "crops_per_gpu_step": sum(length),
                    "parallelism": "dp%d (images sharded, RCCL all-gather of heatmaps)" % world if world > 1 else "single GPU",
                    "gflop_per_crop": round(GFLOP_PER_CROP, 3)},
