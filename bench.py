@@ -1,21 +1,26 @@
 #!/usr/bin/env python
 """bench.py -- throughput of the I2R-Net inference hot path on MI355X (BASELINE.json metric).
 
-  python bench.py [--gpus N] [--steps K] [--warmup W]
+  python bench.py [--gpus N] [--steps K] [--warmup W] [--config NAME] [--precision P] [--pipeline]
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
          bench.py --gpus N --steps K --warmup W
 
-A "step" is ONE forward of the vanilla I2R-Net (HRNet-W48-S, 256x192, 6 encoder layers, fp32) over one
-synthetic batch of 8 images x 4 persons = 32 crops per GPU (BASELINE.json configs[1]); inputs are resident in
-HBM before the timed region; weights are the seeded synthetic set.  With N > 1 every rank runs its own 8 images
-(weak scaling, images are the independent unit) and the per-crop heatmaps are all-gathered over RCCL each step.
+A "step" is ONE forward over one synthetic batch (inputs resident in HBM before the timed region, seeded synthetic weights).
+Default workload = BASELINE.json configs[1]: vanilla I2R-Net (HRNet-W48-S, 256x192, 6 encoder layers), fp32, 8 images x 4 persons
+= 32 crops per GPU.  --config selects the other BASELINE workloads with THEIR batch shapes and dtypes (WORKLOADS below):
+configs[2] tph_192_p6_b4 bf16 (16 ragged images, 1-6 persons), configs[3] hrt_192_p4_b4 bf16 (4 images x 4), configs[4]
+coco_hrt_288_p2_b4 fp16 (one image of 12 persons at 384x288).  With N > 1 every rank runs its own batch of that shape (weak scaling,
+images are the independent unit) and the per-crop results are all-gathered over RCCL each step.
 
 One JSON line is printed by rank 0:
-  value      = crops/s of the whole job (all ranks), from the max-over-ranks wall time of exactly K steps
-  roofline   = the dominant kernel (fp32-MFMA implicit-GEMM conv): algorithmic FLOPs per launch / average launch
-               duration, both from a per-launch HIP-event timing pass inside this script, vs the 157.3 TFLOP/s fp32
-               matrix peak (MI355X_MICROARCH.md)
-  cpu_baseline = the CPU oracle (oracle/i2r_cpu.py, a port of the reference forward) timed on this host, rank 0 only
+  value        crops/s of the whole job (all ranks), from the max-over-ranks wall time of exactly K steps
+  roofline     the dominant kernel (implicit-GEMM conv on the matrix pipe): algorithmic FLOPs per launch / average launch duration,
+               both from a per-launch HIP-event timing pass inside this script, vs the dense MFMA peak of the operand type
+               (MI355X_MICROARCH.md: fp32 157.3 TFLOP/s, bf16/fp16 2500 TFLOP/s); attention_blocks = the encoder kernels
+  parity       max-abs difference of the first image of the timed batch against the CPU oracle (fp32: the 1e-3 bar of BASELINE.json)
+  cpu_baseline the CPU oracle (oracle/i2r_cpu.py, a port of the reference forward) timed on this host, rank 0, N = 1 only
+--pipeline times the validate() step around the forward as one unit: uint8 image -> affine crops + bbox masks -> flip-test forward
+-> key-point decode, all on the device (lib/core/function.py:124-200); see pipeline_step().
 """
 import argparse
 import json
@@ -28,6 +33,7 @@ for p in (ROOT, os.path.join(ROOT, "oracle")):
     if p not in sys.path:
         sys.path.insert(0, p)
 
+import numpy as np  # noqa: E402
 import torch  # noqa: E402
 import torch.distributed as dist  # noqa: E402
 
@@ -35,9 +41,34 @@ import i2r_amd  # noqa: E402,F401
 from i2r_amd import arch, cabi, config, models, synth  # noqa: E402
 from i2r_amd import dist as i2r_dist  # noqa: E402
 
-FP32_MFMA_PEAK_TFLOPS = 157.3  # MI355X_MICROARCH.md: v_mfma_f32_16x16x4_f32, 256 CU x 2.4 GHz
-IMAGES_PER_GPU, PERSONS = 8, 4
-GFLOP_PER_CROP = 19.085 + 0.0849 * PERSONS  # BASELINE.md section 3 (N = 4 persons / image)
+MFMA_PEAK_TFLOPS = {"fp32": 157.3, "bf16": 2500.0, "fp16": 2500.0}  # MI355X_MICROARCH.md (dense)
+DTYPE_NAME = {"fp32": "f32", "bf16": "bf16", "fp16": "f16"}
+
+
+def _config3_length():
+    """BASELINE config 3: 16 images, length_i = rng(seed 0).integers(1, 7)"""
+    return [int(v) for v in np.random.default_rng(0).integers(1, 7, size=16)]
+
+
+# name -> per-GPU batch (persons per image), BASELINE dtype, algorithmic GFLOP per crop as a function of persons per image (SURVEY 8d)
+WORKLOADS = {
+    "w48_pure_en6": dict(length=[4] * 8, precision="fp32", gflop=lambda n: 19.085 + 0.0849 * n,
+                         label="vanilla I2R-Net HRNet-W48-S 256x192, 6 encoder layers, fp32, random weights (BASELINE configs[1]: w48_pure_en6)"),
+    "tph_192_p6_b4": dict(length=_config3_length(), precision="bf16", gflop=lambda n: 34.956 + 0.0283 * n,
+                          label="I2R-Net TransPose-H first stage 256x192 p6_b4, 16 CrowdPose-shaped images of 1-6 persons (BASELINE configs[2])"),
+    "hrt_192_p4_b4": dict(length=[4] * 4, precision="bf16", gflop=lambda n: 28.048 + 0.023 * n,
+                          label="I2R-Net HRFormer-B 256x192 p4_b4, per-GPU batch 16 = 4 images x 4 persons (BASELINE configs[3])"),
+    "coco_hrt_288_p2_b4": dict(length=[12], precision="fp16", gflop=lambda n: 61.439 + 0.1165 * n,
+                               label="I2R-Net HRFormer-B 384x288, one image of 12 persons (BASELINE configs[4])"),
+}
+
+
+def refuse_tuning_env():
+    """A bench number must not depend on a tuning switch: no I2R_* variable may be set (the product library ignores them anyway --
+    the kernel-side hooks only exist in a -DI2R_TUNING build -- but the Python side has two: I2R_CONV_CHAIN, I2R_BRANCH_LANES)."""
+    bad = sorted(k for k in os.environ if k.startswith("I2R_") and k != "I2R_REFERENCE_ROOT")
+    if bad:
+        raise SystemExit("bench.py refuses to run with tuning variables set: %s" % ", ".join(bad))
 
 
 def conv_kernel_name(members):
@@ -62,9 +93,12 @@ def _op_name_flop(kind, st):
     if kind == cabi.OP_CONV_CHAIN:
         members = [st.descs[i].contents for i in range(st.n_layers * st.n_members)]
         return "conv_chain_f32<%d, %d, %d, %d>" % (st.mt, st.nt, st.cap, st.pf), sum(conv_flop(m) for m in members)
-    name = {cabi.OP_STEM: "stem_conv_k", cabi.OP_MAXPOOL: "maxpool_k", cabi.OP_HEAD: "head_k",
-            cabi.OP_ENC_KV: "enc_kv_k", cabi.OP_ENC_LAYER: "enc_layer4_k", cabi.OP_LAYERNORM: "layernorm_k",
-            cabi.OP_WINATTN: "window_attn_k", cabi.OP_DWCONV: "dwconv3x3_k", cabi.OP_UPSAMPLE: "upsample_add_k"}[kind]
+    if kind in (cabi.OP_ENC_KV, cabi.OP_ENC_LAYER):
+        lp = st.dtype != 0
+        return {cabi.OP_ENC_KV: "enc_kv_lp_k" if lp else "enc_kv_k", cabi.OP_ENC_LAYER: "enc_layer_lp_k" if lp else "enc_layer4_k"}[kind], 0.0
+    name = {cabi.OP_STEM: "stem_conv_k", cabi.OP_MAXPOOL: "maxpool_k", cabi.OP_HEAD: "head_k", cabi.OP_LAYERNORM: "layernorm_k",
+            cabi.OP_WINATTN: "window_attn_k", cabi.OP_DWCONV: "dwconv3x3_k", cabi.OP_UPSAMPLE: "upsample_add_k",
+            cabi.OP_PE_RES_STEM: "pe_res_stem_k"}.get(kind, "op%d" % kind)
     return name, 0.0
 
 
@@ -105,18 +139,55 @@ def per_launch_timing(program, reps=3):
     return stats, reps
 
 
-def hbm_traffic():
-    """HBM bytes per launch of the dominant (grouped stage-3 conv) kernel from the committed PMC passes
-    (profiles/round1_hbm_traffic.json: separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE runs, FETCH_SIZE doubled per
-    MI355X_MICROARCH.md).  bench.py itself cannot collect PMC counters; null when the profile is absent."""
-    try:
-        with open(os.path.join(ROOT, "profiles", "round1_hbm_traffic.json")) as f:
-            return round(json.load(f)["hbm_bytes_per_launch"])
-    except (OSError, KeyError, ValueError):
-        return None
+def attention_flop(program):
+    """algorithmic FLOPs of the encoder stacks of a program (north_star 'attention blocks'): per layer and token the q/k/v/out
+    projections (8 d^2), the FFN (4 d dff) and QK^T + AV over the token's own group (4 d L_g)"""
+    total = 0.0
+    for st in program.enc_stacks:
+        offs = st["current"]
+        lens = [offs[i + 1] - offs[i] for i in range(len(offs) - 1)]
+        for d, _ in st["descs"]:
+            dm, dff = d.d, 192
+            total += sum(L * (8.0 * dm * dm + 4.0 * dm * dff + 4.0 * dm * L) for L in lens)
+    return total
 
 
-def cpu_baseline(cfg, sd, budget_s=20.0):
+def hbm_traffic(cname):
+    """HBM bytes per launch of the dominant kernel from the committed PMC passes (separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE
+    runs, FETCH_SIZE doubled per MI355X_MICROARCH.md).  bench.py itself cannot collect PMC counters: this is a constant read from
+    profiles/ (named in traffic_source), null when no profile of this round exists for the workload."""
+    for rnd in ("round2", "round1"):
+        path = os.path.join(ROOT, "profiles", "%s_hbm_traffic%s.json" % (rnd, "" if cname == "w48_pure_en6" else "_" + cname))
+        try:
+            with open(path) as f:
+                return round(json.load(f)["hbm_bytes_per_launch"]), os.path.relpath(path, ROOT)
+        except (OSError, KeyError, ValueError):
+            continue
+    return None, None
+
+
+def oracle_parity(cfg, sd, x, m, length, y, precision):
+    """first image of the timed batch through the CPU oracle (the checker, never the thing measured)"""
+    import i2r_cpu
+    n = length[0]
+    torch.set_num_threads(min(len(os.sched_getaffinity(0)), 32))
+    ref = i2r_cpu.forward(sd, cfg, x[:n].cpu(), m[:n].cpu(), [n])
+    ref = ref["multi"] if isinstance(ref, dict) else ref
+    # the image must be re-run alone: its crops depend on its own image only, so the batch rows are the same numbers
+    diff = (y[:n].cpu() - ref).abs().max().item()
+    out = {"max_abs": float("%.3e" % diff), "vs": "oracle/i2r_cpu.py fp32 on image 0 of the timed batch (%d crops)" % n,
+           "ref_max_abs": round(ref.abs().max().item(), 3)}
+    if precision == "fp32":
+        out["tolerance"] = 1e-3
+        out["ok"] = diff < 1e-3
+    else:
+        out["rel_max"] = float("%.3e" % (diff / ref.abs().max().item()))
+        out["tolerance"] = "tests/test_model_gpu.py LP_TOL (%s): max-abs <= %s of max|ref|" % (precision, {"bf16": "5 %", "fp16": "1 %"}[precision])
+        out["ok"] = out["rel_max"] <= {"bf16": 5e-2, "fp16": 1e-2}[precision]
+    return out
+
+
+def cpu_baseline(cfg, sd, H, W, persons, budget_s=20.0):
     """The CPU oracle (a port of the reference forward) timed on this host; bounded to ~budget_s seconds."""
     import i2r_cpu
     try:
@@ -125,12 +196,12 @@ def cpu_baseline(cfg, sd, budget_s=20.0):
         cores = os.cpu_count() or 1
     threads = min(cores, 32)  # torch CPU convs stop scaling (and oversubscribe badly) far below 256 threads
     torch.set_num_threads(threads)
-    x, m, length = synth.make_inputs([1], 256, 192)
+    x, m, length = synth.make_inputs([1], H, W)
     t0 = time.perf_counter()
     i2r_cpu.forward(sd, cfg, x, m, length)  # warm-up + cost probe on ONE crop
     probe = time.perf_counter() - t0
-    persons = PERSONS if probe * PERSONS * 3 < budget_s else 1
-    x, m, length = synth.make_inputs([persons], 256, 192)
+    persons = persons if probe * persons * 3 < budget_s else 1
+    x, m, length = synth.make_inputs([persons], H, W)
     n, t0 = 0, time.perf_counter()
     while True:
         i2r_cpu.forward(sd, cfg, x, m, length)
@@ -139,8 +210,39 @@ def cpu_baseline(cfg, sd, budget_s=20.0):
             break
     dt = time.perf_counter() - t0
     return {"value": round(n * persons / dt, 3), "unit": "images/sec", "cores": threads, "kind": "port",
-            "sample": "%d forwards of 1 image x %d person(s), fp32, oracle/i2r_cpu.py on torch %s CPU, %d threads "
-                      "(%d cores visible)" % (n, persons, torch.__version__, threads, cores)}
+            "sample": "%d forwards of 1 image x %d person(s) at %dx%d, fp32, oracle/i2r_cpu.py on torch %s CPU, %d threads "
+                      "(%d cores visible)" % (n, persons, H, W, torch.__version__, threads, cores)}
+
+
+def make_pipeline(net, cfg, length, H, W, dev, seed):
+    """The validate() step around the forward as one device-side unit (lib/core/function.py:124-200, JointsDataset.py:296-333):
+    uint8 image + person boxes -> affine crops + bbox masks (i2r_crop_affine / i2r_box_mask) -> flip-test forward -> key points
+    (i2r_decode).  Synthetic 640x480 images, boxes from the seeded generator; returns step() -> (preds [S,J,2], maxvals [S,J,1])."""
+    from i2r_amd import caller, input as i2r_input
+    rng = np.random.default_rng(seed)
+    ih, iw = 480, 640
+    images, boxes = [], []
+    for n in length:
+        images.append(torch.from_numpy(rng.integers(0, 256, size=(ih, iw, 3), dtype=np.uint8)).to(dev))
+        b = np.stack([rng.uniform(20, iw * 0.5, n), rng.uniform(20, ih * 0.5, n), rng.uniform(60, iw * 0.45, n), rng.uniform(90, ih * 0.45, n)], 1)
+        boxes.append(b)
+    ds = cfg.DATASET.DATASET.lower() if cfg.DATASET.DATASET.lower() in caller.FLIP_PAIRS else ("crowdpose" if cfg.MODEL.NUM_JOINTS == 14 else "coco")
+    pairs = caller.FLIP_PAIRS[ds]
+    cs = [[i2r_input.box_to_center_scale(b, (W, H)) for b in bs] for bs in boxes]
+    centers = np.concatenate([np.stack([c for c, _ in one]) for one in cs])
+    scales = np.concatenate([np.stack([s for _, s in one]) for one in cs])
+
+    def step():
+        xs, ms = [], []
+        for img, bs, one in zip(images, boxes, cs):  # per image, as JointsDataset.__getitem__ does (host: 2x3 affine solve per person)
+            x, m = i2r_input.person_inputs(img, [c for c, _ in one], [s for _, s in one], bs, (W, H),
+                                           color_rgb=bool(cfg.DATASET.COLOR_RGB), device=dev)
+            xs.append(x)
+            ms.append(m)
+        x, m, lens = i2r_input.collate(list(zip(xs, ms)))
+        hm = net.forward_flip(x, m, lens, pairs)
+        return caller.decode(hm, centers, scales, cfg.TEST.BLUR_KERNEL)
+    return step
 
 
 def main():
@@ -148,13 +250,18 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=30)
     ap.add_argument("--warmup", type=int, default=10)
-    ap.add_argument("--config", default="w48_pure_en6", help="workload config (default = BASELINE configs[1]); others are "
-                    "exploratory: tph_192_p6_b4, hrt_192_p4_b4, coco_hrt_288_p2_b4")
-    ap.add_argument("--precision", default="fp32", choices=["fp32", "bf16", "fp16"],
-                    help="MFMA operand type of the conv kernels (default fp32 = the BASELINE configs[1] parity mode)")
+    ap.add_argument("--config", default="w48_pure_en6", choices=sorted(WORKLOADS),
+                    help="workload (default = BASELINE configs[1]); the others are BASELINE configs[2..4] with their own batch shapes")
+    ap.add_argument("--precision", default=None, choices=["fp32", "bf16", "fp16"],
+                    help="MFMA operand type (default: the workload's BASELINE dtype -- fp32 / bf16 / bf16 / fp16)")
+    ap.add_argument("--pipeline", action="store_true", help="time image -> crops -> flip-test forward -> key points instead of the bare forward")
+    ap.add_argument("--gather", default="keypoints", choices=["keypoints", "heatmaps"],
+                    help="N > 1: payload of the per-step all-gather (decoded key points [S,J,3], or the heat maps)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--no-parity", action="store_true")
     args = ap.parse_args()
+    refuse_tuning_env()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -169,47 +276,62 @@ def main():
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         dist.init_process_group("nccl", device_id=dev)  # RCCL
 
+    wl = WORKLOADS[args.config]
+    precision = args.precision or wl["precision"]
     cfg = config.load_config(args.config)
-    if args.config != "w48_pure_en6":
-        args.no_cpu_baseline = True
     sd = synth.make_state_dict(arch.param_spec(cfg))
     net = eval("models." + cfg.MODEL.NAME + ".get_pose_net")(cfg, is_train=False)
     net.load_state_dict(sd, strict=True)
-    net = net.to(dev).set_precision(args.precision)
+    net = net.to(dev).set_precision(precision)
 
-    # global workload: world * 8 images of 4 persons; this rank's contiguous shard
-    length_all = [PERSONS] * (IMAGES_PER_GPU * world)
-    lo, hi, off = i2r_dist.shard_images(length_all, rank, world)
-    length = length_all[lo:hi]
-    counts = [sum(length_all[a:b]) for a, b in
-              [i2r_dist.shard_images(length_all, r, world)[:2] for r in range(world)]]
+    # global workload: every rank's batch has the workload's shape (weak scaling); this rank's contiguous shard of the image list
+    per_gpu = list(wl["length"])
+    length_all = per_gpu * world
+    bounds = i2r_dist.shard_bounds(length_all, world) if world > 1 else [0, len(length_all)]
+    if world > 1:  # identical shapes -> the balanced cuts are the per-GPU batches
+        assert [bounds[r + 1] - bounds[r] for r in range(world)] == [len(per_gpu)] * world, bounds
+    length = length_all[bounds[rank]:bounds[rank + 1]]
+    counts = [sum(length_all[bounds[r]:bounds[r + 1]]) for r in range(world)]
     W_, H_ = cfg.MODEL.IMAGE_SIZE
     x, m, _ = synth.make_inputs(length, H_, W_, seed=rank)
     x, m = x.to(dev), m.to(dev)
+    gflop_per_step = sum(n * wl["gflop"](n) for n in length_all)
 
+    from i2r_amd import caller
     pending = [None]
+    pipe = make_pipeline(net, cfg, length, H_, W_, dev, seed=rank) if args.pipeline else None
 
     def step():
         """one forward over this rank's images; N > 1: the all-gather of step k is waited for after step k+1 has been issued"""
-        y = net(x, m, length)
-        if isinstance(y, dict):
-            y = y["multi"]
+        if pipe is not None:
+            preds, maxv = pipe()
+            y = torch.cat([preds, maxv], 2)
+            if world > 1:
+                h = i2r_dist.gather_heatmaps_async(y, counts)
+        else:
+            y = net(x, m, length)
+            if isinstance(y, dict):
+                y = y["multi"]
+            if world > 1:
+                if args.gather == "keypoints":  # decode on the device, gather [S, J, 3] (168 B/crop) instead of 172 KB/crop
+                    preds, maxv = caller.decode(y, None, None, cfg.TEST.BLUR_KERNEL, transform_back=False)
+                    h = i2r_dist.gather_keypoints(preds, maxv, counts, async_op=True)
+                else:
+                    h = i2r_dist.gather_heatmaps_async(y, counts)
         if world > 1:
-            h = i2r_dist.gather_heatmaps_async(y, counts)
             if pending[0] is not None:
-                y = pending[0].wait()
+                pending[0].wait()
             pending[0] = h
         return y
 
-    def drain(y):
+    def drain():
         if pending[0] is not None:
-            y = pending[0].wait()
+            pending[0].wait()
             pending[0] = None
-        return y
 
     for _ in range(args.warmup):
         y = step()
-    drain(y)
+    drain()
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
@@ -217,7 +339,7 @@ def main():
     t0 = time.perf_counter()
     for _ in range(args.steps):
         y = step()
-    y = drain(y)
+    drain()
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
@@ -232,48 +354,58 @@ def main():
     crops_per_step = sum(length_all)
     value = crops_per_step * args.steps / dt
     out = {
-        "metric": "images/sec (256x192 crops) I2R-Net HRNet-W48 inference", "value": round(value, 2), "unit": "images/sec",
+        "metric": "images/sec (%dx%d crops) I2R-Net inference" % (H_, W_) if args.config != "w48_pure_en6"
+                  else "images/sec (256x192 crops) I2R-Net HRNet-W48 inference",
+        "value": round(value, 2), "unit": "images/sec",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 4),
-        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": {"fp32": "f32", "bf16": "bf16", "fp16": "f16"}[args.precision], "data": "synthetic",
-        "config": {"workload": "vanilla I2R-Net HRNet-W48-S 256x192, 6 encoder layers, fp32, random weights "
-                               "(BASELINE configs[1]: w48_pure_en6)" if (args.config == "w48_pure_en6" and args.precision == "fp32")
-                               else "%s (exploratory, %s MFMA operands)" % (args.config, args.precision),
-                   "images_per_gpu": IMAGES_PER_GPU, "persons_per_image": PERSONS, "crops_per_gpu_step": sum(length),
-                   "parallelism": "dp%d (images sharded, RCCL all-gather of heatmaps)" % world if world > 1 else "single GPU",
-                   "gflop_per_crop": round(GFLOP_PER_CROP, 3)},
-        "model_tflops": round(value * GFLOP_PER_CROP / 1e3, 2) if args.config == "w48_pure_en6" else None,
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": DTYPE_NAME[precision], "data": "synthetic",
+        "config": {"workload": wl["label"] + ("" if precision == wl["precision"] else " -- run with %s MFMA operands" % precision)
+                               + (" -- PIPELINE: uint8 image -> crops + masks -> flip-test forward -> key points" if args.pipeline else ""),
+                   "images_per_gpu": len(length), "persons_per_image": length if len(set(length)) > 1 else length[0],
+                   "crops_per_gpu_step": sum(length),
+                   "parallelism": "dp%d (images sharded, RCCL all-gather of %s)" % (world, "key points" if (args.pipeline or args.gather == "keypoints") else "heat maps")
+                                  if world > 1 else "single GPU",
+                   "gflop_per_step_per_gpu": round(gflop_per_step / world, 2)},
+        "model_tflops": round(gflop_per_step * (2 if args.pipeline else 1) * args.steps / dt / 1e3, 2),
     }
     if rank == 0:
+        eng = net.engine()
         if not args.no_roofline:
-            prog = next(iter(net.engine().programs.values()))[0]
+            key = next(k for k in eng.programs if k[3] == bool(args.pipeline))
+            prog = eng.programs[key][0]
             stats, reps = per_launch_timing(prog)
             total_ms = sum(s[1] for s in stats.values())
             dom = max((k for k in stats if k.startswith("conv_")), key=lambda k: stats[k][1])
             cnt, ms, flop = stats[dom]
             ach = flop / (ms * 1e-3) / 1e12
             conv_ms = sum(s[1] for k, s in stats.items() if k.startswith("conv_"))
-            conv_flop = sum(s[2] for k, s in stats.items() if k.startswith("conv_"))
+            conv_flop_ = sum(s[2] for k, s in stats.items() if k.startswith("conv_"))
+            peak = MFMA_PEAK_TFLOPS[precision]
+            traffic, traffic_src = hbm_traffic(args.config)
             out["roofline"] = {
-                "bound": "mfma", "kernel": dom, "achieved": round(ach, 2), "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-                "frac": round(ach / FP32_MFMA_PEAK_TFLOPS, 4), "traffic": hbm_traffic(),
+                "bound": "mfma", "kernel": dom, "achieved": round(ach, 2), "peak": peak, "unit": "TFLOP/s",
+                "frac": round(ach / peak, 4), "traffic": traffic, "traffic_source": traffic_src,
                 "launches_per_step": cnt // reps, "avg_launch_us": round(ms / cnt * 1e3, 2),
                 "gflop_per_launch": round(flop / cnt / 1e9, 4),
                 "share_of_step_kernel_time": round(ms / total_ms, 3),
-                "all_conv_tflops": round(conv_flop / (conv_ms * 1e-3) / 1e12, 2),
+                "all_conv_tflops": round(conv_flop_ / (conv_ms * 1e-3) / 1e12, 2),
                 "per_kernel_ms_per_step": {k: round(s[1] / reps, 3) for k, s in sorted(stats.items(), key=lambda kv: -kv[1][1])},
             }
-            if args.config == "w48_pure_en6":
-                # attention blocks (north_star): QKV/out projections + QK^T/AV + FFN of the 6 encoder layers, algorithmic FLOPs
-                d_, dff_, tok = 96, 192, 192
-                per_tok = 2 * d_ * d_ * 4 + 2 * 2 * d_ * dff_ + 2 * 2 * d_ * (PERSONS * tok)
-                att_flop = per_tok * sum(length) * tok * cfg.MODEL.ENCODER_LAYERS
-                att_ms = sum(s[1] for k, s in stats.items() if k.startswith("enc_")) / reps
+            att_flop = attention_flop(prog)
+            att_k = sorted(k for k in stats if k.startswith("enc_"))
+            att_ms = sum(stats[k][1] for k in att_k) / reps
+            if att_flop and att_ms:
                 att = att_flop / (att_ms * 1e-3) / 1e12
-                out["roofline"]["attention_blocks"] = {"kernels": "enc_kv_k + enc_layer4_k", "gflop_per_step": round(att_flop / 1e9, 3),
+                att_peak = MFMA_PEAK_TFLOPS["fp32" if "enc_layer4_k" in att_k and "enc_layer_lp_k" not in att_k else precision]
+                out["roofline"]["attention_blocks"] = {"kernels": " + ".join(att_k), "gflop_per_step": round(att_flop / 1e9, 3),
                                                        "ms_per_step": round(att_ms, 3), "achieved": round(att, 2),
-                                                       "peak": FP32_MFMA_PEAK_TFLOPS, "frac": round(att / FP32_MFMA_PEAK_TFLOPS, 4)}
-        if not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(cfg, sd)
+                                                       "peak": att_peak, "frac": round(att / att_peak, 4)}
+        if not args.no_parity and not args.pipeline:
+            y1 = net(x, m, length)
+            y1 = y1["multi"] if isinstance(y1, dict) else y1
+            out["parity"] = oracle_parity(cfg, sd, x, m, length, y1, precision)
+        if not args.no_cpu_baseline and world == 1:
+            out["cpu_baseline"] = cpu_baseline(cfg, sd, H_, W_, max(length))
         print(json.dumps(out))
     if world > 1:
         dist.barrier()

@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define I2R_ABI_VERSION 1
+#define I2R_ABI_VERSION 2
 
 #define I2R_OK 0
 #define I2R_E_ARG (-1)      /* bad argument (shape / alignment / unsupported combination) */
@@ -132,9 +132,19 @@ int i2r_conv_chain(const i2r_conv_chain_args* a, void* stream);
  * (position_embedding.py:99-101).   w: float[9][cin][cout], bias[cout]; cout % 16 == 0.
  * n_src: the input holds n_src images; output images n_src..n_img-1 (n_img == 2*n_src) are computed from the
  * horizontally mirrored input (np.flip(input, 3) of the flip test, lib/core/function.py:145-150); n_src == n_img: none.
+ * n_valid (1..n_src): the input tensor really holds n_valid images; output slots n_valid..n_src-1 (capacity padding of a
+ * pre-built launch program) are computed from image n_valid-1 and are the caller's to drop.
  * ------------------------------------------------------------------------------------------------ */
 int i2r_stem_conv(const float* in_nchw, const float* w, const float* bias, float* out_nhwc, int32_t n_img,
-                  int32_t cin, int32_t in_h, int32_t in_w, int32_t cout, int32_t out_cs, int32_t n_src, void* stream);
+                  int32_t cin, int32_t in_h, int32_t in_w, int32_t cout, int32_t out_cs, int32_t n_src, int32_t n_valid, void* stream);
+
+/* i2r_pe_res_stem -- front end of PositionEmbeddingImage mode 'res' (lib/models/position_embedding.py:14-17,93-95):
+ * conv_pre (nn.Conv2d(1, 3, 3, padding=1, bias=False)) followed by torchvision resnet18's conv1 (3 -> 64, 7x7, stride 2, pad 3,
+ * no bias) + bn1 (eval, folded by the host) + ReLU, reading the boundary NCHW bbox mask [n_src, 1, in_h, in_w] and writing NHWC
+ * [n_img, in_h/2, in_w/2, out_cs].  w_pre: float[9][3] (tap-major), w7: float[49][3][64] (tap, cin, cout) with the BN scale
+ * folded in, bias[64].  n_src / n_valid as in i2r_stem_conv (mirrored copies for the flip test, capacity padding). */
+int i2r_pe_res_stem(const float* mask_nchw, const float* w_pre, const float* w7, const float* bias, float* out_nhwc,
+                    int32_t n_img, int32_t in_h, int32_t in_w, int32_t cout, int32_t out_cs, int32_t n_src, int32_t n_valid, void* stream);
 
 /* i2r_maxpool3x3s2 -- nn.MaxPool2d(kernel_size=3, stride=2, padding=1) on NHWC
  * (interformer.py:162,260-264; position_embedding.py:9,106-109).  c % 4 == 0. */
@@ -256,10 +266,12 @@ typedef struct i2r_encoder_desc {
     int32_t pos_period;    /* 0: pos row = token; >0: pos row = token % pos_period */
     int32_t n_qtiles32;    /* sum over groups of ceil(group_len / 32) (host knows the lengths): work items of the two-tile kernel */
     float ln_eps;
-    /* 16-bit MFMA mode (dtype 1 bf16 / 2 f16; cs == 96, group offsets multiples of 32): q-proj, QK^T, PV, out-proj and FFN run
-     * on v_mfma_f32_16x16x32 with fp32 accumulation; kbuf / vbuf then hold 16-bit data (same byte budget is enough).
-     * w_*_lp: the matrices above as 16-bit [out][in] with the columns of every 32-block permuted to
-     * new position 8g + 4*half + r  <-  column 32c + 16*half + 4g + r  (g < 4, half < 2, r < 4). */
+    /* 16-bit MFMA mode (dtype 1 bf16 / 2 f16; cs 96 or 80, any group offsets): q-proj, QK^T, PV, out-proj and FFN run on
+     * v_mfma_f32_16x16x32 with fp32 accumulation; kbuf / vbuf then hold 16-bit data, one image per 32-token block of a group,
+     * blocks numbered group by group (n_qtiles32 of them; the same byte budget is enough).  The model dim is padded to
+     * csp = 96 = three 32-feature MFMA steps for BOTH widths (d = 78: zero weights beyond feature 77, rows stay 80 floats in HBM).
+     * w_*_lp: the matrices above zero-padded to csp / dff_pad, as 16-bit [out][in] with the columns of every 32-block permuted to
+     * new position 8g + 4*half + r  <-  column 32c + 16*half + 4g + r  (g < 4, half < 2, r < 4), fragment-packed. */
     int32_t dtype;
     int32_t n_qtiles16, n_qtiles64;   /* like n_qtiles32 for 16- and 64-query tiles (n_qtiles16 = number of K / V fragments) */
     const void* w_in_lp; const void* w_out_lp; const void* w1_lp; const void* w2_lp;
@@ -267,6 +279,9 @@ typedef struct i2r_encoder_desc {
      * next_w_in / next_b_in = the next layer's padded in_proj (its k and v rows are used), written to next_kbuf / next_vbuf
      * (layouts as kbuf / vbuf, distinct buffers).  All null = no fusion (then the next layer needs i2r_encoder_kv). */
     const float* next_w_in; const float* next_b_in; float* next_kbuf; float* next_vbuf;
+    /* 16-bit mode: the per-feature fp32 vectors padded to csp = 96 and concatenated:
+     * b_in[3*csp] | b_out[csp] | ln1_w | ln1_b | b1[dff_pad] | b2[csp] | ln2_w | ln2_b   (9*csp + dff_pad floats) */
+    const float* vec_lp;
 } i2r_encoder_desc;
 
 int i2r_encoder_kv(const i2r_encoder_desc* d, void* stream);
@@ -280,13 +295,19 @@ int i2r_encoder_layer(const i2r_encoder_desc* d, void* stream);
 enum {
     I2R_OP_CONV = 1, I2R_OP_STEM = 2, I2R_OP_MAXPOOL = 3, I2R_OP_HEAD = 4,
     I2R_OP_ENC_KV = 5, I2R_OP_ENC_LAYER = 6, I2R_OP_FORK = 7, I2R_OP_JOIN = 8, I2R_OP_CONV_GROUP = 9,
-    I2R_OP_LAYERNORM = 10, I2R_OP_WINATTN = 11, I2R_OP_DWCONV = 12, I2R_OP_UPSAMPLE = 13, I2R_OP_CONV_CHAIN = 14
+    I2R_OP_LAYERNORM = 10, I2R_OP_WINATTN = 11, I2R_OP_DWCONV = 12, I2R_OP_UPSAMPLE = 13, I2R_OP_CONV_CHAIN = 14,
+    I2R_OP_PE_RES_STEM = 15
 };
 
 typedef struct i2r_stem_args {
     const float* in; const float* w; const float* bias; float* out;
-    int32_t n_img, cin, in_h, in_w, cout, out_cs, n_src;
+    int32_t n_img, cin, in_h, in_w, cout, out_cs, n_src, n_valid;
 } i2r_stem_args;
+
+typedef struct i2r_pe_res_args {
+    const float* in; const float* w_pre; const float* w7; const float* bias; float* out;
+    int32_t n_img, in_h, in_w, cout, out_cs, n_src, n_valid;
+} i2r_pe_res_args;
 
 typedef struct i2r_pool_args {
     const float* in; float* out;

@@ -3,7 +3,7 @@
 The drop-in contract is "same state-dict keys and shapes as the reference" (tools/test.py:93-96 loads a
 bare state_dict by key).  Instead of mirroring the reference's nn.Module class tree, the keys are
 generated here from the config by small rules; models/_base.py materialises them as a parameter tree
-and engine.py packs them for the kernels.  tests/test_arch.py checks every list against key/shape
+and engine.py packs them for the kernels.  tests/test_host.py::test_parameter_inventory_equals_reference_manifest checks every list against key/shape
 manifests captured from the imported reference (tests/golden/*_keys.json).
 
 Key rules follow the reference constructors:

@@ -3,7 +3,7 @@
 This is the ONLY way the product path reaches arithmetic: there is no CPU / eager fallback.  If the
 shared library is missing, or the visible GPU is not gfx950, ``lib()`` raises -- loudly.
 
-Build: ``python -m i2r_amd.build`` / ``__graft_entry__.build()`` (hipcc --offload-arch=gfx950, in-tree .so).
+Build: ``__graft_entry__.build()`` (hipcc --offload-arch=gfx950, in-tree .so).
 """
 import ctypes as C
 import os
@@ -14,10 +14,12 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libi2r_hip.so")
 
 MAX_TAPS = 9
+ABI_VERSION = 2  # I2R_ABI_VERSION of include/i2r_hip.h
 OP_CONV, OP_STEM, OP_MAXPOOL, OP_HEAD, OP_ENC_KV, OP_ENC_LAYER, OP_FORK, OP_JOIN, OP_CONV_GROUP = 1, 2, 3, 4, 5, 6, 7, 8, 9
 MAX_GROUP = 4
 OP_LAYERNORM, OP_WINATTN, OP_DWCONV, OP_UPSAMPLE = 10, 11, 12, 13
 OP_CONV_CHAIN = 14
+OP_PE_RES_STEM = 15
 
 _fp = C.c_void_p  # device pointers travel as integers
 _i32 = C.c_int32
@@ -43,13 +45,19 @@ class EncoderDesc(C.Structure):
         ("n_tok", _i32), ("n_grp", _i32), ("d", _i32), ("cs", _i32), ("dff_pad", _i32), ("pos_period", _i32),
         ("n_qtiles32", _i32), ("ln_eps", C.c_float), ("dtype", _i32), ("n_qtiles16", _i32), ("n_qtiles64", _i32),
         ("w_in_lp", _fp), ("w_out_lp", _fp), ("w1_lp", _fp), ("w2_lp", _fp),
-        ("next_w_in", _fp), ("next_b_in", _fp), ("next_kbuf", _fp), ("next_vbuf", _fp),
+        ("next_w_in", _fp), ("next_b_in", _fp), ("next_kbuf", _fp), ("next_vbuf", _fp), ("vec_lp", _fp),
     ]
 
 
 class StemArgs(C.Structure):
     _fields_ = [("in_", _fp), ("w", _fp), ("bias", _fp), ("out", _fp),
-                ("n_img", _i32), ("cin", _i32), ("in_h", _i32), ("in_w", _i32), ("cout", _i32), ("out_cs", _i32), ("n_src", _i32)]
+                ("n_img", _i32), ("cin", _i32), ("in_h", _i32), ("in_w", _i32), ("cout", _i32), ("out_cs", _i32), ("n_src", _i32),
+                ("n_valid", _i32)]
+
+
+class PeResArgs(C.Structure):
+    _fields_ = [("in_", _fp), ("w_pre", _fp), ("w7", _fp), ("bias", _fp), ("out", _fp),
+                ("n_img", _i32), ("in_h", _i32), ("in_w", _i32), ("cout", _i32), ("out_cs", _i32), ("n_src", _i32), ("n_valid", _i32)]
 
 
 class PoolArgs(C.Structure):
@@ -96,8 +104,8 @@ class Op(C.Structure):
     _fields_ = [("kind", _i32), ("lane", _i32), ("args", C.c_void_p)]
 
 
-# every symbol include/i2r_hip.h declares (tests/test_cabi.py checks the built library exports them all)
-EXPORTS = ("i2r_conv", "i2r_conv_grouped", "i2r_conv_kernel_name", "i2r_stem_conv", "i2r_maxpool3x3s2", "i2r_head", "i2r_layernorm", "i2r_window_attn", "i2r_dwconv3x3",
+# every symbol include/i2r_hip.h declares (tests/test_host.py::test_cabi_library_exports_every_declared_symbol checks the built library exports them all)
+EXPORTS = ("i2r_conv", "i2r_conv_grouped", "i2r_conv_kernel_name", "i2r_stem_conv", "i2r_pe_res_stem", "i2r_maxpool3x3s2", "i2r_head", "i2r_layernorm", "i2r_window_attn", "i2r_dwconv3x3",
            "i2r_upsample_bilinear_add", "i2r_flip_merge", "i2r_decode", "i2r_crop_affine", "i2r_box_mask", "i2r_conv_chain_pack", "i2r_conv_chain", "i2r_encoder_kv", "i2r_encoder_layer",
            "i2r_run_program", "i2r_abi_version", "i2r_last_error", "i2r_device_check")
 
@@ -120,7 +128,8 @@ def load_library(path=LIB_PATH):
     L.i2r_conv_chain_pack.argtypes = [C.POINTER(ConvChainArgs), C.c_void_p, C.c_int64]
     L.i2r_conv_chain.argtypes = [C.POINTER(ConvChainArgs), C.c_void_p]
     L.i2r_conv_kernel_name.argtypes = [C.POINTER(C.POINTER(ConvDesc)), _i32, C.c_char_p, _i32]
-    L.i2r_stem_conv.argtypes = [_fp, _fp, _fp, _fp, _i32, _i32, _i32, _i32, _i32, _i32, _i32, C.c_void_p]
+    L.i2r_stem_conv.argtypes = [_fp, _fp, _fp, _fp, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, C.c_void_p]
+    L.i2r_pe_res_stem.argtypes = [_fp, _fp, _fp, _fp, _fp, _i32, _i32, _i32, _i32, _i32, _i32, _i32, C.c_void_p]
     L.i2r_flip_merge.argtypes = [_fp, _fp, _fp, _fp, _i32, _i32, _i32, _i32, C.c_void_p]
     L.i2r_decode.argtypes = [_fp, _fp, _fp, _fp, _fp, _i32, _i32, _i32, _i32, _i32, _i32, C.c_void_p]
     L.i2r_crop_affine.argtypes = [_fp, _i32, _i32, _i32, _i32, _fp, _fp, _fp, _fp, _i32, _i32, _i32, C.c_void_p]
@@ -147,8 +156,8 @@ def lib():
     global _LIB
     if _LIB is None:
         L = load_library()
-        if L.i2r_abi_version() != 1:
-            raise I2RError("libi2r_hip.so ABI version %d != 1 -- rebuild" % L.i2r_abi_version())
+        if L.i2r_abi_version() != ABI_VERSION:
+            raise I2RError("libi2r_hip.so ABI version %d != %d -- rebuild" % (L.i2r_abi_version(), ABI_VERSION))
         _LIB = L
     return _LIB
 

@@ -176,13 +176,26 @@ def default_config():
 
 CONFIG_DIR = os.path.join(os.path.dirname(os.path.abspath(__file__)), "configs")
 
-# short names for the shipped workload configs (BASELINE.json configs 1-5)
+# short names for the shipped workload configs (BASELINE.json configs 1-5) and for the rest of the reference's experiments/*.yaml;
+# REFERENCE_YAML maps each name to the reference file it mirrors (checked by tests/test_host.py in the build container)
+REFERENCE_YAML = {
+    "w48_pure_en6": "crowdpose/interformer_crowdpose_w48_pure_en6", "tph_192_p6_b4": "crowdpose/interformer_crowdpose_tph_192_p6_b4",
+    "hrt_192_p4_b4": "crowdpose/interformer_crowdpose_hrt_192_p4_b4", "coco_hrt_288_p2_b4": "coco/interformer_coco_hrt_288_p2_b4",
+    "coco_tph_192_p4_b4": "coco/interformer_coco_tph_192_p4_b4", "coco_hrt_192_p2_b12": "coco/interformer_coco_hrt_192_p2_b12",
+    "coco_w48_pure_en6": "coco/interformer_coco_w48_pure_en6", "ochuman_tph_192_p3_b8": "OCHuman/interformer_ochuman_tph_192_p3_b8",
+    "ochuman_hrt_192_p3_b8": "OCHuman/interformer_ochuman_hrt_192_p3_b8", "ochuman_w48_pure_en6": "OCHuman/interformer_ochuman_w48_pure_en6",
+}
 NAMED = {
     "w48_pure_en6": "crowdpose_w48_pure_en6.yaml",
     "tph_192_p6_b4": "crowdpose_tph_192_p6_b4.yaml",
     "hrt_192_p4_b4": "crowdpose_hrt_192_p4_b4.yaml",
     "coco_hrt_288_p2_b4": "coco_hrt_288_p2_b4.yaml",
     "coco_tph_192_p4_b4": "coco_tph_192_p4_b4.yaml",
+    "ochuman_tph_192_p3_b8": "ochuman_tph_192_p3_b8.yaml",   # MULTI_POS_EMBEDDING 'res' with USE_MULTI_POS true
+    "ochuman_hrt_192_p3_b8": "ochuman_hrt_192_p3_b8.yaml",
+    "ochuman_w48_pure_en6": "ochuman_w48_pure_en6.yaml",     # vanilla without the multi-position embedding
+    "coco_hrt_192_p2_b12": "coco_hrt_192_p2_b12.yaml",
+    "coco_w48_pure_en6": "coco_w48_pure_en6.yaml",
     "w48_bare_p6": "crowdpose_w48_bare_p6.yaml",   # interformer without a first stage (bare HRNet backbone)
 }
 

@@ -72,7 +72,12 @@ extern "C" int i2r_run_program(const i2r_op* ops, int32_t n_ops, void* const* st
             }
             case I2R_OP_STEM: {
                 const i2r_stem_args* a = (const i2r_stem_args*)op.args;
-                rc = i2r_stem_conv(a->in, a->w, a->bias, a->out, a->n_img, a->cin, a->in_h, a->in_w, a->cout, a->out_cs, a->n_src, st);
+                rc = i2r_stem_conv(a->in, a->w, a->bias, a->out, a->n_img, a->cin, a->in_h, a->in_w, a->cout, a->out_cs, a->n_src, a->n_valid, st);
+                break;
+            }
+            case I2R_OP_PE_RES_STEM: {
+                const i2r_pe_res_args* a = (const i2r_pe_res_args*)op.args;
+                rc = i2r_pe_res_stem(a->in, a->w_pre, a->w7, a->bias, a->out, a->n_img, a->in_h, a->in_w, a->cout, a->out_cs, a->n_src, a->n_valid, st);
                 break;
             }
             case I2R_OP_MAXPOOL: {

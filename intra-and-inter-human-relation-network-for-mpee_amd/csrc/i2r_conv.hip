@@ -20,6 +20,14 @@
 
 #include "i2r_common.h"
 
+// Tuning hooks (ablation switches, phase stamps, env overrides) exist only in a -DI2R_TUNING build (tools/ scripts build one with
+// __graft_entry__.build(defines=("I2R_TUNING",))); the product library has none of them: no env var changes what a kernel does.
+#ifdef I2R_TUNING
+#define I2R_DBG(p) ((p).dbg)
+#else
+#define I2R_DBG(p) 0
+#endif
+
 namespace {
 
 struct ConvK {
@@ -66,7 +74,7 @@ struct ConvGroupK {
 template <int MT, int NT>
 __device__ __forceinline__ void conv_epilogue(const ConvK& p, f32x4 (&acc)[MT][NT], int img, int oy0, int ox0, int wm, int n_base,
                                               int li, int g, int tile_px) {
-    if ((p.dbg & 1) && acc[0][0][0] != 12345.678f) return;
+    if ((I2R_DBG(p) & 1) && acc[0][0][0] != 12345.678f) return;
     const int j4 = li & 3;
     const int pj = li >> 2, pq = li & 3;  // after the lane permutation: this lane's pixel (4g + pj) and 16-byte piece (pq)
     const int perm_src = (g * 16 + pq * 4 + pj) * 4;  // ds_bpermute byte address of the lane holding (q = pq, j = pj)
@@ -103,7 +111,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvK& p, f32x4 (&acc)[MT][N
         nok[nt] = n < p.cout_pad && (n + 4 <= p.cout || n + 4 <= p.out_cs);
         bias[nt] = n < p.cout_pad ? *reinterpret_cast<const f32x4*>(p.bias + n) : (f32x4){0.f, 0.f, 0.f, 0.f};
     }
-    if (p.rep == 1 && !(p.dbg & 16)) {
+    if (p.rep == 1 && !(I2R_DBG(p) & 16)) {
         // ---- every output pixel written once: issue ALL residual loads of the tile first (one memory latency instead of
         //      MT x NT dependent load -> add -> store round trips), then transform and store ----
         size_t off[MT];
@@ -303,7 +311,7 @@ __device__ __forceinline__ void conv_body(const ConvK& p, int bid, f32x4* lds) {
     const int tid = threadIdx.x;
     // tuning aid (I2R_CONV_DBG & 8): per-workgroup phase time stamps (s_memtime) into the buffer passed as res2
     unsigned long long ts0 = 0, ts1 = 0, ts2 = 0;
-    const bool stamp = (p.dbg & 8) != 0;
+    const bool stamp = (I2R_DBG(p) & 8) != 0;
     const int bid_stamp = bid;
     if (stamp) ts0 = __builtin_amdgcn_s_memtime();
     const int lane = tid & 63, wave = tid >> 6;
@@ -384,7 +392,7 @@ __device__ __forceinline__ void conv_body(const ConvK& p, int bid, f32x4* lds) {
         int cs_n = 0, tx_n = 0, ty_n = 0;  // position of the next step to fetch
         auto fetch = [&](f32x4(&a)[MT], f32x4(&b)[NT]) {
 #pragma unroll
-            for (int nt = 0; nt < NT; ++nt) b[nt] = (p.dbg & 4) ? wp0[nt * 16] : wp[nt * 16];
+            for (int nt = 0; nt < NT; ++nt) b[nt] = (I2R_DBG(p) & 4) ? wp0[nt * 16] : wp[nt * 16];
             const int abase = (cs_n * 4 + g) * p.plane + ty_n * p.pw + tx_n;
 #pragma unroll
             for (int mt = 0; mt < MT; ++mt) a[mt] = buf[abase + ppix[mt]];
@@ -433,7 +441,7 @@ __device__ __forceinline__ void conv_body(const ConvK& p, int bid, f32x4* lds) {
                 if (uq * 4 < ckg) {
 #pragma unroll
                     for (int j = 0; j < PJ; ++j)
-                        if (!(p.dbg & 2)) v[uq][j] = *reinterpret_cast<const f32x4*>(p.in + goff[j] + c0 + (uq * 4 + ul) * 4);
+                        if (!(I2R_DBG(p) & 2)) v[uq][j] = *reinterpret_cast<const f32x4*>(p.in + goff[j] + c0 + (uq * 4 + ul) * 4);
                 }
             if (p.in2) {
 #pragma unroll
@@ -481,7 +489,7 @@ __device__ __forceinline__ void conv_body(const ConvK& p, int bid, f32x4* lds) {
                 for (int u = 0; u < 4; ++u)
 #pragma unroll
                     for (int j = 0; j < kMaxPP; ++j)
-                        if (j < npp && !(p.dbg & 2)) v[u][j] = *reinterpret_cast<const f32x4*>(p.in + goff[j] + c0 + (cg0 + u) * 4);
+                        if (j < npp && !(I2R_DBG(p) & 2)) v[u][j] = *reinterpret_cast<const f32x4*>(p.in + goff[j] + c0 + (cg0 + u) * 4);
                 if (p.in2) {
 #pragma unroll
                     for (int u = 0; u < 4; ++u)
@@ -758,7 +766,11 @@ static int prepare(const i2r_conv_desc* d, int force_mt, int force_cap, int forc
     k.ph = (th - 1) * d->stride + max_dy + 1;
     k.pw = (tw - 1) * d->stride + max_dx + 1;
     I2R_CHECK_ARG(k.ph * k.pw <= kMaxPP * 256, "i2r_conv: patch %dx%d too large", k.ph, k.pw);
+#ifdef I2R_TUNING
     static const int plane_pad = getenv("I2R_CONV_PLANE_PAD") ? atoi(getenv("I2R_CONV_PLANE_PAD")) : 0;  // tuning switch (LDS banks)
+#else
+    constexpr int plane_pad = 0;
+#endif
     k.plane = cdiv(k.ph * k.pw, 16) * 16 + plane_pad;
     k.tap_kw = max_dx + 1;
     k.tap_kh = max_dy + 1;
@@ -768,7 +780,11 @@ static int prepare(const i2r_conv_desc* d, int force_mt, int force_cap, int forc
     // staging variant: double-buffered chunks when the patch fits 1-2 pixels per thread (the common case); a grouped
     // launch must agree on one variant (force_pf: -1 = free choice, else force_cap/force_pf are imposed)
     const int npp = cdiv(k.ph * k.pw, 256);
+#ifdef I2R_TUNING
     static const int pf_env = getenv("I2R_CONV_PF") ? atoi(getenv("I2R_CONV_PF")) : 1;  // tuning switch: 0 disables prefetch
+#else
+    constexpr int pf_env = 1;
+#endif
     const int cin_g = d->cin / 4;
     int pf = (pf_env && d->dtype == 0 && d->ck == 0 && npp <= 2 && cin_g % 4 == 0) ? npp : 0;
     int cap = 4;
@@ -811,10 +827,14 @@ static int prepare(const i2r_conv_desc* d, int force_mt, int force_cap, int forc
     I2R_CHECK_ARG(lds_bytes <= 160 * 1024, "i2r_conv: LDS %zu B", lds_bytes);
     k.wn = wn;
     k.dtype = d->dtype;
+#ifdef I2R_TUNING
     {
         static const int dbg = getenv("I2R_CONV_DBG") ? atoi(getenv("I2R_CONV_DBG")) : 0;
         k.dbg = dbg;
     }
+#else
+    k.dbg = 0;
+#endif
     const long long nblk = (long long)d->n_img * k.tiles_y * k.tiles_x * k.n_cblk;
     I2R_CHECK_ARG(nblk > 0 && nblk < (1ll << 30), "i2r_conv: grid");
     *nt_out = nt; *mt_out = mt; *cap_out = cap; *pf_out = pf; *lds_out = lds_bytes; *nblk_out = nblk;

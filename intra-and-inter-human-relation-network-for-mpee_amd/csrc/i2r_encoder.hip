@@ -40,6 +40,7 @@ struct EncK {
     float ln_eps, qscale;
     // 16-bit MFMA mode: weights as bf16/f16 [out][in] with the columns of every 32-block permuted to the MFMA operand order
     const void* w_in_lp; const void* w_out_lp; const void* w1_lp; const void* w2_lp;
+    const float* vec_lp;  // 16-bit mode: the per-feature fp32 vectors of the layer, padded to csp = 96 and concatenated (LpVec below)
     // fused K/V projection of the NEXT layer (enc_layer4_k): its in_proj (k, v rows used), destination buffers; null = none
     const float* next_w_in; const float* next_b_in; float* next_kbuf; float* next_vbuf;
     long long* stamp;  // tuning only (env I2R_ENC_STAMP = device address): 8 s_memtime stamps per wave
@@ -231,7 +232,11 @@ __global__ __launch_bounds__(256, 2) void enc_layer4_k(const EncK p) {
     __shared__ __attribute__((aligned(16))) float Ps[P_END];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int li = lane & 15, g = lane >> 4;
+#ifdef I2R_TUNING
 #define STAMP(i) do { if (p.stamp && lane == 0) p.stamp[((size_t)blockIdx.x * 4 + wave) * 8 + (i)] = (long long)__builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define STAMP(i) do { } while (0)
+#endif
     STAMP(0);
 
     // Every GEMM of the layer hands wave w the output fragments w, w+4, ... ("slots"; a slot past the end is computed on a
@@ -611,39 +616,75 @@ __device__ __forceinline__ void gemm_T_lp(const void* W, const float* bias, int 
     }
 }
 
-template <int DC, int DT>
+// Offsets (floats) into EncK::vec_lp: every per-feature vector of the layer padded to csp = DC * 16 (= 96 for d = 96 AND d = 78:
+// the 16-bit MFMA contracts 32 features at a time, so a 78-wide model runs as 3 blocks with zero weights beyond feature 77)
+template <int DC, int FC>
+struct LpVec {
+    static constexpr int csp = DC * 16, dff = FC * 16;
+    static constexpr int BIN = 0, BOUT = 3 * csp, LN1W = 4 * csp, LN1B = 5 * csp, B1 = 6 * csp, B2 = 6 * csp + dff, LN2W = 7 * csp + dff,
+                         LN2B = 8 * csp + dff, END = 9 * csp + dff;
+};
+
+// one 32-feature block c of a token row as the packed B operand: features 32c + 4g.. and 32c + 16 + 4g..; CSR = 16-feature blocks that
+// exist in the HBM row (cs / 16: 6, or 5 for the 80-float rows of d = 78 -- block 5 is read as zeros)
+template <int CSR, int DT>
+__device__ __forceinline__ f32x4 load_xblk(const float* row, const float* prow, int c, int g) {
+    f32x4 a0 = ld4(row + 32 * c + 4 * g), a1 = (f32x4){0.f, 0.f, 0.f, 0.f};
+    if (2 * c + 1 < CSR) a1 = ld4(row + 32 * c + 16 + 4 * g);
+    if (prow) {
+        a0 += ld4(prow + 32 * c + 4 * g);
+        if (2 * c + 1 < CSR) a1 += ld4(prow + 32 * c + 16 + 4 * g);
+    }
+    return pack8<DT>(a0, a1);
+}
+
+// K / V projection, one 32-token block of ONE group per workgroup (blocks are numbered group by group, like the 16-key fragments of
+// the fp32 kernels: block b of group g sits at index sum_{g' < g} ceil(len_g' / 32) + b, so group offsets need no alignment)
+template <int DC, int CSR, int DT>
 __global__ __launch_bounds__(64) void enc_kv_lp_k(const EncK p) {
-    constexpr int cs = DC * 16, KC = DC / 2;
+    constexpr int KC = DC / 2, cs = CSR * 16, csp = DC * 16;
     const int lane = threadIdx.x, li = lane & 15, g = lane >> 4;
-    const int t0 = blockIdx.x * 32;
+    int b = blockIdx.x, gs = 0, ge = 0, base32 = 0;
+    for (int grp = 0; grp < p.n_grp; ++grp) {
+        gs = p.grp_off[grp];
+        ge = p.grp_off[grp + 1];
+        const int nb = (ge - gs + 31) >> 5;
+        if (b < nb) break;
+        b -= nb;
+        base32 += nb;
+    }
+    const int t0 = gs + b * 32;
     // B operands of the two 16-token fragments: src + pos (keys) and src (values), packed to 16 bit like every GEMM input here
     f32x4 xq[2][KC], xs[2][KC];
+    bool valid[2];
 #pragma unroll
     for (int tf = 0; tf < 2; ++tf) {
-        const int row = min(t0 + tf * 16 + li, p.n_tok - 1);  // (rows past the end: finite duplicates, masked as keys)
+        const int tok = t0 + tf * 16 + li;
+        valid[tf] = tok < ge;
+        const int row = valid[tf] ? tok : ge - 1;  // (rows past the group: finite duplicates, masked as keys, zeroed as values)
         const int prow = p.pos_period > 0 ? row % p.pos_period : row;
 #pragma unroll
         for (int c = 0; c < KC; ++c) {
-            const f32x4 a0 = ld4(p.src + (size_t)row * cs + 32 * c + 4 * g), a1 = ld4(p.src + (size_t)row * cs + 32 * c + 16 + 4 * g);
-            xs[tf][c] = pack8<DT>(a0, a1);
-            xq[tf][c] = xs[tf][c];
-            if (p.pos)
-                xq[tf][c] = pack8<DT>(a0 + ld4(p.pos + (size_t)prow * cs + 32 * c + 4 * g), a1 + ld4(p.pos + (size_t)prow * cs + 32 * c + 16 + 4 * g));
+            xs[tf][c] = load_xblk<CSR, DT>(p.src + (size_t)row * cs, nullptr, c, g);
+            xq[tf][c] = p.pos ? load_xblk<CSR, DT>(p.src + (size_t)row * cs, p.pos + (size_t)prow * cs, c, g) : xs[tf][c];
         }
     }
     // K rows of the in_proj: row blocks [DC, 2DC) of the fragment-packed 16-bit matrix, V rows: [2DC, 3DC)
     const unsigned short* w16 = reinterpret_cast<const unsigned short*>(p.w_in_lp);
+    const float* bin = p.vec_lp;  // LpVec::BIN = 0
     f32x4 ak[2][DC], av[2][DC];
-    gemm_T_lp<DC, KC, 2, DT>(w16 + (size_t)DC * KC * 512, p.b_in + cs, cs, xq, li, g, [&](int nt, int tf, f32x4 a) { ak[tf][nt] = a; });
-    gemm_T_lp<DC, KC, 2, DT>(w16 + (size_t)2 * DC * KC * 512, p.b_in + 2 * cs, cs, xs, li, g, [&](int nt, int tf, f32x4 a) { av[tf][nt] = a; });
-    // fragment-packed 16-bit operand images of this 32-token block (blockIdx.x), one 16-byte store per lane:
+    gemm_T_lp<DC, KC, 2, DT>(w16 + (size_t)DC * KC * 512, bin + csp, csp, xq, li, g, [&](int nt, int tf, f32x4 a) { ak[tf][nt] = a; });
+    gemm_T_lp<DC, KC, 2, DT>(w16 + (size_t)2 * DC * KC * 512, bin + 2 * csp, csp, xs, li, g, [&](int nt, int tf, f32x4 a) {
+        av[tf][nt] = valid[tf] ? a : (f32x4){0.f, 0.f, 0.f, 0.f};
+    });
+    // fragment-packed 16-bit operand images of this 32-token block, one 16-byte store per lane:
     //   K:   [(blk*2 + tf)*KC + c][lane][8]      lane (li, g): key 16tf + li, the 8 permuted features g*8.. of 32-block c
     //   V^T: [blk*DC + nt][lane'][8]              lane' (li' = feature in fragment nt, g' = key quad): 8 keys in the block's
     //        permuted order (position 8*((k%16)/4) + 4*(k/16) + k%4); a 4x4 quad transpose turns (key li, features 4g+r) into
     //        (feature 4g + (li&3), keys 4(li>>2) + r') so both 16-key halves pack into the destination lane's 16 bytes
     unsigned short* k16 = reinterpret_cast<unsigned short*>(p.kbuf);
     unsigned short* v16 = reinterpret_cast<unsigned short*>(p.vbuf);
-    const size_t blk = blockIdx.x;
+    const size_t blk = (size_t)(base32 + b);
 #pragma unroll
     for (int c = 0; c < KC; ++c)
 #pragma unroll
@@ -656,23 +697,26 @@ __global__ __launch_bounds__(64) void enc_kv_lp_k(const EncK p) {
     }
 }
 
-template <int DC, int FC, int QF, int DT>
+template <int DC, int FC, int QF, int DT, int CSR>
 __global__ __launch_bounds__(64) void enc_layer_lp_k(const EncK p) {
-    constexpr int cs = DC * 16, dff = FC * 16, KC = DC / 2, FKC = FC / 2;
+    constexpr int cs = CSR * 16, csp = DC * 16, dff = FC * 16, KC = DC / 2, FKC = FC / 2;
+    typedef LpVec<DC, FC> V;
     const int lane = threadIdx.x, li = lane & 15, g = lane >> 4;
     constexpr int QT = QF * 16;
-    int b = blockIdx.x, gs = 0, ge = 0;
+    int b = blockIdx.x, gs = 0, ge = 0, base32 = 0;
     for (int grp = 0; grp < p.n_grp; ++grp) {
         gs = p.grp_off[grp];
         ge = p.grp_off[grp + 1];
         const int nq = (ge - gs + QT - 1) / QT;
         if (b < nq) break;
         b -= nq;
+        base32 += (ge - gs + 31) >> 5;
     }
     const int q0 = gs + b * QT;
     int qrow[QF];
 #pragma unroll
     for (int qf = 0; qf < QF; ++qf) qrow[qf] = min(q0 + qf * 16 + li, ge - 1);
+    const float* vec = p.vec_lp;
 
     // ---- q projection: B operand = packed (src + pos) ----
     f32x4 qB[QF][KC];
@@ -682,24 +726,18 @@ __global__ __launch_bounds__(64) void enc_layer_lp_k(const EncK p) {
         for (int qf = 0; qf < QF; ++qf) {
             const int prow = p.pos_period > 0 ? qrow[qf] % p.pos_period : qrow[qf];
 #pragma unroll
-            for (int c = 0; c < KC; ++c) {
-                f32x4 a0 = ld4(p.src + (size_t)qrow[qf] * cs + 32 * c + 4 * g), a1 = ld4(p.src + (size_t)qrow[qf] * cs + 32 * c + 16 + 4 * g);
-                if (p.pos) {
-                    a0 += ld4(p.pos + (size_t)prow * cs + 32 * c + 4 * g);
-                    a1 += ld4(p.pos + (size_t)prow * cs + 32 * c + 16 + 4 * g);
-                }
-                xB[qf][c] = pack8<DT>(a0, a1);
-            }
+            for (int c = 0; c < KC; ++c)
+                xB[qf][c] = load_xblk<CSR, DT>(p.src + (size_t)qrow[qf] * cs, p.pos ? p.pos + (size_t)prow * cs : nullptr, c, g);
         }
         f32x4 q32[QF][DC];
-        gemm_T_lp<DC, KC, QF, DT>(p.w_in_lp, p.b_in, cs, xB, li, g, [&](int nt, int qf, f32x4 a) { q32[qf][nt] = a * (p.qscale * 1.4426950408889634f); });
+        gemm_T_lp<DC, KC, QF, DT>(p.w_in_lp, vec + V::BIN, csp, xB, li, g, [&](int nt, int qf, f32x4 a) { q32[qf][nt] = a * (p.qscale * 1.4426950408889634f); });
 #pragma unroll
         for (int qf = 0; qf < QF; ++qf)
 #pragma unroll
             for (int c = 0; c < KC; ++c) qB[qf][c] = pack8<DT>(q32[qf][2 * c], q32[qf][2 * c + 1]);
     }
 
-    // ---- flash attention over 32-key blocks; K rows / V^T blocks stream from L2 into registers, one block ahead ----
+    // ---- flash attention over the group's 32-key blocks; K rows / V^T blocks stream from L2 into registers, one block ahead ----
     f32x4 o[QF][DC];
     float m_run[QF], l_run[QF];
 #pragma unroll
@@ -709,8 +747,8 @@ __global__ __launch_bounds__(64) void enc_layer_lp_k(const EncK p) {
 #pragma unroll
         for (int nt = 0; nt < DC; ++nt) o[qf][nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
     }
-    auto fetch_kv = [&](int k0, f32x4(&ka)[2][KC], f32x4(&va)[DC]) {  // fragment-packed images of the 32-key block k0 / 32
-        const size_t blk = (size_t)(k0 >> 5);
+    auto fetch_kv = [&](int k0, f32x4(&ka)[2][KC], f32x4(&va)[DC]) {  // fragment-packed images of the group's block (k0 - gs) / 32
+        const size_t blk = (size_t)(base32 + ((k0 - gs) >> 5));
 #pragma unroll
         for (int kf = 0; kf < 2; ++kf)
 #pragma unroll
@@ -763,11 +801,12 @@ __global__ __launch_bounds__(64) void enc_layer_lp_k(const EncK p) {
     {
         f32x4 ka0[2][KC], va0[DC], ka1[2][KC], va1[DC];
         fetch_kv(gs, ka0, va0);
+        const int last = gs + (((ge - 1 - gs) >> 5) << 5);  // first key of the group's last block
         int k0 = gs;
         for (; k0 + 64 <= ge; k0 += 64) {
             fetch_kv(k0 + 32, ka1, va1);
             attend(k0, ka0, va0);
-            fetch_kv(min(k0 + 64, (ge - 1) & ~31), ka0, va0);  // (look-ahead past the end re-reads the last block, unused)
+            fetch_kv(min(k0 + 64, last), ka0, va0);  // (look-ahead past the end re-reads the last block, unused)
             attend(k0 + 32, ka1, va1);
         }
         if (k0 < ge) {
@@ -786,33 +825,33 @@ __global__ __launch_bounds__(64) void enc_layer_lp_k(const EncK p) {
         for (int c = 0; c < KC; ++c) oB[qf][c] = pack8<DT>(o[qf][2 * c] * inv, o[qf][2 * c + 1] * inv);
     }
     f32x4 x1[QF][DC];
-    gemm_T_lp<DC, KC, QF, DT>(p.w_out_lp, p.b_out, cs, oB, li, g, [&](int nt, int qf, f32x4 a) {
-        x1[qf][nt] = ld4(p.src + (size_t)qrow[qf] * cs + 16 * nt + 4 * g) + a;
+    gemm_T_lp<DC, KC, QF, DT>(p.w_out_lp, vec + V::BOUT, csp, oB, li, g, [&](int nt, int qf, f32x4 a) {
+        x1[qf][nt] = nt < CSR ? ld4(p.src + (size_t)qrow[qf] * cs + 16 * nt + 4 * g) + a : a;  // (features >= cs: zero weights -> a = 0)
     });
     f32x4 x1B[QF][KC];
 #pragma unroll
     for (int qf = 0; qf < QF; ++qf) {
-        layer_norm<DC>(x1[qf], p.ln1_w, p.ln1_b, p.d, p.ln_eps, g);
+        layer_norm<DC>(x1[qf], vec + V::LN1W, vec + V::LN1B, p.d, p.ln_eps, g);
 #pragma unroll
         for (int c = 0; c < KC; ++c) x1B[qf][c] = pack8<DT>(x1[qf][2 * c], x1[qf][2 * c + 1]);
     }
     f32x4 hB[QF][FKC];
     {
         f32x4 hprev[QF];
-        gemm_T_lp<FC, KC, QF, DT>(p.w1_lp, p.b1, cs, x1B, li, g, [&](int ft, int qf, f32x4 a) {
+        gemm_T_lp<FC, KC, QF, DT>(p.w1_lp, vec + V::B1, csp, x1B, li, g, [&](int ft, int qf, f32x4 a) {
 #pragma unroll
             for (int r = 0; r < 4; ++r) a[r] = fmaxf(a[r], 0.f);
             if (ft & 1) hB[qf][ft >> 1] = pack8<DT>(hprev[qf], a); else hprev[qf] = a;
         });
     }
-    gemm_T_lp<DC, FKC, QF, DT>(p.w2_lp, p.b2, dff, hB, li, g, [&](int nt, int qf, f32x4 a) { x1[qf][nt] += a; });
+    gemm_T_lp<DC, FKC, QF, DT>(p.w2_lp, vec + V::B2, dff, hB, li, g, [&](int nt, int qf, f32x4 a) { x1[qf][nt] += a; });
 #pragma unroll
     for (int qf = 0; qf < QF; ++qf) {
-        layer_norm<DC>(x1[qf], p.ln2_w, p.ln2_b, p.d, p.ln_eps, g);
+        layer_norm<DC>(x1[qf], vec + V::LN2W, vec + V::LN2B, p.d, p.ln_eps, g);
         const int qtok = q0 + qf * 16 + li;
         if (qtok < ge) {
 #pragma unroll
-            for (int nt = 0; nt < DC; ++nt) *reinterpret_cast<f32x4*>(p.out + (size_t)qtok * cs + 16 * nt + 4 * g) = x1[qf][nt];
+            for (int nt = 0; nt < CSR; ++nt) *reinterpret_cast<f32x4*>(p.out + (size_t)qtok * cs + 16 * nt + 4 * g) = x1[qf][nt];
         }
     }
 }
@@ -831,19 +870,22 @@ int fill(const i2r_encoder_desc* d, EncK& k) {
     k.n_tok = d->n_tok; k.n_tok_pad = ((d->n_tok + 63) / 64) * 64 + 64; k.n_grp = d->n_grp; k.d = d->d; k.cs = d->cs;
     k.dff_pad = d->dff_pad; k.pos_period = d->pos_period; k.ln_eps = d->ln_eps; k.n_qblk = d->n_qtiles16;
     k.qscale = 1.0f / sqrtf((float)d->d);
-    k.w_in_lp = d->w_in_lp; k.w_out_lp = d->w_out_lp; k.w1_lp = d->w1_lp; k.w2_lp = d->w2_lp;
+    k.w_in_lp = d->w_in_lp; k.w_out_lp = d->w_out_lp; k.w1_lp = d->w1_lp; k.w2_lp = d->w2_lp; k.vec_lp = d->vec_lp;
     k.next_w_in = d->next_w_in; k.next_b_in = d->next_b_in; k.next_kbuf = d->next_kbuf; k.next_vbuf = d->next_vbuf;
-    {   // tuning only: I2R_ENC_STAMP=<device address of 32 B x waves>, I2R_ENC_STAMP_FUSED=1 stamps the layers with a fused K/V tail
+    k.stamp = nullptr;
+#ifdef I2R_TUNING
+    {   // tuning build only: I2R_ENC_STAMP=<device address of 32 B x waves>, I2R_ENC_STAMP_FUSED=1 stamps the layers with a fused K/V tail
         static const char* se = getenv("I2R_ENC_STAMP");
         static const bool fused = getenv("I2R_ENC_STAMP_FUSED") && atoi(getenv("I2R_ENC_STAMP_FUSED"));
         k.stamp = (se && fused == (d->next_w_in != nullptr)) ? (long long*)strtoull(se, nullptr, 0) : nullptr;
     }
+#endif
     I2R_CHECK_ARG(!d->next_w_in || (d->next_b_in && d->next_kbuf && d->next_vbuf && d->next_kbuf != d->kbuf && d->next_vbuf != d->vbuf && d->dtype == 0),
                   "i2r_encoder: fused next-layer K/V needs its own buffers (fp32 mode only)");
     I2R_CHECK_ARG(d->dtype >= 0 && d->dtype <= 2, "i2r_encoder: dtype %d", d->dtype);
     if (d->dtype != 0)
-        I2R_CHECK_ARG(d->cs == 96 && d->w_in_lp && d->w_out_lp && d->w1_lp && d->w2_lp && d->n_qtiles16 > 0 && d->n_qtiles64 > 0,
-                      "i2r_encoder: the 16-bit MFMA mode needs cs == 96 and the permuted 16-bit weights");
+        I2R_CHECK_ARG(d->w_in_lp && d->w_out_lp && d->w1_lp && d->w2_lp && d->vec_lp && d->n_qtiles16 > 0 && d->n_qtiles32 > 0 && d->n_qtiles64 > 0,
+                      "i2r_encoder: the 16-bit MFMA mode needs the permuted 16-bit weights, vec_lp and the tile counts");
     return I2R_OK;
 }
 
@@ -853,12 +895,17 @@ extern "C" int i2r_encoder_kv(const i2r_encoder_desc* d, void* stream) {
     EncK k;
     int rc = fill(d, k);
     if (rc) return rc;
-    const unsigned nblk = (unsigned)((d->n_tok + 31) / 32);
-    if (d->dtype == 1)
-        hipLaunchKernelGGL((enc_kv_lp_k<6, 1>), dim3(nblk), dim3(64), 0, (hipStream_t)stream, k);
-    else if (d->dtype == 2)
-        hipLaunchKernelGGL((enc_kv_lp_k<6, 2>), dim3(nblk), dim3(64), 0, (hipStream_t)stream, k);
-    else {
+    if (d->dtype != 0) {
+        const unsigned nblk = (unsigned)d->n_qtiles32;  // one 32-token block of a group per workgroup
+        const bool c6 = d->cs == 96;
+        if (d->dtype == 1) {
+            if (c6) hipLaunchKernelGGL((enc_kv_lp_k<6, 6, 1>), dim3(nblk), dim3(64), 0, (hipStream_t)stream, k);
+            else hipLaunchKernelGGL((enc_kv_lp_k<6, 5, 1>), dim3(nblk), dim3(64), 0, (hipStream_t)stream, k);
+        } else {
+            if (c6) hipLaunchKernelGGL((enc_kv_lp_k<6, 6, 2>), dim3(nblk), dim3(64), 0, (hipStream_t)stream, k);
+            else hipLaunchKernelGGL((enc_kv_lp_k<6, 5, 2>), dim3(nblk), dim3(64), 0, (hipStream_t)stream, k);
+        }
+    } else {
         I2R_CHECK_ARG(d->n_qtiles16 > 0, "i2r_encoder_kv: n_qtiles16");
         if (d->cs == 96)
             hipLaunchKernelGGL(enc_kv_k<6>, dim3((unsigned)d->n_qtiles16), dim3(256), 0, (hipStream_t)stream, k);
@@ -869,6 +916,14 @@ extern "C" int i2r_encoder_kv(const i2r_encoder_desc* d, void* stream) {
     return I2R_OK;
 }
 
+namespace {
+template <int QF, int DT>
+void launch_lp(const EncK& k, bool c6, unsigned grid, hipStream_t st) {
+    if (c6) hipLaunchKernelGGL((enc_layer_lp_k<6, 12, QF, DT, 6>), dim3(grid), dim3(64), 0, st, k);
+    else hipLaunchKernelGGL((enc_layer_lp_k<6, 12, QF, DT, 5>), dim3(grid), dim3(64), 0, st, k);
+}
+}  // namespace
+
 extern "C" int i2r_encoder_layer(const i2r_encoder_desc* d, void* stream) {
     EncK k;
     int rc = fill(d, k);
@@ -877,19 +932,22 @@ extern "C" int i2r_encoder_layer(const i2r_encoder_desc* d, void* stream) {
         // 64 queries per wave when that still gives >= 2 waves per SIMD-pair of the chip, else 16 (more, shorter waves)
         const bool big = d->n_qtiles64 >= 512;
         const unsigned grid = (unsigned)(big ? d->n_qtiles64 : d->n_qtiles16);
+        const bool c6 = d->cs == 96;
         if (d->dtype == 1) {
-            if (big) hipLaunchKernelGGL((enc_layer_lp_k<6, 12, 4, 1>), dim3(grid), dim3(64), 0, (hipStream_t)stream, k);
-            else hipLaunchKernelGGL((enc_layer_lp_k<6, 12, 1, 1>), dim3(grid), dim3(64), 0, (hipStream_t)stream, k);
+            if (big) launch_lp<4, 1>(k, c6, grid, (hipStream_t)stream); else launch_lp<1, 1>(k, c6, grid, (hipStream_t)stream);
         } else {
-            if (big) hipLaunchKernelGGL((enc_layer_lp_k<6, 12, 4, 2>), dim3(grid), dim3(64), 0, (hipStream_t)stream, k);
-            else hipLaunchKernelGGL((enc_layer_lp_k<6, 12, 1, 2>), dim3(grid), dim3(64), 0, (hipStream_t)stream, k);
+            if (big) launch_lp<4, 2>(k, c6, grid, (hipStream_t)stream); else launch_lp<1, 2>(k, c6, grid, (hipStream_t)stream);
         }
         I2R_CHECK_LAUNCH("i2r_encoder_layer");
         return I2R_OK;
     }
     I2R_CHECK_ARG(d->n_qtiles16 > 0 && d->n_qtiles32 > 0, "i2r_encoder_layer: n_qtiles16 / n_qtiles32");
     // two 16-query tiles per workgroup halve the K / V traffic per MFMA; worth it once there are enough workgroups for the chip
+#ifdef I2R_TUNING
     static const int qt_env = getenv("I2R_ENC_QT") ? atoi(getenv("I2R_ENC_QT")) : 0;  // tuning switch: force 1 or 2
+#else
+    constexpr int qt_env = 0;
+#endif
     const int qt = qt_env ? qt_env : (d->n_qtiles32 >= 512 ? 2 : 1);
     k.n_qblk = qt == 2 ? d->n_qtiles32 : d->n_qtiles16;
     const unsigned grid = (unsigned)((k.n_qblk + 7) / 8 * 8);  // (XCD-major tile order inside the kernel)

@@ -10,7 +10,7 @@ namespace {
 template <int CIN>
 __global__ __launch_bounds__(256) void stem_conv_k(const float* __restrict__ in, const float* __restrict__ w,
                                                    const float* __restrict__ bias, float* __restrict__ out, int n_img,
-                                                   int in_h, int in_w, int out_h, int out_w, int cout, int out_cs, int n_src) {
+                                                   int in_h, int in_w, int out_h, int out_w, int cout, int out_cs, int n_src, int n_valid) {
     extern __shared__ __attribute__((aligned(16))) float wl[];  // [9*CIN][cout] weights + [cout] bias
     for (int i = threadIdx.x; i < (9 * CIN + 1) * cout; i += 256) wl[i] = i < 9 * CIN * cout ? w[i] : bias[i - 9 * CIN * cout];
     __syncthreads();
@@ -23,8 +23,9 @@ __global__ __launch_bounds__(256) void stem_conv_k(const float* __restrict__ in,
     const int ox = (int)(pix % out_w);
     const int oy = (int)((pix / out_w) % out_h);
     const int img = (int)(pix / ((long long)out_w * out_h));
-    // images >= n_src are the horizontally MIRRORED copies of images 0..n_src-1 (flip test batched into one forward)
-    const int simg = img % n_src;
+    // images >= n_src are the horizontally MIRRORED copies of images 0..n_src-1 (flip test batched into one forward);
+    // slots n_valid..n_src-1 are capacity padding of the program (they re-read the last real crop, their results are dropped)
+    const int simg = min(img % n_src, n_valid - 1);
     const bool mirror = img >= n_src;
 
     // input taps first (9*CIN scalars), then the FMAs against the LDS-resident weights (same address across the 16 lanes
@@ -67,6 +68,86 @@ __global__ __launch_bounds__(256) void stem_conv_k(const float* __restrict__ in,
     for (int q = 0; q < 4; ++q)
         o[q] = (f32x4){fmaxf(acc[q * 4], 0.f), fmaxf(acc[q * 4 + 1], 0.f), fmaxf(acc[q * 4 + 2], 0.f),
                        fmaxf(acc[q * 4 + 3], 0.f)};
+}
+
+// PositionEmbeddingImage mode 'res' front end (position_embedding.py:14-17,93-95): conv_pre (1 -> 3, 3x3, pad 1, no bias) followed
+// by torchvision resnet18's conv1 (3 -> 64, 7x7, stride 2, pad 3) + bn1 (folded) + ReLU, boundary NCHW mask -> NHWC.
+// The two convolutions are NOT merged into one 9x9 filter: conv1 zero-pads conv_pre's OUTPUT, so near the border the composite is
+// not a convolution of the mask.  One workgroup = an 8x8 output tile x 64 channels: the 23x23 mask patch goes to LDS, the 21x21x3
+// conv_pre patch is computed into LDS (exact zeros outside the image), then thread (pixel, 16-channel group) runs the 147-tap
+// dot products against the LDS-resident filter (VALU-bound: 0.23 GFLOP per crop).
+__global__ __launch_bounds__(256) void pe_res_stem_k(const float* __restrict__ in, const float* __restrict__ w_pre,
+                                                     const float* __restrict__ w7, const float* __restrict__ bias,
+                                                     float* __restrict__ out, int n_img, int in_h, int in_w, int out_h, int out_w,
+                                                     int out_cs, int n_src, int n_valid, int tiles_x, int tiles_y) {
+    constexpr int T = 8, PW = 2 * T + 5, MW = PW + 2, COUT = 64;
+    __shared__ __attribute__((aligned(16))) float wl[147 * COUT + COUT];
+    __shared__ float ms[MW * MW];
+    __shared__ float pre[3 * PW * PW];
+    __shared__ float wp[27];
+    const int tid = threadIdx.x;
+    int bid = blockIdx.x;
+    const int tx = bid % tiles_x; bid /= tiles_x;
+    const int ty = bid % tiles_y;
+    const int img = bid / tiles_y;
+    const int simg = min(img % n_src, n_valid - 1);
+    const bool mirror = img >= n_src;
+    for (int i = tid; i < (147 * COUT + COUT) / 4; i += 256)
+        reinterpret_cast<f32x4*>(wl)[i] = i < 147 * COUT / 4 ? reinterpret_cast<const f32x4*>(w7)[i] : reinterpret_cast<const f32x4*>(bias)[i - 147 * COUT / 4];
+    if (tid < 27) wp[tid] = w_pre[tid];
+    const int oy0 = ty * T, ox0 = tx * T;
+    const int py0 = 2 * oy0 - 3, px0 = 2 * ox0 - 3;  // image coordinate of pre[.][0][0]
+    for (int i = tid; i < MW * MW; i += 256) {
+        const int y = py0 - 1 + i / MW, x = px0 - 1 + i % MW;
+        float v = 0.f;
+        if (y >= 0 && y < in_h && x >= 0 && x < in_w) v = in[((size_t)simg * in_h + y) * in_w + (mirror ? in_w - 1 - x : x)];
+        ms[i] = v;
+    }
+    __syncthreads();
+    for (int i = tid; i < 3 * PW * PW; i += 256) {
+        const int c = i / (PW * PW), r = i - c * PW * PW;
+        const int yy = r / PW, xx = r - yy * PW;
+        const int y = py0 + yy, x = px0 + xx;
+        float a = 0.f;
+        if (y >= 0 && y < in_h && x >= 0 && x < in_w) {  // conv1 pads conv_pre's output with zeros
+#pragma unroll
+            for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+                for (int kx = 0; kx < 3; ++kx) a = fmaf(ms[(yy + ky) * MW + xx + kx], wp[(ky * 3 + kx) * 3 + c], a);
+        }
+        pre[i] = a;
+    }
+    __syncthreads();
+    const int cg = tid & 3, p = tid >> 2;
+    const int ly = p >> 3, lx = p & 7;
+    float acc[16];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const f32x4 bv = *reinterpret_cast<const f32x4*>(wl + 147 * COUT + cg * 16 + q * 4);
+        acc[q * 4] = bv[0]; acc[q * 4 + 1] = bv[1]; acc[q * 4 + 2] = bv[2]; acc[q * 4 + 3] = bv[3];
+    }
+    for (int ky = 0; ky < 7; ++ky)
+        for (int kx = 0; kx < 7; ++kx) {
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+                const float x = pre[c * PW * PW + (2 * ly + ky) * PW + 2 * lx + kx];
+                const f32x4* wr = reinterpret_cast<const f32x4*>(wl + ((ky * 7 + kx) * 3 + c) * COUT + cg * 16);
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const f32x4 wv = wr[q];
+                    acc[q * 4 + 0] = fmaf(x, wv[0], acc[q * 4 + 0]);
+                    acc[q * 4 + 1] = fmaf(x, wv[1], acc[q * 4 + 1]);
+                    acc[q * 4 + 2] = fmaf(x, wv[2], acc[q * 4 + 2]);
+                    acc[q * 4 + 3] = fmaf(x, wv[3], acc[q * 4 + 3]);
+                }
+            }
+        }
+    const int oy = oy0 + ly, ox = ox0 + lx;
+    if (oy >= out_h || ox >= out_w) return;
+    f32x4* o = reinterpret_cast<f32x4*>(out + (((size_t)img * out_h + oy) * out_w + ox) * out_cs + cg * 16);
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+        o[q] = (f32x4){fmaxf(acc[q * 4], 0.f), fmaxf(acc[q * 4 + 1], 0.f), fmaxf(acc[q * 4 + 2], 0.f), fmaxf(acc[q * 4 + 3], 0.f)};
 }
 
 // nn.MaxPool2d(3, 2, 1) on NHWC; thread = one output pixel x 4 channels (padding behaves as -inf)
@@ -132,9 +213,11 @@ __global__ __launch_bounds__(256) void head_k(const float* __restrict__ in, cons
 }  // namespace
 
 extern "C" int i2r_stem_conv(const float* in_nchw, const float* w, const float* bias, float* out_nhwc, int32_t n_img,
-                             int32_t cin, int32_t in_h, int32_t in_w, int32_t cout, int32_t out_cs, int32_t n_src, void* stream) {
+                             int32_t cin, int32_t in_h, int32_t in_w, int32_t cout, int32_t out_cs, int32_t n_src, int32_t n_valid,
+                             void* stream) {
     I2R_CHECK_ARG(in_nchw && w && bias && out_nhwc, "i2r_stem_conv: null pointer");
-    I2R_CHECK_ARG(n_src >= 1 && (n_img == n_src || n_img == 2 * n_src), "i2r_stem_conv: n_img=%d n_src=%d", n_img, n_src);
+    I2R_CHECK_ARG(n_src >= 1 && (n_img == n_src || n_img == 2 * n_src) && n_valid >= 1 && n_valid <= n_src,
+                  "i2r_stem_conv: n_img=%d n_src=%d n_valid=%d", n_img, n_src, n_valid);
     I2R_CHECK_ARG(cout > 0 && cout % 16 == 0 && out_cs >= cout && out_cs % 4 == 0, "i2r_stem_conv: cout=%d out_cs=%d", cout, out_cs);
     I2R_CHECK_ARG(cin == 1 || cin == 3, "i2r_stem_conv: cin=%d (1 or 3)", cin);
     const int out_h = (in_h - 1) / 2 + 1, out_w = (in_w - 1) / 2 + 1;
@@ -142,11 +225,26 @@ extern "C" int i2r_stem_conv(const float* in_nchw, const float* w, const float* 
     const unsigned nblk = (unsigned)((nthr + 255) / 256);
     if (cin == 3)
         hipLaunchKernelGGL(stem_conv_k<3>, dim3(nblk), dim3(256), (size_t)(27 + 1) * cout * sizeof(float), (hipStream_t)stream, in_nchw, w, bias, out_nhwc, n_img,
-                           in_h, in_w, out_h, out_w, cout, out_cs, n_src);
+                           in_h, in_w, out_h, out_w, cout, out_cs, n_src, n_valid);
     else
         hipLaunchKernelGGL(stem_conv_k<1>, dim3(nblk), dim3(256), (size_t)(9 + 1) * cout * sizeof(float), (hipStream_t)stream, in_nchw, w, bias, out_nhwc, n_img,
-                           in_h, in_w, out_h, out_w, cout, out_cs, n_src);
+                           in_h, in_w, out_h, out_w, cout, out_cs, n_src, n_valid);
     I2R_CHECK_LAUNCH("i2r_stem_conv");
+    return I2R_OK;
+}
+
+extern "C" int i2r_pe_res_stem(const float* mask_nchw, const float* w_pre, const float* w7, const float* bias, float* out_nhwc,
+                               int32_t n_img, int32_t in_h, int32_t in_w, int32_t cout, int32_t out_cs, int32_t n_src, int32_t n_valid,
+                               void* stream) {
+    I2R_CHECK_ARG(mask_nchw && w_pre && w7 && bias && out_nhwc, "i2r_pe_res_stem: null pointer");
+    I2R_CHECK_ARG(n_src >= 1 && (n_img == n_src || n_img == 2 * n_src) && n_valid >= 1 && n_valid <= n_src,
+                  "i2r_pe_res_stem: n_img=%d n_src=%d n_valid=%d", n_img, n_src, n_valid);
+    I2R_CHECK_ARG(cout == 64 && out_cs >= cout && out_cs % 4 == 0, "i2r_pe_res_stem: cout=%d (resnet18 conv1 has 64) out_cs=%d", cout, out_cs);
+    const int out_h = (in_h - 1) / 2 + 1, out_w = (in_w - 1) / 2 + 1;
+    const int tiles_y = (out_h + 7) / 8, tiles_x = (out_w + 7) / 8;
+    hipLaunchKernelGGL(pe_res_stem_k, dim3((unsigned)(n_img * tiles_y * tiles_x)), dim3(256), 0, (hipStream_t)stream, mask_nchw, w_pre, w7,
+                       bias, out_nhwc, n_img, in_h, in_w, out_h, out_w, out_cs, n_src, n_valid, tiles_x, tiles_y);
+    I2R_CHECK_LAUNCH("i2r_pe_res_stem");
     return I2R_OK;
 }
 

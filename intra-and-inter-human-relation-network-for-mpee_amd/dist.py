@@ -2,28 +2,41 @@
 
 Persons interact only within an image (reference interformer.py:294-306: the encoder's batch dim is the image),
 so images are the independent unit: rank r runs the full forward on its images with replicated weights and the
-per-crop heatmaps are all-gathered once per step (RCCL over xGMI when backend == 'nccl'; gloo in the CPU tests).
+per-crop results are all-gathered once per step (RCCL over xGMI when backend == 'nccl'; gloo in the CPU tests): the decoded
+key points [S, J, 3] (gather_keypoints: what validate() keeps of a batch, function.py:190-200 -- 168 B per crop at J = 14) or,
+optionally, the heat maps themselves (gather_heatmaps: 172 KB per crop).
 The reference itself has no counterpart (its DataParallel/DDP eval does not shard).
 """
 import torch
 import torch.distributed as dist
 
 
-def shard_images(length, rank, world):
-    """Contiguous image chunks balanced by crop count (cost is proportional to crops).
-    -> (image index range [lo, hi), crop offset of image lo)."""
+def shard_bounds(length, world):
+    """Image index cuts [b_0 = 0, b_1, ..., b_world = n] of contiguous chunks balanced by crop count (cost is proportional to
+    crops).  Every rank gets at least one image whenever there are at least as many images as ranks (a rank with an empty shard
+    would skip the forward and hang the collective); with fewer images than ranks the trailing ranks are empty."""
     n = len(length)
     total = sum(length)
-    bounds, acc, nxt = [0], 0, 1
+    bounds, acc = [0], 0
     for i, l in enumerate(length):
         acc += l
-        # cut after image i when the running crop count passes the next equal share (keep >= 1 image per remaining rank)
-        while nxt < world and acc >= total * nxt / world and (n - (i + 1)) >= (world - nxt) and len(bounds) == nxt:
+        nxt = len(bounds)                     # the next cut to place (1 .. world-1)
+        if nxt >= world:
+            break
+        left_imgs, left_ranks = n - (i + 1), world - nxt
+        # at most ONE cut per image: after image i when the running crop count has reached the next equal share, or when the
+        # images left are just enough to give every remaining rank one
+        if left_imgs >= left_ranks and (acc * world >= total * nxt) or left_imgs == left_ranks:
             bounds.append(i + 1)
-            nxt += 1
     while len(bounds) < world:
-        bounds.append(min(n, bounds[-1] + 1))
+        bounds.append(n)
     bounds.append(n)
+    return bounds
+
+
+def shard_images(length, rank, world):
+    """-> (image index range [lo, hi) of this rank, crop offset of image lo)."""
+    bounds = shard_bounds(length, world)
     lo, hi = bounds[rank], bounds[rank + 1]
     return lo, hi, sum(length[:lo])
 
@@ -79,3 +92,13 @@ def gather_heatmaps(local, counts, group=None):
         return out
     out = out.view(world, smax, *local.shape[1:])
     return torch.cat([out[r, :c] for r, c in enumerate(counts)], dim=0)
+
+
+def gather_keypoints(preds, maxvals, counts, group=None, async_op=False):
+    """The per-step collective when the decode runs on the device (caller.decode): preds [S_r, J, 2] + maxvals [S_r, J, 1] ->
+    [sum(counts), J, 3] (x, y, score) in global crop order -- what validate() stores per batch (all_preds[idx:idx+n, :, 0:2] = preds,
+    [..., 2:3] = maxvals, lib/core/function.py:193-195).  ~1000x smaller than the heat maps.  async_op: returns a PendingGather."""
+    kp = torch.cat([preds, maxvals], dim=2).contiguous()
+    if async_op:
+        return gather_heatmaps_async(kp, counts, group)
+    return gather_heatmaps(kp, counts, group)

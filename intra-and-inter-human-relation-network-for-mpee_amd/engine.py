@@ -162,6 +162,22 @@ class Packer:
         return dict(w=self._dev(wf.permute(2, 3, 1, 0).reshape(9, cin, cout).float()), bias=self._dev(bf.float()),
                     cin=cin, cout=cout)
 
+    def pe_res(self, p):
+        """PositionEmbeddingImage mode 'res' (position_embedding.py:14-18): conv_pre 1->3 (3x3, no bias) and torchvision resnet18
+        children()[:5] = conv1 7x7-s2 3->64 + bn1 + relu + maxpool + layer1 (2 BasicBlocks of 64), then conv_end 64->d (3x3, no BN)."""
+        w_pre = self.sd[p + ".conv_pre.weight"]           # [3, 1, 3, 3]
+        assert tuple(w_pre.shape) == (3, 1, 3, 3)
+        w7 = self.sd[p + ".res.0.weight"]                 # [64, 3, 7, 7]
+        assert tuple(w7.shape) == (64, 3, 7, 7)
+        wf, bf = fold_bn(w7, self._bn(p + ".res.1"), None, 1e-5)
+        blocks = []
+        for b in range(2):
+            q = "%s.res.4.%d" % (p, b)
+            blocks.append((self.conv(q + ".conv1", q + ".bn1"), self.conv(q + ".conv2", q + ".bn2")))
+        return dict(w_pre=self._dev(w_pre.view(3, 9).t().contiguous().float()),               # [tap][c]
+                    w7=self._dev(wf.permute(2, 3, 1, 0).reshape(49 * 3, 64).float()), bias=self._dev(bf.float()), cout=64,
+                    blocks=blocks, conv_end=self.conv(p + ".conv_end"))
+
     def head(self, key):
         w = self.sd[key + ".weight"]
         cout, cin, kh, kw = w.shape
@@ -196,10 +212,13 @@ class Packer:
             w2=padm(s[p + ".linear2.weight"], cs, fs), b2=padv(s[p + ".linear2.bias"], cs),
             ln2_w=padv(s[p + ".norm2.weight"], cs), ln2_b=padv(s[p + ".norm2.bias"], cs))
         lp = {}
-        if self.dtype != 0 and cs == 96:
-            # 16-bit copies for the 16-bit MFMA encoder: columns of every 32-block permuted to the operand order
+        if self.dtype != 0:
+            # 16-bit copies for the 16-bit MFMA encoder, model dim padded to csp = 96 (three 32-feature MFMA steps) for d = 96 and
+            # d = 78 alike; columns of every 32-block permuted to the operand order
             # new position 8g + 4*half + r  <-  column 32c + 16*half + 4g + r   (csrc/i2r_encoder.hip)
             tdt = torch.bfloat16 if self.dtype == 1 else torch.float16
+            csp = 96
+            assert cs <= csp and fs == 192
 
             def perm(m):
                 rows, cols = m.shape
@@ -207,7 +226,13 @@ class Packer:
                 v = v.permute(0, 1, 3, 2, 4).reshape(rows // 16, 16, cols // 32, 4, 8)   # [rb, li, c, g, (half, r)]
                 # ... and fragment-packed like the fp32 matrices: [rb][c][g][li][8] = one 1 KB contiguous load per fragment
                 return v.permute(0, 2, 3, 1, 4).reshape(rows, cols).to(tdt).contiguous()
-            lp = dict(w_in_lp=perm(t["w_in"]), w_out_lp=perm(t["w_out"]), w1_lp=perm(t["w1"]), w2_lp=perm(t["w2"]))
+            w_in_p = torch.cat([padm(wi[i * d:(i + 1) * d], csp, csp) for i in range(3)], 0)
+            b_in_p = torch.cat([padv(bi[i * d:(i + 1) * d], csp) for i in range(3)], 0)
+            lp = dict(w_in_lp=perm(w_in_p), w_out_lp=perm(padm(s[p + ".self_attn.out_proj.weight"], csp, csp)),
+                      w1_lp=perm(padm(s[p + ".linear1.weight"], fs, csp)), w2_lp=perm(padm(s[p + ".linear2.weight"], csp, fs)),
+                      vec_lp=torch.cat([b_in_p, padv(s[p + ".self_attn.out_proj.bias"], csp), padv(s[p + ".norm1.weight"], csp),
+                                        padv(s[p + ".norm1.bias"], csp), padv(s[p + ".linear1.bias"], fs), padv(s[p + ".linear2.bias"], csp),
+                                        padv(s[p + ".norm2.weight"], csp), padv(s[p + ".norm2.bias"], csp)]).float())
             lp = {k: self._dev(v) for k, v in lp.items()}
         for k in ("w_in", "w_out", "w1", "w2"):
             t[k] = pack_frag(t[k])
@@ -355,6 +380,7 @@ class Program:
         self.lane_pool = {}  # (lane, numel) -> buffers released by that lane inside the current fork region
         self.lane_ctx = 0    # lane whose ops are being emitted (set by the emitters inside a fork region)
         self.groupings = []  # (grouping, tokens per crop) of encoders whose groups follow `length` (set_groups)
+        self.enc_stacks = []
         self.in_fork = False
         self.nbytes = 0
         self._c_ops = None
@@ -385,9 +411,17 @@ class Program:
         """n_src < n: crops n_src.. are computed from the mirrored input (flip test batched into the same forward)."""
         out = self.alloc(n, (h - 1) // 2 + 1, (w - 1) // 2 + 1, st["cout"])
         self.keep.append(st)
-        a = cabi.StemArgs(in_ptr, st["w"].data_ptr(), st["bias"].data_ptr(), out.ptr, n, st["cin"], h, w, st["cout"], out.cs,
-                          n if n_src is None else n_src)
+        ns = n if n_src is None else n_src
+        a = cabi.StemArgs(in_ptr, st["w"].data_ptr(), st["bias"].data_ptr(), out.ptr, n, st["cin"], h, w, st["cout"], out.cs, ns, ns)
         self.ops.append((cabi.OP_STEM, lane, a))
+        return out, a
+
+    def pe_res_stem(self, st, n, h, w, lane=0, n_src=None):
+        out = self.alloc(n, (h - 1) // 2 + 1, (w - 1) // 2 + 1, st["cout"])
+        self.keep.append(st)
+        ns = n if n_src is None else n_src
+        a = cabi.PeResArgs(0, st["w_pre"].data_ptr(), st["w7"].data_ptr(), st["bias"].data_ptr(), out.ptr, n, h, w, st["cout"], out.cs, ns, ns)
+        self.ops.append((cabi.OP_PE_RES_STEM, lane, a))
         return out, a
 
     def conv(self, x, pc, relu=False, res1=None, res2=None, res_post=None, in2=None, up=1, out=None, out_step=1,
@@ -615,7 +649,7 @@ class Program:
         nbuf = 2 if fuse_kv else 1
         # K / V^T workspaces: fragment-packed per 16-token tile of a group (fp32 kernels; <= n_tok/16 + groups tiles) or the
         # 16-bit kernels' [n_tok, cs] / [cs, n_pad] images -- sized for either
-        kv_floats = max((n_tok // 16 + x.n + 1) * 16 * cs, cs * n_pad)
+        kv_floats = max((n_tok // 16 + x.n + 1) * 16 * cs, (n_tok // 32 + x.n + 1) * 32 * 96 // 2)
         kbufs = [torch.zeros(kv_floats, dtype=torch.float32, device=self.device) for _ in range(nbuf)]
         vbufs = [torch.zeros(kv_floats, dtype=torch.float32, device=self.device) for _ in range(nbuf)]
         goff = torch.zeros(x.n + 1, dtype=torch.int32, device=self.device)
@@ -634,7 +668,7 @@ class Program:
             d.n_tok, d.d, d.cs, d.dff_pad = n_tok, L["d"], cs, L["dff_pad"]
             d.pos_period, d.ln_eps = pos_period, 1e-5
             if L.get("dtype", 0):
-                d.w_in_lp, d.w_out_lp, d.w1_lp, d.w2_lp = (L[k].data_ptr() for k in ("w_in_lp", "w_out_lp", "w1_lp", "w2_lp"))
+                d.w_in_lp, d.w_out_lp, d.w1_lp, d.w2_lp, d.vec_lp = (L[k].data_ptr() for k in ("w_in_lp", "w_out_lp", "w1_lp", "w2_lp", "vec_lp"))
             if fuse_kv and i + 1 < len(layers):
                 nxt = layers[i + 1]
                 d.next_w_in, d.next_b_in = nxt["w_in"].data_ptr(), nxt["b_in"].data_ptr()
@@ -648,6 +682,7 @@ class Program:
             cur = out
         grouping = dict(descs=descs, goff=goff, current=None)
         self.set_groups(grouping, grp_off_host)
+        self.enc_stacks.append(grouping)  # every encoder stack of the program (bench.py: algorithmic FLOPs of the attention blocks)
         if regroupable:
             self.groupings.append((grouping, x.h * x.w))
         return cur
@@ -657,15 +692,14 @@ class Program:
         offs = tuple(int(o) for o in grp_off_host)
         if grouping["current"] == offs:
             return
-        assert all(o % 4 == 0 for o in offs), "token group offsets must be multiples of 4"
         assert len(offs) <= grouping["goff"].numel()
         lens = [offs[i + 1] - offs[i] for i in range(len(offs) - 1)]
+        assert all(l > 0 for l in lens)
         nq, nq16, nq64 = (sum(-(-l // t) for l in lens) for t in (32, 16, 64))
-        lp_ok = all(o % 32 == 0 for o in offs)  # the 16-bit kernels walk absolute 32-key blocks
         grouping["goff"][:len(offs)].copy_(torch.tensor(offs, dtype=torch.int32))
         for d, dt in grouping["descs"]:
             d.n_grp, d.n_qtiles32, d.n_qtiles16, d.n_qtiles64 = len(offs) - 1, nq, nq16, nq64
-            d.dtype = dt if lp_ok else 0
+            d.dtype = dt  # (both kernel families take any group offsets: K / V blocks are numbered group by group)
         grouping["current"] = offs
 
     def fork(self, mask):
@@ -1040,16 +1074,50 @@ class HRFormerB:
         return ys, stem_args
 
 
+def validate_config(cfg, name=None):
+    """Everything the engine refuses, checked without a GPU (Engine.__init__ runs it first; tests/test_host.py runs it over all ten
+    reference experiments/*.yaml).  Raises NotImplementedError for a combination the reference can express but no shipped yaml uses."""
+    M = cfg["MODEL"]
+    name = name or M["NAME"]
+    if M["N_HEAD"] != 1:
+        raise NotImplementedError("MODEL.N_HEAD=%r: the shipped configs use single-head inter-human attention" % (M["N_HEAD"],))
+    if M["NORMALIZE_BEFORE"]:
+        raise NotImplementedError("NORMALIZE_BEFORE: every shipped config is post-norm")
+    if name not in ("hrnet", "transpose_h", "hrformer", "interformer_pureMulti", "interformer", "interformer_2stage"):
+        raise NotImplementedError("MODEL.NAME=%r" % (name,))
+    if name in ("hrnet", "transpose_h", "hrformer"):
+        return
+    if M["USE_MULTI_POS"] and M["MULTI_POS_EMBEDDING"] not in ("conv", "res"):
+        raise NotImplementedError("MULTI_POS_EMBEDDING=%r with USE_MULTI_POS (shipped configs use 'conv' or 'res')" % (M["MULTI_POS_EMBEDDING"],))
+    if name != "interformer_pureMulti":
+        sf = M["SINGLEFORMER"]
+        if sf not in ("transpose_h", "hrformer") and sf:
+            raise NotImplementedError("MODEL.SINGLEFORMER=%r" % (sf,))
+        if not sf and name != "interformer":
+            raise NotImplementedError("interformer_2stage always has a first stage")
+        if sf == "hrformer" and M["DIM_MODEL"] != 78:
+            raise NotImplementedError("HRFormer-B emits 78 channels (hrformer.py:2527), DIM_MODEL=%r" % (M["DIM_MODEL"],))
+        if M["UPSAMPLE_TYPE"] not in ("deconv", "multiplex"):
+            raise NotImplementedError("UPSAMPLE_TYPE=%r" % (M["UPSAMPLE_TYPE"],))
+        if M["ATTENTION_TYPE"] != "default":
+            raise NotImplementedError("ATTENTION_TYPE=%r" % (M["ATTENTION_TYPE"],))
+    if M["EXTRA"]["FINAL_CONV_KERNEL"] != 1:
+        raise NotImplementedError("FINAL_CONV_KERNEL=%r (shipped configs: 1)" % (M["EXTRA"]["FINAL_CONV_KERNEL"],))
+
+
 class Engine:
     """Packed model + program cache for one device. Built by models/_base.I2RModule."""
 
     def __init__(self, cfg, state_dict, device, precision="fp32", name=None):
+        validate_config(cfg, name)
         cabi.lib()  # fail loudly here when the HIP library is absent
         self.precision = precision
         self.cfg = cfg
         self.device = torch.device(device)
         assert self.device.type == "cuda", "the product path runs on the GPU only (device=%s)" % (device,)
-        cabi.require_gfx950(self.device.index or 0)
+        if self.device.index is None:  # a bare 'cuda' means the CURRENT device, not device 0
+            self.device = torch.device("cuda", torch.cuda.current_device())
+        cabi.require_gfx950(self.device.index)
         self.programs = {}
         self.multi_lane = False  # (grouped launches replaced per-branch stream lanes)
         self.side_streams = [torch.cuda.Stream(device=self.device) for _ in range(3)]
@@ -1057,52 +1125,34 @@ class Engine:
         self.name = name or M["NAME"]
         pk = Packer(state_dict, self.device, precision)
         d, dff = M["DIM_MODEL"], M["DIM_FEEDFORWARD"]
-        assert M["N_HEAD"] == 1, "the shipped configs use single-head attention (N_HEAD=1)"
-        assert not M["NORMALIZE_BEFORE"], "NORMALIZE_BEFORE is false in every shipped config (post-norm only)"
         self.singleformer = None
         if self.name == "hrnet":  # stand-alone backbone (models/hrnet.py): tower + reduce, see forward_backbone()
             self.tower = HRNetW48(pk, "", M["EXTRA"])
             self.reduce = pk.conv("reduce")
+        elif self.name in ("transpose_h", "hrformer"):  # stand-alone first stage (models/transpose_h.py, models/hrformer.py): forward_single()
+            self.singleformer = self.name
+            self._pack_single(pk, self.name, "")
         elif self.name == "interformer_pureMulti":
             self.tower = HRNetW48(pk, "", M["EXTRA"])
             self.reduce = pk.conv("reduce")
             self.use_pos = bool(M["USE_MULTI_POS"])
             if self.use_pos:
-                assert M["MULTI_POS_EMBEDDING"] == "conv", "only MULTI_POS_EMBEDDING 'conv' is wired"
-                self.pe_stem = pk.stem("position_embedding.conv1", "position_embedding.bn1")
-                self.pe_conv2 = pk.conv("position_embedding.conv2", "position_embedding.bn2", stride=2)
+                self._pack_pos(pk, "position_embedding", M["MULTI_POS_EMBEDDING"])
             self.layers = [pk.encoder_layer("global_encoder.layers.%d" % l, d, dff) for l in range(M["ENCODER_LAYERS"])]
             self.deconvs = [pk.deconv("deconv_layers.0", "deconv_layers.1")] * 2  # the same layer twice (:774-775)
             self.head = pk.head("final_layer")
         elif self.name in ("interformer", "interformer_2stage"):
             sf = M["SINGLEFORMER"]
             self.singleformer = sf
-            p = "singleformer."
-            if sf == "transpose_h":
-                self.tower = HRNetW48(pk, p, M["EXTRA"])
-                self.res_layer = M["HRNET_RES_LAYER"]
-                self.reduce = pk.conv(p + "reduce")
-                w, h = M["IMAGE_SIZE"]
-                self.single_tokens = (h // 2 ** self.res_layer // 4) * (w // 2 ** self.res_layer // 4)
-                self.single_pos = pk.table(p + "pos_embedding", self.single_tokens, d) if M["POS_EMBEDDING"] != "none" else None
-                self.single_layers = [pk.encoder_layer("%sglobal_encoder.layers.%d" % (p, l), d, dff)
-                                      for l in range(M["ENCODER_LAYERS"])]
-                self.single_head = pk.head(p + "final_layer")
-            elif sf == "hrformer":
-                assert d == 78, "HRFormer-B emits 78 channels (hrformer.py:2527)"
-                self.tower = HRFormerB(pk, p)
-                self.single_head = pk.head(p + "keypoint_head.final_layer")
+            if sf:
+                self._pack_single(pk, sf, "singleformer.")
             elif not sf:  # bare backbone: hrnet.HRNet.forward = reduce(lowest branch) (hrnet.py:419-446), no first-stage head
                 assert self.name == "interformer", "interformer_2stage always has a first stage"
                 self.tower = HRNetW48(pk, "backbone.body.", M["EXTRA"])
                 self.reduce = pk.conv("backbone.body.reduce")
-            else:
-                raise NotImplementedError("MODEL.SINGLEFORMER=%r" % (sf,))
             self.use_pos = bool(M["USE_MULTI_POS"])
             if self.use_pos:
-                assert M["MULTI_POS_EMBEDDING"] == "conv", "only MULTI_POS_EMBEDDING 'conv' is wired"
-                self.pe_stem = pk.stem("multi_position_embedding.conv1", "multi_position_embedding.bn1")
-                self.pe_conv2 = pk.conv("multi_position_embedding.conv2", "multi_position_embedding.bn2", stride=2)
+                self._pack_pos(pk, "multi_position_embedding", M["MULTI_POS_EMBEDDING"])
             self.layers = [pk.encoder_layer("multi_global_encoder.layers.%d" % l, d, dff)
                            for l in range(M["ENCODER_MULTI_LAYERS"])]
             up = M["UPSAMPLE_TYPE"]
@@ -1123,11 +1173,69 @@ class Engine:
         else:
             raise NotImplementedError("MODEL.NAME=%r" % self.name)
 
+    def _pack_single(self, pk, sf, p):
+        """first (intra-human) stage under key prefix p: transpose_h.TransPoseH (:418-480) or hrformer.HRFormer (:2470-2476)"""
+        M = self.cfg["MODEL"]
+        d, dff = M["DIM_MODEL"], M["DIM_FEEDFORWARD"]
+        if sf == "transpose_h":
+            self.tower = HRNetW48(pk, p, M["EXTRA"])
+            self.res_layer = M["HRNET_RES_LAYER"]
+            self.reduce = pk.conv(p + "reduce")
+            w, h = M["IMAGE_SIZE"]
+            self.single_tokens = (h // 2 ** self.res_layer // 4) * (w // 2 ** self.res_layer // 4)
+            self.single_pos = pk.table(p + "pos_embedding", self.single_tokens, d) if M["POS_EMBEDDING"] != "none" else None
+            self.single_layers = [pk.encoder_layer("%sglobal_encoder.layers.%d" % (p, l), d, dff) for l in range(M["ENCODER_LAYERS"])]
+            self.single_head = pk.head(p + "final_layer")
+        else:
+            self.tower = HRFormerB(pk, p)
+            self.single_head = pk.head(p + "keypoint_head.final_layer")
+
+    def _emit_single(self, P, S, H, W, n_src):
+        """-> (first-stage feature Act [S, H/4, W/4, d], stem args): tower (+ reduce + per-crop encoder for TransPose-H, :649-655)"""
+        xs, stem_args = self.tower.emit(P, S, H, W, n_src=n_src)
+        if self.singleformer == "hrformer":
+            return xs[0], stem_args
+        f = P.conv(xs[self.res_layer], self.reduce)
+        P.release(*xs)
+        tok = f.h * f.w
+        assert tok == self.single_tokens, "input size does not match MODEL.IMAGE_SIZE (pos_embedding rows)"
+        g = P.encoder(f, self.single_layers, [i * tok for i in range(S + 1)],
+                      pos=self.single_pos.data_ptr() if self.single_pos is not None else 0, pos_period=tok)
+        P.release(f)
+        return g, stem_args
+
+    def _pack_pos(self, pk, p, mode):
+        """PositionEmbeddingImage (position_embedding.py:6-32): the two image modes that produce a per-token embedding from the bbox
+        mask.  'cat_vec' changes the encoder width (interformer.py:297-303) and 'sine' ignores the mask; no shipped yaml enables
+        either together with USE_MULTI_POS."""
+        self.pe_mode = mode
+        if mode == "conv":
+            self.pe_stem = pk.stem(p + ".conv1", p + ".bn1")
+            self.pe_conv2 = pk.conv(p + ".conv2", p + ".bn2", stride=2)
+        elif mode == "res":
+            self.pe_res = pk.pe_res(p)
+        else:
+            raise NotImplementedError("MULTI_POS_EMBEDDING=%r with USE_MULTI_POS (shipped configs use 'conv' or 'res')" % (mode,))
+
     # ---- program construction ----
     def _pos_branch(self, P, n, h, w, trans_w, n_src=None):
-        a, pe_args = P.stem(self.pe_stem, n, h, w, n_src=n_src)
-        b = P.conv(a, self.pe_conv2, relu=True)
-        P.release(a)
+        if self.pe_mode == "res":  # conv_pre -> resnet18[:5] -> conv_end (position_embedding.py:93-97), then the pooling loop (:106-109)
+            r = self.pe_res
+            a, pe_args = P.pe_res_stem(r, n, h, w, n_src=n_src)
+            b = P.maxpool(a)
+            P.release(a)
+            for c1, c2 in r["blocks"]:  # torchvision BasicBlock: conv-bn-relu-conv-bn, + identity, relu
+                t = P.conv(b, c1, relu=True)
+                y = P.conv(t, c2, relu=True, res1=b)
+                P.release(t, b)
+                b = y
+            a = b
+            b = P.conv(a, r["conv_end"])
+            P.release(a)
+        else:
+            a, pe_args = P.stem(self.pe_stem, n, h, w, n_src=n_src)
+            b = P.conv(a, self.pe_conv2, relu=True)
+            P.release(a)
         for _ in range(int(math.log(b.w // trans_w, 2))):
             c = P.maxpool(b)
             P.release(b)
@@ -1143,22 +1251,13 @@ class Engine:
         n_src = S
         if flip:
             S, length = 2 * S, list(length) + list(length)
-        xs, patch["x"] = self.tower.emit(P, S, H, W, n_src=n_src)
         if self.name == "interformer_pureMulti" or not self.singleformer:
+            xs, patch["x"] = self.tower.emit(P, S, H, W, n_src=n_src)
             f = P.conv(xs[-1], self.reduce)
             P.release(*xs)
             single_feat = None
         else:
-            if self.singleformer == "hrformer":
-                g = xs[0]
-            else:
-                f = P.conv(xs[self.res_layer], self.reduce)
-                P.release(*xs)
-                tok = f.h * f.w
-                assert tok == self.single_tokens, "input size does not match MODEL.IMAGE_SIZE (pos_embedding rows)"
-                g = P.encoder(f, self.single_layers, [i * tok for i in range(S + 1)],
-                              pos=self.single_pos.data_ptr() if self.single_pos is not None else 0, pos_period=tok)
-                P.release(f)
+            g, patch["x"] = self._emit_single(P, S, H, W, n_src)
             single_feat = g
             if self.return_dict:
                 patch["single"] = P.head(g, self.single_head)
@@ -1194,18 +1293,57 @@ class Engine:
         S, _, H, W = x.shape
         x = x.to(self.device).contiguous()
         key = (S, H, W, "backbone")
-        if key not in self.programs:
-            P = Program(self.device)
-            xs, px = self.tower.emit(P, S, H, W, n_src=S)
-            f = P.conv(xs[-1], self.reduce)
-            P.release(*xs)
-            P.finalize()
-            self.programs[key] = (P, px, f)
-        P, px, f = self.programs[key]
-        px.in_ = x.data_ptr()
-        P.run()
-        # (NHWC arena buffer -> the reference's NCHW tensor: a torch view + copy, boundary plumbing only)
-        return f.t.view(S, f.h, f.w, f.cs)[..., :f.c].permute(0, 3, 1, 2).contiguous()
+        with torch.cuda.device(self.device):
+            if key not in self.programs:
+                P = Program(self.device)
+                xs, px = self.tower.emit(P, S, H, W, n_src=S)
+                f = P.conv(xs[-1], self.reduce)
+                P.release(*xs)
+                P.finalize()
+                self.programs[key] = (P, px, f)
+            P, px, f = self.programs[key]
+            px.in_ = x.data_ptr()
+            P.run()
+            # (NHWC arena buffer -> the reference's NCHW tensor: a torch view + copy, boundary plumbing only)
+            return f.t.view(S, f.h, f.w, f.cs)[..., :f.c].permute(0, 3, 1, 2).contiguous()
+
+    def forward_single(self, x):
+        """Stand-alone first stage, as the reference's InterFormer calls it (interformer.py:288): transpose_h.TransPoseH.forward
+        (:649-655) / hrformer.HRFormer.forward (:2477-2480): x [S,3,H,W] -> (features [S,d,H/4,W/4], heatmaps [S,J,H/4,W/4])."""
+        assert self.name in ("transpose_h", "hrformer") and x.dim() == 4 and x.shape[1] == 3 and x.dtype == torch.float32
+        S, _, H, W = x.shape
+        x = x.to(self.device).contiguous()
+        key = (S, H, W, "single")
+        with torch.cuda.device(self.device):
+            if key not in self.programs:
+                P = Program(self.device)
+                g, px = self._emit_single(P, S, H, W, S)
+                hd = P.head(g, self.single_head)
+                P.finalize()
+                self.programs[key] = (P, px, g, hd)
+            P, px, g, hd = self.programs[key]
+            px.in_ = x.data_ptr()
+            J = self.cfg["MODEL"]["NUM_JOINTS"]
+            hm = torch.empty(S, J, g.h, g.w, dtype=torch.float32, device=self.device)
+            hd.out = hm.data_ptr()
+            P.run(self.side_streams if P.uses_lanes else None)
+            # (NHWC arena buffer -> the reference's NCHW feature tensor: a torch view + copy, boundary plumbing only)
+            feat = g.t.view(S, g.h, g.w, g.cs)[..., :g.c].permute(0, 3, 1, 2).contiguous()
+        return feat, hm
+
+    @staticmethod
+    def capacity(S):
+        """Crop capacity of the program that serves a batch of S crops: exact up to 8, then the next multiple of 4 (<= 64) or 8.
+        In the reference's validate() loop S = sum(length) changes with nearly every batch (persons per image vary); building a
+        program costs tens of ms (arena, block maps, descriptors), so programs are built per CAPACITY and a batch runs in the
+        smallest one that holds it -- the unused slots are extra single-person groups whose heat maps are dropped (<= 3 / 7 wasted
+        crops, i.e. <= 11 % above 32 crops)."""
+        if S <= 8:
+            return S
+        step = 4 if S <= 64 else 8
+        return -(-S // step) * step
+
+    MAX_PROGRAMS = 12  # least-recently-used programs beyond this are dropped (each owns ~20 MB of activations per crop)
 
     def forward(self, x, pos_mask, length, flip_joint_map=None):
         """flip_joint_map (device int32 [J], see caller.joint_map): run the flip test in the same forward and return the merged
@@ -1215,17 +1353,27 @@ class Engine:
         S, _, H, W = x.shape
         assert S == sum(length), "sum(length)=%d != number of crops %d" % (sum(length), S)
         assert all(n >= 1 for n in length), "every image needs at least one person"
+        with torch.cuda.device(self.device):  # kernels and events go to the CURRENT device: make it this engine's
+            return self._forward(x, pos_mask, list(length), flip_joint_map, S, H, W)
+
+    def _forward(self, x, pos_mask, length, flip_joint_map, S, H, W):
+        M = self.cfg["MODEL"]
         x = x.to(self.device).contiguous()
         flip = flip_joint_map is not None
-        # one program per (S, H, W, flip): the launch list and every buffer depend on the crop count only; the persons-per-image
-        # grouping enters through the encoder's offset table, which is re-uploaded when `length` changes
-        key = (S, H, W, flip)
-        if key not in self.programs:
-            if len(self.programs) >= 8:  # bounded cache (each program owns ~20 MB of activations per crop)
+        # one program per (capacity, H, W, flip): the launch list and every buffer depend on the crop capacity only; the
+        # persons-per-image grouping enters through the encoder's offset table, the real crop count through the stem kernels
+        cap = self.capacity(S)
+        key = (cap, H, W, flip)
+        if key in self.programs:
+            self.programs[key] = self.programs.pop(key)  # most recently used last
+        else:
+            while len(self.programs) >= self.MAX_PROGRAMS:
                 self.programs.pop(next(iter(self.programs)))
-            self.programs[key] = self._build(S, H, W, list(length), flip)
+            self.programs[key] = self._build(cap, H, W, list(length) + [1] * (cap - S), flip)
         P, patch = self.programs[key]
-        glen = list(length) + list(length) if flip else list(length)
+        glen = list(length) + [1] * (cap - S)
+        if flip:
+            glen = glen + glen
         for grouping, tok in P.groupings:
             offs = [0]
             for n in glen:
@@ -1233,13 +1381,15 @@ class Engine:
             P.set_groups(grouping, offs)
         J = M["NUM_JOINTS"]
         patch["x"].in_ = x.data_ptr()
+        patch["x"].n_valid = S
         keep = [x]
         if "pos_mask" in patch:
             pm = pos_mask.to(self.device, torch.float32).contiguous()
             assert pm.shape == (S, 1, H, W)
             patch["pos_mask"].in_ = pm.data_ptr()
+            patch["pos_mask"].n_valid = S
             keep.append(pm)
-        n_out = 2 * S if flip else S
+        n_out = 2 * cap if flip else cap
         out = torch.empty(n_out, J, H // 4, W // 4, dtype=torch.float32, device=self.device)
         patch["multi"].out = out.data_ptr()
         single = None
@@ -1250,9 +1400,9 @@ class Engine:
         if flip:
             merged = torch.empty(S, J, H // 4, W // 4, dtype=torch.float32, device=self.device)
             st = torch.cuda.current_stream(self.device).cuda_stream
-            cabi.check(cabi.lib().i2r_flip_merge(out.data_ptr(), out[S:].data_ptr(), flip_joint_map.data_ptr(), merged.data_ptr(),
+            cabi.check(cabi.lib().i2r_flip_merge(out.data_ptr(), out[cap:].data_ptr(), flip_joint_map.data_ptr(), merged.data_ptr(),
                                                  S, J, H // 4, W // 4, st), "i2r_flip_merge")
             return merged
         if self.name != "interformer_pureMulti" and self.return_dict:
-            return {"single": single, "multi": out}
-        return out
+            return {"single": single[:S], "multi": out[:S]}
+        return out[:S]

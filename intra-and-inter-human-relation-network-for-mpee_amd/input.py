@@ -56,6 +56,22 @@ def invert_affine(t):
     return np.concatenate([A, -A @ t[:, 2:]], axis=1)
 
 
+def box_to_center_scale(box, image_size, pixel_std=200.0):
+    """_box2cs / _xywh2cs of the dataset classes (lib/dataset/crowdpose.py:239-258, coco.py, ochuman.py): box (x, y, w, h) -> centre
+    of the box and the aspect-corrected scale (in units of pixel_std = 200 px, enlarged by 1.25), both float32 like the reference."""
+    x, y, w, h = [float(v) for v in box[:4]]
+    aspect = float(image_size[0]) / float(image_size[1])
+    center = np.array([x + (w - 1) * 0.5, y + (h - 1) * 0.5], dtype=np.float32)
+    if w > aspect * h:
+        h = w * 1.0 / aspect
+    elif w < aspect * h:
+        w = h * aspect
+    scale = np.array([w * 1.0 / pixel_std, h * 1.0 / pixel_std], dtype=np.float32)
+    if center[0] != -1:
+        scale = scale * 1.25
+    return center, scale
+
+
 def person_inputs(image, centers, scales, boxes, image_size, color_rgb=False, mean=IMAGENET_MEAN, std=IMAGENET_STD, device="cuda:0"):
     """image: uint8 [ih, iw, 3] (numpy or tensor, channel order as cv2.imread delivers it); centers / scales: per-person (2,) pairs in
     the dataset convention (scale in units of 200 px); boxes: per-person (x, y, w, h); image_size = cfg.MODEL.IMAGE_SIZE = (W, H).

@@ -3,6 +3,7 @@ tools/test.py:87 reaches with ``eval('models.'+cfg.MODEL.NAME+'.get_pose_net')(c
 from . import hrnet  # noqa: F401
 from . import backbone  # noqa: F401
 from . import transpose_h  # noqa: F401
+from . import hrformer  # noqa: F401
 from . import interformer_pureMulti  # noqa: F401
 from . import interformer  # noqa: F401
 from . import interformer_2stage  # noqa: F401

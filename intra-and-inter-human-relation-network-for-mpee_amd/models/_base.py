@@ -1,6 +1,8 @@
 """nn.Module shell shared by the model factories: a parameter tree with the reference's state-dict keys
 whose forward() runs the HIP engine.  The module owns the parameters (load_state_dict / .cuda() / DataParallel
-work as for the reference, tools/test.py:87-118); packed device copies are rebuilt lazily after any change."""
+work as for the reference, tools/test.py:87-118); packed device copies (one Engine per device, shared with DataParallel
+replicas) are rebuilt lazily after any change.  After an in-place weight edit that bypasses load_state_dict / .to(),
+call _invalidate()."""
 import math
 
 import torch
@@ -32,8 +34,10 @@ class I2RModule(nn.Module):
     def __init__(self, cfg, spec=None):
         super().__init__()
         self.cfg = cfg
-        self._engine = None
-        self._engine_key = None
+        # device -> Engine.  ONE dict object shared by every shallow copy of this module: nn.DataParallel.replicate() copies
+        # __dict__ per forward, so replicas on other devices find the engine packed by an earlier forward instead of re-packing
+        # all weights each time (tools/test.py:118 wraps the model in DataParallel).
+        self._engines = {}
         self.precision = "fp32"  # MFMA operand type of the conv kernels: 'fp32' (reference parity), 'bf16', 'fp16'
         spec = arch.param_spec(cfg) if spec is None else spec
         for key, shape, dtype in spec:
@@ -74,7 +78,7 @@ class I2RModule(nn.Module):
         return self
 
     def _invalidate(self):
-        self._engine = None
+        self._engines.clear()
 
     def load_state_dict(self, state_dict, strict=True, **kw):
         out = super().load_state_dict(state_dict, strict=strict, **kw)
@@ -92,11 +96,13 @@ class I2RModule(nn.Module):
             raise RuntimeError(
                 "i2r_amd models run on an MI355X through the HIP extension only; move the module to the GPU "
                 "(model.cuda()) -- there is no CPU execution path in the product (the CPU oracle lives in oracle/).")
-        if self._engine is None or self._engine_key != dev:
+        if dev.index is None:
+            dev = torch.device("cuda", torch.cuda.current_device())
+        eng = self._engines.get(dev)
+        if eng is None:
             from ..engine import Engine
-            self._engine = Engine(self.cfg, self.state_dict(), dev, self.precision, name=self._engine_name())
-            self._engine_key = dev
-        return self._engine
+            eng = self._engines[dev] = Engine(self.cfg, self.state_dict(), dev, self.precision, name=self._engine_name())
+        return eng
 
     def _engine_name(self):
         return None  # MODEL.NAME

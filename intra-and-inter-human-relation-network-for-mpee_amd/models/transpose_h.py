@@ -1,15 +1,32 @@
-"""TransPose-H intra-human stage. Mirror of reference lib/models/transpose_h.py: TransPoseH (:416),
-get_pose_net(cfg, is_train, pretrained_path, is_end2end) (:691).  Stand-alone use returns
-(features, heatmaps) in the reference; here it is only built as InterFormer.singleformer, whose parameters
-live under the ``singleformer.`` prefix of the 2-stage module (models/interformer.py)."""
+"""TransPose-H intra-human stage. Mirror of reference lib/models/transpose_h.py: TransPoseH (:416), forward (:649-655) returning
+(features [S, d, H/4, W/4], heatmaps [S, J, H/4, W/4]), get_pose_net(cfg, is_train, pretrained_path, is_end2end) (:691) -- the
+factory InterFormer.__init__ reaches with eval('models.' + cfg.MODEL.SINGLEFORMER + '.get_pose_net') (interformer.py:139).
+Inside the 2-stage module the same parameters live under the ``singleformer.`` prefix and run as part of one program
+(models/interformer.py); this module is the stand-alone form (e.g. for checking a first-stage checkpoint on its own)."""
+import torch
+
 from .. import arch
+from ._base import I2RModule
 
 
 def param_spec(cfg, prefix=""):
     return arch.transpose_h_spec(cfg, prefix)
 
 
+class TransPoseH(I2RModule):
+    def __init__(self, cfg, **kwargs):
+        super().__init__(cfg, arch.transpose_h_spec(cfg, ""))
+
+    def _engine_name(self):
+        return "transpose_h"
+
+    def forward(self, x):
+        """x [S, 3, H, W] -> (features, heatmaps)  (transpose_h.py:649-655)"""
+        with torch.no_grad():
+            return self.engine().forward_single(x)
+
+
 def get_pose_net(cfg, is_train, pretrained_path="", is_end2end=False, **kwargs):
-    raise NotImplementedError(
-        "transpose_h is consumed through models.interformer (MODEL.SINGLEFORMER: transpose_h); "
-        "a stand-alone TransPose-H forward is not part of the I2R-Net inference path")
+    if is_train:
+        raise NotImplementedError("i2r_amd implements the inference path only (is_train=False)")
+    return TransPoseH(cfg, **kwargs).eval()

@@ -202,14 +202,33 @@ def inter_human_encoder(sd, p, n_layers, feat, pos, length, n_head=1, collect=No
     return _unpad_persons(out, length)
 
 
-def multi_position_embedding(sd, p, pos_mask, trans_w):
-    """PositionEmbeddingImage mode 'conv' (position_embedding.py:99-109): [S,1,H,W] -> [S,d,h,w].
+def multi_position_embedding(sd, p, pos_mask, trans_w, mode="conv"):
+    """PositionEmbeddingImage modes 'conv' (position_embedding.py:99-104) and 'res' (:93-97), then the pooling loop
+    (:106-109): [S,1,H,W] -> [S,d,h,w].
 
     The reference also runs this on the zero masks of padded persons; those tokens are masked keys /
     discarded queries, so evaluating only the S real persons is output-equivalent.
+
+    'res': conv_pre (1->3, 3x3, pad 1, no bias), torchvision resnet18 children()[:5] (:16-17) -- restated from torchvision's
+    published ResNet-18 definition (torchvision is not in this image, unpinned in the reference's requirements.txt): conv1
+    7x7 stride 2 pad 3 no bias, bn1, relu, MaxPool2d(3, 2, 1), layer1 = 2 BasicBlocks(64) each conv3x3-bn-relu-conv3x3-bn,
+    + identity, relu -- then conv_end (64->d, 3x3, pad 1, no bias, no norm / activation).
     """
-    x = F.relu(_bn(sd, p + ".bn1", _conv(sd, p + ".conv1", pos_mask, stride=2)))
-    x = F.relu(_bn(sd, p + ".bn2", _conv(sd, p + ".conv2", x, stride=2)))
+    if mode == "res":
+        x = _conv(sd, p + ".conv_pre", pos_mask)
+        x = F.relu(_bn(sd, p + ".res.1", _conv(sd, p + ".res.0", x, stride=2, pad=3)))
+        x = _maxpool(x)
+        for b in range(2):
+            q = "%s.res.4.%d" % (p, b)
+            o = F.relu(_bn(sd, q + ".bn1", _conv(sd, q + ".conv1", x)))
+            o = _bn(sd, q + ".bn2", _conv(sd, q + ".conv2", o))
+            x = F.relu(o + x)
+        x = _conv(sd, p + ".conv_end", x)
+    elif mode == "conv":
+        x = F.relu(_bn(sd, p + ".bn1", _conv(sd, p + ".conv1", pos_mask, stride=2)))
+        x = F.relu(_bn(sd, p + ".bn2", _conv(sd, p + ".conv2", x, stride=2)))
+    else:
+        raise NotImplementedError("MULTI_POS_EMBEDDING=%r is not restated (no shipped yaml enables it with USE_MULTI_POS)" % (mode,))
     for _ in range(int(math.log(x.shape[-1] // trans_w, 2))):
         x = _maxpool(x)
     return x
@@ -226,7 +245,7 @@ def forward_vanilla(sd, cfg, x, pos_mask, length, collect=None):
         collect["reduce"] = f
     pos = None
     if M["USE_MULTI_POS"]:
-        pos = multi_position_embedding(sd, "position_embedding", pos_mask, M["TRANS_SIZE"][-1])
+        pos = multi_position_embedding(sd, "position_embedding", pos_mask, M["TRANS_SIZE"][-1], M["MULTI_POS_EMBEDDING"])
         if collect is not None:
             collect["pos"] = pos
     f = inter_human_encoder(sd, "global_encoder", M["ENCODER_LAYERS"], f, pos, length, M["N_HEAD"], collect)
@@ -305,8 +324,9 @@ def forward_two_stage(sd, cfg, x, pos_mask, length, collect=None):
             f = _maxpool(f)
     pos = None
     if M["USE_MULTI_POS"]:
-        assert M["MULTI_POS_EMBEDDING"] == "conv", "only the 'conv' multi-position mode is restated"
-        pos = multi_position_embedding(sd, "multi_position_embedding", pos_mask, M["TRANS_SIZE"][-1])
+        pos = multi_position_embedding(sd, "multi_position_embedding", pos_mask, M["TRANS_SIZE"][-1], M["MULTI_POS_EMBEDDING"])
+        if collect is not None:
+            collect["pos"] = pos
     f = inter_human_encoder(sd, "multi_global_encoder", M["ENCODER_MULTI_LAYERS"], f, pos, length,
                             M["N_HEAD"], collect)
     if collect is not None:

@@ -39,6 +39,7 @@ CASES = [
     ("hrt_l21", "hrt_192_p4_b4", [2, 1], (256, 192), True),
     ("hrt288_l2", "coco_hrt_288_p2_b4", [2], (384, 288), False),     # 96x72 maps, 24x18 inter-human tokens
     ("tph2s_l12", "coco_tph_192_p4_b4", [1, 2], (256, 192), False),  # interformer_2stage wiring (multiplex deconv, multi-pos)
+    ("ochtph_l21", "ochuman_tph_192_p3_b8", [2, 1], (256, 192), True),  # multi-position mode 'res' (resnet18 front end)
     ("bare_l21", "w48_bare_p6", [2, 1], (256, 192), False),          # interformer with MODEL.SINGLEFORMER unset (models/hrnet.py)
 ]
 

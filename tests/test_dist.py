@@ -23,6 +23,24 @@ def test_shard_images_partitions_everything():
             assert seen == list(range(len(length))) and crops == sum(length)
 
 
+def test_shard_images_never_starves_a_rank():
+    """property: with at least as many images as ranks every rank gets >= 1 image, cuts are monotone, and no rank
+    carries more than an equal share plus one image's crops"""
+    import random
+    rnd = random.Random(0)
+    for length, world in (([1, 1, 10, 1, 1], 3), ([8, 1, 1, 1], 4)):
+        b = i2r_dist.shard_bounds(length, world)
+        assert all(b[i] < b[i + 1] for i in range(world)), (length, world, b)
+    for _ in range(5000):
+        n, world = rnd.randint(1, 40), rnd.randint(1, 8)
+        length = [rnd.choice([1, 1, 1, 2, 3, 6, 10]) for _ in range(n)]
+        b = i2r_dist.shard_bounds(length, world)
+        assert len(b) == world + 1 and b[0] == 0 and b[-1] == n and all(b[i] <= b[i + 1] for i in range(world))
+        if n >= world:
+            assert all(b[i] < b[i + 1] for i in range(world)), (length, world, b)
+            assert max(sum(length[b[i]:b[i + 1]]) for i in range(world)) <= sum(length) / world + max(length)
+
+
 def _worker(rank, world, port, length):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     dist.init_process_group("gloo", rank=rank, world_size=world)
@@ -39,12 +57,20 @@ def _worker(rank, world, port, length):
         h1 = i2r_dist.gather_heatmaps_async(local, counts)       # two collectives in flight, waited in order (bench.py pattern)
         h2 = i2r_dist.gather_heatmaps_async(local * 2, counts)
         assert torch.equal(h1.wait(), full) and torch.equal(h2.wait(), full * 2)
+        # decoded key points: [S_r, J, 2] + [S_r, J, 1] -> [S, J, 3] in global crop order
+        S, J = sum(length), 5
+        preds = torch.arange(S * J * 2, dtype=torch.float32).view(S, J, 2)
+        maxv = -torch.arange(S * J, dtype=torch.float32).view(S, J, 1)
+        kp = i2r_dist.gather_keypoints(preds[off:off + counts[rank]], maxv[off:off + counts[rank]], counts)
+        assert torch.equal(kp, torch.cat([preds, maxv], 2))
+        kp2 = i2r_dist.gather_keypoints(preds[off:off + counts[rank]], maxv[off:off + counts[rank]], counts, async_op=True).wait()
+        assert torch.equal(kp2, kp)
     finally:
         dist.destroy_process_group()
 
 
 def test_gather_heatmaps_world2_gloo():
-    for length in ([4, 4], [1, 3, 2]):
+    for length in ([4, 4], [1, 3, 2], [5]):   # [5]: fewer images than ranks -- rank 1 contributes zero rows
         with socket.socket() as s:
             s.bind(("127.0.0.1", 0))
             port = s.getsockname()[1]

@@ -106,7 +106,7 @@ def test_cabi_library_exports_every_declared_symbol():
     L = cabi.load_library()
     for name in cabi.EXPORTS:
         assert hasattr(L, name)
-    assert L.i2r_abi_version() == 1
+    assert L.i2r_abi_version() == cabi.ABI_VERSION
     # struct sizes must match the C side: a descriptor with a null pointer is rejected with I2R_E_ARG, not a crash
     d = cabi.ConvDesc()
     assert L.i2r_conv(ctypes.byref(d), None) == -1
@@ -121,7 +121,7 @@ def test_struct_layouts_match_header():
     src = r'''
 #include <stdio.h>
 #include "i2r_hip.h"
-int main(void){ printf("%zu %zu %zu %zu %zu %zu %zu %zu %zu %zu %zu\n", sizeof(i2r_conv_desc), sizeof(i2r_encoder_desc), sizeof(i2r_stem_args),
+int main(void){ printf("%zu %zu %zu %zu %zu %zu %zu %zu %zu %zu %zu %zu\n", sizeof(i2r_pe_res_args), sizeof(i2r_conv_desc), sizeof(i2r_encoder_desc), sizeof(i2r_stem_args),
  sizeof(i2r_pool_args), sizeof(i2r_head_args), sizeof(i2r_op), sizeof(i2r_conv_group_args), sizeof(i2r_ln_args), sizeof(i2r_winattn_args), sizeof(i2r_dw_args), sizeof(i2r_up_args)); return 0; }
 '''
     import tempfile
@@ -131,6 +131,51 @@ int main(void){ printf("%zu %zu %zu %zu %zu %zu %zu %zu %zu %zu %zu\n", sizeof(i
         exe = os.path.join(td, "s")
         subprocess.check_call(["gcc", "-I", os.path.join(ROOT, "include"), c, "-o", exe])
         sizes = [int(v) for v in subprocess.check_output([exe]).split()]
-    mine = [ctypes.sizeof(t) for t in (cabi.ConvDesc, cabi.EncoderDesc, cabi.StemArgs, cabi.PoolArgs, cabi.HeadArgs, cabi.Op, cabi.ConvGroupArgs, cabi.LnArgs,
+    mine = [ctypes.sizeof(t) for t in (cabi.PeResArgs, cabi.ConvDesc, cabi.EncoderDesc, cabi.StemArgs, cabi.PoolArgs, cabi.HeadArgs, cabi.Op, cabi.ConvGroupArgs, cabi.LnArgs,
                                        cabi.WinAttnArgs, cabi.DwArgs, cabi.UpArgs)]
     assert sizes == mine
+
+
+@pytest.mark.skipif(not os.path.isdir("/root/reference/experiments"), reason="reference tree only in the build container")
+def test_named_configs_equal_reference_yaml():
+    """every shipped configs/*.yaml carries its reference yaml's MODEL section (checkpoint paths aside) and the TEST keys of validate()"""
+    assert len(config.REFERENCE_YAML) == 10
+    for name, rel in config.REFERENCE_YAML.items():
+        a = config.load_config(name)
+        b = config.load_config("/root/reference/experiments/%s.yaml" % rel)
+        for k in b.MODEL:
+            if k == "EXTRA":
+                for e in b.MODEL.EXTRA:
+                    assert a.MODEL.EXTRA[e] == b.MODEL.EXTRA[e], (name, e)
+            else:
+                assert a.MODEL[k] == b.MODEL[k] or k in ("PRETRAINED", "SINGLE_MODEL", "INIT_WEIGHTS"), (name, k)
+        for k in ("FLIP_TEST", "BLUR_KERNEL", "BATCH_SIZE_PER_GPU", "POST_PROCESS", "SHIFT_HEATMAP"):
+            assert a.TEST[k] == b.TEST[k], (name, k)
+
+
+@pytest.mark.parametrize("name", sorted(config.REFERENCE_YAML))
+def test_every_shipped_yaml_builds(name):
+    """all ten experiments/*.yaml of the reference: the engine accepts the configuration (engine.validate_config is what
+    Engine.__init__ runs first), the parameter tree is built by the factory and every weight the packer will ask for exists"""
+    from i2r_amd import engine
+    cfg = config.load_config(name)
+    engine.validate_config(cfg)
+    net = eval("models." + cfg.MODEL.NAME + ".get_pose_net")(cfg, is_train=False)
+    sd = net.state_dict()
+    if os.path.isdir("/root/reference/experiments"):
+        ref = config.load_config("/root/reference/experiments/%s.yaml" % config.REFERENCE_YAML[name])
+        engine.validate_config(ref)
+        assert [k for k, _, _ in arch.param_spec(ref)] == list(sd)
+    M = cfg.MODEL
+    if M.USE_MULTI_POS:
+        p = "position_embedding" if M.NAME == "interformer_pureMulti" else "multi_position_embedding"
+        need = {"conv": [".conv1.weight", ".bn2.running_var"], "res": [".conv_pre.weight", ".res.0.weight", ".res.1.running_var",
+                                                                        ".res.4.1.bn2.weight", ".conv_end.weight"]}[M.MULTI_POS_EMBEDDING]
+        assert all(p + k in sd for k in need)
+
+
+def test_validate_config_refuses_unshipped_combinations():
+    from i2r_amd import engine
+    for opts in (["MODEL.N_HEAD", "8"], ["MODEL.MULTI_POS_EMBEDDING", "cat_vec"], ["MODEL.NORMALIZE_BEFORE", "True"]):
+        with pytest.raises(NotImplementedError):
+            engine.validate_config(config.load_config("w48_pure_en6", opts))

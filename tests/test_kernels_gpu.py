@@ -191,6 +191,38 @@ def test_conv_chain_matches_per_layer_launches():
         assert torch.equal(a, b)
 
 
+@pytest.mark.parametrize("h,w,flip", [(256, 192, False), (64, 48, True), (38, 30, False)])
+def test_pe_res_front_end(h, w, flip):
+    """i2r_pe_res_stem + max-pool + 2 BasicBlocks + conv_end == conv_pre -> resnet18[:5] -> conv_end (position_embedding.py:93-97);
+    sizes that are not multiples of the 8x8 tile; mirrored copies as the flip-test batch makes them"""
+    import math
+    tag = "pr%d" % h
+    sd = {"pe.conv_pre.weight": _rand((3, 1, 3, 3), "cp" + tag, 0.6), "pe.res.0.weight": _rand((64, 3, 7, 7), "c7" + tag, (6.0 / 147) ** 0.5),
+          "pe.conv_end.weight": _rand((96, 64, 3, 3), "ce" + tag, (6.0 / 576) ** 0.5)}
+    bns = ["pe.res.1"]
+    for b in range(2):
+        for c in (1, 2):
+            sd["pe.res.4.%d.conv%d.weight" % (b, c)] = _rand((64, 64, 3, 3), "bb%d%d%s" % (b, c, tag), (6.0 / 576) ** 0.5)
+            bns.append("pe.res.4.%d.bn%d" % (b, c))
+    for k in bns:
+        sd.update({k + ".weight": _rand((64,), "g" + k + tag, 0.3) + 1.0, k + ".bias": _rand((64,), "b" + k + tag, 0.3),
+                   k + ".running_mean": _rand((64,), "m" + k + tag, 0.3), k + ".running_var": _rand((64,), "v" + k + tag, 0.4) + 1.0})
+    S = 2
+    m = (_rand((S, 1, h, w), "mask" + tag) > 0.2).float()
+    trans_w = w // 16 if w % 16 == 0 else (w + 3) // 4
+    ref = i2r_cpu.multi_position_embedding(sd, "pe", torch.cat([m, m.flip(3)]) if flip else m, trans_w, "res")
+    P = engine.Program(torch.device(DEV))
+    eng = engine.Engine.__new__(engine.Engine)
+    eng.pe_mode, eng.pe_res = "res", engine.Packer(sd, torch.device(DEV)).pe_res("pe")
+    out, args = eng._pos_branch(P, 2 * S if flip else S, h, w, trans_w, n_src=S)
+    md = m.to(DEV)
+    args.in_ = md.data_ptr()
+    run(P)
+    got = from_act(out)
+    assert got.shape == ref.shape, (got.shape, ref.shape)
+    assert (got - ref).abs().max().item() < 2e-4
+
+
 def _encoder_sd(d, dff, tag):
     sd = {}
     p = "L"
@@ -274,15 +306,13 @@ def test_encoder_stack_fused_kv(length, hw):
 
 
 def test_encoder_stack_two_tiles_per_workgroup():
-    """the two-tile variant of the layer kernel (chosen for >= 512 work items, forced here through I2R_ENC_QT=2, which the
-    library reads once per process -> subprocess) on the ragged cases above"""
-    import subprocess, sys
-    env = dict(os.environ, I2R_ENC_QT="2")
-    code = ("import sys; sys.path.insert(0, %r); import conftest; import test_kernels_gpu as t; "
-            "errs = [t._encoder_stack_case(3, l, hw) for l, hw in (([2, 1, 3], (6, 6)), ([1, 4], (16, 12)), ([3], (5, 4)), ([5], (24, 18)))]; "
-            "print('ERRS', errs); assert max(errs) < 3e-4" % os.path.dirname(os.path.abspath(__file__)))
-    r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600)
-    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    """the two-tile variant of the layer kernel is what the library picks for >= 512 two-tile work items: ragged groups
+    (72 / 36 / 108 tokens: odd tile counts, partial last fragments) repeated until there are 513 of them, and aligned 192-token persons"""
+    for length, hw in (([2, 1, 3] * 57, (6, 6)), ([2] * 43 + [1], (16, 12))):
+        lens = [n * hw[0] * hw[1] for n in length]
+        assert sum(-(-l // 32) for l in lens) >= 512
+        err = _encoder_stack_case(3, length, hw)
+        assert err < 3e-4, (len(length), err)
 
 
 def test_encoder_sine_table_period():
@@ -415,12 +445,18 @@ def test_conv_low_precision(precision, tdt, cin, cout, k, stride, h, w):
 
 
 @pytest.mark.parametrize("precision", ["bf16", "fp16"])
-@pytest.mark.parametrize("length,hw,period", [([3, 1, 2], (16, 12), 0), ([1] * 3, (64, 48), 3072), ([5], (16, 12), 0)])
-def test_encoder_layer_low_precision(precision, length, hw, period):
+@pytest.mark.parametrize("d,length,hw,period", [
+    (96, [3, 1, 2], (16, 12), 0), (96, [1] * 3, (64, 48), 3072), (96, [5], (16, 12), 0),
+    (78, [2, 3], (16, 12), 0),        # HRFormer inter-human width: rows of 80 floats, model dim padded to 96 inside the kernel
+    (78, [2, 1], (24, 18), 0),        # 432-token persons (384x288): group offsets that are multiples of 16 only
+    (96, [2, 1, 3], (6, 6), 0),       # 36-token persons: unaligned offsets, ragged last key blocks
+    (78, [12], (24, 18), 0),          # BASELINE config 5: one group of 12 x 432 = 5184 tokens, d = 78
+])
+def test_encoder_layer_low_precision(precision, d, length, hw, period):
     """16-bit MFMA encoder layer vs the fp32 oracle layer: tolerance = 16-bit operand rounding (outputs are LayerNorm-ed, O(1))."""
-    d, (h, w) = 96, hw
+    h, w = hw
     S = sum(length)
-    tag = "lpenc%d_%d" % (S, h)
+    tag = "lpenc%d_%d_%d" % (S, h, d)
     sd = _encoder_sd(d, 192, tag)
     feat = _rand((S, d, h, w), "f" + tag)
     sd2 = {k.replace("L.", "E.layers.0."): v for k, v in sd.items()}
@@ -447,3 +483,5 @@ def test_encoder_layer_low_precision(precision, length, hw, period):
     err = (from_act(out) - ref).abs()
     tol_max, tol_mean = (0.12, 0.012) if precision == "bf16" else (0.02, 0.002)
     assert err.max().item() < tol_max and err.mean().item() < tol_mean, (err.max().item(), err.mean().item())
+    if d == 78:
+        assert out.t.view(-1, out.cs)[:, 78:].abs().max().item() == 0.0  # pad channels stay exactly zero

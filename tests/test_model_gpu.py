@@ -24,7 +24,7 @@ def _net(cfg, sd, cname):
 
 
 def test_native_library_is_loaded():
-    assert cabi.lib().i2r_abi_version() == 1
+    assert cabi.lib().i2r_abi_version() == cabi.ABI_VERSION
     cu, lds = cabi.require_gfx950(0)
     assert cu >= 200 and lds >= 64 * 1024
 
@@ -65,6 +65,30 @@ def test_standalone_hrnet_backbone_module():
     assert torch.equal(bb.cuda()(x.cuda()).cpu(), y)
 
 
+@pytest.mark.parametrize("tag,sf", [("tph_l21", "transpose_h"), ("hrt_l21", "hrformer")])
+def test_standalone_first_stage_modules(tag, sf):
+    """models.transpose_h.get_pose_net / models.hrformer.get_pose_net called the way InterFormer.__init__ does (reference
+    interformer.py:139-141, transpose_h.py:649-655,691, hrformer.py:2477-2487): (features, heatmaps), fed with the `singleformer.*`
+    weights of the 2-stage case; heatmaps equal the reference's out['single'] golden."""
+    cfg, sd, x, m, length, g = setup(tag)
+    body = {k[len("singleformer."):]: v for k, v in sd.items() if k.startswith("singleformer.")}
+    net = eval("models." + cfg.MODEL.SINGLEFORMER + ".get_pose_net")(cfg, False, cfg.MODEL.SINGLE_MODEL, cfg.MODEL.END2END)
+    assert cfg.MODEL.SINGLEFORMER == sf
+    net.load_state_dict(body, strict=True)
+    feat, hm = net.cuda()(x.cuda())
+    torch.cuda.synchronize()
+    if sf == "transpose_h":
+        rf, rh = i2r_cpu.forward_transpose_h(sd, "singleformer.", cfg, x)
+    else:
+        from i2r_cpu_hrformer import forward_hrformer
+        with torch.no_grad():
+            rf, rh = forward_hrformer(sd, "singleformer.", cfg, x)
+    assert feat.shape == rf.shape and hm.shape == rh.shape == g["out_single"].shape
+    assert (feat.cpu() - rf).abs().max().item() < TOL
+    assert (hm.cpu() - rh).abs().max().item() < TOL
+    assert np.abs(hm.cpu().numpy() - g["out_single"]).max() < TOL
+
+
 def test_ragged_batches_and_program_cache():
     """var-len groups: a crop's heatmaps depend only on its own image; different `length` signatures coexist."""
     cfg, sd, x, m, length, g = setup("w48_l213")
@@ -79,6 +103,35 @@ def test_ragged_batches_and_program_cache():
         o += n
     with pytest.raises(AssertionError):
         net(x.cuda(), m.cuda(), [1, 1])
+
+
+def test_capacity_padded_programs():
+    """S = 9 crops run in the capacity-12 program (Engine.capacity): the 3 unused slots re-read the last crop as extra single-person
+    groups and are dropped; batches of 9..12 crops share that one program; the flip-test batch pads both halves"""
+    from i2r_amd import caller, synth
+    from i2r_amd.engine import Engine
+    assert [Engine.capacity(s) for s in (1, 7, 8, 9, 12, 13, 33, 64, 65)] == [1, 7, 8, 12, 12, 16, 36, 64, 72]
+    cfg, sd, _, _, _, _ = setup("w48_l1")
+    net = _net(cfg, sd, "w48_pure_en6")
+    eng = net.engine()
+    x, m, length = synth.make_inputs([2, 3, 4], 256, 192, seed=11)
+    y = net(x.cuda(), m.cuda(), length)
+    assert y.shape == (9, 14, 64, 48) and y.is_contiguous()
+    y = y.cpu()
+    o = 0
+    for n in length:
+        alone = net(x[o:o + n].cuda(), m[o:o + n].cuda(), [n]).cpu()
+        assert (alone - y[o:o + n]).abs().max().item() < 1e-4
+        o += n
+    x2, m2, l2 = synth.make_inputs([5, 6], 256, 192, seed=12)
+    y2 = net(x2.cuda(), m2.cuda(), l2).cpu()
+    assert sum(1 for k in eng.programs if k[0] == 12 and not k[3]) == 1
+    ref = i2r_cpu.forward(sd, cfg, x2[:5], m2[:5], [5])
+    assert (y2[:5] - ref).abs().max().item() < TOL
+    jm = caller.FLIP_PAIRS["crowdpose"]
+    f9 = net.forward_flip(x.cuda(), m.cuda(), length, jm).cpu()
+    f4 = net.forward_flip(x[5:].cuda(), m[5:].cuda(), [4], jm).cpu()
+    assert f9.shape == (9, 14, 64, 48) and (f9[5:] - f4).abs().max().item() < 1e-4
 
 
 def test_many_token_groups():
@@ -142,6 +195,79 @@ def test_low_precision_modes_within_stated_tolerance(tag, precision):
         assert d.abs().max().item() <= tol_max * zs[k].abs().max().item(), (tag, k, d.abs().max().item())
         assert d.pow(2).mean().sqrt().item() <= tol_rms * zs[k].pow(2).mean().sqrt().item()
         assert d.abs().max().item() > 1e-4  # it really is the 16-bit path
+
+
+def _variants(net):
+    """which kernel variant each encoder layer of the cached programs resolved to: (d, dtype) per layer descriptor"""
+    out = []
+    for P, _ in net.engine().programs.values():
+        for st in P.enc_stacks:
+            out += [(d.d, d.dtype) for d, _ in st["descs"]]
+    return out
+
+
+def test_config3_ragged_batch_real_size():
+    """BASELINE config 3 at its real size: 16 CrowdPose-shaped images, length_i = rng(0).integers(1, 7) -> 57 crops of the TransPose-H
+    2-stage model.  fp32: the 6-person image 0 and the 1-person image 5 against the oracle (1e-3), image permutation permutes the
+    rows; bf16: within the stated tolerance of the oracle on those images, and the 16-bit encoder kernels are the ones that ran."""
+    import bench
+    from i2r_amd import synth
+    length = bench.WORKLOADS["tph_192_p6_b4"]["length"]
+    assert length == [6, 4, 4, 2, 2, 1, 1, 1, 2, 5, 4, 6, 4, 4, 6, 5]
+    cfg, sd, _, _, _, _ = setup("tph_l21")
+    net = _net(cfg, sd, "tph_192_p6_b4")
+    x, m, length = synth.make_inputs(length, 256, 192, seed=3)
+    y = net(x.cuda(), m.cuda(), length)
+    ym, ys = y["multi"].cpu(), y["single"].cpu()
+    assert ym.shape == (57, 14, 64, 48) and torch.isfinite(ym).all()
+    starts = [sum(length[:i]) for i in range(len(length))]
+    refs = {}
+    for i in (0, 5):
+        o, n = starts[i], length[i]
+        refs[i] = i2r_cpu.forward(sd, cfg, x[o:o + n], m[o:o + n], [n])
+        assert (ym[o:o + n] - refs[i]["multi"]).abs().max().item() < TOL
+        assert (ys[o:o + n] - refs[i]["single"]).abs().max().item() < TOL
+    perm = [5, 11, 0, 15, 2, 7, 9, 1, 14, 3, 8, 13, 4, 10, 6, 12]
+    idx = torch.cat([torch.arange(starts[p], starts[p] + length[p]) for p in perm])
+    yp = net(x[idx].cuda(), m[idx].cuda(), [length[p] for p in perm])["multi"].cpu()
+    assert (yp - ym[idx]).abs().max().item() < 1e-4
+    try:
+        yb = net.set_precision("bf16")(x.cuda(), m.cuda(), length)["multi"].cpu()
+        var = _variants(net)
+    finally:
+        net.set_precision("fp32")
+    assert var and all(dt == 1 for _, dt in var), "bf16 mode must run the 16-bit encoder kernels: %r" % (var,)
+    tol_max, tol_rms = LP_TOL["bf16"]
+    for i in (0, 5):
+        o, n = starts[i], length[i]
+        d = yb[o:o + n] - refs[i]["multi"]
+        assert d.abs().max().item() <= tol_max * refs[i]["multi"].abs().max().item()
+        assert d.pow(2).mean().sqrt().item() <= tol_rms * refs[i]["multi"].pow(2).mean().sqrt().item()
+
+
+def test_config5_twelve_persons_384x288():
+    """BASELINE config 5 at its real size: one image of 12 persons at 384x288 through HRFormer-B; the inter-human encoder sees
+    L = 12 * 432 = 5184 tokens of width 78.  fp32 vs the oracle end to end (1e-3); fp16 within the stated tolerance, with the
+    inter-human layers on the 16-bit kernels (cs = 80 instantiation, 432-token groups)."""
+    from i2r_amd import synth
+    cfg, sd, _, _, _, _ = setup("hrt288_l2")
+    net = _net(cfg, sd, "coco_hrt_288_p2_b4")
+    x, m, length = synth.make_inputs([12], 384, 288, seed=4)
+    y = net(x.cuda(), m.cuda(), length)
+    ref = i2r_cpu.forward(sd, cfg, x, m, length)
+    for k in ("single", "multi"):
+        assert y[k].shape == (12, 17, 96, 72)
+        assert (y[k].cpu() - ref[k]).abs().max().item() < TOL, k
+    try:
+        yh = net.set_precision("fp16")(x.cuda(), m.cuda(), length)["multi"].cpu()
+        var = _variants(net)
+    finally:
+        net.set_precision("fp32")
+    assert var and all(d == 78 and dt == 2 for d, dt in var), "fp16 mode must run the 16-bit inter-human encoder (d = 78): %r" % (var,)
+    tol_max, tol_rms = LP_TOL["fp16"]
+    d = yh - ref["multi"]
+    assert d.abs().max().item() <= tol_max * ref["multi"].abs().max().item()
+    assert d.pow(2).mean().sqrt().item() <= tol_rms * ref["multi"].pow(2).mean().sqrt().item()
 
 
 def test_regrouping_same_crop_count_reuses_program():
