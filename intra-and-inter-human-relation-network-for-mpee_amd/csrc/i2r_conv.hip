@@ -441,14 +441,18 @@ __device__ __forceinline__ void conv_body(const ConvK& p, int bid, f32x4* lds) {
                 if (uq * 4 < ckg) {
 #pragma unroll
                     for (int j = 0; j < PJ; ++j)
-                        if (!(I2R_DBG(p) & 2)) v[uq][j] = *reinterpret_cast<const f32x4*>(p.in + goff[j] + c0 + (uq * 4 + ul) * 4);
+                        // (predicated on the pixel lying inside the image: halo pixels outside cost no memory access -- and the
+                        //  exec-masked loads keep this block of loads together: with unconditional loads the same kernel measured 8 % slower)
+                        v[uq][j] = (gval[j] && !(I2R_DBG(p) & 2)) ? *reinterpret_cast<const f32x4*>(p.in + goff[j] + c0 + (uq * 4 + ul) * 4)
+                                                                  : (f32x4){0.f, 0.f, 0.f, 0.f};
                 }
             if (p.in2) {
 #pragma unroll
                 for (int uq = 0; uq < UQ; ++uq)
                     if (uq * 4 < ckg) {
 #pragma unroll
-                        for (int j = 0; j < PJ; ++j) v[uq][j] += *reinterpret_cast<const f32x4*>(p.in2 + goff[j] + c0 + (uq * 4 + ul) * 4);
+                        for (int j = 0; j < PJ; ++j)
+                            if (gval[j]) v[uq][j] += *reinterpret_cast<const f32x4*>(p.in2 + goff[j] + c0 + (uq * 4 + ul) * 4);
                     }
             }
         };
@@ -459,7 +463,7 @@ __device__ __forceinline__ void conv_body(const ConvK& p, int bid, f32x4* lds) {
 #pragma unroll
                     for (int j = 0; j < PJ; ++j) {
                         const int pp = (tid >> 2) + j * 64;
-                        if (pp < phw) buf[(uq * 4 + ul) * p.plane + pp] = gval[j] ? v[uq][j] : (f32x4){0.f, 0.f, 0.f, 0.f};
+                        if (pp < phw) buf[(uq * 4 + ul) * p.plane + pp] = v[uq][j];
                     }
                 }
         };
@@ -489,13 +493,14 @@ __device__ __forceinline__ void conv_body(const ConvK& p, int bid, f32x4* lds) {
                 for (int u = 0; u < 4; ++u)
 #pragma unroll
                     for (int j = 0; j < kMaxPP; ++j)
-                        if (j < npp && !(I2R_DBG(p) & 2)) v[u][j] = *reinterpret_cast<const f32x4*>(p.in + goff[j] + c0 + (cg0 + u) * 4);
+                        v[u][j] = (j < npp && gval[j] && !(I2R_DBG(p) & 2)) ? *reinterpret_cast<const f32x4*>(p.in + goff[j] + c0 + (cg0 + u) * 4)
+                                                                             : (f32x4){0.f, 0.f, 0.f, 0.f};
                 if (p.in2) {
 #pragma unroll
                     for (int u = 0; u < 4; ++u)
 #pragma unroll
                         for (int j = 0; j < kMaxPP; ++j)
-                            if (j < npp) v[u][j] += *reinterpret_cast<const f32x4*>(p.in2 + goff[j] + c0 + (cg0 + u) * 4);
+                            if (j < npp && gval[j]) v[u][j] += *reinterpret_cast<const f32x4*>(p.in2 + goff[j] + c0 + (cg0 + u) * 4);
                 }
 #pragma unroll
                 for (int u = 0; u < 4; ++u)
@@ -503,7 +508,7 @@ __device__ __forceinline__ void conv_body(const ConvK& p, int bid, f32x4* lds) {
                     for (int j = 0; j < kMaxPP; ++j) {
                         const int pp = tid + j * 256;
                         if (j < npp && pp < phw)
-                            lds[(cg0 + u) * p.plane + pp] = gval[j] ? v[u][j] : (f32x4){0.f, 0.f, 0.f, 0.f};
+                            lds[(cg0 + u) * p.plane + pp] = v[u][j];
                     }
             }
             __syncthreads();
