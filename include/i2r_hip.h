@@ -79,7 +79,10 @@ typedef struct i2r_conv_desc {
     int32_t wn;                    /* waves along cout in the 4-wave workgroup: 1, 2 or 4 (0 = choose) */
     int32_t mt;                    /* 16-pixel fragments per wave, 1..4 (0 = derive from the tile) */
     int32_t dtype;                 /* MFMA operand type: 0 fp32 (w = k4 fp32), 1 bf16, 2 f16 (w = "k8" [tap][cin32/8][cout_pad][8],
-                                      cin zero-padded to a multiple of 32; activations stay fp32 in HBM, accumulate fp32) */
+                                      cin zero-padded to a multiple of 32; accumulate fp32) */
+    int32_t in_f16, out_f16;       /* dtype != 0 only: activation STORAGE of `in` / of `out`, res1, res2 and res_post -- 0 fp32,
+                                      1 = 16 bit of the operand type (bf16 / f16; the pointers then address 2-byte elements, all strides
+                                      and offsets stay in elements).  The conv towers of the 16-bit modes keep their maps in 16 bit. */
 } i2r_conv_desc;
 
 int i2r_conv(const i2r_conv_desc* d, void* stream);
@@ -136,7 +139,8 @@ int i2r_conv_chain(const i2r_conv_chain_args* a, void* stream);
  * pre-built launch program) are computed from image n_valid-1 and are the caller's to drop.
  * ------------------------------------------------------------------------------------------------ */
 int i2r_stem_conv(const float* in_nchw, const float* w, const float* bias, float* out_nhwc, int32_t n_img,
-                  int32_t cin, int32_t in_h, int32_t in_w, int32_t cout, int32_t out_cs, int32_t n_src, int32_t n_valid, void* stream);
+                  int32_t cin, int32_t in_h, int32_t in_w, int32_t cout, int32_t out_cs, int32_t n_src, int32_t n_valid,
+                  int32_t out_dt /* storage of out: 0 fp32, 1 bf16, 2 f16 (see i2r_conv_desc.in_f16) */, void* stream);
 
 /* i2r_pe_res_stem -- front end of PositionEmbeddingImage mode 'res' (lib/models/position_embedding.py:14-17,93-95):
  * conv_pre (nn.Conv2d(1, 3, 3, padding=1, bias=False)) followed by torchvision resnet18's conv1 (3 -> 64, 7x7, stride 2, pad 3,
@@ -301,7 +305,7 @@ enum {
 
 typedef struct i2r_stem_args {
     const float* in; const float* w; const float* bias; float* out;
-    int32_t n_img, cin, in_h, in_w, cout, out_cs, n_src, n_valid;
+    int32_t n_img, cin, in_h, in_w, cout, out_cs, n_src, n_valid, out_dt;
 } i2r_stem_args;
 
 typedef struct i2r_pe_res_args {

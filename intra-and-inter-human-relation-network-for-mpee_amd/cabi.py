@@ -34,6 +34,7 @@ class ConvDesc(C.Structure):
         ("dy", _i32 * MAX_TAPS), ("dx", _i32 * MAX_TAPS),
         ("out_step", _i32), ("out_off_y", _i32), ("out_off_x", _i32), ("rep", _i32), ("relu", _i32),
         ("tile_h", _i32), ("tile_w", _i32), ("ck", _i32), ("wn", _i32), ("mt", _i32), ("dtype", _i32),
+        ("in_f16", _i32), ("out_f16", _i32),
     ]
 
 
@@ -52,7 +53,7 @@ class EncoderDesc(C.Structure):
 class StemArgs(C.Structure):
     _fields_ = [("in_", _fp), ("w", _fp), ("bias", _fp), ("out", _fp),
                 ("n_img", _i32), ("cin", _i32), ("in_h", _i32), ("in_w", _i32), ("cout", _i32), ("out_cs", _i32), ("n_src", _i32),
-                ("n_valid", _i32)]
+                ("n_valid", _i32), ("out_dt", _i32)]
 
 
 class PeResArgs(C.Structure):
@@ -128,7 +129,7 @@ def load_library(path=LIB_PATH):
     L.i2r_conv_chain_pack.argtypes = [C.POINTER(ConvChainArgs), C.c_void_p, C.c_int64]
     L.i2r_conv_chain.argtypes = [C.POINTER(ConvChainArgs), C.c_void_p]
     L.i2r_conv_kernel_name.argtypes = [C.POINTER(C.POINTER(ConvDesc)), _i32, C.c_char_p, _i32]
-    L.i2r_stem_conv.argtypes = [_fp, _fp, _fp, _fp, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, C.c_void_p]
+    L.i2r_stem_conv.argtypes = [_fp, _fp, _fp, _fp, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, C.c_void_p]
     L.i2r_pe_res_stem.argtypes = [_fp, _fp, _fp, _fp, _fp, _i32, _i32, _i32, _i32, _i32, _i32, _i32, C.c_void_p]
     L.i2r_flip_merge.argtypes = [_fp, _fp, _fp, _fp, _i32, _i32, _i32, _i32, C.c_void_p]
     L.i2r_decode.argtypes = [_fp, _fp, _fp, _fp, _fp, _i32, _i32, _i32, _i32, _i32, _i32, C.c_void_p]

@@ -72,7 +72,7 @@ extern "C" int i2r_run_program(const i2r_op* ops, int32_t n_ops, void* const* st
             }
             case I2R_OP_STEM: {
                 const i2r_stem_args* a = (const i2r_stem_args*)op.args;
-                rc = i2r_stem_conv(a->in, a->w, a->bias, a->out, a->n_img, a->cin, a->in_h, a->in_w, a->cout, a->out_cs, a->n_src, a->n_valid, st);
+                rc = i2r_stem_conv(a->in, a->w, a->bias, a->out, a->n_img, a->cin, a->in_h, a->in_w, a->cout, a->out_cs, a->n_src, a->n_valid, a->out_dt, st);
                 break;
             }
             case I2R_OP_PE_RES_STEM: {

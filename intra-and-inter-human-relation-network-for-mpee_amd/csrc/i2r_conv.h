@@ -1,0 +1,208 @@
+// Shared pieces of the implicit-GEMM convolution kernels (internal): kernel-side descriptor, epilogue, activation load / store helpers.
+// Included by i2r_conv.hip (fp32 matrix pipe + the launch logic) and by the 16-bit translation units (i2r_conv_lp.inc).
+#pragma once
+#include "i2r_common.h"
+
+// Tuning hooks (ablation switches, phase stamps, env overrides) exist only in a -DI2R_TUNING build (tools/ scripts build one with
+// __graft_entry__.build(defines=("I2R_TUNING",))); the product library has none of them: no env var changes what a kernel does.
+#ifdef I2R_TUNING
+#define I2R_DBG(p) ((p).dbg)
+#else
+#define I2R_DBG(p) 0
+#endif
+
+namespace {
+
+struct ConvK {
+    const float* in;
+    const float* in2;
+    const float* w;
+    const float* bias;
+    const float* res1;
+    const float* res2;
+    const float* res_post;
+    float* out;
+    int n_img, in_h, in_w, in_cs, cin;
+    int conv_h, conv_w, out_h, out_w, out_cs, cout, cout_pad;
+    int stride, iy0, ix0, ntaps;
+    int tap_kh, tap_kw;  // taps form a dense kh x kw grid, row-major: tap t sits at patch offset (t / kw, t % kw)
+    int out_step, out_off_y, out_off_x, rep, relu;
+    int tile_h, tile_w, tiles_y, tiles_x, n_cblk;
+    int ph, pw, plane;  // patch dims (pixels) and plane stride (float4 slots, multiple of 16)
+    int ck;             // channels staged per pass (multiple of 16)
+    int wn;             // waves along cout (1, 2, 4); waves along pixels = 4 / wn
+    int dtype;          // 0 fp32 MFMA, 1 bf16, 2 f16 (fp32 accumulate)
+    int in16, out16;    // 16-bit modes: activation storage of the input / of out + res1 + res2 + res_post (0 = fp32, 1 = 16-bit of `dtype`)
+    int dbg;            // ablation switches (env I2R_CONV_DBG; tuning only): 1 no epilogue, 2 no staging loads, 4 no weight loads
+};
+
+constexpr int kMaxPP = 5;  // patch pixels per thread (256 threads) -> patches up to 1280 pixels
+
+constexpr int kMaxGroups = 4;
+struct ConvGroupK {
+    ConvK g[kMaxGroups];
+    int blk_end[kMaxGroups];  // exclusive prefix sums of workgroups per group
+    int n;
+    const int* blk_map;       // optional dispatch-order table: entry = (group << 24) | workgroup index within the group
+};
+
+// 4 consecutive channels of an activation tensor at ELEMENT offset `off`: fp32 (16 bytes) or, in the 16-bit kernels when h16 is set,
+// bf16 / f16 storage (8 bytes; BASELINE configs 3-5 keep the activations of the conv towers in 16 bit: half the HBM traffic)
+template <int DT>
+__device__ __forceinline__ f32x4 ld_act4(const float* base, size_t off, bool h16) {
+    if constexpr (DT != 0) {
+        if (h16) {
+            const uint2 u = *reinterpret_cast<const uint2*>(reinterpret_cast<const unsigned short*>(base) + off);
+            if constexpr (DT == 1)
+                return (f32x4){__uint_as_float(u.x << 16), __uint_as_float(u.x & 0xFFFF0000u), __uint_as_float(u.y << 16), __uint_as_float(u.y & 0xFFFF0000u)};
+            else {
+                typedef _Float16 h4 __attribute__((ext_vector_type(4)));
+                const h4 h = __builtin_bit_cast(h4, u);
+                return (f32x4){(float)h[0], (float)h[1], (float)h[2], (float)h[3]};
+            }
+        }
+    }
+    return *reinterpret_cast<const f32x4*>(base + off);
+}
+template <int DT>
+__device__ __forceinline__ void st_act4(float* base, size_t off, f32x4 v, bool h16) {
+    if constexpr (DT != 0) {
+        if (h16) {
+            uint2 u;
+            if constexpr (DT == 1) {
+                typedef __bf16 b4 __attribute__((ext_vector_type(4)));
+                const b4 b = {(__bf16)v[0], (__bf16)v[1], (__bf16)v[2], (__bf16)v[3]};
+                u = __builtin_bit_cast(uint2, b);
+            } else {
+                typedef _Float16 h4 __attribute__((ext_vector_type(4)));
+                const h4 h = {(_Float16)v[0], (_Float16)v[1], (_Float16)v[2], (_Float16)v[3]};
+                u = __builtin_bit_cast(uint2, h);
+            }
+            *reinterpret_cast<uint2*>(reinterpret_cast<unsigned short*>(base) + off) = u;
+            return;
+        }
+    }
+    *reinterpret_cast<f32x4*>(base + off) = v;
+}
+
+// ---- epilogue (shared by the fp32 and the bf16/f16 MFMA bodies: the C/D register layout is dtype independent) ----
+// D layout: lane (li = l&15, g) holds channel n = nt*16 + li of pixels 4g + r (r = 0..3).  A 4x4 transpose inside each
+// lane quad (two DPP butterfly stages, no LDS) turns that into: lane (q = li>>2, j = li&3, g) holds channels
+// nt*16 + 4q .. +3 of pixel 4g + j, so bias / residual / store are 16-byte accesses (4x fewer VMEM instructions;
+// the scalar-store epilogue measured 24 % of the kernel).  A second step swaps the roles of q and j across the 16 lanes of a
+// row (ds_bpermute, lane 4j+q <- lane 4q+j): then the four CONSECUTIVE lanes of a quad hold the four 16-byte pieces of ONE
+// pixel's 64 contiguous bytes.  The texture addresser retires a 64-lane 16-byte access in 16 cycles only when every quad
+// falls into one 64-byte segment, 64 cycles otherwise (tools/probe/load_pattern.hip) -- with residual loads that was
+// 2 x MT x NT slow accesses per wave.
+template <int MT, int NT, int DT>
+__device__ __forceinline__ void conv_epilogue(const ConvK& p, f32x4 (&acc)[MT][NT], int img, int oy0, int ox0, int wm, int n_base,
+                                              int li, int g, int tile_px) {
+    if ((I2R_DBG(p) & 1) && acc[0][0][0] != 12345.678f) return;
+    const int j4 = li & 3;
+    const int pj = li >> 2, pq = li & 3;  // after the lane permutation: this lane's pixel (4g + pj) and 16-byte piece (pq)
+    const int perm_src = (g * 16 + pq * 4 + pj) * 4;  // ds_bpermute byte address of the lane holding (q = pq, j = pj)
+    auto to_pixel_major = [&](f32x4 v) {
+        v = quad_transpose(v, j4);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const float x = v[e];  // (scalar copy: __builtin_bit_cast on a vector element lvalue miscompiles)
+            v[e] = __int_as_float(__builtin_amdgcn_ds_bpermute(perm_src, __float_as_int(x)));
+        }
+        return v;
+    };
+    const bool h16 = DT != 0 && p.out16;
+    auto finish = [&](f32x4 t, int n, bool full, bool res_post_at, size_t res_post_off) {
+        if (p.relu == 1) {
+            t[0] = fmaxf(t[0], 0.f); t[1] = fmaxf(t[1], 0.f); t[2] = fmaxf(t[2], 0.f); t[3] = fmaxf(t[3], 0.f);
+        } else if (p.relu == 2) {  // exact-erf GELU (HRFormer MlpDWBN, hrformer.py:1197)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) t[e] = 0.5f * t[e] * (1.f + erff(t[e] * 0.70710678118654752f));
+        }
+        if (res_post_at) t += ld_act4<DT>(p.res_post, res_post_off, h16);
+        if (!full) {  // channels >= cout are padding: keep them exactly zero
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+                if (n + e >= p.cout) t[e] = 0.f;
+        }
+        return t;
+    };
+    // per-lane channel piece of every N fragment: bias fetched once, up front
+    f32x4 bias[NT];
+    bool nok[NT];
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+        const int n = n_base + nt * 16 + pq * 4;
+        nok[nt] = n < p.cout_pad && (n + 4 <= p.cout || n + 4 <= p.out_cs);
+        bias[nt] = n < p.cout_pad ? *reinterpret_cast<const f32x4*>(p.bias + n) : (f32x4){0.f, 0.f, 0.f, 0.f};
+    }
+    if (p.rep == 1 && !(I2R_DBG(p) & 16)) {
+        // ---- every output pixel written once: issue ALL residual loads of the tile first (one memory latency instead of
+        //      MT x NT dependent load -> add -> store round trips), then transform and store ----
+        size_t off[MT];
+        bool pv[MT];
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) {
+            const int m = (wm * MT + mt) * 16 + g * 4 + pj;
+            const int ty = m / p.tile_w, tx = m - ty * p.tile_w;
+            const int oy = oy0 + ty, ox = ox0 + tx;
+            pv[mt] = m < tile_px && oy < p.conv_h && ox < p.conv_w;
+            off[mt] = ((size_t)(img * p.out_h + oy * p.out_step + p.out_off_y) * p.out_w + ox * p.out_step + p.out_off_x) * p.out_cs;
+        }
+        f32x4 r[MT][NT];
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) {
+                const size_t o = off[mt] + n_base + nt * 16 + pq * 4;
+                r[mt][nt] = bias[nt];
+                if (pv[mt] && nok[nt]) {
+                    if (p.res1) r[mt][nt] += ld_act4<DT>(p.res1, o, h16);
+                    if (p.res2) r[mt][nt] += ld_act4<DT>(p.res2, o, h16);
+                }
+            }
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) {
+                const f32x4 v = to_pixel_major(acc[mt][nt]);
+                const int n = n_base + nt * 16 + pq * 4;
+                if (!pv[mt] || !nok[nt]) continue;
+                const size_t o = off[mt] + n;
+                st_act4<DT>(p.out, o, finish(v + r[mt][nt], n, n + 4 <= p.cout, p.res_post != nullptr, o), h16);
+            }
+        return;
+    }
+    // ---- nearest-neighbour upsample scatter (HRNet fuse layers): rep x rep destinations per conv pixel ----
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) {
+        const int m = (wm * MT + mt) * 16 + g * 4 + pj;
+        const int ty = m / p.tile_w, tx = m - ty * p.tile_w;
+        const int oy = oy0 + ty, ox = ox0 + tx;
+        const bool pvalid = m < tile_px && oy < p.conv_h && ox < p.conv_w;
+        const int by = oy * p.out_step + p.out_off_y, bx = ox * p.out_step + p.out_off_x;
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) {
+            const f32x4 v = to_pixel_major(acc[mt][nt]) + bias[nt];
+            const int n = n_base + nt * 16 + pq * 4;
+            if (!pvalid || !nok[nt]) continue;
+            for (int ry = 0; ry < p.rep; ++ry)
+                for (int rx = 0; rx < p.rep; ++rx) {
+                    const size_t o = ((size_t)(img * p.out_h + by + ry) * p.out_w + bx + rx) * p.out_cs + n;
+                    f32x4 t = v;
+                    if (p.res1) t += ld_act4<DT>(p.res1, o, h16);
+                    if (p.res2) t += ld_act4<DT>(p.res2, o, h16);
+                    st_act4<DT>(p.out, o, finish(t, n, n + 4 <= p.cout, p.res_post != nullptr, o), h16);
+                }
+        }
+    }
+}
+
+
+
+typedef void (*conv_fn)(const ConvGroupK);
+
+}  // namespace
+
+// kernel pickers of the 16-bit translation units (one per operand type, so the three conv files compile in parallel); null = no such variant
+void* i2r_pick_conv_bf16(int nt, int mt, int cap, int pf);
+void* i2r_pick_conv_f16(int nt, int mt, int cap, int pf);

@@ -18,293 +18,9 @@
 //    accumulating into `out` in place through res1 == out is race-free).
 #include <stdlib.h>
 
-#include "i2r_common.h"
-
-// Tuning hooks (ablation switches, phase stamps, env overrides) exist only in a -DI2R_TUNING build (tools/ scripts build one with
-// __graft_entry__.build(defines=("I2R_TUNING",))); the product library has none of them: no env var changes what a kernel does.
-#ifdef I2R_TUNING
-#define I2R_DBG(p) ((p).dbg)
-#else
-#define I2R_DBG(p) 0
-#endif
+#include "i2r_conv.h"
 
 namespace {
-
-struct ConvK {
-    const float* in;
-    const float* in2;
-    const float* w;
-    const float* bias;
-    const float* res1;
-    const float* res2;
-    const float* res_post;
-    float* out;
-    int n_img, in_h, in_w, in_cs, cin;
-    int conv_h, conv_w, out_h, out_w, out_cs, cout, cout_pad;
-    int stride, iy0, ix0, ntaps;
-    int tap_kh, tap_kw;  // taps form a dense kh x kw grid, row-major: tap t sits at patch offset (t / kw, t % kw)
-    int out_step, out_off_y, out_off_x, rep, relu;
-    int tile_h, tile_w, tiles_y, tiles_x, n_cblk;
-    int ph, pw, plane;  // patch dims (pixels) and plane stride (float4 slots, multiple of 16)
-    int ck;             // channels staged per pass (multiple of 16)
-    int wn;             // waves along cout (1, 2, 4); waves along pixels = 4 / wn
-    int dtype;          // 0 fp32 MFMA, 1 bf16, 2 f16 (fp32 accumulate, fp32 activations in HBM)
-    int dbg;            // ablation switches (env I2R_CONV_DBG; tuning only): 1 no epilogue, 2 no staging loads, 4 no weight loads
-};
-
-constexpr int kMaxPP = 5;  // patch pixels per thread (256 threads) -> patches up to 1280 pixels
-
-constexpr int kMaxGroups = 4;
-struct ConvGroupK {
-    ConvK g[kMaxGroups];
-    int blk_end[kMaxGroups];  // exclusive prefix sums of workgroups per group
-    int n;
-    const int* blk_map;       // optional dispatch-order table: entry = (group << 24) | workgroup index within the group
-};
-
-// ---- epilogue (shared by the fp32 and the bf16/f16 MFMA bodies: the C/D register layout is dtype independent) ----
-// D layout: lane (li = l&15, g) holds channel n = nt*16 + li of pixels 4g + r (r = 0..3).  A 4x4 transpose inside each
-// lane quad (two DPP butterfly stages, no LDS) turns that into: lane (q = li>>2, j = li&3, g) holds channels
-// nt*16 + 4q .. +3 of pixel 4g + j, so bias / residual / store are 16-byte accesses (4x fewer VMEM instructions;
-// the scalar-store epilogue measured 24 % of the kernel).  A second step swaps the roles of q and j across the 16 lanes of a
-// row (ds_bpermute, lane 4j+q <- lane 4q+j): then the four CONSECUTIVE lanes of a quad hold the four 16-byte pieces of ONE
-// pixel's 64 contiguous bytes.  The texture addresser retires a 64-lane 16-byte access in 16 cycles only when every quad
-// falls into one 64-byte segment, 64 cycles otherwise (tools/probe/load_pattern.hip) -- with residual loads that was
-// 2 x MT x NT slow accesses per wave.
-template <int MT, int NT>
-__device__ __forceinline__ void conv_epilogue(const ConvK& p, f32x4 (&acc)[MT][NT], int img, int oy0, int ox0, int wm, int n_base,
-                                              int li, int g, int tile_px) {
-    if ((I2R_DBG(p) & 1) && acc[0][0][0] != 12345.678f) return;
-    const int j4 = li & 3;
-    const int pj = li >> 2, pq = li & 3;  // after the lane permutation: this lane's pixel (4g + pj) and 16-byte piece (pq)
-    const int perm_src = (g * 16 + pq * 4 + pj) * 4;  // ds_bpermute byte address of the lane holding (q = pq, j = pj)
-    auto to_pixel_major = [&](f32x4 v) {
-        v = quad_transpose(v, j4);
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            const float x = v[e];  // (scalar copy: __builtin_bit_cast on a vector element lvalue miscompiles)
-            v[e] = __int_as_float(__builtin_amdgcn_ds_bpermute(perm_src, __float_as_int(x)));
-        }
-        return v;
-    };
-    auto finish = [&](f32x4 t, int n, bool full, const float* res_post_at) {
-        if (p.relu == 1) {
-            t[0] = fmaxf(t[0], 0.f); t[1] = fmaxf(t[1], 0.f); t[2] = fmaxf(t[2], 0.f); t[3] = fmaxf(t[3], 0.f);
-        } else if (p.relu == 2) {  // exact-erf GELU (HRFormer MlpDWBN, hrformer.py:1197)
-#pragma unroll
-            for (int e = 0; e < 4; ++e) t[e] = 0.5f * t[e] * (1.f + erff(t[e] * 0.70710678118654752f));
-        }
-        if (res_post_at) t += *reinterpret_cast<const f32x4*>(res_post_at);
-        if (!full) {  // channels >= cout are padding: keep them exactly zero
-#pragma unroll
-            for (int e = 0; e < 4; ++e)
-                if (n + e >= p.cout) t[e] = 0.f;
-        }
-        return t;
-    };
-    // per-lane channel piece of every N fragment: bias fetched once, up front
-    f32x4 bias[NT];
-    bool nok[NT];
-#pragma unroll
-    for (int nt = 0; nt < NT; ++nt) {
-        const int n = n_base + nt * 16 + pq * 4;
-        nok[nt] = n < p.cout_pad && (n + 4 <= p.cout || n + 4 <= p.out_cs);
-        bias[nt] = n < p.cout_pad ? *reinterpret_cast<const f32x4*>(p.bias + n) : (f32x4){0.f, 0.f, 0.f, 0.f};
-    }
-    if (p.rep == 1 && !(I2R_DBG(p) & 16)) {
-        // ---- every output pixel written once: issue ALL residual loads of the tile first (one memory latency instead of
-        //      MT x NT dependent load -> add -> store round trips), then transform and store ----
-        size_t off[MT];
-        bool pv[MT];
-#pragma unroll
-        for (int mt = 0; mt < MT; ++mt) {
-            const int m = (wm * MT + mt) * 16 + g * 4 + pj;
-            const int ty = m / p.tile_w, tx = m - ty * p.tile_w;
-            const int oy = oy0 + ty, ox = ox0 + tx;
-            pv[mt] = m < tile_px && oy < p.conv_h && ox < p.conv_w;
-            off[mt] = ((size_t)(img * p.out_h + oy * p.out_step + p.out_off_y) * p.out_w + ox * p.out_step + p.out_off_x) * p.out_cs;
-        }
-        f32x4 r[MT][NT];
-#pragma unroll
-        for (int mt = 0; mt < MT; ++mt)
-#pragma unroll
-            for (int nt = 0; nt < NT; ++nt) {
-                const size_t o = off[mt] + n_base + nt * 16 + pq * 4;
-                r[mt][nt] = bias[nt];
-                if (pv[mt] && nok[nt]) {
-                    if (p.res1) r[mt][nt] += *reinterpret_cast<const f32x4*>(p.res1 + o);
-                    if (p.res2) r[mt][nt] += *reinterpret_cast<const f32x4*>(p.res2 + o);
-                }
-            }
-#pragma unroll
-        for (int mt = 0; mt < MT; ++mt)
-#pragma unroll
-            for (int nt = 0; nt < NT; ++nt) {
-                const f32x4 v = to_pixel_major(acc[mt][nt]);
-                const int n = n_base + nt * 16 + pq * 4;
-                if (!pv[mt] || !nok[nt]) continue;
-                const size_t o = off[mt] + n;
-                *reinterpret_cast<f32x4*>(p.out + o) = finish(v + r[mt][nt], n, n + 4 <= p.cout, p.res_post ? p.res_post + o : nullptr);
-            }
-        return;
-    }
-    // ---- nearest-neighbour upsample scatter (HRNet fuse layers): rep x rep destinations per conv pixel ----
-#pragma unroll
-    for (int mt = 0; mt < MT; ++mt) {
-        const int m = (wm * MT + mt) * 16 + g * 4 + pj;
-        const int ty = m / p.tile_w, tx = m - ty * p.tile_w;
-        const int oy = oy0 + ty, ox = ox0 + tx;
-        const bool pvalid = m < tile_px && oy < p.conv_h && ox < p.conv_w;
-        const int by = oy * p.out_step + p.out_off_y, bx = ox * p.out_step + p.out_off_x;
-#pragma unroll
-        for (int nt = 0; nt < NT; ++nt) {
-            const f32x4 v = to_pixel_major(acc[mt][nt]) + bias[nt];
-            const int n = n_base + nt * 16 + pq * 4;
-            if (!pvalid || !nok[nt]) continue;
-            for (int ry = 0; ry < p.rep; ++ry)
-                for (int rx = 0; rx < p.rep; ++rx) {
-                    const size_t o = ((size_t)(img * p.out_h + by + ry) * p.out_w + bx + rx) * p.out_cs + n;
-                    f32x4 t = v;
-                    if (p.res1) t += *reinterpret_cast<const f32x4*>(p.res1 + o);
-                    if (p.res2) t += *reinterpret_cast<const f32x4*>(p.res2 + o);
-                    *reinterpret_cast<f32x4*>(p.out + o) = finish(t, n, n + 4 <= p.cout, p.res_post ? p.res_post + o : nullptr);
-                }
-        }
-    }
-}
-
-
-// ---- bf16 / f16 MFMA body (BASELINE configs 3-5): same tiling, patch-in-LDS and epilogue as the fp32 body, but
-//  * activations (fp32 in HBM) are converted while staging: one LDS slot = 8 channels of a patch pixel (16 B), planes
-//    lds[cg8][patch_pixel]; weights are pre-packed "k8" bf16/f16 [tap][cin32/8][cout_pad][8];
-//  * one v_mfma_f32_16x16x32_{bf16,f16} contracts 32 channels: lane (l&15, g = l>>4) supplies channels 8g..8g+7, i.e. one
-//    ds_read_b128 (A) / one 16-byte global load (B) per MFMA operand; accumulation stays fp32.
-template <int MT, int NT, int DT>
-__device__ __forceinline__ void conv_body_lp(const ConvK& p, int bid, f32x4* lds) {
-    const int tid = threadIdx.x;
-    const int lane = tid & 63, wave = tid >> 6;
-    const int WN = p.wn;
-    const int wm = wave / WN, wn = wave % WN;
-    const int li = lane & 15, g = lane >> 4;
-
-    const int cb = bid % p.n_cblk;
-    bid /= p.n_cblk;
-    const int tile_x = bid % p.tiles_x;
-    bid /= p.tiles_x;
-    const int tile_y = bid % p.tiles_y;
-    const int img = bid / p.tiles_y;
-    const int oy0 = tile_y * p.tile_h, ox0 = tile_x * p.tile_w;
-    const int py0 = oy0 * p.stride + p.iy0, px0 = ox0 * p.stride + p.ix0;
-    const int phw = p.ph * p.pw;
-
-    int goff[kMaxPP];
-    bool gval[kMaxPP];
-#pragma unroll
-    for (int j = 0; j < kMaxPP; ++j) {
-        const int pp = tid + j * 256;
-        goff[j] = 0;
-        gval[j] = false;
-        if (pp < phw) {
-            const int py = pp / p.pw, px = pp - py * p.pw;
-            const int iy = py0 + py, ix = px0 + px;
-            if (iy >= 0 && iy < p.in_h && ix >= 0 && ix < p.in_w) {
-                goff[j] = ((img * p.in_h + iy) * p.in_w + ix) * p.in_cs;
-                gval[j] = true;
-            }
-        }
-    }
-    const int npp = (phw + 255) >> 8;
-    const int tile_px = p.tile_h * p.tile_w;
-    int ppix[MT];
-#pragma unroll
-    for (int mt = 0; mt < MT; ++mt) {
-        int m = (wm * MT + mt) * 16 + li;
-        if (m >= tile_px) m = 0;
-        const int ty = m / p.tile_w, tx = m - ty * p.tile_w;
-        ppix[mt] = ty * p.stride * p.pw + tx * p.stride;
-    }
-    f32x4 acc[MT][NT];
-#pragma unroll
-    for (int mt = 0; mt < MT; ++mt)
-#pragma unroll
-        for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
-
-    const int n_base = (cb * WN + wn) * NT * 16;
-    const int g8_real = p.cin >> 3;             // 8-channel groups that exist in the activation tensor
-    const int g8_pad = (g8_real + 3) & ~3;      // padded to whole 32-channel MFMA steps (zero weights / zero LDS beyond)
-    const f32x4* wq = reinterpret_cast<const f32x4*>(p.w) + n_base + li;  // 16-byte units: ((tap*g8_pad + cg8) * cout_pad + n)
-    const int ckg = p.ck >> 3;                  // groups staged per pass (multiple of 4)
-
-    for (int G0 = 0; G0 < g8_pad; G0 += ckg) {
-        const int ng = min(ckg, g8_pad - G0);
-        if (G0 != 0) __syncthreads();
-        for (int cg = 0; cg < ng; cg += 2) {  // two groups per trip: 4 float4 global loads in flight per patch pixel
-            f32x4 v[2][kMaxPP];
-#pragma unroll
-            for (int u = 0; u < 2; ++u) {
-                const bool real = G0 + cg + u < g8_real;
-#pragma unroll
-                for (int j = 0; j < kMaxPP; ++j) {
-                    v[u][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
-                    if (j < npp && real && gval[j]) {
-                        const float* src = p.in + goff[j] + (G0 + cg + u) * 8;
-                        v[u][j] = pack8<DT>(*reinterpret_cast<const f32x4*>(src), *reinterpret_cast<const f32x4*>(src + 4));
-                    }
-                }
-            }
-#pragma unroll
-            for (int u = 0; u < 2; ++u)
-#pragma unroll
-                for (int j = 0; j < kMaxPP; ++j) {
-                    const int pp = tid + j * 256;
-                    if (j < npp && pp < phw) lds[(cg + u) * p.plane + pp] = v[u][j];
-                }
-        }
-        __syncthreads();
-
-        const int ncs = ng >> 2;
-        const int nit = p.ntaps * ncs;
-        const f32x4* const wp0 = wq + (size_t)(G0 + g) * p.cout_pad;
-        const f32x4* wp = wp0;
-        const size_t inc_cs = (size_t)4 * p.cout_pad;
-        const size_t inc_tap = (size_t)(g8_pad - (ncs - 1) * 4) * p.cout_pad;
-        int cs_n = 0, tx_n = 0, ty_n = 0;
-        auto fetch = [&](f32x4(&a)[MT], f32x4(&b)[NT]) {
-#pragma unroll
-            for (int nt = 0; nt < NT; ++nt) b[nt] = wp[nt * 16];
-            const int abase = (cs_n * 4 + g) * p.plane + ty_n * p.pw + tx_n;
-#pragma unroll
-            for (int mt = 0; mt < MT; ++mt) a[mt] = lds[abase + ppix[mt]];
-            if (++cs_n == ncs) {
-                cs_n = 0;
-                wp += inc_tap;
-                if (++tx_n == p.tap_kw) {
-                    tx_n = 0;
-                    if (++ty_n == p.tap_kh) { ty_n = 0; wp = wp0; }
-                }
-            } else {
-                wp += inc_cs;
-            }
-        };
-        auto fma_step = [&](const f32x4(&a)[MT], const f32x4(&b)[NT]) {
-#pragma unroll
-            for (int mt = 0; mt < MT; ++mt)
-#pragma unroll
-                for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = mfma32_lp<DT>(a[mt], b[nt], acc[mt][nt]);
-        };
-        f32x4 a0[MT], a1[MT], b0[NT], b1[NT];
-        fetch(a0, b0);
-        int it = 0;
-        for (; it + 2 <= nit; it += 2) {
-            fetch(a1, b1);
-            fma_step(a0, b0);
-            fetch(a0, b0);
-            fma_step(a1, b1);
-        }
-        if (it < nit) fma_step(a0, b0);
-    }
-    conv_epilogue<MT, NT>(p, acc, img, oy0, ox0, wm, n_base, li, g, tile_px);
-}
 
 template <int MT, int NT, int CAP, int PF>
 __device__ __forceinline__ void conv_body(const ConvK& p, int bid, f32x4* lds) {
@@ -520,7 +236,7 @@ __device__ __forceinline__ void conv_body(const ConvK& p, int bid, f32x4* lds) {
         ts2 = __builtin_amdgcn_s_memtime();
         ConvK q = p;
         q.res2 = nullptr;
-        conv_epilogue<MT, NT>(q, acc, img, oy0, ox0, wm, n_base, li, g, tile_px);
+        conv_epilogue<MT, NT, 0>(q, acc, img, oy0, ox0, wm, n_base, li, g, tile_px);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         const unsigned long long ts3 = __builtin_amdgcn_s_memtime();
         if (tid == 0) {
@@ -529,7 +245,7 @@ __device__ __forceinline__ void conv_body(const ConvK& p, int bid, f32x4* lds) {
         }
         return;
     }
-    conv_epilogue<MT, NT>(p, acc, img, oy0, ox0, wm, n_base, li, g, tile_px);
+    conv_epilogue<MT, NT, 0>(p, acc, img, oy0, ox0, wm, n_base, li, g, tile_px);
 }
 
 // One launch = up to kMaxGroups independent convolutions that share (MT, NT): "horizontal fusion" of the
@@ -628,49 +344,6 @@ __global__ __launch_bounds__(256) void conv_chain_f32(const ChainK c) {
     }
 }
 
-template <int MT, int NT, int DT>
-__global__ __launch_bounds__(256) void conv_igemm_lp(const ConvGroupK grp) {
-    extern __shared__ __attribute__((aligned(16))) f32x4 lds[];
-    int bid = blockIdx.x, gi = 0, start = 0;
-    if (grp.blk_map) {
-        const int v = grp.blk_map[bid];
-        gi = v >> 24;
-        bid = v & 0xFFFFFF;
-    } else {
-#pragma unroll
-        for (int i = 0; i < kMaxGroups - 1; ++i)
-            if (i + 1 < grp.n && bid >= grp.blk_end[i]) { gi = i + 1; start = grp.blk_end[i]; }
-    }
-    conv_body_lp<MT, NT, DT>(grp.g[gi], bid - start, lds);
-}
-
-typedef void (*conv_fn)(const ConvGroupK);
-
-template <int NT, int DT>
-conv_fn pick_lp_mt(int mt) {
-    switch (mt) {
-        case 1: return conv_igemm_lp<1, NT, DT>;
-        case 2: return conv_igemm_lp<2, NT, DT>;
-        case 3: return conv_igemm_lp<3, NT, DT>;
-        case 4: return conv_igemm_lp<4, NT, DT>;
-    }
-    return nullptr;
-}
-template <int DT>
-conv_fn pick_lp_nt(int nt, int mt) {
-    switch (nt) {
-        case 3: return pick_lp_mt<3, DT>(mt);
-        case 4: return pick_lp_mt<4, DT>(mt);
-        case 5: return pick_lp_mt<5, DT>(mt);
-    }
-    return nullptr;
-}
-conv_fn pick_lp(int nt, int mt, int dtype) {
-    if (dtype == 1) return pick_lp_nt<1>(nt, mt);
-    if (dtype == 2) return pick_lp_nt<2>(nt, mt);
-    return nullptr;
-}
-
 
 template <int NT, int CAP, int PF>
 conv_fn pick_mt(int mt) {
@@ -717,6 +390,9 @@ static int prepare(const i2r_conv_desc* d, int force_mt, int force_cap, int forc
                   "i2r_conv: cout=%d cout_pad=%d out_cs=%d", d->cout, d->cout_pad, d->out_cs);
     I2R_CHECK_ARG(d->stride == 1 || d->stride == 2, "i2r_conv: stride %d", d->stride);
     I2R_CHECK_ARG(d->dtype >= 0 && d->dtype <= 2 && (d->dtype == 0 || d->in2 == nullptr), "i2r_conv: dtype %d", d->dtype);
+    I2R_CHECK_ARG((d->in_f16 == 0 || d->in_f16 == 1) && (d->out_f16 == 0 || d->out_f16 == 1) && (d->dtype != 0 || (!d->in_f16 && !d->out_f16)),
+                  "i2r_conv: 16-bit activation storage (in_f16=%d out_f16=%d) needs a 16-bit operand type (dtype=%d)", d->in_f16, d->out_f16, d->dtype);
+    I2R_CHECK_ARG(!d->in_f16 || d->in_cs % 8 == 0, "i2r_conv: 16-bit input needs in_cs %% 8 == 0 (in_cs=%d)", d->in_cs);
     I2R_CHECK_ARG(d->ntaps >= 1 && d->ntaps <= I2R_MAX_TAPS, "i2r_conv: ntaps %d", d->ntaps);
     I2R_CHECK_ARG(d->rep >= 1 && d->out_step >= 1, "i2r_conv: rep/out_step");
     I2R_CHECK_ARG((d->conv_h - 1) * d->out_step + d->out_off_y + d->rep <= d->out_h &&
@@ -790,8 +466,10 @@ static int prepare(const i2r_conv_desc* d, int force_mt, int force_cap, int forc
 #else
     constexpr int pf_env = 1;
 #endif
-    const int cin_g = d->cin / 4;
-    int pf = (pf_env && d->dtype == 0 && d->ck == 0 && npp <= 2 && cin_g % 4 == 0) ? npp : 0;
+    // channel groups = 16-byte LDS slots per patch pixel: 4 fp32 channels, or 8 16-bit channels padded to whole 32-channel MFMA steps
+    const int cin_g = d->dtype == 0 ? d->cin / 4 : (d->cin / 8 + 3) / 4 * 4;
+    const int g_ch = d->dtype == 0 ? 4 : 8;
+    int pf = (pf_env && d->ck == 0 && npp <= 2 && cin_g % 4 == 0) ? npp : 0;
     int cap = 4;
     if (force_pf >= 0) {
         I2R_CHECK_ARG(force_pf == 0 || (npp <= force_pf && d->ck == 0 && cin_g % 4 == 0), "i2r_conv: grouped members disagree on the staging mode");
@@ -805,7 +483,7 @@ static int prepare(const i2r_conv_desc* d, int force_mt, int force_cap, int forc
         for (int cand : {12, 8, 4})
             if (cand <= cap_lim && cin_g % cand == 0 && (size_t)2 * cand * k.plane * 16 <= 40 * 1024) { ckg = cand; break; }
         cap = force_pf >= 0 ? force_cap : (ckg > 4 ? 12 : 4);
-        ck = ckg * 4;
+        ck = ckg * g_ch;
         lds_bytes = (size_t)2 * ckg * k.plane * 16;
     } else if (d->dtype != 0) {
         // bf16/f16 body: LDS slots hold 8 channels; stage whole 32-channel steps, <= ~24 KB per pass
@@ -832,6 +510,7 @@ static int prepare(const i2r_conv_desc* d, int force_mt, int force_cap, int forc
     I2R_CHECK_ARG(lds_bytes <= 160 * 1024, "i2r_conv: LDS %zu B", lds_bytes);
     k.wn = wn;
     k.dtype = d->dtype;
+    k.in16 = d->in_f16; k.out16 = d->out_f16;
 #ifdef I2R_TUNING
     {
         static const int dbg = getenv("I2R_CONV_DBG") ? atoi(getenv("I2R_CONV_DBG")) : 0;
@@ -902,7 +581,8 @@ extern "C" int i2r_conv_grouped(const i2r_conv_desc* const* descs, int32_t n, co
     if (rc) return rc;
     grp.blk_map = block_map;
     I2R_CHECK_ARG(block_map == nullptr || map_len == (int32_t)total, "i2r_conv_grouped: block_map has %d entries, grid has %lld", map_len, total);
-    conv_fn fn = descs[0]->dtype ? pick_lp(nt0, mt0, descs[0]->dtype) : pick_kernel(nt0, mt0, cap0, pf0);
+    conv_fn fn = descs[0]->dtype == 0 ? pick_kernel(nt0, mt0, cap0, pf0)
+                                      : reinterpret_cast<conv_fn>(descs[0]->dtype == 1 ? i2r_pick_conv_bf16(nt0, mt0, cap0, pf0) : i2r_pick_conv_f16(nt0, mt0, cap0, pf0));
     I2R_CHECK_ARG(fn != nullptr, "i2r_conv: no kernel for nt=%d mt=%d cap=%d pf=%d dtype=%d", nt0, mt0, cap0, pf0, descs[0]->dtype);
     if (lds_max > 64 * 1024)
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_max);
@@ -1014,7 +694,7 @@ extern "C" int i2r_conv_kernel_name(const i2r_conv_desc* const* descs, int32_t n
     if (rc) return rc;
     I2R_CHECK_ARG(buf && buflen > 0, "i2r_conv_kernel_name: buffer");
     if (descs[0]->dtype)
-        snprintf(buf, (size_t)buflen, "conv_igemm_lp<%d, %d, %d>", mt0, nt0, descs[0]->dtype);
+        snprintf(buf, (size_t)buflen, "conv_igemm_lp<%d, %d, %d, %d>/%s", mt0, nt0, cap0, pf0, descs[0]->dtype == 1 ? "bf16" : "f16");
     else
         snprintf(buf, (size_t)buflen, "conv_igemm_f32<%d, %d, %d, %d>", mt0, nt0, cap0, pf0);
     return I2R_OK;

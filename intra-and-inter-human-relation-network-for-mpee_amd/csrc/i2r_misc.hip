@@ -1,13 +1,13 @@
 // Boundary / glue kernels: NCHW stem conv, NHWC max-pool, NHWC -> NCHW heatmap head.  All HBM-bound
 // element-wise-class work (a few % of the forward); written for coalesced 16-byte accesses.
-#include "i2r_common.h"
+#include "i2r_conv.h"  // (st_act4: fp32 / bf16 / f16 activation stores)
 
 namespace {
 
 // 3x3 stride-2 pad-1 conv with tiny cin (3 = RGB crop, 1 = person box mask) + folded BN + ReLU.
 // thread = one output pixel x 16 output channels; the cout/16 threads of a pixel are adjacent lanes, so a
 // pixel's cout floats are written as one contiguous run (NHWC).  w: [9][CIN][cout].
-template <int CIN>
+template <int CIN, int ODT>
 __global__ __launch_bounds__(256) void stem_conv_k(const float* __restrict__ in, const float* __restrict__ w,
                                                    const float* __restrict__ bias, float* __restrict__ out, int n_img,
                                                    int in_h, int in_w, int out_h, int out_w, int cout, int out_cs, int n_src, int n_valid) {
@@ -63,11 +63,10 @@ __global__ __launch_bounds__(256) void stem_conv_k(const float* __restrict__ in,
         }
     }
     if (!valid) return;
-    f32x4* o = reinterpret_cast<f32x4*>(out + (size_t)pix * out_cs + cg * 16);
 #pragma unroll
-    for (int q = 0; q < 4; ++q)
-        o[q] = (f32x4){fmaxf(acc[q * 4], 0.f), fmaxf(acc[q * 4 + 1], 0.f), fmaxf(acc[q * 4 + 2], 0.f),
-                       fmaxf(acc[q * 4 + 3], 0.f)};
+    for (int q = 0; q < 4; ++q)  // ODT != 0: the tower keeps its activations in 16 bit (bf16 / f16), element offsets are the same
+        st_act4<ODT>(out, (size_t)pix * out_cs + cg * 16 + q * 4,
+                     (f32x4){fmaxf(acc[q * 4], 0.f), fmaxf(acc[q * 4 + 1], 0.f), fmaxf(acc[q * 4 + 2], 0.f), fmaxf(acc[q * 4 + 3], 0.f)}, ODT != 0);
 }
 
 // PositionEmbeddingImage mode 'res' front end (position_embedding.py:14-17,93-95): conv_pre (1 -> 3, 3x3, pad 1, no bias) followed
@@ -214,8 +213,9 @@ __global__ __launch_bounds__(256) void head_k(const float* __restrict__ in, cons
 
 extern "C" int i2r_stem_conv(const float* in_nchw, const float* w, const float* bias, float* out_nhwc, int32_t n_img,
                              int32_t cin, int32_t in_h, int32_t in_w, int32_t cout, int32_t out_cs, int32_t n_src, int32_t n_valid,
-                             void* stream) {
+                             int32_t out_dt, void* stream) {
     I2R_CHECK_ARG(in_nchw && w && bias && out_nhwc, "i2r_stem_conv: null pointer");
+    I2R_CHECK_ARG(out_dt >= 0 && out_dt <= 2, "i2r_stem_conv: out_dt %d (0 fp32, 1 bf16, 2 f16)", out_dt);
     I2R_CHECK_ARG(n_src >= 1 && (n_img == n_src || n_img == 2 * n_src) && n_valid >= 1 && n_valid <= n_src,
                   "i2r_stem_conv: n_img=%d n_src=%d n_valid=%d", n_img, n_src, n_valid);
     I2R_CHECK_ARG(cout > 0 && cout % 16 == 0 && out_cs >= cout && out_cs % 4 == 0, "i2r_stem_conv: cout=%d out_cs=%d", cout, out_cs);
@@ -223,12 +223,10 @@ extern "C" int i2r_stem_conv(const float* in_nchw, const float* w, const float* 
     const int out_h = (in_h - 1) / 2 + 1, out_w = (in_w - 1) / 2 + 1;
     const long long nthr = (long long)n_img * out_h * out_w * (cout / 16);
     const unsigned nblk = (unsigned)((nthr + 255) / 256);
-    if (cin == 3)
-        hipLaunchKernelGGL(stem_conv_k<3>, dim3(nblk), dim3(256), (size_t)(27 + 1) * cout * sizeof(float), (hipStream_t)stream, in_nchw, w, bias, out_nhwc, n_img,
-                           in_h, in_w, out_h, out_w, cout, out_cs, n_src, n_valid);
-    else
-        hipLaunchKernelGGL(stem_conv_k<1>, dim3(nblk), dim3(256), (size_t)(9 + 1) * cout * sizeof(float), (hipStream_t)stream, in_nchw, w, bias, out_nhwc, n_img,
-                           in_h, in_w, out_h, out_w, cout, out_cs, n_src, n_valid);
+    typedef void (*stem_fn)(const float*, const float*, const float*, float*, int, int, int, int, int, int, int, int, int);
+    static const stem_fn fns[2][3] = {{stem_conv_k<1, 0>, stem_conv_k<1, 1>, stem_conv_k<1, 2>}, {stem_conv_k<3, 0>, stem_conv_k<3, 1>, stem_conv_k<3, 2>}};
+    hipLaunchKernelGGL(fns[cin == 3][out_dt], dim3(nblk), dim3(256), (size_t)(9 * cin + 1) * cout * sizeof(float), (hipStream_t)stream, in_nchw, w,
+                       bias, out_nhwc, n_img, in_h, in_w, out_h, out_w, cout, out_cs, n_src, n_valid);
     I2R_CHECK_LAUNCH("i2r_stem_conv");
     return I2R_OK;
 }

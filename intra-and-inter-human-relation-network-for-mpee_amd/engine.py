@@ -298,11 +298,17 @@ class Packer:
 # program
 # ------------------------------------------------------------------------------------------------
 class Act:
-    """NHWC fp32 activation buffer [n, h, w, cs] holding c real channels."""
-    __slots__ = ("t", "n", "h", "w", "c", "cs")
+    """NHWC activation buffer [n, h, w, cs] holding c real channels; dt = storage type: 0 fp32, 1 bf16, 2 f16 (the conv towers of
+    the 16-bit modes keep their maps in 16 bit; `t` is the raw storage as a float32 tensor of numel * (4 or 2) / 4 words)."""
+    __slots__ = ("t", "n", "h", "w", "c", "cs", "dt")
+    TORCH_DT = {0: torch.float32, 1: torch.bfloat16, 2: torch.float16}
 
-    def __init__(self, t, n, h, w, c, cs):
-        self.t, self.n, self.h, self.w, self.c, self.cs = t, n, h, w, c, cs
+    def __init__(self, t, n, h, w, c, cs, dt=0):
+        self.t, self.n, self.h, self.w, self.c, self.cs, self.dt = t, n, h, w, c, cs, dt
+
+    def view(self):
+        """[n, h, w, cs] tensor view of the storage in its own dtype"""
+        return self.t.view(self.TORCH_DT[self.dt])[:self.n * self.h * self.w * self.cs].view(self.n, self.h, self.w, self.cs)
 
     @property
     def ptr(self):
@@ -381,14 +387,15 @@ class Program:
         self.lane_ctx = 0    # lane whose ops are being emitted (set by the emitters inside a fork region)
         self.groupings = []  # (grouping, tokens per crop) of encoders whose groups follow `length` (set_groups)
         self.enc_stacks = []
+        self.store_dt = 0    # storage type the conv TOWER keeps its maps in (set by the engine in the 16-bit modes: 1 bf16, 2 f16)
         self.in_fork = False
         self.nbytes = 0
         self._c_ops = None
 
     # ---- buffers ----
-    def alloc(self, n, h, w, c):
+    def alloc(self, n, h, w, c, dt=0):
         cs = _r16(c)
-        numel = n * h * w * cs
+        numel = (n * h * w * cs + 1) // 2 if dt else n * h * w * cs  # float32 words of storage
         # inside a fork region a lane first re-uses what IT released (same stream: ordered), then buffers freed before the fork
         lst = (self.lane_pool.get((self.lane_ctx, numel)) if self.in_fork else None) or self.pool.get(numel)
         if lst:
@@ -397,7 +404,7 @@ class Program:
             t = torch.empty(numel, dtype=torch.float32, device=self.device)
             self.nbytes += numel * 4
             self.keep.append(t)
-        return Act(t, n, h, w, c, cs)
+        return Act(t, n, h, w, c, cs, dt)
 
     def release(self, *acts):
         for a in acts:
@@ -407,12 +414,12 @@ class Program:
                 self.pool.setdefault(a.t.numel(), []).append(a.t)
 
     # ---- ops ----
-    def stem(self, st, n, h, w, in_ptr=0, lane=0, n_src=None):
+    def stem(self, st, n, h, w, in_ptr=0, lane=0, n_src=None, out_dt=0):
         """n_src < n: crops n_src.. are computed from the mirrored input (flip test batched into the same forward)."""
-        out = self.alloc(n, (h - 1) // 2 + 1, (w - 1) // 2 + 1, st["cout"])
+        out = self.alloc(n, (h - 1) // 2 + 1, (w - 1) // 2 + 1, st["cout"], out_dt)
         self.keep.append(st)
         ns = n if n_src is None else n_src
-        a = cabi.StemArgs(in_ptr, st["w"].data_ptr(), st["bias"].data_ptr(), out.ptr, n, st["cin"], h, w, st["cout"], out.cs, ns, ns)
+        a = cabi.StemArgs(in_ptr, st["w"].data_ptr(), st["bias"].data_ptr(), out.ptr, n, st["cin"], h, w, st["cout"], out.cs, ns, ns, out_dt)
         self.ops.append((cabi.OP_STEM, lane, a))
         return out, a
 
@@ -425,8 +432,11 @@ class Program:
         return out, a
 
     def conv(self, x, pc, relu=False, res1=None, res2=None, res_post=None, in2=None, up=1, out=None, out_step=1,
-             out_off=(0, 0), out_hw=None, lane=0, group=None, act=None):
+             out_off=(0, 0), out_hw=None, lane=0, group=None, act=None, out_dt=None):
+        """out_dt: storage type of a newly allocated output (default: the input's, so a 16-bit tower stays 16-bit; pass 0 where the
+        consumer is an fp32 kernel: encoder, max-pool, head, ...)"""
         assert x.cs >= pc.cin_pad and x.c == pc.cin, "conv input channels %d/%d vs weight %d" % (x.c, x.cs, pc.cin)
+        assert x.dt in (0, pc.dtype), "16-bit stored input needs the matching 16-bit conv (input %d, conv %d)" % (x.dt, pc.dtype)
         k = pc.ksize
         if pc.stride == 1:
             conv_h, conv_w = x.h, x.w  # 'same' geometry for 1x1 / 3x3 pad 1 / deconv parity 2x2
@@ -436,8 +446,9 @@ class Program:
             out_step = up
         if out is None:
             oh, ow = out_hw if out_hw else (conv_h * out_step, conv_w * out_step)
-            out = self.alloc(x.n, oh, ow, pc.cout)
+            out = self.alloc(x.n, oh, ow, pc.cout, x.dt if out_dt is None else out_dt)
         assert out.cs >= pc.cout_pad or out.cs >= pc.cout
+        assert out.dt in (0, pc.dtype) and all(r is None or r.dt == out.dt for r in (res1, res2, res_post)), "residuals share the output's storage type"
         self.keep.append(pc)  # the descriptor holds raw pointers: keep the packed weights alive with the program
         d = cabi.ConvDesc()
         d.in_, d.in2, d.w, d.bias = x.ptr, (in2.ptr if in2 is not None else None), pc.w.data_ptr(), pc.bias.data_ptr()
@@ -459,6 +470,7 @@ class Program:
         th, tw, mt = choose_tile(conv_h, conv_w, 4 // wn, pc.stride, max_d, x.n, n_cblk)
         d.tile_h, d.tile_w, d.mt, d.wn, d.ck = th, tw, mt, wn, 0
         d.dtype = pc.dtype
+        d.in_f16, d.out_f16 = int(x.dt != 0), int(out.dt != 0)
         if group is not None:
             group.append((d, (conv_h, conv_w, 4 // wn, pc.stride, max_d, x.n, n_cblk), nt))
         else:
@@ -588,18 +600,20 @@ class Program:
 
     def deconv(self, x, pcs, relu=True, res_post=None, lane=0):
         """ConvTranspose(k4,s2,p1)+BN(+ReLU)(+post-ReLU residual) as four parity convs writing the interleaved 2x output."""
-        out = self.alloc(x.n, 2 * x.h, 2 * x.w, pcs[(0, 0)].cout)
+        out = self.alloc(x.n, 2 * x.h, 2 * x.w, pcs[(0, 0)].cout, x.dt)
         for (py, px), pc in pcs.items():
             self.conv(x, pc, relu=relu, res_post=res_post, out=out, out_step=2, out_off=(py, px), lane=lane)
         return out
 
     def maxpool(self, x, lane=0):
+        assert x.dt == 0, "fp32 kernel: the producer must store fp32 (conv(..., out_dt=0))"
         out = self.alloc(x.n, (x.h - 1) // 2 + 1, (x.w - 1) // 2 + 1, x.c)
         a = cabi.PoolArgs(x.ptr, out.ptr, x.n, x.h, x.w, x.cs, x.cs, out.cs)  # pool all cs channels (pads stay 0)
         self.ops.append((cabi.OP_MAXPOOL, lane, a))
         return out
 
     def layernorm(self, x, ln, eps=1e-6, lane=0):
+        assert x.dt == 0, "fp32 kernel: the producer must store fp32 (conv(..., out_dt=0))"
         out = self.alloc(x.n, x.h, x.w, x.c)
         self.keep.append(ln)
         a = cabi.LnArgs(x.ptr, ln["w"].data_ptr(), ln["b"].data_ptr(), out.ptr, x.n * x.h * x.w, x.c, x.cs, eps)
@@ -616,6 +630,7 @@ class Program:
         return out
 
     def dwconv(self, x, dw, stride=1, act=0, lane=0):
+        assert x.dt == 0, "fp32 kernel: the producer must store fp32 (conv(..., out_dt=0))"
         assert x.c == dw["c"] and x.cs == dw["cs"]
         out = self.alloc(x.n, (x.h - 1) // stride + 1, (x.w - 1) // stride + 1, x.c)
         self.keep.append(dw)
@@ -631,6 +646,7 @@ class Program:
         return out
 
     def head(self, x, hd, out_ptr=0, lane=0):
+        assert x.dt == 0, "fp32 kernel: the producer must store fp32 (conv(..., out_dt=0))"
         self.keep.append(hd)
         a = cabi.HeadArgs(x.ptr, hd["w"].data_ptr(), hd["bias"].data_ptr(), out_ptr, x.n, x.h, x.w, hd["cin"], x.cs, hd["cout"])
         self.ops.append((cabi.OP_HEAD, lane, a))
@@ -640,6 +656,7 @@ class Program:
         """x: Act viewed as tokens [n*h*w, cs]; grp_off_host: python list of token offsets per group.
         regroupable: the grouping (persons per image) may be changed later with set_groups() without rebuilding the program:
         the offset table gets capacity for one group per crop."""
+        assert x.dt == 0, "the encoder kernels read fp32 token rows"
         n_tok = x.n * x.h * x.w
         cs = x.cs
         n_pad = (n_tok + 63) // 64 * 64 + 64
@@ -864,7 +881,7 @@ class HRNetW48:
                 else:
                     _, j, pc, res, up, final = st
                     if ys[i] is None:
-                        ys[i] = P.alloc(xs[i].n, xs[i].h, xs[i].w, xs[i].c)
+                        ys[i] = P.alloc(xs[i].n, xs[i].h, xs[i].w, xs[i].c, xs[i].dt)
                     rr = [xs[i] if r == "x" else ys[i] for r in res]
                     P.conv(src, pc, relu=final, res1=rr[0] if rr else None, res2=rr[1] if len(rr) > 1 else None,
                            up=up, out=ys[i], group=grp)
@@ -878,7 +895,7 @@ class HRNetW48:
 
     def emit(self, P, n, h, w, n_src=None):
         """-> (list of branch Acts, stem StemArgs to patch the input pointer into)."""
-        a, stem_args = P.stem(self.stem1, n, h, w, n_src=n_src)
+        a, stem_args = P.stem(self.stem1, n, h, w, n_src=n_src, out_dt=P.store_dt)  # 16-bit modes: the whole tower stores 16 bit
         b = P.conv(a, self.conv2, relu=True)
         P.release(a)
         x = b
@@ -1112,6 +1129,7 @@ class Engine:
         validate_config(cfg, name)
         cabi.lib()  # fail loudly here when the HIP library is absent
         self.precision = precision
+        self.store_dt = PRECISIONS[precision]  # 16-bit modes: the conv tower keeps its activations in bf16 / f16 (half the HBM traffic)
         self.cfg = cfg
         self.device = torch.device(device)
         assert self.device.type == "cuda", "the product path runs on the GPU only (device=%s)" % (device,)
@@ -1195,7 +1213,7 @@ class Engine:
         xs, stem_args = self.tower.emit(P, S, H, W, n_src=n_src)
         if self.singleformer == "hrformer":
             return xs[0], stem_args
-        f = P.conv(xs[self.res_layer], self.reduce)
+        f = P.conv(xs[self.res_layer], self.reduce, out_dt=0)
         P.release(*xs)
         tok = f.h * f.w
         assert tok == self.single_tokens, "input size does not match MODEL.IMAGE_SIZE (pos_embedding rows)"
@@ -1247,13 +1265,14 @@ class Engine:
         the mirrored copies (mirroring happens inside the stem kernels), every image appears twice as a token group."""
         M = self.cfg["MODEL"]
         P = Program(self.device, multi_lane=self.multi_lane)
+        P.store_dt = self.store_dt
         patch = {}
         n_src = S
         if flip:
             S, length = 2 * S, list(length) + list(length)
         if self.name == "interformer_pureMulti" or not self.singleformer:
             xs, patch["x"] = self.tower.emit(P, S, H, W, n_src=n_src)
-            f = P.conv(xs[-1], self.reduce)
+            f = P.conv(xs[-1], self.reduce, out_dt=0)
             P.release(*xs)
             single_feat = None
         else:
@@ -1296,8 +1315,9 @@ class Engine:
         with torch.cuda.device(self.device):
             if key not in self.programs:
                 P = Program(self.device)
+                P.store_dt = self.store_dt
                 xs, px = self.tower.emit(P, S, H, W, n_src=S)
-                f = P.conv(xs[-1], self.reduce)
+                f = P.conv(xs[-1], self.reduce, out_dt=0)
                 P.release(*xs)
                 P.finalize()
                 self.programs[key] = (P, px, f)
@@ -1317,6 +1337,7 @@ class Engine:
         with torch.cuda.device(self.device):
             if key not in self.programs:
                 P = Program(self.device)
+                P.store_dt = self.store_dt
                 g, px = self._emit_single(P, S, H, W, S)
                 hd = P.head(g, self.single_head)
                 P.finalize()

@@ -444,6 +444,39 @@ def test_conv_low_precision(precision, tdt, cin, cout, k, stride, h, w):
     assert (from_act(out) - exact).abs().max().item() < (0.05 if precision == "bf16" else 0.01)
 
 
+@pytest.mark.parametrize("precision,tdt,dt", [("bf16", torch.bfloat16, 1), ("fp16", torch.float16, 2)])
+@pytest.mark.parametrize("in16,out16", [(True, True), (True, False), (False, True)])
+@pytest.mark.parametrize("cin,cout,k,stride,h,w,up", [(48, 48, 3, 1, 64, 48, 1), (96, 192, 3, 2, 32, 24, 1), (192, 48, 1, 1, 16, 12, 4),
+                                                      (64, 256, 1, 1, 13, 9, 1), (192, 192, 3, 1, 16, 12, 1)])
+def test_conv_16bit_activation_storage(precision, tdt, dt, in16, out16, cin, cout, k, stride, h, w, up):
+    """The conv towers of the 16-bit modes keep their maps in bf16 / f16 (i2r_conv_desc.in_f16 / out_f16): 16-bit input slots go
+    straight to LDS, residuals are read and results written as 16-bit.  Reference: inputs / weights / residual rounded to the type,
+    fp32 accumulation, result rounded once when stored in 16 bit."""
+    tag = "st%s_%d_%d_%d_%d" % (precision, cin, cout, k, up)
+    sd = {"c.weight": _rand((cout, cin, k, k), "w" + tag, (6.0 / (cin * k * k)) ** 0.5)}
+    x = _rand((2, cin, h, w), "x" + tag)
+    oh, ow = ((h - 1) // stride + 1) * up, ((w - 1) // stride + 1) * up
+    res = _rand((2, cout, oh, ow), "r" + tag)
+    xq, wq = x.to(tdt).float(), sd["c.weight"].to(tdt).float()
+    rq = res.to(tdt).float() if out16 else res
+    y = F.conv2d(xq, wq, None, stride=stride, padding=k // 2)
+    if up > 1:
+        y = F.interpolate(y, scale_factor=up, mode="nearest")
+    ref = F.relu(y + rq)
+    P = engine.Program(torch.device(DEV))
+    pc = engine.Packer(sd, torch.device(DEV), precision).conv("c", None, stride=stride)
+    out = P.conv(to_act(P, x, dt if in16 else 0), pc, relu=True, res1=to_act(P, res, dt if out16 else 0), up=up, out_dt=dt if out16 else 0)
+    assert out.dt == (dt if out16 else 0)
+    run(P)
+    got = from_act(out)
+    if out16:
+        ulp = 2.0 ** -8 if precision == "bf16" else 2.0 ** -11
+        assert ((got - ref).abs() <= ulp * ref.abs() + 5e-4).all(), (got - ref).abs().max().item()
+    else:
+        assert (got - ref).abs().max().item() < 5e-4
+    assert out.view()[..., cout:].abs().max().item() == 0.0 if out.cs > cout else True
+
+
 @pytest.mark.parametrize("precision", ["bf16", "fp16"])
 @pytest.mark.parametrize("d,length,hw,period", [
     (96, [3, 1, 2], (16, 12), 0), (96, [1] * 3, (64, 48), 3072), (96, [5], (16, 12), 0),
