@@ -479,10 +479,11 @@ static int prepare(const i2r_conv_desc* d, int force_mt, int force_cap, int forc
     size_t lds_bytes;
     if (pf > 0) {
         int ckg = 4;
-        const int cap_lim = force_pf >= 0 ? force_cap : (pf == 1 ? 12 : 4);
+        const int cap_max = d->dtype == 0 ? 12 : 8;  // prefetch registers of the kernel variants: fp32 up to 12 groups, 16-bit up to 8
+        const int cap_lim = force_pf >= 0 ? force_cap : (pf == 1 ? cap_max : 4);
         for (int cand : {12, 8, 4})
             if (cand <= cap_lim && cin_g % cand == 0 && (size_t)2 * cand * k.plane * 16 <= 40 * 1024) { ckg = cand; break; }
-        cap = force_pf >= 0 ? force_cap : (ckg > 4 ? 12 : 4);
+        cap = force_pf >= 0 ? force_cap : (ckg > 4 ? cap_max : 4);
         ck = ckg * g_ch;
         lds_bytes = (size_t)2 * ckg * k.plane * 16;
     } else if (d->dtype != 0) {
@@ -586,7 +587,8 @@ extern "C" int i2r_conv_grouped(const i2r_conv_desc* const* descs, int32_t n, co
     I2R_CHECK_ARG(fn != nullptr, "i2r_conv: no kernel for nt=%d mt=%d cap=%d pf=%d dtype=%d", nt0, mt0, cap0, pf0, descs[0]->dtype);
     if (lds_max > 64 * 1024)
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_max);
-    hipLaunchKernelGGL(fn, dim3((unsigned)total), dim3(256), lds_max, (hipStream_t)stream, grp);
+    const unsigned grid = (unsigned)total;
+    hipLaunchKernelGGL(fn, dim3(grid), dim3(256), lds_max, (hipStream_t)stream, grp);
     I2R_CHECK_LAUNCH("i2r_conv");
     return I2R_OK;
 }
