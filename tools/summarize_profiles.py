@@ -86,6 +86,23 @@ def counters_of(d, kernel):
     return {k: sum(v) / len(v) for k, v in acc.items()} if acc else None
 
 
+# the other BASELINE workloads: bench line + trimmed kernel stats each
+for cfg in ("tph_192_p6_b4", "hrt_192_p4_b4", "coco_hrt_288_p2_b4"):
+    src = os.path.join(O, "bench_%s.json" % cfg)
+    if os.path.exists(src):
+        shutil.copy(src, os.path.join(P, "%s_bench_%s.json" % (tag, cfg)))
+    ks_ = glob.glob(os.path.join(O, "prof_stats_" + cfg, "*", "*_kernel_stats.csv"))
+    if ks_:
+        rows_ = list(csv.reader(open(ks_[0])))
+        with open(os.path.join(P, "%s_%s_kernel_stats.csv" % (tag, cfg)), "w", newline="") as fh:
+            w = csv.writer(fh, quoting=csv.QUOTE_ALL)
+            w.writerow(rows_[0])
+            for r in rows_[1:]:
+                if float(r[4]) >= 0.05:
+                    w.writerow(r)
+if os.path.exists(os.path.join(O, "bench_pipeline.json")):
+    shutil.copy(os.path.join(O, "bench_pipeline.json"), os.path.join(P, tag + "_bench_pipeline.json"))
+
 enc = counters_of("prof_pmc_enc", "enc_layer4_k")
 if enc:
     mem = counters_of("prof_pmc_enc_mem", "enc_layer4_k") or {}
