@@ -213,6 +213,20 @@ int i2r_layernorm(const float* in, const float* w, const float* b, float* out, i
 int i2r_window_attn(const float* qkv, const float* bias_qkv, float* out, int32_t n_img, int32_t h, int32_t w, int32_t c,
                     int32_t hs, int32_t heads, void* stream);
 
+/* i2r_hrt_attn_block -- 16-bit modes only: the attention half of a GeneralTransformerBlock in ONE launch,
+ *     out = x + out_proj(window_attention(q|k|v_proj(LayerNorm(x))))      (hrformer.py:1230-1236; same semantics as
+ * i2r_layernorm + i2r_conv(q|k|v) + i2r_window_attn + i2r_conv(out_proj, res1 = x)), one workgroup per 7x7 window, on
+ * v_mfma_f32_16x16x16_{bf16,f16} with fp32 LayerNorm / softmax / accumulation; x and out are fp32 NHWC [n, h, w, cs] (may not alias).
+ * Built for the two high-resolution HRFormer-B branches: (c, heads, cs) = (78, 2, 80) or (156, 4, 160); head_dim 39 padded to 48.
+ * Operand images (16-bit, fragment-packed: element r of lane l of a fragment = M[16*rowblk + (l & 15)][16*colblk + 4*(l >> 4) + r]):
+ *   wqkv  [head][q, k, v][3 dim blocks][cs/16 input blocks][64 lanes][4]: rows = the head's 39 output dims (+ 9 zero rows) of
+ *         q_proj / k_proj / v_proj, columns = input channels; q rows (and bias) pre-multiplied by head_dim^-0.5 * log2(e);
+ *   bqkv  float [head][3][48];   wo [cs/16 output blocks][head][3 dim blocks][64 lanes][4]: rows = out_proj outputs, columns = the
+ *         head's dims (zero beyond 39);   bo float [cs];   ln_w, ln_b float [cs] zero-padded. */
+int i2r_hrt_attn_block(const float* x, float* out, const float* ln_w, const float* ln_b, const void* wqkv, const float* bqkv,
+                       const void* wo, const float* bo, int32_t n_img, int32_t h, int32_t w, int32_t c, int32_t cs, int32_t heads,
+                       float eps, int32_t dtype, void* stream);
+
 /* i2r_dwconv3x3 -- depth-wise 3x3 conv, pad 1, stride 1|2, + bias (eval BN folded) + activation (0 none, 1 ReLU,
  * 2 GELU): MlpDWBN.dw3x3+norm2+act2 (hrformer.py:1070-1080,1106-1108) and the DW down-sampling hops of the fuse
  * layers (:1651-1704). w: [9][cs] (tap-major), bias [cs]. */
@@ -300,7 +314,7 @@ enum {
     I2R_OP_CONV = 1, I2R_OP_STEM = 2, I2R_OP_MAXPOOL = 3, I2R_OP_HEAD = 4,
     I2R_OP_ENC_KV = 5, I2R_OP_ENC_LAYER = 6, I2R_OP_FORK = 7, I2R_OP_JOIN = 8, I2R_OP_CONV_GROUP = 9,
     I2R_OP_LAYERNORM = 10, I2R_OP_WINATTN = 11, I2R_OP_DWCONV = 12, I2R_OP_UPSAMPLE = 13, I2R_OP_CONV_CHAIN = 14,
-    I2R_OP_PE_RES_STEM = 15
+    I2R_OP_PE_RES_STEM = 15, I2R_OP_HRT_ATTN = 16
 };
 
 typedef struct i2r_stem_args {
@@ -332,6 +346,11 @@ typedef struct i2r_winattn_args {
     const float* qkv; const float* bias; float* out;
     int32_t n_img, h, w_, c, cs, heads;
 } i2r_winattn_args;
+
+typedef struct i2r_hrt_attn_args {
+    const float* x; float* out; const float* ln_w; const float* ln_b; const void* wqkv; const float* bqkv; const void* wo; const float* bo;
+    int32_t n_img, h, w_, c, cs, heads; float eps; int32_t dtype;
+} i2r_hrt_attn_args;
 
 typedef struct i2r_dw_args {
     const float* in; const float* w; const float* bias; float* out;

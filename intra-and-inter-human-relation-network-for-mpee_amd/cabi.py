@@ -20,6 +20,7 @@ MAX_GROUP = 4
 OP_LAYERNORM, OP_WINATTN, OP_DWCONV, OP_UPSAMPLE = 10, 11, 12, 13
 OP_CONV_CHAIN = 14
 OP_PE_RES_STEM = 15
+OP_HRT_ATTN = 16
 
 _fp = C.c_void_p  # device pointers travel as integers
 _i32 = C.c_int32
@@ -80,6 +81,11 @@ class WinAttnArgs(C.Structure):
                 ("n_img", _i32), ("h", _i32), ("w_", _i32), ("c", _i32), ("cs", _i32), ("heads", _i32)]
 
 
+class HrtAttnArgs(C.Structure):
+    _fields_ = [("x", _fp), ("out", _fp), ("ln_w", _fp), ("ln_b", _fp), ("wqkv", _fp), ("bqkv", _fp), ("wo", _fp), ("bo", _fp),
+                ("n_img", _i32), ("h", _i32), ("w_", _i32), ("c", _i32), ("cs", _i32), ("heads", _i32), ("eps", C.c_float), ("dtype", _i32)]
+
+
 class DwArgs(C.Structure):
     _fields_ = [("in_", _fp), ("w", _fp), ("bias", _fp), ("out", _fp),
                 ("n_img", _i32), ("in_h", _i32), ("in_w", _i32), ("c", _i32), ("cs", _i32), ("stride", _i32), ("act", _i32)]
@@ -106,7 +112,7 @@ class Op(C.Structure):
 
 
 # every symbol include/i2r_hip.h declares (tests/test_host.py::test_cabi_library_exports_every_declared_symbol checks the built library exports them all)
-EXPORTS = ("i2r_conv", "i2r_conv_grouped", "i2r_conv_kernel_name", "i2r_stem_conv", "i2r_pe_res_stem", "i2r_maxpool3x3s2", "i2r_head", "i2r_layernorm", "i2r_window_attn", "i2r_dwconv3x3",
+EXPORTS = ("i2r_conv", "i2r_conv_grouped", "i2r_conv_kernel_name", "i2r_stem_conv", "i2r_pe_res_stem", "i2r_maxpool3x3s2", "i2r_head", "i2r_layernorm", "i2r_window_attn", "i2r_hrt_attn_block", "i2r_dwconv3x3",
            "i2r_upsample_bilinear_add", "i2r_flip_merge", "i2r_decode", "i2r_crop_affine", "i2r_box_mask", "i2r_conv_chain_pack", "i2r_conv_chain", "i2r_encoder_kv", "i2r_encoder_layer",
            "i2r_run_program", "i2r_abi_version", "i2r_last_error", "i2r_device_check")
 
@@ -139,6 +145,7 @@ def load_library(path=LIB_PATH):
     L.i2r_head.argtypes = [_fp, _fp, _fp, _fp, _i32, _i32, _i32, _i32, _i32, _i32, C.c_void_p]
     L.i2r_layernorm.argtypes = [_fp, _fp, _fp, _fp, _i32, _i32, _i32, C.c_float, C.c_void_p]
     L.i2r_window_attn.argtypes = [_fp, _fp, _fp, _i32, _i32, _i32, _i32, _i32, _i32, C.c_void_p]
+    L.i2r_hrt_attn_block.argtypes = [_fp, _fp, _fp, _fp, _fp, _fp, _fp, _fp, _i32, _i32, _i32, _i32, _i32, _i32, C.c_float, _i32, C.c_void_p]
     L.i2r_dwconv3x3.argtypes = [_fp, _fp, _fp, _fp, _i32, _i32, _i32, _i32, _i32, _i32, _i32, C.c_void_p]
     L.i2r_upsample_bilinear_add.argtypes = [_fp, _fp, _fp, _i32, _i32, _i32, _i32, _i32, _i32, _i32, C.c_void_p]
     L.i2r_encoder_kv.argtypes = [C.POINTER(EncoderDesc), C.c_void_p]

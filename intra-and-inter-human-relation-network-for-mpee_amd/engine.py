@@ -286,6 +286,41 @@ class Packer:
         W[:, cols] = self.sd[p + ".out_proj.weight"].double()
         return self.linear_as_conv(W, self.sd[p + ".out_proj.bias"])
 
+    @staticmethod
+    def _frag16(m, tdt):
+        """[rows, cols] (multiples of 16) -> v_mfma_f32_16x16x16 A-operand images: [rows/16][cols/16][64 lanes][4] 16-bit,
+        element r of lane l = m[16 rb + (l & 15)][16 cb + 4 (l >> 4) + r]  (include/i2r_hip.h, i2r_hrt_attn_block)"""
+        rows, cols = m.shape
+        v = m.reshape(rows // 16, 16, cols // 16, 4, 4)              # [rb, i, cb, g, r]
+        return v.permute(0, 2, 3, 1, 4).contiguous().to(tdt)         # [rb, cb, g, i, r] = lane (g, i) order
+
+    def attn_block_lp(self, p, c, heads):
+        """operands of the fused 16-bit attention half of a transformer block (i2r_hrt_attn_block); r = block key prefix"""
+        tdt = torch.bfloat16 if self.dtype == 1 else torch.float16
+        hd, cs = c // heads, _r16(c)
+        assert hd == 39
+        a = p + ".attn.attn"
+        wq = torch.zeros(heads, 3, 48, cs, dtype=torch.float64)
+        bq = torch.zeros(heads, 3, 48, dtype=torch.float64)
+        for i, n in enumerate(("q_proj", "k_proj", "v_proj")):
+            sc = float(hd) ** -0.5 * 1.4426950408889634 if i == 0 else 1.0   # softmax in base 2
+            W = self.sd["%s.%s.weight" % (a, n)].double() * sc
+            b = self.sd["%s.%s.bias" % (a, n)].double() * sc
+            for hh in range(heads):
+                wq[hh, i, :hd, :c] = W[hh * hd:(hh + 1) * hd]
+                bq[hh, i, :hd] = b[hh * hd:(hh + 1) * hd]
+        wqkv = self._frag16(wq.reshape(heads * 3 * 48, cs).float(), tdt)            # [(h, part, db)][cb][64][4]
+        Wo = self.sd[a + ".out_proj.weight"].double()
+        wo = torch.zeros(cs, heads, 48, dtype=torch.float64)
+        for hh in range(heads):
+            wo[:c, hh, :hd] = Wo[:, hh * hd:(hh + 1) * hd]
+        wo = self._frag16(wo.reshape(cs, heads * 48).float(), tdt)                   # [ob][(h, db)][64][4]
+        bo = torch.zeros(cs)
+        bo[:c] = self.sd[a + ".out_proj.bias"]
+        ln = self.ln(p + ".norm1", c)
+        return dict(wqkv=self._dev(wqkv), bqkv=self._dev(bq.float()), wo=self._dev(wo), bo=self._dev(bo), ln=ln, c=c, cs=cs, heads=heads,
+                    dtype=self.dtype)
+
     def table(self, key, rows, d):
         """[rows, 1, d] parameter (TransPose-H pos_embedding) -> [rows, cs] device table."""
         v = self.sd[key].reshape(rows, d)
@@ -629,6 +664,16 @@ class Program:
         self.ops.append((cabi.OP_WINATTN, lane, a))
         return out
 
+    def hrt_attn(self, x, ab, eps=1e-6, lane=0):
+        """fused x + out_proj(window_attn(qkv(LN1 x))) (16-bit modes, i2r_hrt_attn_block)"""
+        assert x.dt == 0 and x.c == ab["c"] and x.cs == ab["cs"]
+        out = self.alloc(x.n, x.h, x.w, x.c)
+        self.keep.append(ab)
+        a = cabi.HrtAttnArgs(x.ptr, out.ptr, ab["ln"]["w"].data_ptr(), ab["ln"]["b"].data_ptr(), ab["wqkv"].data_ptr(), ab["bqkv"].data_ptr(),
+                             ab["wo"].data_ptr(), ab["bo"].data_ptr(), x.n, x.h, x.w, x.c, x.cs, ab["heads"], eps, ab["dtype"])
+        self.ops.append((cabi.OP_HRT_ATTN, lane, a))
+        return out
+
     def dwconv(self, x, dw, stride=1, act=0, lane=0):
         assert x.dt == 0, "fp32 kernel: the producer must store fp32 (conv(..., out_dt=0))"
         assert x.c == dw["c"] and x.cs == dw["cs"]
@@ -960,7 +1005,8 @@ class HRFormerB:
             blks = []
             for k in range(st["num_blocks"][i]):
                 r = "%s.branches.%d.%d" % (q, i, k)
-                blks.append(dict(c=ch[i], heads=st["num_heads"][i], ln1=pk.ln(r + ".norm1", ch[i]), ln2=pk.ln(r + ".norm2", ch[i]),
+                fused = pk.attn_block_lp(r, ch[i], st["num_heads"][i]) if (pk.dtype != 0 and ch[i] in (78, 156)) else None
+                blks.append(dict(c=ch[i], heads=st["num_heads"][i], ln1=pk.ln(r + ".norm1", ch[i]), ln2=pk.ln(r + ".norm2", ch[i]), attn_lp=fused,
                                  qkv=pk.qkv(r + ".attn.attn", ch[i], st["num_heads"][i]),
                                  out=pk.attn_out(r + ".attn.attn", ch[i], st["num_heads"][i]),
                                  fc1=pk.conv(r + ".mlp.fc1", r + ".mlp.norm1"), dw=pk.dw(r + ".mlp.dw3x3", r + ".mlp.norm2"),
@@ -980,13 +1026,17 @@ class HRFormerB:
     def _emit_block(P, blk, x, lane=0):
         """GeneralTransformerBlock.forward (hrformer.py:1230-1240): x += attn(LN1 x); x += mlp(LN2 x)."""
         P.lane_ctx = lane
-        n1 = P.layernorm(x, blk["ln1"], lane=lane)
-        qkv = P.conv(n1, blk["qkv"], lane=lane)
-        P.release(n1)
-        a = P.winattn(qkv, blk["qkv"].bias, blk["c"], blk["heads"], lane=lane)
-        P.release(qkv)
-        x1 = P.conv(a, blk["out"], res1=x, lane=lane)
-        P.release(a, x)
+        if blk.get("attn_lp") is not None:  # 16-bit modes, high-resolution branches: the whole attention half in one launch
+            x1 = P.hrt_attn(x, blk["attn_lp"], lane=lane)
+            P.release(x)
+        else:
+            n1 = P.layernorm(x, blk["ln1"], lane=lane)
+            qkv = P.conv(n1, blk["qkv"], lane=lane)
+            P.release(n1)
+            a = P.winattn(qkv, blk["qkv"].bias, blk["c"], blk["heads"], lane=lane)
+            P.release(qkv)
+            x1 = P.conv(a, blk["out"], res1=x, lane=lane)
+            P.release(a, x)
         n2 = P.layernorm(x1, blk["ln2"], lane=lane)
         h1 = P.conv(n2, blk["fc1"], act=2, lane=lane)
         P.release(n2)

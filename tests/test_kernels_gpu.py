@@ -374,6 +374,33 @@ def test_window_attention_block_matches_oracle(c, heads, h, w):
     assert err < 2e-4, "window attention c=%d max-abs %.3e" % (c, err)
 
 
+@pytest.mark.parametrize("precision", ["bf16", "fp16"])
+@pytest.mark.parametrize("c,heads,h,w", [(78, 2, 64, 48), (156, 4, 32, 24), (78, 2, 24, 18), (156, 4, 9, 12)])
+def test_fused_attention_block_16bit(precision, c, heads, h, w):
+    """i2r_hrt_attn_block (one launch: LN1 + q|k|v + window attention + out_proj + residual, 16-bit MFMA) vs the fp32 oracle
+    x + attn(LN1 x); tolerance = 16-bit operand rounding of a residual branch (|x| ~ 1, branch ~ 1)."""
+    import i2r_cpu_hrformer as H
+    tag = "fa%d_%d" % (c, h)
+    p = "b.attn.attn"
+    sd = {"b.norm1.weight": _rand((c,), "n1w" + tag, 0.3) + 1.0, "b.norm1.bias": _rand((c,), "n1b" + tag, 0.2)}
+    for n in ("q_proj", "k_proj", "v_proj", "out_proj"):
+        sd["%s.%s.weight" % (p, n)] = _rand((c, c), n + "w" + tag, 2.0 * (3.0 / c) ** 0.5)
+        sd["%s.%s.bias" % (p, n)] = _rand((c,), n + "b" + tag, 0.3)
+    x = _rand((2, c, h, w), "x" + tag)
+    t = x.permute(0, 2, 3, 1)
+    n1 = F.layer_norm(t, (c,), sd["b.norm1.weight"], sd["b.norm1.bias"], 1e-6)
+    ref = (t + H.window_attention(sd, p, n1, heads)).permute(0, 3, 1, 2)
+    P = engine.Program(torch.device(DEV))
+    pk = engine.Packer(sd, torch.device(DEV), precision)
+    out = P.hrt_attn(to_act(P, x), pk.attn_block_lp("b", c, heads))
+    run(P)
+    d = from_act(out) - ref
+    tol_max, tol_rms = (6e-2, 2e-2) if precision == "bf16" else (1e-2, 3e-3)   # relative, like LP_TOL of the model tests
+    rel_max, rel_rms = d.abs().max().item() / ref.abs().max().item(), d.pow(2).mean().sqrt().item() / ref.pow(2).mean().sqrt().item()
+    assert rel_max < tol_max and rel_rms < tol_rms, (rel_max, rel_rms)
+    assert out.view()[..., c:].abs().max().item() == 0.0
+
+
 @pytest.mark.parametrize("c,stride,act", [(312, 1, 2), (78, 2, 0), (160, 2, 1)])
 def test_dwconv(c, stride, act):
     sd = {"d.weight": _rand((c, 1, 3, 3), "dww%d" % c, 0.5), "d.bias": _rand((c,), "dwb%d" % c, 0.2),

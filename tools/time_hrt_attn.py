@@ -1,0 +1,33 @@
+"""GPU tuning aid: time the fused HRFormer attention-block kernel (i2r_hrt_attn_block) on the two high-resolution branch shapes."""
+import os, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import torch
+import i2r_amd  # noqa
+from i2r_amd import engine, synth
+DEV = torch.device("cuda:0")
+prec = sys.argv[1] if len(sys.argv) > 1 else "bf16"
+n = int(sys.argv[2]) if len(sys.argv) > 2 else 16
+for c, heads, h, w in ((78, 2, 64, 48), (156, 4, 32, 24)):
+    sd = {"b.norm1.weight": torch.ones(c), "b.norm1.bias": torch.zeros(c)}
+    for k in ("q_proj", "k_proj", "v_proj", "out_proj"):
+        sd["b.attn.attn.%s.weight" % k] = torch.from_numpy(synth._sym(1, k + str(c), (c, c), 0.1))
+        sd["b.attn.attn.%s.bias" % k] = torch.zeros(c)
+    P = engine.Program(DEV)
+    ab = engine.Packer(sd, DEV, prec).attn_block_lp("b", c, heads)
+    x = P.alloc(n, h, w, c)
+    x.t.normal_()
+    y = x
+    for _ in range(4):
+        y = P.hrt_attn(y, ab)
+    P.finalize()
+    for _ in range(3):
+        P.run()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(10):
+        P.run()
+    e1.record()
+    torch.cuda.synchronize()
+    print("C=%d %dx%d n=%d: %.1f us per launch" % (c, h, w, n, e0.elapsed_time(e1) / 40 * 1e3))

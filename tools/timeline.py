@@ -6,7 +6,7 @@ rows = [r for r in csv.DictReader(open(f))]
 ev = [(int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Kernel_Name"].replace("void ", "").replace("(anonymous namespace)::", "").split("(")[0][:40]) for r in rows]
 ev.sort()
 # last step: from the last stem_conv_k<3> launch to the end
-starts = [i for i, e in enumerate(ev) if e[2].startswith("stem_conv_k<3>")]
+starts = [i for i, e in enumerate(ev) if e[2].startswith("stem_conv_k<3")]
 lo = starts[-2] if len(starts) > 1 else 0
 hi = starts[-1] if len(starts) > 1 else len(ev)
 step = ev[lo:hi]
