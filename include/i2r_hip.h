@@ -199,7 +199,7 @@ int i2r_box_mask(const int32_t* boxes, int32_t ih, int32_t iw, float* out, int32
 /* i2r_layernorm -- nn.LayerNorm(c, eps) over the channels of every pixel/token of an NHWC tensor
  * (GeneralTransformerBlock.norm1/norm2, hrformer.py:1198,1235-1237). w, b: [cs] zero-padded. */
 int i2r_layernorm(const float* in, const float* w, const float* b, float* out, int32_t npix, int32_t c, int32_t cs,
-                  float eps, void* stream);
+                  float eps, int32_t out_dt /* storage of out: 0 fp32, 1 bf16, 2 f16 */, void* stream);
 
 /* i2r_window_attn -- the softmax(q k^T) v core of InterlacedPoolAttention / MHA_ over 7x7 windows
  * (hrformer.py:1164-1180, 692-935): centre zero-padding to multiples of 7 (:947-956), window gather (:978-987),
@@ -231,7 +231,8 @@ int i2r_hrt_attn_block(const float* x, float* out, const float* ln_w, const floa
  * 2 GELU): MlpDWBN.dw3x3+norm2+act2 (hrformer.py:1070-1080,1106-1108) and the DW down-sampling hops of the fuse
  * layers (:1651-1704). w: [9][cs] (tap-major), bias [cs]. */
 int i2r_dwconv3x3(const float* in, const float* w, const float* bias, float* out, int32_t n_img, int32_t in_h, int32_t in_w,
-                  int32_t c, int32_t cs, int32_t stride, int32_t act, void* stream);
+                  int32_t c, int32_t cs, int32_t stride, int32_t act, int32_t dt /* storage of in and out: 0 fp32, 1 bf16, 2 f16 (stride 1) */,
+                  void* stream);
 
 /* i2r_upsample_bilinear_add -- out = act(res + F.interpolate(low, scale_factor=scale, mode='bilinear',
  * align_corners=False)): the up-sampling terms of HighResolutionTransformerModule.forward (hrformer.py:1629-1646,
@@ -339,7 +340,7 @@ typedef struct i2r_head_args {
 
 typedef struct i2r_ln_args {
     const float* in; const float* w; const float* b; float* out;
-    int32_t npix, c, cs; float eps;
+    int32_t npix, c, cs; float eps; int32_t out_dt;
 } i2r_ln_args;
 
 typedef struct i2r_winattn_args {
@@ -354,7 +355,7 @@ typedef struct i2r_hrt_attn_args {
 
 typedef struct i2r_dw_args {
     const float* in; const float* w; const float* bias; float* out;
-    int32_t n_img, in_h, in_w, c, cs, stride, act;
+    int32_t n_img, in_h, in_w, c, cs, stride, act, dt;
 } i2r_dw_args;
 
 typedef struct i2r_up_args {

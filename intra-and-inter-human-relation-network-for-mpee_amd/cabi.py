@@ -73,7 +73,8 @@ class HeadArgs(C.Structure):
 
 
 class LnArgs(C.Structure):
-    _fields_ = [("in_", _fp), ("w", _fp), ("b", _fp), ("out", _fp), ("npix", _i32), ("c", _i32), ("cs", _i32), ("eps", C.c_float)]
+    _fields_ = [("in_", _fp), ("w", _fp), ("b", _fp), ("out", _fp), ("npix", _i32), ("c", _i32), ("cs", _i32), ("eps", C.c_float),
+                ("out_dt", _i32)]
 
 
 class WinAttnArgs(C.Structure):
@@ -88,7 +89,7 @@ class HrtAttnArgs(C.Structure):
 
 class DwArgs(C.Structure):
     _fields_ = [("in_", _fp), ("w", _fp), ("bias", _fp), ("out", _fp),
-                ("n_img", _i32), ("in_h", _i32), ("in_w", _i32), ("c", _i32), ("cs", _i32), ("stride", _i32), ("act", _i32)]
+                ("n_img", _i32), ("in_h", _i32), ("in_w", _i32), ("c", _i32), ("cs", _i32), ("stride", _i32), ("act", _i32), ("dt", _i32)]
 
 
 class UpArgs(C.Structure):
@@ -143,10 +144,10 @@ def load_library(path=LIB_PATH):
     L.i2r_box_mask.argtypes = [_fp, _i32, _i32, _fp, _i32, _i32, _i32, C.c_void_p]
     L.i2r_maxpool3x3s2.argtypes = [_fp, _fp, _i32, _i32, _i32, _i32, _i32, _i32, C.c_void_p]
     L.i2r_head.argtypes = [_fp, _fp, _fp, _fp, _i32, _i32, _i32, _i32, _i32, _i32, C.c_void_p]
-    L.i2r_layernorm.argtypes = [_fp, _fp, _fp, _fp, _i32, _i32, _i32, C.c_float, C.c_void_p]
+    L.i2r_layernorm.argtypes = [_fp, _fp, _fp, _fp, _i32, _i32, _i32, C.c_float, _i32, C.c_void_p]
     L.i2r_window_attn.argtypes = [_fp, _fp, _fp, _i32, _i32, _i32, _i32, _i32, _i32, C.c_void_p]
     L.i2r_hrt_attn_block.argtypes = [_fp, _fp, _fp, _fp, _fp, _fp, _fp, _fp, _i32, _i32, _i32, _i32, _i32, _i32, C.c_float, _i32, C.c_void_p]
-    L.i2r_dwconv3x3.argtypes = [_fp, _fp, _fp, _fp, _i32, _i32, _i32, _i32, _i32, _i32, _i32, C.c_void_p]
+    L.i2r_dwconv3x3.argtypes = [_fp, _fp, _fp, _fp, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, C.c_void_p]
     L.i2r_upsample_bilinear_add.argtypes = [_fp, _fp, _fp, _i32, _i32, _i32, _i32, _i32, _i32, _i32, C.c_void_p]
     L.i2r_encoder_kv.argtypes = [C.POINTER(EncoderDesc), C.c_void_p]
     L.i2r_encoder_layer.argtypes = [C.POINTER(EncoderDesc), C.c_void_p]

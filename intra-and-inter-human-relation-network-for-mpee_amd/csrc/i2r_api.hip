@@ -92,7 +92,7 @@ extern "C" int i2r_run_program(const i2r_op* ops, int32_t n_ops, void* const* st
             }
             case I2R_OP_LAYERNORM: {
                 const i2r_ln_args* a = (const i2r_ln_args*)op.args;
-                rc = i2r_layernorm(a->in, a->w, a->b, a->out, a->npix, a->c, a->cs, a->eps, st);
+                rc = i2r_layernorm(a->in, a->w, a->b, a->out, a->npix, a->c, a->cs, a->eps, a->out_dt, st);
                 break;
             }
             case I2R_OP_CONV_CHAIN:
@@ -111,7 +111,7 @@ extern "C" int i2r_run_program(const i2r_op* ops, int32_t n_ops, void* const* st
             }
             case I2R_OP_DWCONV: {
                 const i2r_dw_args* a = (const i2r_dw_args*)op.args;
-                rc = i2r_dwconv3x3(a->in, a->w, a->bias, a->out, a->n_img, a->in_h, a->in_w, a->c, a->cs, a->stride, a->act, st);
+                rc = i2r_dwconv3x3(a->in, a->w, a->bias, a->out, a->n_img, a->in_h, a->in_w, a->c, a->cs, a->stride, a->act, a->dt, st);
                 break;
             }
             case I2R_OP_UPSAMPLE: {

@@ -1,7 +1,7 @@
 // HRFormer-B building blocks that are not convolutions: channel LayerNorm, 7x7-window multi-head attention,
 // depth-wise 3x3 conv (+folded BN, +GELU/ReLU) and bilinear-upsample-accumulate of the multi-scale fuse.
 // All are HBM / LDS-bound glue around the MFMA conv kernel (window attention is 5 % of the HRFormer FLOPs).
-#include "i2r_common.h"
+#include "i2r_conv.h"  // (ld_act4 / st_act4: fp32 or bf16 / f16 activation storage)
 
 namespace {
 
@@ -18,6 +18,7 @@ __device__ __forceinline__ f32x4 act4(f32x4 v, int act) {
 
 // ---- LayerNorm over the c real channels of each pixel; 16 lanes per pixel, values cached in registers ----
 constexpr int kLnMaxChunks = 10;  // 16 lanes x 10 float4 = 640 channels
+template <int ODT>  // storage type of the output: 0 fp32, 1 bf16, 2 f16 (16-bit modes: it only feeds a 16-bit conv)
 __global__ __launch_bounds__(256) void layernorm_k(const float* __restrict__ in, const float* __restrict__ w,
                                                    const float* __restrict__ b, float* __restrict__ out, int npix, int c,
                                                    int cs, float eps) {
@@ -58,7 +59,7 @@ __global__ __launch_bounds__(256) void layernorm_k(const float* __restrict__ in,
             f32x4 o;
 #pragma unroll
             for (int e = 0; e < 4; ++e) o[e] = (v[k][e] - mean) * rstd * wv[e] + bv[e];  // padded w = b = 0 -> 0
-            *reinterpret_cast<f32x4*>(out + (size_t)pix * cs + ch * 4) = o;
+            st_act4<ODT>(out, (size_t)pix * cs + ch * 4, o, ODT != 0);
         }
     }
 }
@@ -202,6 +203,7 @@ __global__ __launch_bounds__(256) void dwconv3x3_k(const float* __restrict__ in,
 
 // stride-1 variant: one thread = 4 vertically adjacent output pixels x 4 channels -- 18 input loads and 9 weight loads
 // for 4 outputs instead of 36 + 36 (the kernel is L1 / addresser bound, not HBM bound, with one output per thread)
+template <int DT>  // activation storage of in AND out: 0 fp32, 1 bf16, 2 f16 (the MLP hidden tensor of the 16-bit modes)
 __global__ __launch_bounds__(256) void dwconv3x3_s1_k(const float* __restrict__ in, const float* __restrict__ w,
                                                       const float* __restrict__ bias, float* __restrict__ out, int n_img, int h,
                                                       int wd, int c4, int cs, int act) {
@@ -226,7 +228,7 @@ __global__ __launch_bounds__(256) void dwconv3x3_s1_k(const float* __restrict__ 
         for (int kx = 0; kx < 3; ++kx) {
             const int ix = ox - 1 + kx;
             if (ix < 0 || ix >= wd) continue;
-            const f32x4 v = *reinterpret_cast<const f32x4*>(in + ((size_t)(img * h + iy) * wd + ix) * cs + cg * 4);
+            const f32x4 v = ld_act4<DT>(in, ((size_t)(img * h + iy) * wd + ix) * cs + cg * 4, DT != 0);
 #pragma unroll
             for (int o = 0; o < 4; ++o) {
                 const int ky = r - o;  // output row oy0 + o takes input row oy0 + o - 1 + ky
@@ -240,7 +242,7 @@ __global__ __launch_bounds__(256) void dwconv3x3_s1_k(const float* __restrict__ 
     }
 #pragma unroll
     for (int o = 0; o < 4; ++o)
-        if (oy0 + o < h) *reinterpret_cast<f32x4*>(out + ((size_t)(img * h + oy0 + o) * wd + ox) * cs + cg * 4) = act4(acc[o], act);
+        if (oy0 + o < h) st_act4<DT>(out, ((size_t)(img * h + oy0 + o) * wd + ox) * cs + cg * 4, act4(acc[o], act), DT != 0);
 }
 
 // ---- out = act(res + bilinear_upsample(low)), align_corners = False, integer scale ----
@@ -275,12 +277,14 @@ __global__ __launch_bounds__(256) void upsample_add_k(const float* __restrict__ 
 }  // namespace
 
 extern "C" int i2r_layernorm(const float* in, const float* w, const float* b, float* out, int32_t npix, int32_t c, int32_t cs,
-                             float eps, void* stream) {
+                             float eps, int32_t out_dt, void* stream) {
     I2R_CHECK_ARG(in && w && b && out, "i2r_layernorm: null pointer");
+    I2R_CHECK_ARG(out_dt >= 0 && out_dt <= 2, "i2r_layernorm: out_dt %d", out_dt);
     I2R_CHECK_ARG(c > 0 && c <= cs && cs % 4 == 0 && cs <= 16 * 4 * kLnMaxChunks, "i2r_layernorm: c=%d cs=%d", c, cs);
     const long long nthr = (long long)npix * 16;
-    hipLaunchKernelGGL(layernorm_k, dim3((unsigned)((nthr + 255) / 256)), dim3(256), 0, (hipStream_t)stream, in, w, b, out, npix, c,
-                       cs, eps);
+    typedef void (*ln_fn)(const float*, const float*, const float*, float*, int, int, int, float);
+    static const ln_fn fns[3] = {layernorm_k<0>, layernorm_k<1>, layernorm_k<2>};
+    hipLaunchKernelGGL(fns[out_dt], dim3((unsigned)((nthr + 255) / 256)), dim3(256), 0, (hipStream_t)stream, in, w, b, out, npix, c, cs, eps);
     I2R_CHECK_LAUNCH("i2r_layernorm");
     return I2R_OK;
 }
@@ -302,14 +306,17 @@ extern "C" int i2r_window_attn(const float* qkv, const float* bias_qkv, float* o
 }
 
 extern "C" int i2r_dwconv3x3(const float* in, const float* w, const float* bias, float* out, int32_t n_img, int32_t in_h,
-                             int32_t in_w, int32_t c, int32_t cs, int32_t stride, int32_t act, void* stream) {
+                             int32_t in_w, int32_t c, int32_t cs, int32_t stride, int32_t act, int32_t dt, void* stream) {
     I2R_CHECK_ARG(in && w && bias && out && in != out, "i2r_dwconv3x3: bad pointers");
+    I2R_CHECK_ARG(dt >= 0 && dt <= 2 && (dt == 0 || stride == 1), "i2r_dwconv3x3: 16-bit storage (dt=%d) is built for the stride-1 MLP conv", dt);
     I2R_CHECK_ARG(c > 0 && c <= cs && cs % 4 == 0 && (stride == 1 || stride == 2) && act >= 0 && act <= 2, "i2r_dwconv3x3: args");
     const int out_h = (in_h - 1) / stride + 1, out_w = (in_w - 1) / stride + 1;
     if (stride == 1) {
         const long long nthr = (long long)n_img * ((in_h + 3) / 4) * in_w * (cs / 4);
-        hipLaunchKernelGGL(dwconv3x3_s1_k, dim3((unsigned)((nthr + 255) / 256)), dim3(256), 0, (hipStream_t)stream, in, w, bias, out,
-                           n_img, in_h, in_w, cs / 4, cs, act);
+        typedef void (*dw_fn)(const float*, const float*, const float*, float*, int, int, int, int, int, int);
+        static const dw_fn fns[3] = {dwconv3x3_s1_k<0>, dwconv3x3_s1_k<1>, dwconv3x3_s1_k<2>};
+        hipLaunchKernelGGL(fns[dt], dim3((unsigned)((nthr + 255) / 256)), dim3(256), 0, (hipStream_t)stream, in, w, bias, out, n_img, in_h, in_w,
+                           cs / 4, cs, act);
     } else {
         const long long nthr = (long long)n_img * out_h * out_w * (cs / 4);
         hipLaunchKernelGGL(dwconv3x3_k, dim3((unsigned)((nthr + 255) / 256)), dim3(256), 0, (hipStream_t)stream, in, w, bias, out, n_img,

@@ -647,11 +647,12 @@ class Program:
         self.ops.append((cabi.OP_MAXPOOL, lane, a))
         return out
 
-    def layernorm(self, x, ln, eps=1e-6, lane=0):
+    def layernorm(self, x, ln, eps=1e-6, lane=0, out_dt=0):
+        """out_dt: storage type of the normalised map (16-bit modes: it only feeds a 16-bit conv)"""
         assert x.dt == 0, "fp32 kernel: the producer must store fp32 (conv(..., out_dt=0))"
-        out = self.alloc(x.n, x.h, x.w, x.c)
+        out = self.alloc(x.n, x.h, x.w, x.c, out_dt)
         self.keep.append(ln)
-        a = cabi.LnArgs(x.ptr, ln["w"].data_ptr(), ln["b"].data_ptr(), out.ptr, x.n * x.h * x.w, x.c, x.cs, eps)
+        a = cabi.LnArgs(x.ptr, ln["w"].data_ptr(), ln["b"].data_ptr(), out.ptr, x.n * x.h * x.w, x.c, x.cs, eps, out_dt)
         self.ops.append((cabi.OP_LAYERNORM, lane, a))
         return out
 
@@ -675,11 +676,12 @@ class Program:
         return out
 
     def dwconv(self, x, dw, stride=1, act=0, lane=0):
-        assert x.dt == 0, "fp32 kernel: the producer must store fp32 (conv(..., out_dt=0))"
+        """the output keeps the input's storage type (stride 1: fp32 or 16 bit; stride 2: fp32 only)"""
+        assert x.dt == 0 or stride == 1
         assert x.c == dw["c"] and x.cs == dw["cs"]
-        out = self.alloc(x.n, (x.h - 1) // stride + 1, (x.w - 1) // stride + 1, x.c)
+        out = self.alloc(x.n, (x.h - 1) // stride + 1, (x.w - 1) // stride + 1, x.c, x.dt)
         self.keep.append(dw)
-        a = cabi.DwArgs(x.ptr, dw["w"].data_ptr(), dw["bias"].data_ptr(), out.ptr, x.n, x.h, x.w, x.c, x.cs, stride, act)
+        a = cabi.DwArgs(x.ptr, dw["w"].data_ptr(), dw["bias"].data_ptr(), out.ptr, x.n, x.h, x.w, x.c, x.cs, stride, act, x.dt)
         self.ops.append((cabi.OP_DWCONV, lane, a))
         return out
 
@@ -1030,19 +1032,21 @@ class HRFormerB:
             x1 = P.hrt_attn(x, blk["attn_lp"], lane=lane)
             P.release(x)
         else:
-            n1 = P.layernorm(x, blk["ln1"], lane=lane)
-            qkv = P.conv(n1, blk["qkv"], lane=lane)
+            n1 = P.layernorm(x, blk["ln1"], lane=lane, out_dt=P.store_dt)
+            qkv = P.conv(n1, blk["qkv"], lane=lane, out_dt=0)
             P.release(n1)
             a = P.winattn(qkv, blk["qkv"].bias, blk["c"], blk["heads"], lane=lane)
             P.release(qkv)
             x1 = P.conv(a, blk["out"], res1=x, lane=lane)
             P.release(a, x)
-        n2 = P.layernorm(x1, blk["ln2"], lane=lane)
-        h1 = P.conv(n2, blk["fc1"], act=2, lane=lane)
+        # 16-bit modes: LN2's output and the 4C-wide hidden tensor of the MLP (the largest maps of the block) are stored in 16 bit;
+        # the residual stream x stays fp32
+        n2 = P.layernorm(x1, blk["ln2"], lane=lane, out_dt=P.store_dt)
+        h1 = P.conv(n2, blk["fc1"], act=2, lane=lane)           # (keeps n2's storage type)
         P.release(n2)
         h2 = P.dwconv(h1, blk["dw"], 1, act=2, lane=lane)
         P.release(h1)
-        x2 = P.conv(h2, blk["fc2"], act=2, res_post=x1, lane=lane)
+        x2 = P.conv(h2, blk["fc2"], act=2, res_post=x1, lane=lane, out_dt=0)
         P.release(h2, x1)
         return x2
 

@@ -416,6 +416,30 @@ def test_dwconv(c, stride, act):
     assert (from_act(out) - ref).abs().max().item() < 5e-5
 
 
+@pytest.mark.parametrize("dt,tdt", [(1, torch.bfloat16), (2, torch.float16)])
+def test_layernorm_and_dwconv_16bit_storage(dt, tdt):
+    """16-bit modes: LayerNorm writes its output in 16 bit (it only feeds a 16-bit conv), the MLP's depth-wise conv reads and writes the
+    hidden tensor in 16 bit; arithmetic stays fp32, so the results are the fp32 ones rounded once (inputs rounded for the conv)."""
+    c = 78
+    sd = {"n.weight": _rand((c,), "lw16", 0.3) + 1.0, "n.bias": _rand((c,), "lb16", 0.2)}
+    x = _rand((2, c, 9, 7), "lx16", 2.0)
+    ref = F.layer_norm(x.permute(0, 2, 3, 1), (c,), sd["n.weight"], sd["n.bias"], 1e-6).permute(0, 3, 1, 2)
+    P = engine.Program(torch.device(DEV))
+    out = P.layernorm(to_act(P, x), engine.Packer(sd, torch.device(DEV)).ln("n", c), out_dt=dt)
+    assert out.dt == dt
+    c2 = 312
+    sd2 = {"d.weight": _rand((c2, 1, 3, 3), "dw16", 0.5), "d.bias": _rand((c2,), "db16", 0.2)}
+    h = _rand((2, c2, 10, 7), "dh16")
+    hq = h.to(tdt).float()
+    ref2 = F.gelu(F.conv2d(hq, sd2["d.weight"], sd2["d.bias"], padding=1, groups=c2))
+    out2 = P.dwconv(to_act(P, h, dt), engine.Packer(sd2, torch.device(DEV)).dw("d", None), 1, act=2)
+    assert out2.dt == dt
+    run(P)
+    ulp = 2.0 ** -8 if dt == 1 else 2.0 ** -11
+    assert ((from_act(out) - ref).abs() <= ulp * ref.abs() + 1e-5).all()
+    assert ((from_act(out2) - ref2).abs() <= ulp * ref2.abs() + 1e-5).all()
+
+
 @pytest.mark.parametrize("scale", [2, 4, 8])
 def test_upsample_bilinear_add(scale):
     low = _rand((2, 78, 6, 5), "upl%d" % scale)
