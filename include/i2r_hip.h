@@ -195,6 +195,16 @@ int i2r_crop_affine(const unsigned char* img, int32_t ih, int32_t iw, int32_t ro
  * resolution, resized bilinearly (half-pixel centres) to [n, 1, oh, ow], values in [0, 1].  Same parity note as above. */
 int i2r_box_mask(const int32_t* boxes, int32_t ih, int32_t iw, float* out, int32_t n, int32_t oh, int32_t ow, void* stream);
 
+/* i2r_crop_affine_cv2 / i2r_box_mask_cv2 -- the same two steps in cv2's OWN arithmetic, restated from OpenCV's published algorithm
+ * (imgwarp.cpp warpAffine -> remap with the 1/32-pixel fixed-point bilinear table, 15-bit weights, 8-bit result; resize.cpp 8-bit
+ * linear resize with 11-bit coefficients; rotate_bound(mask, 0)'s half-pixel shift along odd image dimensions, JointsDataset.py:180-202).
+ * inv_m: device double [n, 6] = the INVERSE of get_affine_transform(...) computed in double precision the way cv2.warpAffine does.
+ * Default of the host side (input.person_inputs); still "parity unpinned": cv2 is absent from the build image, nothing could be
+ * compared with a cv2 output (oracle/input_cpu.py carries the same restatement in numpy). */
+int i2r_crop_affine_cv2(const unsigned char* img, int32_t ih, int32_t iw, int32_t row_bytes, int32_t swap_rb, const double* inv_m,
+                        const float* mean, const float* inv_std, float* out, int32_t n, int32_t oh, int32_t ow, void* stream);
+int i2r_box_mask_cv2(const int32_t* boxes, int32_t ih, int32_t iw, float* out, int32_t n, int32_t oh, int32_t ow, void* stream);
+
 /* ---- HRFormer-B glue (reference lib/models/hrformer.py) ---------------------------------------------------- */
 /* i2r_layernorm -- nn.LayerNorm(c, eps) over the channels of every pixel/token of an NHWC tensor
  * (GeneralTransformerBlock.norm1/norm2, hrformer.py:1198,1235-1237). w, b: [cs] zero-padded. */

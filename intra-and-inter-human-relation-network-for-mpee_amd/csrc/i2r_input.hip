@@ -61,7 +61,110 @@ __global__ __launch_bounds__(256) void box_mask_k(const int* __restrict__ boxes,
     out[((size_t)p * oh + y) * ow + x] = ((1.f - ax) * ix0 + ax * ix1) * ((1.f - ay) * iy0 + ay * iy1);
 }
 
+// ---- cv2's own arithmetic (OpenCV imgwarp.cpp / resize.cpp, restated in oracle/input_cpu.py): fixed-point bilinear ----
+// weights of initInterTab2D(INTER_LINEAR, fixpt) for the 1/32-pixel fractions (fx, fy): taps (0,0), (0,1), (1,0), (1,1), sum 1 << 15
+__device__ __forceinline__ void cv2_tab(int fx, int fy, int (&w)[4]) {
+    w[0] = min((32 - fx) * (32 - fy) * 32, 32767);
+    w[1] = fx * (32 - fy) * 32;
+    w[2] = (32 - fx) * fy * 32;
+    w[3] = fx * fy * 32 + ((fx | fy) == 0 ? 1 : 0);
+}
+
+// cv2.warpAffine(img, trans, (ow, oh), INTER_LINEAR), BORDER_CONSTANT 0, then ToTensor + Normalize.  m: the INVERSE map in double, as
+// cv2 derives it from `trans`; coordinates on the 1/32 grid: X = (rint((m1 y + m2) 1024) + 16 + rint(m0 x 1024)) >> 5.
+__global__ __launch_bounds__(256) void crop_affine_cv2_k(const unsigned char* __restrict__ img, int ih, int iw, int row_bytes, int swap_rb,
+                                                         const double* __restrict__ inv_m, const float* __restrict__ mean,
+                                                         const float* __restrict__ inv_std, float* __restrict__ out, int n, int oh, int ow) {
+    const long long gid = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (gid >= (long long)n * oh * ow) return;
+    const int x = (int)(gid % ow);
+    const int y = (int)((gid / ow) % oh);
+    const int p = (int)(gid / ((long long)ow * oh));
+    const double* m = inv_m + p * 6;
+    const long long X = (llrint((m[1] * y + m[2]) * 1024.0) + 16 + llrint(m[0] * x * 1024.0)) >> 5;
+    const long long Y = (llrint((m[4] * y + m[5]) * 1024.0) + 16 + llrint(m[3] * x * 1024.0)) >> 5;
+    const long long sxl = X >> 5, syl = Y >> 5;
+    int w[4];
+    cv2_tab((int)(X & 31), (int)(Y & 31), w);
+    int acc[3] = {1 << 14, 1 << 14, 1 << 14};
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const long long xi = sxl + (k & 1), yi = syl + (k >> 1);
+        if (xi < 0 || xi >= iw || yi < 0 || yi >= ih) continue;
+        const unsigned char* px = img + (size_t)yi * row_bytes + (size_t)xi * 3;
+#pragma unroll
+        for (int c = 0; c < 3; ++c) acc[c] += w[k] * px[swap_rb ? 2 - c : c];
+    }
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        const int v = min(max(acc[c] >> 15, 0), 255);
+        out[(((size_t)p * 3 + c) * oh + y) * ow + x] = ((float)v * (1.f / 255.f) - mean[c]) * inv_std[c];
+    }
+}
+
+// get_position + rotate_bound(., 0) + cv2.resize(., (ow, oh)) + ToTensor, all in cv2's 8-bit arithmetic: the filled rectangle (255) is
+// first shifted by half a pixel along every odd image dimension (rotate_bound's nW / 2 - w // 2, a fixed-point warp), then resized
+// with 11-bit coefficients: ((b0 (H0 >> 4)) >> 16) + ((b1 (H1 >> 4)) >> 16) + 2 >> 2.
+__global__ __launch_bounds__(256) void box_mask_cv2_k(const int* __restrict__ boxes, int ih, int iw, float* __restrict__ out, int n, int oh,
+                                                      int ow) {
+    const long long gid = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (gid >= (long long)n * oh * ow) return;
+    const int x = (int)(gid % ow);
+    const int y = (int)((gid / ow) % oh);
+    const int p = (int)(gid / ((long long)ow * oh));
+    const int bx0 = max(boxes[p * 4], 0), by0 = max(boxes[p * 4 + 1], 0), bx1 = min(boxes[p * 4 + 2], iw - 1), by1 = min(boxes[p * 4 + 3], ih - 1);
+    const int ox = iw & 1, oy = ih & 1;  // odd dimension: source coordinate = pixel - 1/2, i.e. taps (pixel - 1, pixel) at fraction 16/32
+    int wt[4];
+    cv2_tab(16 * ox, 16 * oy, wt);
+    auto shifted = [&](int px, int py) -> int {  // rotate_bound(mask, 0) at integer pixel (px, py)
+        int acc = 1 << 14;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int xi = px - ox + (k & 1), yi = py - oy + (k >> 1);
+            if (xi >= bx0 && xi <= bx1 && yi >= by0 && yi <= by1) acc += wt[k] * 255;  // (the rectangle lies inside the image: border taps are 0)
+        }
+        return acc >> 15;
+    };
+    auto coef = [](int d, int n_out, int n_in, int& s0, int& s1, int& c0, int& c1, bool zero_at_ends) {
+        double f = ((double)d + 0.5) * ((double)n_in / (double)n_out) - 0.5;
+        const int s = (int)floor(f);
+        const float fr = (float)(f - (double)s);
+        c0 = (int)rintf((1.f - fr) * 2048.f);
+        c1 = (int)rintf(fr * 2048.f);
+        if (zero_at_ends && (s < 0 || s >= n_in - 1)) { c0 = 2048; c1 = 0; }
+        s0 = min(max(s, 0), n_in - 1);
+        s1 = min(max(s + 1, 0), n_in - 1);
+    };
+    int x0, x1, a0, a1, y0, y1, b0, b1;
+    coef(x, ow, iw, x0, x1, a0, a1, true);
+    coef(y, oh, ih, y0, y1, b0, b1, false);
+    const int h0 = shifted(x0, y0) * a0 + shifted(x1, y0) * a1;
+    const int h1 = shifted(x0, y1) * a0 + shifted(x1, y1) * a1;
+    const int v = (((b0 * (h0 >> 4)) >> 16) + ((b1 * (h1 >> 4)) >> 16) + 2) >> 2;
+    out[((size_t)p * oh + y) * ow + x] = (float)min(max(v, 0), 255) * (1.f / 255.f);
+}
+
 }  // namespace
+
+extern "C" int i2r_crop_affine_cv2(const unsigned char* img, int32_t ih, int32_t iw, int32_t row_bytes, int32_t swap_rb, const double* inv_m,
+                                   const float* mean, const float* inv_std, float* out, int32_t n, int32_t oh, int32_t ow, void* stream) {
+    I2R_CHECK_ARG(img && inv_m && mean && inv_std && out, "i2r_crop_affine_cv2: null pointer");
+    I2R_CHECK_ARG(ih > 0 && iw > 0 && row_bytes >= 3 * iw && n > 0 && oh > 0 && ow > 0, "i2r_crop_affine_cv2: sizes");
+    const long long nthr = (long long)n * oh * ow;
+    hipLaunchKernelGGL(crop_affine_cv2_k, dim3((unsigned)((nthr + 255) / 256)), dim3(256), 0, (hipStream_t)stream, img, ih, iw, row_bytes,
+                       swap_rb, inv_m, mean, inv_std, out, n, oh, ow);
+    I2R_CHECK_LAUNCH("i2r_crop_affine_cv2");
+    return I2R_OK;
+}
+
+extern "C" int i2r_box_mask_cv2(const int32_t* boxes, int32_t ih, int32_t iw, float* out, int32_t n, int32_t oh, int32_t ow, void* stream) {
+    I2R_CHECK_ARG(boxes && out, "i2r_box_mask_cv2: null pointer");
+    I2R_CHECK_ARG(ih > 0 && iw > 0 && n > 0 && oh > 0 && ow > 0, "i2r_box_mask_cv2: sizes");
+    const long long nthr = (long long)n * oh * ow;
+    hipLaunchKernelGGL(box_mask_cv2_k, dim3((unsigned)((nthr + 255) / 256)), dim3(256), 0, (hipStream_t)stream, boxes, ih, iw, out, n, oh, ow);
+    I2R_CHECK_LAUNCH("i2r_box_mask_cv2");
+    return I2R_OK;
+}
 
 extern "C" int i2r_crop_affine(const unsigned char* img, int32_t ih, int32_t iw, int32_t row_bytes, int32_t swap_rb,
                                const float* inv_trans, const float* mean, const float* inv_std, float* out, int32_t n, int32_t oh,

@@ -5,7 +5,9 @@ cv2 for every person of an image (reference lib/dataset/JointsDataset.py:207-356
     x, pos_mask, length = collate([(crops0, masks0), (crops1, masks1), ...])  # -> model(x, pos_mask, length)
 
 The affine matrices are built on the host in float64 exactly as lib/utils/transforms.py:61-96 does (cv2.getAffineTransform is a
-3-point solve); interpolation runs in csrc/i2r_input.hip.  cv2 itself is absent here, so this step is NOT pinned against it."""
+3-point solve); interpolation runs in csrc/i2r_input.hip -- by default in cv2's own fixed-point arithmetic (restated from OpenCV's
+published algorithm: 1/32-pixel coordinates, 15-bit weights, 8-bit results, the half-pixel shift rotate_bound applies to masks of
+odd-sized images), optionally in plain fp32.  cv2 itself is absent here, so this step is NOT pinned against a cv2 output."""
 import numpy as np
 import torch
 
@@ -72,7 +74,19 @@ def box_to_center_scale(box, image_size, pixel_std=200.0):
     return center, scale
 
 
-def person_inputs(image, centers, scales, boxes, image_size, color_rgb=False, mean=IMAGENET_MEAN, std=IMAGENET_STD, device="cuda:0"):
+def cv2_inverse(t):
+    """the dst -> src matrix cv2.warpAffine derives from a forward 2x3 map (imgwarp.cpp: closed form in double precision)"""
+    t = np.asarray(t, dtype=np.float64)
+    D = t[0, 0] * t[1, 1] - t[0, 1] * t[1, 0]
+    D = 1.0 / D if D != 0 else 0.0
+    m = np.array([[t[1, 1] * D, -t[0, 1] * D, 0.0], [-t[1, 0] * D, t[0, 0] * D, 0.0]])
+    m[0, 2] = -m[0, 0] * t[0, 2] - m[0, 1] * t[1, 2]
+    m[1, 2] = -m[1, 0] * t[0, 2] - m[1, 1] * t[1, 2]
+    return m
+
+
+def person_inputs(image, centers, scales, boxes, image_size, color_rgb=False, mean=IMAGENET_MEAN, std=IMAGENET_STD, device="cuda:0",
+                  fixed_point=True):
     """image: uint8 [ih, iw, 3] (numpy or tensor, channel order as cv2.imread delivers it); centers / scales: per-person (2,) pairs in
     the dataset convention (scale in units of 200 px); boxes: per-person (x, y, w, h); image_size = cfg.MODEL.IMAGE_SIZE = (W, H).
     -> (input [n, 3, H, W], pos_mask [n, 1, H, W]) fp32 on `device`, ready for model(input, pos_mask, [n])."""
@@ -84,8 +98,7 @@ def person_inputs(image, centers, scales, boxes, image_size, color_rgb=False, me
     n = len(centers)
     assert n >= 1 and len(scales) == n and len(boxes) == n
     W, H = int(image_size[0]), int(image_size[1])
-    inv = np.stack([invert_affine(get_affine_transform(centers[i], scales[i], 0, (W, H))) for i in range(n)]).reshape(n, 6)
-    inv_t = torch.from_numpy(inv.astype(np.float32)).to(dev)
+    trans = [get_affine_transform(centers[i], scales[i], 0, (W, H)) for i in range(n)]
     # cv2.rectangle(mask, (int(x), int(y)), (int(x+w), int(y+h)), 255, -1): inclusive corners (JointsDataset.py:168-169)
     bx = torch.tensor([[int(b[0]), int(b[1]), int(b[0] + b[2]), int(b[1] + b[3])] for b in boxes], dtype=torch.int32, device=dev)
     mean_t = torch.tensor(mean, dtype=torch.float32, device=dev)
@@ -94,9 +107,16 @@ def person_inputs(image, centers, scales, boxes, image_size, color_rgb=False, me
     m = torch.empty(n, 1, H, W, dtype=torch.float32, device=dev)
     st = torch.cuda.current_stream(dev).cuda_stream
     L = cabi.lib()
-    cabi.check(L.i2r_crop_affine(img.data_ptr(), ih, iw, iw * 3, int(bool(color_rgb)), inv_t.data_ptr(), mean_t.data_ptr(),
-                                 istd_t.data_ptr(), x.data_ptr(), n, H, W, st), "i2r_crop_affine")
-    cabi.check(L.i2r_box_mask(bx.data_ptr(), ih, iw, m.data_ptr(), n, H, W, st), "i2r_box_mask")
+    if fixed_point:  # cv2's own fixed-point arithmetic (the default: it is what the reference's data loader computes)
+        inv_t = torch.from_numpy(np.stack([cv2_inverse(t) for t in trans]).reshape(n, 6)).to(dev)  # float64
+        cabi.check(L.i2r_crop_affine_cv2(img.data_ptr(), ih, iw, iw * 3, int(bool(color_rgb)), inv_t.data_ptr(), mean_t.data_ptr(),
+                                         istd_t.data_ptr(), x.data_ptr(), n, H, W, st), "i2r_crop_affine_cv2")
+        cabi.check(L.i2r_box_mask_cv2(bx.data_ptr(), ih, iw, m.data_ptr(), n, H, W, st), "i2r_box_mask_cv2")
+    else:            # fp32 interpolation of the same geometry (no 8-bit rounding, no half-pixel shift of the mask)
+        inv_t = torch.from_numpy(np.stack([invert_affine(t) for t in trans]).reshape(n, 6).astype(np.float32)).to(dev)
+        cabi.check(L.i2r_crop_affine(img.data_ptr(), ih, iw, iw * 3, int(bool(color_rgb)), inv_t.data_ptr(), mean_t.data_ptr(),
+                                     istd_t.data_ptr(), x.data_ptr(), n, H, W, st), "i2r_crop_affine")
+        cabi.check(L.i2r_box_mask(bx.data_ptr(), ih, iw, m.data_ptr(), n, H, W, st), "i2r_box_mask")
     return x, m
 
 

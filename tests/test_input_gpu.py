@@ -35,7 +35,7 @@ def _scene(seed, ih, iw, n):
 @pytest.mark.parametrize("ih,iw,n,rgb", [(480, 640, 3, False), (333, 517, 2, True), (64, 48, 1, False)])
 def test_crops_and_masks_match_cpu_restatement(ih, iw, n, rgb):
     img, centers, scales, boxes = _scene(ih + n, ih, iw, n)
-    x, m = inp.person_inputs(img, centers, scales, boxes, (192, 256), color_rgb=rgb)
+    x, m = inp.person_inputs(img, centers, scales, boxes, (192, 256), color_rgb=rgb, fixed_point=False)
     torch.cuda.synchronize()
     inv = np.stack([inp.invert_affine(inp.get_affine_transform(centers[i], scales[i], 0, (192, 256))) for i in range(n)]).astype(np.float32)
     ref_x = input_cpu.crop_affine(img, inv, inp.IMAGENET_MEAN, inp.IMAGENET_STD, 256, 192, swap_rb=rgb)
@@ -45,6 +45,25 @@ def test_crops_and_masks_match_cpu_restatement(ih, iw, n, rgb):
     # fp32 bilinear on both sides; contraction order of the four taps may differ by an ulp of a 0..255 value
     assert np.abs(x.cpu().numpy() - ref_x).max() < 2e-4
     assert np.abs(m.cpu().numpy() - ref_m).max() < 1e-6
+
+
+@pytest.mark.parametrize("ih,iw,n,rgb", [(480, 640, 3, False), (333, 517, 2, True), (64, 48, 1, False), (121, 90, 2, False)])
+def test_crops_and_masks_cv2_fixed_point(ih, iw, n, rgb):
+    """the default mode: cv2's fixed-point arithmetic (1/32-pixel grid, 15-bit weights, 8-bit results; masks of odd-sized images shifted
+    by half a pixel like rotate_bound does) -- integer arithmetic, so the kernel must agree with the numpy restatement EXACTLY"""
+    img, centers, scales, boxes = _scene(ih + n, ih, iw, n)
+    x, m = inp.person_inputs(img, centers, scales, boxes, (192, 256), color_rgb=rgb)
+    torch.cuda.synchronize()
+    trans = np.stack([inp.get_affine_transform(centers[i], scales[i], 0, (192, 256)) for i in range(n)])
+    ref_x = input_cpu.crop_affine_cv2(img, trans, inp.IMAGENET_MEAN, inp.IMAGENET_STD, 256, 192, swap_rb=rgb)
+    bx = [(int(b[0]), int(b[1]), int(b[0] + b[2]), int(b[1] + b[3])) for b in boxes]
+    ref_m = input_cpu.box_mask_cv2(bx, ih, iw, 256, 192)
+    # same 8-bit level everywhere (one level = 1/255/std ~ 0.017); the float normalisation may differ in the last bit
+    assert np.abs(x.cpu().numpy() - ref_x).max() < 1e-5
+    assert np.array_equal(m.cpu().numpy(), ref_m)
+    # and it is close to the fp32 interpolation of the same geometry (half an intensity level + 1/64 pixel)
+    x32, m32 = inp.person_inputs(img, centers, scales, boxes, (192, 256), color_rgb=rgb, fixed_point=False)
+    assert (x - x32).abs().mean().item() < 0.02
 
 
 def test_image_to_heatmaps_chain():

@@ -61,3 +61,23 @@ def test_oracle_box_mask():
     assert np.all(m2 == 1.0)
     m3 = input_cpu.box_mask([(11, 10, 58, 39)], 100, 200, 50, 100)   # 2x down-scale, odd edges: half-covered samples on the rim
     assert m3.min() == 0 and m3.max() == 1 and ((m3 > 0) & (m3 < 1)).any()
+
+
+def test_cv2_fixed_point_restatement_known_answers():
+    """oracle/input_cpu.py's restatement of cv2's fixed-point warp / resize (parity unpinned: cv2 absent) on cases whose answer follows
+    from the published algorithm alone: table sums, identity warp, half-pixel shift = rounded mean of neighbours, identity resize,
+    rotate_bound's shift only for odd dimensions."""
+    tab = input_cpu.cv2_bilinear_tab()
+    assert tab.shape == (32, 32, 4) and (tab.sum(-1) == 1 << 15).all() and list(tab[16, 16]) == [8192] * 4
+    img = np.random.RandomState(0).randint(0, 256, (60, 81, 3)).astype(np.uint8)
+    assert np.array_equal(input_cpu.cv2_warp_affine(img, np.array([[1.0, 0, 0], [0, 1.0, 0]]), (81, 60)), img)
+    half = input_cpu.cv2_warp_affine(img, np.array([[1.0, 0, 0.5], [0, 1.0, 0]]), (81, 60))
+    assert np.array_equal(half[:, 1:].astype(int), (img[:, :-1].astype(int) + img[:, 1:].astype(int) + 1) >> 1)
+    assert (half[:, 0].astype(int) == (img[:, 0].astype(int) + 1) >> 1).all()       # the left tap is outside: border value 0
+    m = np.zeros((61, 81), np.uint8)
+    m[10:40, 20:50] = 255
+    assert np.array_equal(input_cpu.cv2_resize_linear_u8(m, (81, 61)), m)
+    even = input_cpu.box_mask_cv2([(20, 10, 49, 39)], 60, 80, 60, 80)[0, 0]
+    assert set(np.unique(even)) == {0.0, 1.0} and even[10:40, 20:50].min() == 1.0   # even size, same size: the rectangle itself
+    odd = input_cpu.box_mask_cv2([(20, 10, 49, 39)], 61, 81, 61, 81)[0, 0]
+    assert abs(odd[25, 20] - 128 / 255) < 1e-6 and odd[25, 21] == 1.0 and abs(odd[10, 30] - 128 / 255) < 1e-6  # edges blurred by the 0.5 px shift
