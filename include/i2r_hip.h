@@ -237,6 +237,18 @@ int i2r_hrt_attn_block(const float* x, float* out, const float* ln_w, const floa
                        const void* wo, const float* bo, int32_t n_img, int32_t h, int32_t w, int32_t c, int32_t cs, int32_t heads,
                        float eps, int32_t dtype, void* stream);
 
+/* i2r_hrt_mlp_block -- 16-bit modes only: the MLP half of a GeneralTransformerBlock in ONE launch,
+ *     out = x + GELU(BN3(fc2( GELU(BN2(dw3x3( GELU(BN1(fc1( LayerNorm(x) ))) ))) )))      (hrformer.py:1237, MlpDWBN :1094-1119; same
+ * semantics as i2r_layernorm + i2r_conv(fc1, GELU) + i2r_dwconv3x3(GELU) + i2r_conv(fc2, GELU, res_post = x)), one workgroup per 8x8
+ * pixel tile (+ halo of 1, recomputed); the 4C-wide hidden tensor only exists in LDS, chunk by chunk.  x and out: fp32 NHWC [n, h, w, cs], distinct buffers.
+ * (c, cs) = (78, 80) or (156, 160); hidden_pad = 4c rounded up to a multiple of 64 (zero weights / biases beyond 4c).
+ * w1: 16-bit fragments [hidden_pad/16][cs/16][64 lanes][4] of the BN-folded fc1 matrix [hidden, c] (fragment layout as in
+ * i2r_hrt_attn_block), b1 float [hidden_pad]; wdw float [9][hidden_pad] tap-major BN-folded depth-wise weights, bdw [hidden_pad];
+ * w2: fragments [cs/16][hidden_pad/16][64][4] of the BN-folded fc2 matrix [c, hidden], b2 float [cs]. */
+int i2r_hrt_mlp_block(const float* x, float* out, const float* ln_w, const float* ln_b, const void* w1, const float* b1,
+                      const float* wdw, const float* bdw, const void* w2, const float* b2, int32_t n_img, int32_t h, int32_t w,
+                      int32_t c, int32_t cs, int32_t hidden_pad, float eps, int32_t dtype, void* stream);
+
 /* i2r_dwconv3x3 -- depth-wise 3x3 conv, pad 1, stride 1|2, + bias (eval BN folded) + activation (0 none, 1 ReLU,
  * 2 GELU): MlpDWBN.dw3x3+norm2+act2 (hrformer.py:1070-1080,1106-1108) and the DW down-sampling hops of the fuse
  * layers (:1651-1704). w: [9][cs] (tap-major), bias [cs]. */
@@ -325,7 +337,7 @@ enum {
     I2R_OP_CONV = 1, I2R_OP_STEM = 2, I2R_OP_MAXPOOL = 3, I2R_OP_HEAD = 4,
     I2R_OP_ENC_KV = 5, I2R_OP_ENC_LAYER = 6, I2R_OP_FORK = 7, I2R_OP_JOIN = 8, I2R_OP_CONV_GROUP = 9,
     I2R_OP_LAYERNORM = 10, I2R_OP_WINATTN = 11, I2R_OP_DWCONV = 12, I2R_OP_UPSAMPLE = 13, I2R_OP_CONV_CHAIN = 14,
-    I2R_OP_PE_RES_STEM = 15, I2R_OP_HRT_ATTN = 16
+    I2R_OP_PE_RES_STEM = 15, I2R_OP_HRT_ATTN = 16, I2R_OP_HRT_MLP = 17
 };
 
 typedef struct i2r_stem_args {
@@ -362,6 +374,12 @@ typedef struct i2r_hrt_attn_args {
     const float* x; float* out; const float* ln_w; const float* ln_b; const void* wqkv; const float* bqkv; const void* wo; const float* bo;
     int32_t n_img, h, w_, c, cs, heads; float eps; int32_t dtype;
 } i2r_hrt_attn_args;
+
+typedef struct i2r_hrt_mlp_args {
+    const float* x; float* out; const float* ln_w; const float* ln_b; const void* w1; const float* b1; const float* wdw; const float* bdw;
+    const void* w2; const float* b2;
+    int32_t n_img, h, w_, c, cs, hidden_pad; float eps; int32_t dtype;
+} i2r_hrt_mlp_args;
 
 typedef struct i2r_dw_args {
     const float* in; const float* w; const float* bias; float* out;

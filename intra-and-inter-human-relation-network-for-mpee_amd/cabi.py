@@ -21,6 +21,7 @@ OP_LAYERNORM, OP_WINATTN, OP_DWCONV, OP_UPSAMPLE = 10, 11, 12, 13
 OP_CONV_CHAIN = 14
 OP_PE_RES_STEM = 15
 OP_HRT_ATTN = 16
+OP_HRT_MLP = 17
 
 _fp = C.c_void_p  # device pointers travel as integers
 _i32 = C.c_int32
@@ -87,6 +88,12 @@ class HrtAttnArgs(C.Structure):
                 ("n_img", _i32), ("h", _i32), ("w_", _i32), ("c", _i32), ("cs", _i32), ("heads", _i32), ("eps", C.c_float), ("dtype", _i32)]
 
 
+class HrtMlpArgs(C.Structure):
+    _fields_ = [("x", _fp), ("out", _fp), ("ln_w", _fp), ("ln_b", _fp), ("w1", _fp), ("b1", _fp), ("wdw", _fp), ("bdw", _fp), ("w2", _fp),
+                ("b2", _fp), ("n_img", _i32), ("h", _i32), ("w_", _i32), ("c", _i32), ("cs", _i32), ("hidden_pad", _i32), ("eps", C.c_float),
+                ("dtype", _i32)]
+
+
 class DwArgs(C.Structure):
     _fields_ = [("in_", _fp), ("w", _fp), ("bias", _fp), ("out", _fp),
                 ("n_img", _i32), ("in_h", _i32), ("in_w", _i32), ("c", _i32), ("cs", _i32), ("stride", _i32), ("act", _i32), ("dt", _i32)]
@@ -113,7 +120,7 @@ class Op(C.Structure):
 
 
 # every symbol include/i2r_hip.h declares (tests/test_host.py::test_cabi_library_exports_every_declared_symbol checks the built library exports them all)
-EXPORTS = ("i2r_conv", "i2r_conv_grouped", "i2r_conv_kernel_name", "i2r_stem_conv", "i2r_pe_res_stem", "i2r_maxpool3x3s2", "i2r_head", "i2r_layernorm", "i2r_window_attn", "i2r_hrt_attn_block", "i2r_dwconv3x3",
+EXPORTS = ("i2r_conv", "i2r_conv_grouped", "i2r_conv_kernel_name", "i2r_stem_conv", "i2r_pe_res_stem", "i2r_maxpool3x3s2", "i2r_head", "i2r_layernorm", "i2r_window_attn", "i2r_hrt_attn_block", "i2r_hrt_mlp_block", "i2r_dwconv3x3",
            "i2r_upsample_bilinear_add", "i2r_flip_merge", "i2r_decode", "i2r_crop_affine", "i2r_box_mask", "i2r_crop_affine_cv2", "i2r_box_mask_cv2", "i2r_conv_chain_pack", "i2r_conv_chain", "i2r_encoder_kv", "i2r_encoder_layer",
            "i2r_run_program", "i2r_abi_version", "i2r_last_error", "i2r_device_check")
 
@@ -149,6 +156,7 @@ def load_library(path=LIB_PATH):
     L.i2r_layernorm.argtypes = [_fp, _fp, _fp, _fp, _i32, _i32, _i32, C.c_float, _i32, C.c_void_p]
     L.i2r_window_attn.argtypes = [_fp, _fp, _fp, _i32, _i32, _i32, _i32, _i32, _i32, C.c_void_p]
     L.i2r_hrt_attn_block.argtypes = [_fp, _fp, _fp, _fp, _fp, _fp, _fp, _fp, _i32, _i32, _i32, _i32, _i32, _i32, C.c_float, _i32, C.c_void_p]
+    L.i2r_hrt_mlp_block.argtypes = [_fp] * 10 + [_i32] * 6 + [C.c_float, _i32, C.c_void_p]
     L.i2r_dwconv3x3.argtypes = [_fp, _fp, _fp, _fp, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, C.c_void_p]
     L.i2r_upsample_bilinear_add.argtypes = [_fp, _fp, _fp, _i32, _i32, _i32, _i32, _i32, _i32, _i32, C.c_void_p]
     L.i2r_encoder_kv.argtypes = [C.POINTER(EncoderDesc), C.c_void_p]

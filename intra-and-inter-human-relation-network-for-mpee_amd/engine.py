@@ -321,6 +321,32 @@ class Packer:
         return dict(wqkv=self._dev(wqkv), bqkv=self._dev(bq.float()), wo=self._dev(wo), bo=self._dev(bo), ln=ln, c=c, cs=cs, heads=heads,
                     dtype=self.dtype)
 
+    def mlp_block_lp(self, p, c):
+        """operands of the fused 16-bit MLP half of a transformer block (i2r_hrt_mlp_block): fc1+BN1, dw3x3+BN2, fc2+BN3 folded in
+        float64, hidden dim padded to a multiple of 64 with zeros; p = block key prefix"""
+        tdt = torch.bfloat16 if self.dtype == 1 else torch.float16
+        cs, hid = _r16(c), 4 * c
+        hp = (hid + 63) // 64 * 64
+        m = p + ".mlp"
+        w1, b1 = fold_bn(self.sd[m + ".fc1.weight"], self._bn(m + ".norm1"), self.sd.get(m + ".fc1.bias"))      # [hid, c, 1, 1]
+        wd, bd = fold_bn(self.sd[m + ".dw3x3.weight"], self._bn(m + ".norm2"), self.sd.get(m + ".dw3x3.bias"))  # [hid, 1, 3, 3]
+        w2, b2 = fold_bn(self.sd[m + ".fc2.weight"], self._bn(m + ".norm3"), self.sd.get(m + ".fc2.bias"))      # [c, hid, 1, 1]
+        assert tuple(w1.shape[:2]) == (hid, c) and tuple(w2.shape[:2]) == (c, hid)
+        W1 = torch.zeros(hp, cs, dtype=torch.float64)
+        W1[:hid, :c] = w1.view(hid, c)
+        W2 = torch.zeros(cs, hp, dtype=torch.float64)
+        W2[:c, :hid] = w2.view(c, hid)
+        WD = torch.zeros(9, hp, dtype=torch.float64)
+        WD[:, :hid] = wd.view(hid, 9).t()
+
+        def padv(v, n):
+            o = torch.zeros(n, dtype=torch.float64)
+            o[:v.shape[0]] = v
+            return o.float()
+        return dict(w1=self._dev(self._frag16(W1.float(), tdt)), b1=self._dev(padv(b1, hp)), wdw=self._dev(WD.float()), bdw=self._dev(padv(bd, hp)),
+                    w2=self._dev(self._frag16(W2.float(), tdt)), b2=self._dev(padv(b2, cs)), ln=self.ln(p + ".norm2", c), c=c, cs=cs, hidden_pad=hp,
+                    dtype=self.dtype)
+
     def table(self, key, rows, d):
         """[rows, 1, d] parameter (TransPose-H pos_embedding) -> [rows, cs] device table."""
         v = self.sd[key].reshape(rows, d)
@@ -675,6 +701,17 @@ class Program:
         self.ops.append((cabi.OP_HRT_ATTN, lane, a))
         return out
 
+    def hrt_mlp(self, x, mb, eps=1e-6, lane=0):
+        """fused x + mlp(LN2 x) (16-bit modes, i2r_hrt_mlp_block)"""
+        assert x.dt == 0 and x.c == mb["c"] and x.cs == mb["cs"]
+        out = self.alloc(x.n, x.h, x.w, x.c)
+        self.keep.append(mb)
+        a = cabi.HrtMlpArgs(x.ptr, out.ptr, mb["ln"]["w"].data_ptr(), mb["ln"]["b"].data_ptr(), mb["w1"].data_ptr(), mb["b1"].data_ptr(),
+                            mb["wdw"].data_ptr(), mb["bdw"].data_ptr(), mb["w2"].data_ptr(), mb["b2"].data_ptr(), x.n, x.h, x.w, x.c, x.cs,
+                            mb["hidden_pad"], eps, mb["dtype"])
+        self.ops.append((cabi.OP_HRT_MLP, lane, a))
+        return out
+
     def dwconv(self, x, dw, stride=1, act=0, lane=0):
         """the output keeps the input's storage type (stride 1: fp32 or 16 bit; stride 2: fp32 only)"""
         assert x.dt == 0 or stride == 1
@@ -1008,7 +1045,8 @@ class HRFormerB:
             for k in range(st["num_blocks"][i]):
                 r = "%s.branches.%d.%d" % (q, i, k)
                 fused = pk.attn_block_lp(r, ch[i], st["num_heads"][i]) if (pk.dtype != 0 and ch[i] in (78, 156)) else None
-                blks.append(dict(c=ch[i], heads=st["num_heads"][i], ln1=pk.ln(r + ".norm1", ch[i]), ln2=pk.ln(r + ".norm2", ch[i]), attn_lp=fused,
+                fused_mlp = pk.mlp_block_lp(r, ch[i]) if (pk.dtype != 0 and ch[i] in (78, 156)) else None
+                blks.append(dict(c=ch[i], heads=st["num_heads"][i], ln1=pk.ln(r + ".norm1", ch[i]), ln2=pk.ln(r + ".norm2", ch[i]), attn_lp=fused, mlp_lp=fused_mlp,
                                  qkv=pk.qkv(r + ".attn.attn", ch[i], st["num_heads"][i]),
                                  out=pk.attn_out(r + ".attn.attn", ch[i], st["num_heads"][i]),
                                  fc1=pk.conv(r + ".mlp.fc1", r + ".mlp.norm1"), dw=pk.dw(r + ".mlp.dw3x3", r + ".mlp.norm2"),
@@ -1039,6 +1077,10 @@ class HRFormerB:
             P.release(qkv)
             x1 = P.conv(a, blk["out"], res1=x, lane=lane)
             P.release(a, x)
+        if blk.get("mlp_lp") is not None:  # 16-bit modes, high-resolution branches: the whole MLP half in one launch
+            x2 = P.hrt_mlp(x1, blk["mlp_lp"], lane=lane)
+            P.release(x1)
+            return x2
         # 16-bit modes: LN2's output and the 4C-wide hidden tensor of the MLP (the largest maps of the block) are stored in 16 bit;
         # the residual stream x stays fp32
         n2 = P.layernorm(x1, blk["ln2"], lane=lane, out_dt=P.store_dt)

@@ -401,6 +401,37 @@ def test_fused_attention_block_16bit(precision, c, heads, h, w):
     assert out.view()[..., c:].abs().max().item() == 0.0
 
 
+@pytest.mark.parametrize("precision", ["bf16", "fp16"])
+@pytest.mark.parametrize("c,h,w", [(78, 64, 48), (156, 32, 24), (78, 13, 9), (156, 36, 27)])
+def test_fused_mlp_block_16bit(precision, c, h, w):
+    """i2r_hrt_mlp_block (one launch: LN2 + fc1/BN/GELU + DW3x3/BN/GELU + fc2/BN/GELU + residual, hidden tensor only in LDS) vs the fp32
+    oracle x + mlp(LN2 x); maps that are not multiples of the 8x8 tile included"""
+    import i2r_cpu_hrformer as H
+    tag = "fm%d_%d" % (c, h)
+    hid = 4 * c
+    sd = {"b.norm2.weight": _rand((c,), "n2w" + tag, 0.3) + 1.0, "b.norm2.bias": _rand((c,), "n2b" + tag, 0.2),
+          "b.mlp.fc1.weight": _rand((hid, c, 1, 1), "f1" + tag, (3.0 / c) ** 0.5), "b.mlp.fc1.bias": _rand((hid,), "f1b" + tag, 0.2),
+          "b.mlp.dw3x3.weight": _rand((hid, 1, 3, 3), "dw" + tag, 0.5), "b.mlp.dw3x3.bias": _rand((hid,), "dwb" + tag, 0.2),
+          "b.mlp.fc2.weight": _rand((c, hid, 1, 1), "f2" + tag, (3.0 / hid) ** 0.5), "b.mlp.fc2.bias": _rand((c,), "f2b" + tag, 0.2)}
+    for n, ch in (("norm1", hid), ("norm2", hid), ("norm3", c)):
+        k = "b.mlp." + n
+        sd.update({k + ".weight": _rand((ch,), "g" + n + tag, 0.3) + 1.0, k + ".bias": _rand((ch,), "b" + n + tag, 0.2),
+                   k + ".running_mean": _rand((ch,), "m" + n + tag, 0.2), k + ".running_var": _rand((ch,), "v" + n + tag, 0.3) + 1.0})
+    x = _rand((2, c, h, w), "x" + tag)
+    t = x.permute(0, 2, 3, 1)
+    n2 = F.layer_norm(t, (c,), sd["b.norm2.weight"], sd["b.norm2.bias"], 1e-6)
+    ref = x + H.mlp_dwbn(sd, "b.mlp", n2.permute(0, 3, 1, 2))
+    P = engine.Program(torch.device(DEV))
+    pk = engine.Packer(sd, torch.device(DEV), precision)
+    out = P.hrt_mlp(to_act(P, x), pk.mlp_block_lp("b", c))
+    run(P)
+    d = from_act(out) - ref
+    tol_max, tol_rms = (6e-2, 2e-2) if precision == "bf16" else (1e-2, 3e-3)
+    rel_max, rel_rms = d.abs().max().item() / ref.abs().max().item(), d.pow(2).mean().sqrt().item() / ref.pow(2).mean().sqrt().item()
+    assert rel_max < tol_max and rel_rms < tol_rms, (rel_max, rel_rms)
+    assert out.view()[..., c:].abs().max().item() == 0.0
+
+
 @pytest.mark.parametrize("c,stride,act", [(312, 1, 2), (78, 2, 0), (160, 2, 1)])
 def test_dwconv(c, stride, act):
     sd = {"d.weight": _rand((c, 1, 3, 3), "dww%d" % c, 0.5), "d.bias": _rand((c,), "dwb%d" % c, 0.2),
