@@ -89,6 +89,28 @@ def test_standalone_first_stage_modules(tag, sf):
     assert np.abs(hm.cpu().numpy() - g["out_single"]).max() < TOL
 
 
+@pytest.mark.parametrize("name", sorted(__import__("i2r_amd").config.REFERENCE_YAML))
+def test_every_shipped_yaml_runs_and_matches_oracle(name):
+    """all ten experiments/*.yaml of the reference (shipped as configs/<name>.yaml, MODEL sections held equal to the reference files by
+    tests/test_host.py): factory by name, synthetic weights by key, one ragged batch [2, 1] -> fp32 heat maps within 1e-3 of the oracle"""
+    from i2r_amd import arch, config, synth
+    cfg = config.load_config(name)
+    sd = synth.make_state_dict(arch.param_spec(cfg))
+    net = eval("models." + cfg.MODEL.NAME + ".get_pose_net")(cfg, is_train=False)
+    net.load_state_dict(sd, strict=True)
+    W, H = cfg.MODEL.IMAGE_SIZE
+    x, m, length = synth.make_inputs([2, 1], H, W, seed=7)
+    y = net.cuda()(x.cuda(), m.cuda(), length)
+    torch.cuda.synchronize()
+    ref = i2r_cpu.forward(sd, cfg, x, m, length)
+    outs = y if isinstance(y, dict) else {"multi": y}
+    refs = ref if isinstance(ref, dict) else {"multi": ref}
+    assert set(outs) == set(refs)
+    for k in outs:
+        assert outs[k].shape == (3, cfg.MODEL.NUM_JOINTS, H // 4, W // 4)
+        assert (outs[k].cpu() - refs[k]).abs().max().item() < TOL, (name, k)
+
+
 def test_ragged_batches_and_program_cache():
     """var-len groups: a crop's heatmaps depend only on its own image; different `length` signatures coexist."""
     cfg, sd, x, m, length, g = setup("w48_l213")
