@@ -323,6 +323,11 @@ typedef struct i2r_encoder_desc {
     /* 16-bit mode: the per-feature fp32 vectors padded to csp = 96 and concatenated:
      * b_in[3*csp] | b_out[csp] | ln1_w | ln1_b | b1[dff_pad] | b2[csp] | ln2_w | ln2_b   (9*csp + dff_pad floats) */
     const float* vec_lp;
+    /* fp32 mode, optional: scratch of the "partial key split".  A launch with between one and two 16-query tiles per CU (256 < n_qtiles16
+     * < 512) handles just enough tiles with TWO workgroups (each over half of the group's keys) that every CU carries two workgroups
+     * (csrc/i2r_encoder.hip).  split_ws: 256 * 2 * 1792 floats; split_cnt: 256 int32, zero before the first launch (the kernel leaves
+     * them zero).  Both null = one workgroup per tile. */
+    float* split_ws; int32_t* split_cnt;
 } i2r_encoder_desc;
 
 int i2r_encoder_kv(const i2r_encoder_desc* d, void* stream);

@@ -43,6 +43,8 @@ struct EncK {
     const float* vec_lp;  // 16-bit mode: the per-feature fp32 vectors of the layer, padded to csp = 96 and concatenated (LpVec below)
     // fused K/V projection of the NEXT layer (enc_layer4_k): its in_proj (k, v rows used), destination buffers; null = none
     const float* next_w_in; const float* next_b_in; float* next_kbuf; float* next_vbuf;
+    // partial key split (enc_layer4_k<.., KS = 2>): hand-off scratch, per-tile counters, tiles per XCD and how many of them stay whole
+    float* split_ws; int* split_cnt; int tiles_per_xcd, full_per_xcd;
     long long* stamp;  // tuning only (env I2R_ENC_STAMP = device address): 8 s_memtime stamps per wave
 };
 
@@ -215,8 +217,34 @@ __device__ __forceinline__ void layer_norm(f32x4 (&y)[DC], const float* w, const
 // by OUTPUT fragments (wave w computes fragments w, w+4, ...), activations exchanged through LDS (a few KB).  The K / V
 // projection of the NEXT layer is fused into the tail (the layer output is already in registers), removing the separate
 // enc_kv launch for all layers but the first.
-template <int DC, int FC, int QT>
+//
+// KS = 2 ("partial key split"): launches whose tile count lies between one and two per CU (the vanilla model's 384 tiles on 256 CUs)
+// leave half the chip with two workgroups per CU and half with one.  Then exactly as many tiles as needed are handled by TWO
+// workgroups, each over half of the group's keys, so that every CU gets two workgroups and 1.5 tiles of work: per XCD (64 slots)
+// `full_per_xcd` whole tiles come first in the dispatch order (one per CU), the split tiles' halves follow (the second workgroup of
+// each CU).  A half writes its partial softmax state (m, l, O) to a scratch slot with agent-scope (sc1) stores, completes them
+// (s_waitcnt vmcnt(0)) and bumps the tile's counter; the half that finds the other already there merges both states IN A FIXED ORDER
+// (bit-identical results whichever arrives last) and runs the layer tail, the first one exits.  Nobody waits: deadlock-free.
+constexpr int kSplitSlot = 7 * 256;  // floats per (split tile, half): O (DC <= 6 fragments, lane order) + one f32x4 {m, l, -, -} per lane
+__device__ __forceinline__ void st_agent(float* q, f32x4 v) { asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(q), "v"(v) : "memory"); }
+__device__ __forceinline__ f32x4 ld_agent(const float* q) {
+    f32x4 v;
+    asm volatile("global_load_dwordx4 %0, %1, off sc1" : "=v"(v) : "v"(q) : "memory");
+    return v;
+}
+// the compiler does not count the loads above: wait for them with the results as in/out operands, so no use can move ahead of the wait
+template <int N>
+__device__ __forceinline__ void wait_agent_loads(f32x4 (&a)[N], f32x4& b) {
+    static_assert(N == 5 || N == 6, "DC");
+    if constexpr (N == 6)
+        asm volatile("s_waitcnt vmcnt(0)" : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]), "+v"(a[4]), "+v"(a[5]), "+v"(b)::"memory");
+    else
+        asm volatile("s_waitcnt vmcnt(0)" : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]), "+v"(a[4]), "+v"(b)::"memory");
+}
+
+template <int DC, int FC, int QT, int KS = 1>
 __global__ __launch_bounds__(256, 2) void enc_layer4_k(const EncK p) {
+    static_assert(KS == 1 || QT == 1, "the key split serves the small one-tile-per-workgroup launches only");
     constexpr int cs = DC * 16, dff = FC * 16;
     constexpr int SD = (DC + 3) / 4, SF = (FC + 3) / 4, SK = (2 * DC + 3) / 4;  // output-fragment slots per wave of each GEMM
     constexpr int XF = FC > DC ? FC : DC;
@@ -230,6 +258,7 @@ __global__ __launch_bounds__(256, 2) void enc_layer4_k(const EncK p) {
     constexpr int P_BOUT = 0, P_LN1W = cs, P_LN1B = 2 * cs, P_B1 = 3 * cs, P_B2 = 3 * cs + dff, P_LN2W = 4 * cs + dff,
                   P_LN2B = 5 * cs + dff, P_BKV = 6 * cs + dff, P_END = 8 * cs + dff;
     __shared__ __attribute__((aligned(16))) float Ps[P_END];
+    __shared__ int s_arrived;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int li = lane & 15, g = lane >> 4;
 #ifdef I2R_TUNING
@@ -268,13 +297,26 @@ __global__ __launch_bounds__(256, 2) void enc_layer4_k(const EncK p) {
 
     // ---- which (group, query tiles)?  Workgroup b runs on XCD b % 8: give every XCD a contiguous run of tiles, so the K / V
     //      of one group are read through ONE L2 instead of all eight ----
-    const int per_xcd = gridDim.x >> 3;
-    const int v = (blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3);
+    int v, half = 0, slot = 0;
+    bool split = false;
+    if constexpr (KS == 1) {
+        const int per_xcd = gridDim.x >> 3;
+        v = (blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3);
+    } else {
+        const int xcd = blockIdx.x & 7, q = blockIdx.x >> 3, F = p.full_per_xcd;
+        split = q >= F;
+        v = xcd * p.tiles_per_xcd + (split ? F + ((q - F) >> 1) : q);
+        half = split ? (q - F) & 1 : 0;
+        slot = xcd * (p.tiles_per_xcd - F) + ((q - F) >> 1);
+    }
     if (v >= p.n_qblk) return;
     const Tile t = locate_tile<QT>(p, v, lane, gs0, ge0);
     if (tid * 4 < P_END) *reinterpret_cast<f32x4*>(Ps + tid * 4) = pstage;  // (visible after the barrier that follows the q projection)
     const int gs = t.gs, ge = t.ge;
     const int nfrag = (ge - gs + 15) >> 4;
+    // this workgroup's share of the group's 16-key fragments: [f_lo, f_hi) (a split tile: lower / upper half)
+    const int nh = (KS == 2 && split) ? (nfrag + 1) >> 1 : nfrag;
+    const int f_lo = half * nh, f_hi = min(nfrag, f_lo + nh);
     int qtok[QT], qrow[QT], prow[QT];
     bool qvalid[QT];
 #pragma unroll
@@ -305,7 +347,7 @@ __global__ __launch_bounds__(256, 2) void enc_layer4_k(const EncK p) {
                 xq[u][c] = ld4(p.src + (size_t)qrow[u] * cs + 16 * c + 4 * g);
                 if (p.pos) xq[u][c] += ld4(p.pos + (size_t)prow[u] * cs + 16 * c + 4 * g);
             }
-        fetch_kv(min(wave, nfrag - 1), ka0, va0);  // first key fragment of this wave: in flight under the q projection
+        fetch_kv(min(f_lo + wave, nfrag - 1), ka0, va0);  // first key fragment of this wave: in flight under the q projection
         __builtin_amdgcn_sched_barrier(0);
         // ---- q projection (scaled by d^-1/2 * log2 e: the softmax below works in base 2), exchanged through LDS ----
 #pragma unroll
@@ -380,16 +422,16 @@ __global__ __launch_bounds__(256, 2) void enc_layer4_k(const EncK p) {
                 for (int u = 0; u < QT; ++u) o[u][nt] = mfma16(va[nt][s], st[u][s], o[u][nt]);  // O^T[dim][query] += V^T[dim][key] P^T
     };
     {
-        int jj = wave;
-        for (; jj + 4 < nfrag; jj += 8) {  // two fragments (jj, jj+4) per trip, each fetched under the other's arithmetic
+        int jj = f_lo + wave;
+        for (; jj + 4 < f_hi; jj += 8) {  // two fragments (jj, jj+4) per trip, each fetched under the other's arithmetic
             fetch_kv(jj + 4, ka1, va1);
             __builtin_amdgcn_sched_barrier(0);
             attend(gs + 16 * jj, ka0, va0);
-            fetch_kv(jj + 8 < nfrag ? jj + 8 : jj, ka0, va0);  // (past the end: harmless re-read)
+            fetch_kv(jj + 8 < f_hi ? jj + 8 : jj, ka0, va0);  // (past the end: harmless re-read)
             __builtin_amdgcn_sched_barrier(0);
             attend(gs + 16 * jj + 64, ka1, va1);
         }
-        if (jj < nfrag) attend(gs + 16 * jj, ka0, va0);
+        if (jj < f_hi) attend(gs + 16 * jj, ka0, va0);
     }
     STAMP(2);
     // out-proj rows of this wave's slots + the residual pieces they need: in flight under the merge
@@ -414,6 +456,7 @@ __global__ __launch_bounds__(256, 2) void enc_layer4_k(const EncK p) {
     }
     __syncthreads();
     f32x4 oc[QT][DC];
+    float m_wg = 0.f, l_wg = 0.f;  // (KS = 2) state of the workgroup's merged partial
 #pragma unroll
     for (int u = 0; u < QT; ++u) {
         float mw[4], m = -__builtin_inff();
@@ -426,15 +469,54 @@ __global__ __launch_bounds__(256, 2) void enc_layer4_k(const EncK p) {
 #pragma unroll
         for (int w = 0; w < 4; ++w) {
             sc[w] = __builtin_amdgcn_exp2f(mw[w] - m);  // a wave without keys has m = -inf, l = 0, O = 0 -> scale 0
+            if constexpr (KS == 2) sc[w] = mw[w] == -__builtin_inff() ? 0.f : sc[w];  // (a half of a short group may leave ALL waves without keys)
             l += MLs[((w * QT + u) * 2 + 1) * 16 + li] * sc[w];
         }
-        const float inv = 1.f / l;
+        float inv = 1.f / l;
+        if constexpr (KS == 2) {
+            if (split) inv = 1.f;  // keep the partial state un-normalised for the hand-off below
+            m_wg = m;
+            l_wg = l;
+        }
 #pragma unroll
         for (int nt = 0; nt < DC; ++nt) {
             f32x4 a = (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
             for (int w = 0; w < 4; ++w) a += Os[((w * QT + u) * DC + nt) * 64 + lane] * sc[w];
             oc[u][nt] = a * inv;
+        }
+    }
+    if constexpr (KS == 2) {
+        if (split) {  // (workgroup-uniform) ---- hand-off between the two halves of the tile ----
+            float* const mine = p.split_ws + ((size_t)slot * 2 + half) * kSplitSlot + lane * 4;
+            const float* const other = p.split_ws + ((size_t)slot * 2 + (half ^ 1)) * kSplitSlot + lane * 4;
+            if (wave == 0) {
+#pragma unroll
+                for (int nt = 0; nt < DC; ++nt) st_agent(mine + nt * 256, oc[0][nt]);
+                st_agent(mine + 6 * 256, (f32x4){m_wg, l_wg, 0.f, 0.f});
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the partial has reached the coherence point before the counter moves
+                if (lane == 0) s_arrived = __hip_atomic_fetch_add(p.split_cnt + slot, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+            __syncthreads();  // (also: every wave is done reading MLs / Os of the in-workgroup merge)
+            if (s_arrived == 0) return;  // the partner is still at work: it will find this partial and finish the tile
+            if (tid == 0) __hip_atomic_store(p.split_cnt + slot, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // ready for the next launch
+            f32x4 ao[DC], ml;
+#pragma unroll
+            for (int nt = 0; nt < DC; ++nt) ao[nt] = ld_agent(other + nt * 256);
+            ml = ld_agent(other + 6 * 256);
+            wait_agent_loads<DC>(ao, ml);
+            // combine in a fixed order (half 0, then half 1) whichever workgroup finishes
+            const float m0 = half == 0 ? m_wg : ml[0], m1 = half == 0 ? ml[0] : m_wg;
+            const float l0 = half == 0 ? l_wg : ml[1], l1 = half == 0 ? ml[1] : l_wg;
+            const float m2 = fmaxf(m0, m1);
+            const float s0 = m0 == -__builtin_inff() ? 0.f : __builtin_amdgcn_exp2f(m0 - m2);
+            const float s1 = m1 == -__builtin_inff() ? 0.f : __builtin_amdgcn_exp2f(m1 - m2);
+            const float inv2 = 1.f / (l0 * s0 + l1 * s1);
+#pragma unroll
+            for (int nt = 0; nt < DC; ++nt) {
+                const f32x4 x0 = half == 0 ? oc[0][nt] : ao[nt], x1 = half == 0 ? ao[nt] : oc[0][nt];
+                oc[0][nt] = (x0 * s0 + x1 * s1) * inv2;
+            }
         }
     }
     STAMP(3);
@@ -872,6 +954,7 @@ int fill(const i2r_encoder_desc* d, EncK& k) {
     k.qscale = 1.0f / sqrtf((float)d->d);
     k.w_in_lp = d->w_in_lp; k.w_out_lp = d->w_out_lp; k.w1_lp = d->w1_lp; k.w2_lp = d->w2_lp; k.vec_lp = d->vec_lp;
     k.next_w_in = d->next_w_in; k.next_b_in = d->next_b_in; k.next_kbuf = d->next_kbuf; k.next_vbuf = d->next_vbuf;
+    k.split_ws = d->split_ws; k.split_cnt = d->split_cnt; k.tiles_per_xcd = k.full_per_xcd = 0;
     k.stamp = nullptr;
 #ifdef I2R_TUNING
     {   // tuning build only: I2R_ENC_STAMP=<device address of 32 B x waves>, I2R_ENC_STAMP_FUSED=1 stamps the layers with a fused K/V tail
@@ -950,12 +1033,22 @@ extern "C" int i2r_encoder_layer(const i2r_encoder_desc* d, void* stream) {
 #endif
     const int qt = qt_env ? qt_env : (d->n_qtiles32 >= 512 ? 2 : 1);
     k.n_qblk = qt == 2 ? d->n_qtiles32 : d->n_qtiles16;
-    const unsigned grid = (unsigned)((k.n_qblk + 7) / 8 * 8);  // (XCD-major tile order inside the kernel)
+    unsigned grid = (unsigned)((k.n_qblk + 7) / 8 * 8);  // (XCD-major tile order inside the kernel)
+    // between one and two tiles per CU (256 CUs = 8 XCDs x 32): split just enough tiles by keys that every CU gets two workgroups
+    const int t_x = (d->n_qtiles16 + 7) / 8;
+    const bool split = qt == 1 && d->split_ws && d->split_cnt && t_x > 32 && t_x < 64;
+    if (split) {
+        k.tiles_per_xcd = t_x;
+        k.full_per_xcd = 2 * t_x - 64;
+        grid = 512;
+    }
     if (d->cs == 96) {
         if (qt == 2) hipLaunchKernelGGL((enc_layer4_k<6, 12, 2>), dim3(grid), dim3(256), 0, (hipStream_t)stream, k);
+        else if (split) hipLaunchKernelGGL((enc_layer4_k<6, 12, 1, 2>), dim3(grid), dim3(256), 0, (hipStream_t)stream, k);
         else hipLaunchKernelGGL((enc_layer4_k<6, 12, 1>), dim3(grid), dim3(256), 0, (hipStream_t)stream, k);
     } else {
         if (qt == 2) hipLaunchKernelGGL((enc_layer4_k<5, 12, 2>), dim3(grid), dim3(256), 0, (hipStream_t)stream, k);
+        else if (split) hipLaunchKernelGGL((enc_layer4_k<5, 12, 1, 2>), dim3(grid), dim3(256), 0, (hipStream_t)stream, k);
         else hipLaunchKernelGGL((enc_layer4_k<5, 12, 1>), dim3(grid), dim3(256), 0, (hipStream_t)stream, k);
     }
     I2R_CHECK_LAUNCH("i2r_encoder_layer");

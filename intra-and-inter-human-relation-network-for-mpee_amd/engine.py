@@ -754,7 +754,10 @@ class Program:
         kbufs = [torch.zeros(kv_floats, dtype=torch.float32, device=self.device) for _ in range(nbuf)]
         vbufs = [torch.zeros(kv_floats, dtype=torch.float32, device=self.device) for _ in range(nbuf)]
         goff = torch.zeros(x.n + 1, dtype=torch.int32, device=self.device)
-        self.keep += kbufs + vbufs + [goff]
+        # hand-off scratch of the partial key split (launches with 256 < tiles < 512; include/i2r_hip.h): <= 256 split tiles
+        split_ws = torch.empty(256 * 2 * 1792, dtype=torch.float32, device=self.device)
+        split_cnt = torch.zeros(256, dtype=torch.int32, device=self.device)
+        self.keep += kbufs + vbufs + [goff, split_ws, split_cnt]
         cur = x
         self.keep.append(layers)
         descs = []
@@ -768,6 +771,7 @@ class Program:
                 setattr(d, name, L[name].data_ptr())
             d.n_tok, d.d, d.cs, d.dff_pad = n_tok, L["d"], cs, L["dff_pad"]
             d.pos_period, d.ln_eps = pos_period, 1e-5
+            d.split_ws, d.split_cnt = split_ws.data_ptr(), split_cnt.data_ptr()
             if L.get("dtype", 0):
                 d.w_in_lp, d.w_out_lp, d.w1_lp, d.w2_lp, d.vec_lp = (L[k].data_ptr() for k in ("w_in_lp", "w_out_lp", "w1_lp", "w2_lp", "vec_lp"))
             if fuse_kv and i + 1 < len(layers):
