@@ -263,8 +263,10 @@ __global__ __launch_bounds__(256, 2) void enc_layer4_k(const EncK p) {
     const int li = lane & 15, g = lane >> 4;
 #ifdef I2R_TUNING
 #define STAMP(i) do { if (p.stamp && lane == 0) p.stamp[((size_t)blockIdx.x * 4 + wave) * 8 + (i)] = (long long)__builtin_amdgcn_s_memtime(); } while (0)
+#define STAMP0(i) do { if (p.stamp && lane == 0) p.stamp[((size_t)blockIdx.x * 4 + wave) * 8 + (i)] = 0; } while (0)
 #else
 #define STAMP(i) do { } while (0)
+#define STAMP0(i) do { } while (0)
 #endif
     STAMP(0);
 
@@ -304,10 +306,19 @@ __global__ __launch_bounds__(256, 2) void enc_layer4_k(const EncK p) {
         v = (blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3);
     } else {
         const int xcd = blockIdx.x & 7, q = blockIdx.x >> 3, F = p.full_per_xcd;
+#ifndef I2R_SPLIT_WHOLE_FIRST
+        // the halves come FIRST in the dispatch order: the SIMDs issue oldest-first, and the half that finishes its tile is the
+        // longest chain of the launch (start-up + half the keys + hand-off + tail) -- it must not queue behind a whole tile's MFMAs
+        const int H = 2 * (p.tiles_per_xcd - F), qh = q;
+        split = q < H;
+        v = xcd * p.tiles_per_xcd + (split ? F + (q >> 1) : q - H);
+#else
+        const int qh = q - F;
         split = q >= F;
-        v = xcd * p.tiles_per_xcd + (split ? F + ((q - F) >> 1) : q);
-        half = split ? (q - F) & 1 : 0;
-        slot = xcd * (p.tiles_per_xcd - F) + ((q - F) >> 1);
+        v = xcd * p.tiles_per_xcd + (split ? F + (qh >> 1) : q);
+#endif
+        half = split ? qh & 1 : 0;
+        slot = xcd * (p.tiles_per_xcd - F) + (qh >> 1);
     }
     if (v >= p.n_qblk) return;
     const Tile t = locate_tile<QT>(p, v, lane, gs0, ge0);
@@ -498,7 +509,11 @@ __global__ __launch_bounds__(256, 2) void enc_layer4_k(const EncK p) {
                 if (lane == 0) s_arrived = __hip_atomic_fetch_add(p.split_cnt + slot, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }
             __syncthreads();  // (also: every wave is done reading MLs / Os of the in-workgroup merge)
-            if (s_arrived == 0) return;  // the partner is still at work: it will find this partial and finish the tile
+            if (s_arrived == 0) {  // the partner is still at work: it will find this partial and finish the tile
+                STAMP(3);
+                STAMP0(7);
+                return;
+            }
             if (tid == 0) __hip_atomic_store(p.split_cnt + slot, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // ready for the next launch
             f32x4 ao[DC], ml;
 #pragma unroll

@@ -13,8 +13,13 @@ tag = sys.argv[1] if len(sys.argv) > 1 else "round1"
 DOM = "conv_igemm_f32<3, 3, 12, 1>"
 
 
+def newest(pattern):
+    """matches of a glob, newest first (gpurun merges every call's files into the same directories)"""
+    return sorted(glob.glob(pattern), key=os.path.getmtime, reverse=True)
+
+
 def counters(d):
-    f = glob.glob(os.path.join(O, d, "*", "*_counter_collection.csv"))[0]
+    f = newest(os.path.join(O, d, "*", "*_counter_collection.csv"))[0]
     acc = {}
     with open(f) as fh:
         for r in csv.DictReader(fh):
@@ -25,7 +30,7 @@ def counters(d):
 
 shutil.copy(os.path.join(O, "bench.json"), os.path.join(P, tag + "_bench.json"))
 shutil.copy(os.path.join(O, "bench_under_rocprof.json"), os.path.join(P, tag + "_bench_under_rocprof.json"))
-ks = glob.glob(os.path.join(O, "prof_stats", "*", "*_kernel_stats.csv"))[0]
+ks = newest(os.path.join(O, "prof_stats", "*", "*_kernel_stats.csv"))[0]
 rows = list(csv.reader(open(ks)))
 with open(os.path.join(P, tag + "_bench_kernel_stats.csv"), "w", newline="") as fh:
     w = csv.writer(fh, quoting=csv.QUOTE_ALL)
@@ -64,7 +69,7 @@ sq["derived"] = {"kernel_cycles_per_xcd": cyc, "mfma_busy_frac": sq["SQ_VALU_MFM
 sq["_note"] = ("per-dispatch averages over the grouped stage-3 conv launch (%s); profiled runs clock lower than un-profiled ones" % DOM)
 json.dump(sq, open(os.path.join(P, tag + "_pmc_sq_grouped_conv.json"), "w"), indent=1)
 for c in ("FETCH_SIZE", "WRITE_SIZE"):
-    f = glob.glob(os.path.join(O, "prof_pmc_" + c, "*", "*_counter_collection.csv"))[0]
+    f = newest(os.path.join(O, "prof_pmc_" + c, "*", "*_counter_collection.csv"))[0]
     with open(f) as fh, open(os.path.join(P, "%s_pmc_%s_grouped_conv.csv" % (tag, c.lower())), "w", newline="") as out:
         w = csv.writer(out)
         w.writerow(["Kernel_Name", "Grid_Size", "LDS_Block_Size", "VGPR_Count", "Accum_VGPR_Count", "Counter_Name", "Counter_Value"])
@@ -75,7 +80,7 @@ for c in ("FETCH_SIZE", "WRITE_SIZE"):
 
 
 def counters_of(d, kernel):
-    f = glob.glob(os.path.join(O, d, "*", "*_counter_collection.csv"))
+    f = newest(os.path.join(O, d, "*", "*_counter_collection.csv"))
     if not f:
         return None
     acc = {}
@@ -91,7 +96,7 @@ for cfg in ("tph_192_p6_b4", "hrt_192_p4_b4", "coco_hrt_288_p2_b4"):
     src = os.path.join(O, "bench_%s.json" % cfg)
     if os.path.exists(src):
         shutil.copy(src, os.path.join(P, "%s_bench_%s.json" % (tag, cfg)))
-    ks_ = glob.glob(os.path.join(O, "prof_stats_" + cfg, "*", "*_kernel_stats.csv"))
+    ks_ = newest(os.path.join(O, "prof_stats_" + cfg, "*", "*_kernel_stats.csv"))
     if ks_:
         rows_ = list(csv.reader(open(ks_[0])))
         with open(os.path.join(P, "%s_%s_kernel_stats.csv" % (tag, cfg)), "w", newline="") as fh:
