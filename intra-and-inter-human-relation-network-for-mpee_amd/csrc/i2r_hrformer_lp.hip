@@ -68,8 +68,9 @@ struct AttnK {
 
 constexpr int KS = 52, VS = 68;  // LDS row strides (16-bit elements): K rows [key][48 dims], V^T rows [dim][64 keys]
 
+// (waves per SIMD: C = 78 runs 4 workgroups per CU -- a bound of 5 spills 60 VGPRs, 32 -> 49 us; C = 156 with the full register budget of 2: 48 -> 40 us)
 template <int DT, int CB, int HEADS>
-__global__ __launch_bounds__(256) void hrt_attn_block_k(const AttnK p) {
+__global__ __launch_bounds__(256, CB == 5 ? 4 : 2) void hrt_attn_block_k(const AttnK p) {
     constexpr int cs = CB * 16;
     __shared__ __attribute__((aligned(16))) unsigned short Kb[2][64 * KS];
     __shared__ __attribute__((aligned(16))) unsigned short Vt[2][48 * VS];
