@@ -110,7 +110,7 @@ def per_launch_timing(program, reps=3):
     L = cabi.lib()
     cur = torch.cuda.current_stream().cuda_stream
     streams = (C.c_void_p * 4)(cur, cur, cur, cur)
-    ops = [(i, kind, st) for i, (kind, lane, st) in enumerate(program.ops) if kind not in (cabi.OP_FORK, cabi.OP_JOIN)]
+    ops = [(i, kind, st) for i, (kind, lane, st) in enumerate(program.ops) if kind not in cabi.SYNC_OPS]
     named = [(i,) + _op_name_flop(kind, st) for i, kind, st in ops]  # single-stream pass: lanes collapse onto the current stream
     runs = []  # [name, [op indices], flop]
     for i, name, flop in named:
@@ -187,8 +187,9 @@ def oracle_parity(cfg, sd, x, m, length, y, precision):
     return out
 
 
-def cpu_baseline(cfg, sd, H, W, persons, budget_s=20.0):
-    """The CPU oracle (a port of the reference forward) timed on this host; bounded to ~budget_s seconds."""
+def cpu_baseline(cfg, sd, H, W, length, budget_s=20.0):
+    """The CPU oracle (a port of the reference forward) timed on this host on the SAME batch shape as the GPU line (`length`: persons per
+    image) when that fits the time budget, else on its largest image alone; bounded to ~budget_s seconds."""
     import i2r_cpu
     try:
         cores = len(os.sched_getaffinity(0))
@@ -196,22 +197,27 @@ def cpu_baseline(cfg, sd, H, W, persons, budget_s=20.0):
         cores = os.cpu_count() or 1
     threads = min(cores, 32)  # torch CPU convs stop scaling (and oversubscribe badly) far below 256 threads
     torch.set_num_threads(threads)
-    x, m, length = synth.make_inputs([1], H, W)
+    x, m, l1 = synth.make_inputs([1], H, W)
     t0 = time.perf_counter()
-    i2r_cpu.forward(sd, cfg, x, m, length)  # warm-up + cost probe on ONE crop
+    i2r_cpu.forward(sd, cfg, x, m, l1)  # warm-up + cost probe on ONE crop
     probe = time.perf_counter() - t0
-    persons = persons if probe * persons * 3 < budget_s else 1
-    x, m, length = synth.make_inputs([persons], H, W)
+    if probe * sum(length) * 3 < budget_s:
+        sample, what = list(length), "the timed batch shape (%d images, %d crops)" % (len(length), sum(length))
+    elif probe * max(length) * 3 < budget_s:
+        sample, what = [max(length)], "1 image x %d person(s)" % max(length)
+    else:
+        sample, what = [1], "1 image x 1 person"
+    x, m, ls = synth.make_inputs(sample, H, W)
     n, t0 = 0, time.perf_counter()
     while True:
-        i2r_cpu.forward(sd, cfg, x, m, length)
+        i2r_cpu.forward(sd, cfg, x, m, ls)
         n += 1
         if time.perf_counter() - t0 > budget_s * 0.6 or n >= 40:
             break
     dt = time.perf_counter() - t0
-    return {"value": round(n * persons / dt, 3), "unit": "images/sec", "cores": threads, "kind": "port",
-            "sample": "%d forwards of 1 image x %d person(s) at %dx%d, fp32, oracle/i2r_cpu.py on torch %s CPU, %d threads "
-                      "(%d cores visible)" % (n, persons, H, W, torch.__version__, threads, cores)}
+    return {"value": round(n * sum(sample) / dt, 3), "unit": "images/sec", "cores": threads, "kind": "port",
+            "sample": "%d forwards of %s at %dx%d, fp32, oracle/i2r_cpu.py on torch %s CPU, %d threads "
+                      "(%d cores visible)" % (n, what, H, W, torch.__version__, threads, cores)}
 
 
 def make_pipeline(net, cfg, length, H, W, dev, seed):
@@ -405,7 +411,7 @@ def main():
             y1 = y1["multi"] if isinstance(y1, dict) else y1
             out["parity"] = oracle_parity(cfg, sd, x, m, length, y1, precision)
         if not args.no_cpu_baseline and world == 1:
-            out["cpu_baseline"] = cpu_baseline(cfg, sd, H_, W_, max(length))
+            out["cpu_baseline"] = cpu_baseline(cfg, sd, H_, W_, length)
         print(json.dumps(out))
     if world > 1:
         dist.barrier()

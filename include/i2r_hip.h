@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define I2R_ABI_VERSION 2
+#define I2R_ABI_VERSION 3
 
 #define I2R_OK 0
 #define I2R_E_ARG (-1)      /* bad argument (shape / alignment / unsupported combination) */
@@ -336,13 +336,16 @@ int i2r_encoder_layer(const i2r_encoder_desc* d, void* stream);
 /* ------------------------------------------------------------------------------------------------
  * Program runner: replay a pre-built list of launches from one C call (no per-op host overhead, and
  * capturable into a hipGraph by the caller).  Streams: ops carry a lane id 0..3; lane 0 is `stream`,
- * other lanes are forked/joined with events by I2R_OP_FORK / I2R_OP_JOIN.
+ * other lanes are forked/joined with events by I2R_OP_FORK / I2R_OP_JOIN (op.lane = mask of the lanes 1..3 involved).
+ * I2R_OP_XSYNC (op.lane = mask of lanes, bit 0 = lane 0): every lane of the mask continues only after everything issued so far on
+ * every OTHER lane of the mask (one event per lane, all-to-all waits) -- the barrier between the branch blocks and the fuse
+ * layers of an HRFormer module when branch i and fuse output i both live on lane i, so that no lane idles behind lane 0.
  * ------------------------------------------------------------------------------------------------ */
 enum {
     I2R_OP_CONV = 1, I2R_OP_STEM = 2, I2R_OP_MAXPOOL = 3, I2R_OP_HEAD = 4,
     I2R_OP_ENC_KV = 5, I2R_OP_ENC_LAYER = 6, I2R_OP_FORK = 7, I2R_OP_JOIN = 8, I2R_OP_CONV_GROUP = 9,
     I2R_OP_LAYERNORM = 10, I2R_OP_WINATTN = 11, I2R_OP_DWCONV = 12, I2R_OP_UPSAMPLE = 13, I2R_OP_CONV_CHAIN = 14,
-    I2R_OP_PE_RES_STEM = 15, I2R_OP_HRT_ATTN = 16, I2R_OP_HRT_MLP = 17
+    I2R_OP_PE_RES_STEM = 15, I2R_OP_HRT_ATTN = 16, I2R_OP_HRT_MLP = 17, I2R_OP_XSYNC = 18
 };
 
 typedef struct i2r_stem_args {

@@ -37,6 +37,30 @@ extern "C" int i2r_run_program(const i2r_op* ops, int32_t n_ops, void* const* st
     for (int i = 0; i < n_ops; ++i) {
         const i2r_op& op = ops[i];
         int rc = I2R_OK;
+        if (op.kind == I2R_OP_XSYNC) {  // all-to-all among the lanes of the mask: one event per lane, every other lane waits for it
+            if (!streams) continue;  // single-stream replay: program order already is the order
+            bool distinct = false;
+            for (int l = 1; l < 4; ++l)
+                if ((op.lane & (1 << l)) && streams[l] != streams[0]) distinct = true;
+            if (!distinct) continue;
+            I2R_CHECK_ARG(events, "i2r_run_program: xsync needs events");
+            hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
+            for (int l = 0; l < 4 && rc == I2R_OK; ++l)
+                if (op.lane & (1 << l)) {
+                    ev[l] = (hipEvent_t)events[next_event++ & 7];
+                    if (hipEventRecord(ev[l], (hipStream_t)streams[l]) != hipSuccess) rc = I2R_E_LAUNCH;
+                }
+            for (int d = 0; d < 4 && rc == I2R_OK; ++d)
+                if (op.lane & (1 << d))
+                    for (int l = 0; l < 4 && rc == I2R_OK; ++l)
+                        if (l != d && ev[l] && streams[l] != streams[d])
+                            if (hipStreamWaitEvent((hipStream_t)streams[d], ev[l], 0) != hipSuccess) rc = I2R_E_LAUNCH;
+            if (rc != I2R_OK) {
+                i2r_set_error("i2r_run_program: xsync failed at op %d", i);
+                return rc;
+            }
+            continue;
+        }
         if (op.kind == I2R_OP_FORK || op.kind == I2R_OP_JOIN) {
             I2R_CHECK_ARG(streams && events, "i2r_run_program: fork/join needs streams and events");
             if (op.kind == I2R_OP_FORK) {  // lanes in the mask wait for everything issued on lane 0 so far

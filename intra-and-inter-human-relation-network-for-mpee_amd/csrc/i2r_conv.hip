@@ -18,6 +18,8 @@
 //    accumulating into `out` in place through res1 == out is race-free).
 #include <stdlib.h>
 
+#include <algorithm>
+
 #include "i2r_conv.h"
 
 namespace {
@@ -242,6 +244,11 @@ __device__ __forceinline__ void conv_body(const ConvK& p, int bid, f32x4* lds) {
         if (tid == 0) {
             unsigned long long* o = reinterpret_cast<unsigned long long*>(const_cast<float*>(p.res2)) + (size_t)bid_stamp * 4;
             o[0] = ts0; o[1] = ts1; o[2] = ts2; o[3] = ts3;
+            if (I2R_DBG(p) & 32) {  // where did the hardware place this workgroup?  HW_ID (CU / SE / SIMD fields) | XCC_ID << 32
+                const unsigned hw = __builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | (31 << 11));
+                const unsigned xcc = __builtin_amdgcn_s_getreg((20 << 0) | (0 << 6) | (3 << 11));
+                o[1] = ((unsigned long long)xcc << 32) | hw;
+            }
         }
         return;
     }
@@ -479,7 +486,12 @@ static int prepare(const i2r_conv_desc* d, int force_mt, int force_cap, int forc
     size_t lds_bytes;
     if (pf > 0) {
         int ckg = 4;
-        const int cap_max = d->dtype == 0 ? 12 : 8;  // prefetch registers of the kernel variants: fp32 up to 12 groups, 16-bit up to 8
+#ifdef I2R_TUNING
+        static const int cap_env = getenv("I2R_CONV_CAP") ? atoi(getenv("I2R_CONV_CAP")) : 12;  // tuning switch: prefetch capacity limit
+#else
+        constexpr int cap_env = 12;
+#endif
+        const int cap_max = std::min(cap_env, d->dtype == 0 ? 12 : 8);  // prefetch registers of the kernel variants: fp32 up to 12 groups, 16-bit up to 8
         const int cap_lim = force_pf >= 0 ? force_cap : (pf == 1 ? cap_max : 4);
         for (int cand : {12, 8, 4})
             if (cand <= cap_lim && cin_g % cand == 0 && (size_t)2 * cand * k.plane * 16 <= 40 * 1024) { ckg = cand; break; }

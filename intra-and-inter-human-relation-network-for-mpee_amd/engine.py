@@ -474,6 +474,15 @@ class Program:
             else:
                 self.pool.setdefault(a.t.numel(), []).append(a.t)
 
+    def release_deferred(self, *acts):
+        """buffers that SEVERAL lanes of the current fork region read (the branch outputs under the fuse layers): reusable only after
+        the next xsync / join has ordered every lane behind those reads"""
+        for a in acts:
+            if self.in_fork:
+                self.pending.append(a.t)
+            else:
+                self.pool.setdefault(a.t.numel(), []).append(a.t)
+
     # ---- ops ----
     def stem(self, st, n, h, w, in_ptr=0, lane=0, n_src=None, out_dt=0):
         """n_src < n: crops n_src.. are computed from the mirrored input (flip test batched into the same forward)."""
@@ -812,16 +821,26 @@ class Program:
         self.ops.append((cabi.OP_FORK, mask, None))
         self.in_fork = True
 
-    def join(self, mask):
-        """lane 0 continues after the lanes in `mask`; buffers freed inside the region become reusable"""
-        self.ops.append((cabi.OP_JOIN, mask, None))
-        self.in_fork = False
+    def _flush_lane_pools(self):
         for t in self.pending:
             self.pool.setdefault(t.numel(), []).append(t)
         self.pending = []
         for (_, numel), lst in self.lane_pool.items():
             self.pool.setdefault(numel, []).extend(lst)
         self.lane_pool = {}
+
+    def xsync(self, mask):
+        """inside a fork region: every lane of `mask` (bit 0 = lane 0) continues after everything issued so far on the other lanes of
+        the mask.  It must name every lane the region uses: whatever any lane released before it is then reusable by all of them."""
+        assert self.in_fork
+        self.ops.append((cabi.OP_XSYNC, mask, None))
+        self._flush_lane_pools()
+
+    def join(self, mask):
+        """lane 0 continues after the lanes in `mask`; buffers freed inside the region become reusable"""
+        self.ops.append((cabi.OP_JOIN, mask, None))
+        self.in_fork = False
+        self._flush_lane_pools()
         self.lane_ctx = 0
 
     # ---- run ----
@@ -831,7 +850,7 @@ class Program:
             arr[i].kind, arr[i].lane = kind, lane
             arr[i].args = C.cast(C.pointer(st), C.c_void_p) if st is not None else None
         self._c_ops = arr
-        self.uses_lanes = any(lane != 0 or kind in (cabi.OP_FORK, cabi.OP_JOIN) for kind, lane, _ in self.ops)
+        self.uses_lanes = any(lane != 0 or kind in cabi.SYNC_OPS for kind, lane, _ in self.ops)
 
     def run(self, side_streams=None, events=None):
         """side_streams: 3 torch.cuda.Stream for lanes 1..3 (None -> everything on the current stream)."""
@@ -1097,29 +1116,25 @@ class HRFormerB:
         return x2
 
     @classmethod
-    def _emit_module(cls, P, mod, xs):
+    def _emit_module(cls, P, mod, xs, lanes):
+        """One HighResolutionTransformerModule.  With `lanes` the caller has forked lanes 0..nb-1 for the whole STAGE: branch i and fuse
+        output i both run on lane i, so the only synchronisation of a module is one all-to-all xsync between its branch blocks and
+        its fuse layers (every output reads every branch, hrformer.py:1716-1731) -- the next module's blocks of branch i read what
+        lane i itself has just written."""
         nb = mod["nb"]
         xs = list(xs)
         # The branches of a module are independent until the fuse layers (hrformer.py:1708-1715) and the low-resolution ones are far
-        # too small to fill 256 CUs on their own (16x12: 160 workgroups): branch i runs on stream lane i, forked / joined around the
-        # block loops; launches are emitted round-robin over the branches so every lane's queue fills from the start.
-        lanes = nb > 1 and os.environ.get("I2R_BRANCH_LANES", "1") != "0"
-        mask = sum(1 << i for i in range(1, min(nb, 4))) if lanes else 0
-        if lanes:
-            P.fork(mask)
+        # too small to fill 256 CUs on their own (16x12: 160 workgroups): launches are emitted round-robin over the branches so every
+        # lane's queue fills from the start.
         for k in range(max(len(b) for b in mod["blocks"])):
             for i in range(nb):
                 if k < len(mod["blocks"][i]):
-                    xs[i] = cls._emit_block(P, mod["blocks"][i][k], xs[i], lane=min(i, 3) if lanes else 0)
+                    xs[i] = cls._emit_block(P, mod["blocks"][i][k], xs[i], lane=i if lanes else 0)
         if lanes:
-            P.join(mask)
+            P.xsync((1 << nb) - 1)
         outs = []
-        flanes = lanes and mod["n_out"] > 1  # the fuse sums of the outputs are independent of each other as well
-        fmask = sum(1 << i for i in range(1, min(mod["n_out"], 4))) if flanes else 0
-        if flanes:
-            P.fork(fmask)
         for i in range(mod["n_out"]):
-            ln = min(i, 3) if flanes else 0
+            ln = i if lanes else 0
             P.lane_ctx = ln
             # y = ((t_0 + t_1) + ...) then ReLU (hrformer.py:1716-1731); identity terms ride as residual inputs
             acc, y, j = None, None, 0
@@ -1156,9 +1171,7 @@ class HRFormerB:
                             P.release(d)
                 acc, j = y, jn
             outs.append(y)
-        if flanes:
-            P.join(fmask)
-        P.release(*xs)
+        P.release_deferred(*xs)  # (read by every fuse lane: reusable after the next xsync / the stage's join)
         return outs
 
     def emit(self, P, n, h, w, n_src=None):
@@ -1185,8 +1198,16 @@ class HRFormerB:
             for i, pc in enumerate(st["trans"]):  # inputs replaced by a transition conv are dead now
                 if i < st["n_pre"] and pc is not None and not any(ys[i] is x_ for x_ in xs):
                     P.release(ys[i])
+            # one fork region per stage: lanes 1..nb-1 start behind the transition convs (lane 0) and are joined after the last module
+            nb = st["mods"][0]["nb"]
+            lanes = 1 < nb <= 4 and os.environ.get("I2R_BRANCH_LANES", "1") != "0"
+            mask = ((1 << nb) - 1) & ~1
+            if lanes:
+                P.fork(mask)
             for mod in st["mods"]:
-                xs = self._emit_module(P, mod, xs)
+                xs = self._emit_module(P, mod, xs, lanes)
+            if lanes:
+                P.join(mask)
             ys = xs
         return ys, stem_args
 

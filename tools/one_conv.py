@@ -7,6 +7,9 @@ sys.path.insert(0, ROOT)
 import torch
 
 import i2r_amd  # noqa
+from i2r_amd import cabi
+if os.environ.get("I2R_TOOL_LIB"):  # a tuning build (tools/ab/build_tuning.sh)
+    cabi._LIB = cabi.load_library(os.path.join(ROOT, os.environ["I2R_TOOL_LIB"]))
 from i2r_amd import engine, synth
 
 DEV = torch.device("cuda:0")
