@@ -5,8 +5,10 @@
 namespace {
 
 // 3x3 stride-2 pad-1 conv with tiny cin (3 = RGB crop, 1 = person box mask) + folded BN + ReLU.
-// thread = one output pixel x 16 output channels; the cout/16 threads of a pixel are adjacent lanes, so a
-// pixel's cout floats are written as one contiguous run (NHWC).  w: [9][CIN][cout].
+// thread = one output pixel x 16 output channels; the G = cout/16 threads of a pixel are adjacent lanes and own the channel
+// quadruples f = i G + cg (i = 0..3) -- INTERLEAVED, so that store instruction i of a wave writes, per pixel, G x 16 contiguous
+// bytes from G adjacent lanes (cout = 64: the four lanes of a quad fill one 64-byte segment, the texture addresser's fast case;
+// with 16 consecutive channels per lane every lane of a store hit its own segment and the kernel ran at 1.8 TB/s).  w: [9][CIN][cout].
 template <int CIN, int ODT>
 __global__ __launch_bounds__(256) void stem_conv_k(const float* __restrict__ in, const float* __restrict__ w,
                                                    const float* __restrict__ bias, float* __restrict__ out, int n_img,
@@ -46,16 +48,16 @@ __global__ __launch_bounds__(256) void stem_conv_k(const float* __restrict__ in,
     float acc[16];
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
-        const f32x4 bv = *reinterpret_cast<const f32x4*>(wl + 9 * CIN * cout + cg * 16 + q * 4);
+        const f32x4 bv = *reinterpret_cast<const f32x4*>(wl + 9 * CIN * cout + (q * groups + cg) * 4);
         acc[q * 4] = bv[0]; acc[q * 4 + 1] = bv[1]; acc[q * 4 + 2] = bv[2]; acc[q * 4 + 3] = bv[3];
     }
 #pragma unroll 3
     for (int t = 0; t < 9 * CIN; ++t) {
         const float x = xin[t];
-        const f32x4* wr = reinterpret_cast<const f32x4*>(wl + t * cout + cg * 16);
+        const f32x4* wr = reinterpret_cast<const f32x4*>(wl + t * cout) + cg;
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
-            const f32x4 wv = wr[q];
+            const f32x4 wv = wr[q * groups];
             acc[q * 4 + 0] = fmaf(x, wv[0], acc[q * 4 + 0]);
             acc[q * 4 + 1] = fmaf(x, wv[1], acc[q * 4 + 1]);
             acc[q * 4 + 2] = fmaf(x, wv[2], acc[q * 4 + 2]);
@@ -65,7 +67,7 @@ __global__ __launch_bounds__(256) void stem_conv_k(const float* __restrict__ in,
     if (!valid) return;
 #pragma unroll
     for (int q = 0; q < 4; ++q)  // ODT != 0: the tower keeps its activations in 16 bit (bf16 / f16), element offsets are the same
-        st_act4<ODT>(out, (size_t)pix * out_cs + cg * 16 + q * 4,
+        st_act4<ODT>(out, (size_t)pix * out_cs + (q * groups + cg) * 4,
                      (f32x4){fmaxf(acc[q * 4], 0.f), fmaxf(acc[q * 4 + 1], 0.f), fmaxf(acc[q * 4 + 2], 0.f), fmaxf(acc[q * 4 + 3], 0.f)}, ODT != 0);
 }
 
@@ -177,36 +179,53 @@ __global__ __launch_bounds__(256) void maxpool_k(const float* __restrict__ in, f
     *reinterpret_cast<f32x4*>(out + (size_t)pix * out_cs + cg * 4) = m;
 }
 
-// final 1x1 conv with bias: NHWC features -> NCHW heatmaps. thread = one pixel, all joints (JP = padded
-// joint count held in registers); weights are wave-uniform -> scalar loads.  w: [cout][cin].
+// final 1x1 conv with bias: NHWC features -> NCHW heatmaps.  HBM-bound (reads the [S, h, w, cin] map once).  Four lanes share a pixel:
+// lane q of a quad takes the channel groups 4 i + q, so each load instruction of a wave covers 16 pixels x 64 contiguous bytes (the
+// quad rule of the texture addresser; one pixel per lane -- 384-byte strides -- took 4x the addresser time and left 384 workgroups
+// for 256 CUs).  The weights sit in LDS as [cin / 4][JP] float4 (lanes of equal q read the same address: broadcast); the four
+// partial sums of a joint are combined by a transposing reduction (3 shuffles per 4 joints) that leaves joint 4 k + q on lane q,
+// which writes it to the NCHW plane of that joint (16 consecutive pixels = 64 bytes per lane group).
 template <int JP>
 __global__ __launch_bounds__(256) void head_k(const float* __restrict__ in, const float* __restrict__ w,
                                               const float* __restrict__ bias, float* __restrict__ out, int n_img, int hw,
                                               int cin, int in_cs, int cout) {
-    const long long pix = (long long)blockIdx.x * 256 + threadIdx.x;
-    if (pix >= (long long)n_img * hw) return;
+    extern __shared__ __attribute__((aligned(16))) f32x4 wl4[];  // [cin / 4][JP]
+    const int cin4 = cin >> 2;
+    for (int i = threadIdx.x; i < cin4 * JP; i += 256) {
+        const int c4 = i / JP, j = i - c4 * JP;
+        wl4[i] = j < cout ? *reinterpret_cast<const f32x4*>(w + (size_t)j * cin + c4 * 4) : (f32x4){0.f, 0.f, 0.f, 0.f};
+    }
+    __syncthreads();
+    const int q = threadIdx.x & 3;
+    const long long pix_raw = ((long long)blockIdx.x * 256 + threadIdx.x) >> 2;
+    const bool valid = pix_raw < (long long)n_img * hw;
+    const long long pix = valid ? pix_raw : 0;
     float acc[JP];
 #pragma unroll
-    for (int j = 0; j < JP; ++j) acc[j] = j < cout ? bias[j] : 0.f;
+    for (int j = 0; j < JP; ++j) acc[j] = 0.f;
     const f32x4* x = reinterpret_cast<const f32x4*>(in + (size_t)pix * in_cs);
-    for (int c = 0; c < cin; c += 4) {
-        const f32x4 v = x[c >> 2];
+    for (int c4 = q; c4 < cin4; c4 += 4) {  // (all loads of a pixel in flight at once measured slower: 28 vs 23 us at 32 crops)
+        const f32x4 v = x[c4];
+        const f32x4* wr = wl4 + c4 * JP;
 #pragma unroll
         for (int j = 0; j < JP; ++j) {
-            if (j < cout) {
-                const float* wr = w + j * cin + c;
-                acc[j] = fmaf(v[0], wr[0], acc[j]);
-                acc[j] = fmaf(v[1], wr[1], acc[j]);
-                acc[j] = fmaf(v[2], wr[2], acc[j]);
-                acc[j] = fmaf(v[3], wr[3], acc[j]);
-            }
+            const f32x4 wv = wr[j];
+            acc[j] = fmaf(v[0], wv[0], fmaf(v[1], wv[1], fmaf(v[2], wv[2], fmaf(v[3], wv[3], acc[j]))));
         }
     }
     const int img = (int)(pix / hw);
     const int p = (int)(pix - (long long)img * hw);
 #pragma unroll
-    for (int j = 0; j < JP; ++j)
-        if (j < cout) out[((size_t)img * cout + j) * hw + p] = acc[j];
+    for (int k = 0; k < JP / 4; ++k) {
+        // transposing reduction over the quad: lane q ends with the full sum of joint 4 k + q
+        const float a0 = acc[4 * k], a1 = acc[4 * k + 1], a2 = acc[4 * k + 2], a3 = acc[4 * k + 3];
+        const bool o1 = q & 1, o2 = q & 2;
+        const float k0 = (o1 ? a1 : a0) + __shfl_xor(o1 ? a0 : a1, 1);
+        const float k1 = (o1 ? a3 : a2) + __shfl_xor(o1 ? a2 : a3, 1);
+        const float r = (o2 ? k1 : k0) + __shfl_xor(o2 ? k0 : k1, 2);
+        const int j = 4 * k + q;
+        if (valid && j < cout) out[((size_t)img * cout + j) * hw + p] = r + bias[j];
+    }
 }
 
 }  // namespace
@@ -264,13 +283,12 @@ extern "C" int i2r_head(const float* in, const float* w, const float* bias, floa
     I2R_CHECK_ARG(in && w && bias && out_nchw, "i2r_head: null pointer");
     I2R_CHECK_ARG(cin % 4 == 0 && in_cs % 4 == 0 && cin <= in_cs && cout >= 1 && cout <= 32, "i2r_head: cin=%d cout=%d", cin, cout);
     const long long npix = (long long)n_img * h * w_;
-    const unsigned nblk = (unsigned)((npix + 255) / 256);
-    if (cout <= 16)
-        hipLaunchKernelGGL(head_k<16>, dim3(nblk), dim3(256), 0, (hipStream_t)stream, in, w, bias, out_nchw, n_img, h * w_, cin,
-                           in_cs, cout);
-    else
-        hipLaunchKernelGGL(head_k<32>, dim3(nblk), dim3(256), 0, (hipStream_t)stream, in, w, bias, out_nchw, n_img, h * w_, cin,
-                           in_cs, cout);
+    const unsigned nblk = (unsigned)((npix * 4 + 255) / 256);  // 4 lanes per pixel
+    typedef void (*head_fn)(const float*, const float*, const float*, float*, int, int, int, int, int);
+    const int jp = cout <= 16 ? 16 : cout <= 20 ? 20 : 32;
+    const head_fn fn = jp == 16 ? head_k<16> : jp == 20 ? head_k<20> : head_k<32>;
+    hipLaunchKernelGGL(fn, dim3(nblk), dim3(256), (size_t)(cin / 4) * jp * sizeof(f32x4), (hipStream_t)stream, in, w, bias, out_nchw, n_img, h * w_,
+                       cin, in_cs, cout);
     I2R_CHECK_LAUNCH("i2r_head");
     return I2R_OK;
 }
