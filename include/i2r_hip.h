@@ -262,6 +262,14 @@ int i2r_dwconv3x3(const float* in, const float* w, const float* bias, float* out
 int i2r_upsample_bilinear_add(const float* low, const float* res, float* out, int32_t n_img, int32_t low_h, int32_t low_w,
                               int32_t scale, int32_t c, int32_t cs, int32_t act, void* stream);
 
+/* i2r_fuse_up_add -- out = act(base + up(t1, s1) [+ up(t2, s2)]), up = nearest-neighbour up-sampling by s (a power of two; t_k is
+ * [n, h/s_k, w/s_k, cs]).  The closing step of the HRNet fuse sum for the outputs that receive lower-resolution terms
+ * (interformer_pureMulti.py:392-410: y_i = ReLU(x_i + sum_j Upsample(BN(conv1x1(x_j))))): the 1x1 convs write their small maps once
+ * and this HBM-bound pass adds them, instead of s x s read-modify-write scatters from the conv epilogues.  The sum is evaluated
+ * left to right ((base + t1) + t2).  base may alias out; t2 may be null.  dt: storage type of all tensors (0 fp32, 1 bf16, 2 f16). */
+int i2r_fuse_up_add(const float* base, const float* t1, int32_t s1, const float* t2, int32_t s2, float* out, int32_t n_img,
+                    int32_t h, int32_t w, int32_t cs, int32_t act, int32_t dt, void* stream);
+
 /* ------------------------------------------------------------------------------------------------
  * i2r_encoder_desc -- one DETR-style post-norm encoder layer over variable-length token groups
  * (persons of one image attend to each other; no padding, no mask tensor).
@@ -345,7 +353,7 @@ enum {
     I2R_OP_CONV = 1, I2R_OP_STEM = 2, I2R_OP_MAXPOOL = 3, I2R_OP_HEAD = 4,
     I2R_OP_ENC_KV = 5, I2R_OP_ENC_LAYER = 6, I2R_OP_FORK = 7, I2R_OP_JOIN = 8, I2R_OP_CONV_GROUP = 9,
     I2R_OP_LAYERNORM = 10, I2R_OP_WINATTN = 11, I2R_OP_DWCONV = 12, I2R_OP_UPSAMPLE = 13, I2R_OP_CONV_CHAIN = 14,
-    I2R_OP_PE_RES_STEM = 15, I2R_OP_HRT_ATTN = 16, I2R_OP_HRT_MLP = 17, I2R_OP_XSYNC = 18
+    I2R_OP_PE_RES_STEM = 15, I2R_OP_HRT_ATTN = 16, I2R_OP_HRT_MLP = 17, I2R_OP_XSYNC = 18, I2R_OP_FUSE_UP = 19
 };
 
 typedef struct i2r_stem_args {
@@ -398,6 +406,11 @@ typedef struct i2r_up_args {
     const float* low; const float* res; float* out;
     int32_t n_img, low_h, low_w, scale, c, cs, act;
 } i2r_up_args;
+
+typedef struct i2r_fuse_up_args {
+    const float* base; const float* t1; const float* t2; float* out;
+    int32_t n_img, h, w, cs, s1, s2, act, dt;
+} i2r_fuse_up_args;
 
 typedef struct i2r_conv_group_args {
     const i2r_conv_desc* d[I2R_MAX_GROUP];

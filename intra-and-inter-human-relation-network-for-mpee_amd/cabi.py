@@ -23,6 +23,7 @@ OP_PE_RES_STEM = 15
 OP_HRT_ATTN = 16
 OP_HRT_MLP = 17
 OP_XSYNC = 18
+OP_FUSE_UP = 19
 SYNC_OPS = (OP_FORK, OP_JOIN, OP_XSYNC)  # ops whose `lane` field is a lane mask and that launch nothing
 
 _fp = C.c_void_p  # device pointers travel as integers
@@ -107,6 +108,11 @@ class UpArgs(C.Structure):
                 ("n_img", _i32), ("low_h", _i32), ("low_w", _i32), ("scale", _i32), ("c", _i32), ("cs", _i32), ("act", _i32)]
 
 
+class FuseUpArgs(C.Structure):
+    _fields_ = [("base", _fp), ("t1", _fp), ("t2", _fp), ("out", _fp),
+                ("n_img", _i32), ("h", _i32), ("w", _i32), ("cs", _i32), ("s1", _i32), ("s2", _i32), ("act", _i32), ("dt", _i32)]
+
+
 class ConvGroupArgs(C.Structure):
     _fields_ = [("d", C.POINTER(ConvDesc) * MAX_GROUP), ("block_map", _fp), ("n", _i32), ("map_len", _i32)]
 
@@ -124,7 +130,7 @@ class Op(C.Structure):
 
 # every symbol include/i2r_hip.h declares (tests/test_host.py::test_cabi_library_exports_every_declared_symbol checks the built library exports them all)
 EXPORTS = ("i2r_conv", "i2r_conv_grouped", "i2r_conv_kernel_name", "i2r_stem_conv", "i2r_pe_res_stem", "i2r_maxpool3x3s2", "i2r_head", "i2r_layernorm", "i2r_window_attn", "i2r_hrt_attn_block", "i2r_hrt_mlp_block", "i2r_dwconv3x3",
-           "i2r_upsample_bilinear_add", "i2r_flip_merge", "i2r_decode", "i2r_crop_affine", "i2r_box_mask", "i2r_crop_affine_cv2", "i2r_box_mask_cv2", "i2r_conv_chain_pack", "i2r_conv_chain", "i2r_encoder_kv", "i2r_encoder_layer",
+           "i2r_upsample_bilinear_add", "i2r_fuse_up_add", "i2r_flip_merge", "i2r_decode", "i2r_crop_affine", "i2r_box_mask", "i2r_crop_affine_cv2", "i2r_box_mask_cv2", "i2r_conv_chain_pack", "i2r_conv_chain", "i2r_encoder_kv", "i2r_encoder_layer",
            "i2r_run_program", "i2r_abi_version", "i2r_last_error", "i2r_device_check")
 
 _LIB = None
@@ -154,6 +160,7 @@ def load_library(path=LIB_PATH):
     L.i2r_box_mask.argtypes = [_fp, _i32, _i32, _fp, _i32, _i32, _i32, C.c_void_p]
     L.i2r_crop_affine_cv2.argtypes = [_fp, _i32, _i32, _i32, _i32, _fp, _fp, _fp, _fp, _i32, _i32, _i32, C.c_void_p]
     L.i2r_box_mask_cv2.argtypes = [_fp, _i32, _i32, _fp, _i32, _i32, _i32, C.c_void_p]
+    L.i2r_fuse_up_add.argtypes = [_fp, _fp, _i32, _fp, _i32, _fp, _i32, _i32, _i32, _i32, _i32, _i32, C.c_void_p]
     L.i2r_maxpool3x3s2.argtypes = [_fp, _fp, _i32, _i32, _i32, _i32, _i32, _i32, C.c_void_p]
     L.i2r_head.argtypes = [_fp, _fp, _fp, _fp, _i32, _i32, _i32, _i32, _i32, _i32, C.c_void_p]
     L.i2r_layernorm.argtypes = [_fp, _fp, _fp, _fp, _i32, _i32, _i32, C.c_float, _i32, C.c_void_p]

@@ -228,7 +228,53 @@ __global__ __launch_bounds__(256) void head_k(const float* __restrict__ in, cons
     }
 }
 
+// closing pass of an HRNet fuse sum: out = act((base + up(t1)) + up(t2)), nearest-neighbour up-sampling by 2^k.  thread = 4 channels
+// of one output pixel (consecutive lanes = consecutive channel quadruples of a pixel, then the next pixel: fully coalesced);
+// HBM-bound: reads base once, writes out once, the low-resolution maps come from L2.
+template <int DT>
+__global__ __launch_bounds__(256) void fuse_up_add_k(const float* __restrict__ base, const float* __restrict__ t1, int sh1,
+                                                     const float* __restrict__ t2, int sh2, float* __restrict__ out, long long nq, int h,
+                                                     int w, int cs4, int act) {
+    const long long gid = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (gid >= nq) return;
+    const int c4 = (int)(gid % cs4);
+    const long long pix = gid / cs4;
+    const int x = (int)(pix % w);
+    const int y = (int)((pix / w) % h);
+    const long long n = pix / ((long long)w * h);
+    const bool h16 = DT != 0;
+    f32x4 v = ld_act4<DT>(base, (size_t)gid * 4, h16);
+    {
+        const int hh = h >> sh1, ww = w >> sh1;
+        v += ld_act4<DT>(t1, ((size_t)(n * hh + (y >> sh1)) * ww + (x >> sh1)) * cs4 * 4 + c4 * 4, h16);
+    }
+    if (t2) {
+        const int hh = h >> sh2, ww = w >> sh2;
+        v += ld_act4<DT>(t2, ((size_t)(n * hh + (y >> sh2)) * ww + (x >> sh2)) * cs4 * 4 + c4 * 4, h16);
+    }
+    if (act == 1) { v[0] = fmaxf(v[0], 0.f); v[1] = fmaxf(v[1], 0.f); v[2] = fmaxf(v[2], 0.f); v[3] = fmaxf(v[3], 0.f); }
+    st_act4<DT>(out, (size_t)gid * 4, v, h16);
+}
+
 }  // namespace
+
+extern "C" int i2r_fuse_up_add(const float* base, const float* t1, int32_t s1, const float* t2, int32_t s2, float* out, int32_t n_img,
+                               int32_t h, int32_t w, int32_t cs, int32_t act, int32_t dt, void* stream) {
+    I2R_CHECK_ARG(base && t1 && out, "i2r_fuse_up_add: null pointer");
+    auto shift = [](int s) { int k = 0; while ((1 << k) < s) ++k; return (1 << k) == s ? k : -1; };
+    const int sh1 = shift(s1), sh2 = t2 ? shift(s2) : 0;
+    I2R_CHECK_ARG(sh1 >= 1 && sh2 >= 0 && h % s1 == 0 && w % s1 == 0 && (!t2 || (h % s2 == 0 && w % s2 == 0)),
+                  "i2r_fuse_up_add: scales %d / %d must be powers of two dividing %dx%d", s1, s2, h, w);
+    I2R_CHECK_ARG(cs > 0 && cs % 4 == 0 && (act == 0 || act == 1) && dt >= 0 && dt <= 2, "i2r_fuse_up_add: cs=%d act=%d dt=%d", cs, act, dt);
+    I2R_CHECK_ARG(t1 != out && t2 != out, "i2r_fuse_up_add: a low-resolution term aliases out");
+    const long long nq = (long long)n_img * h * w * (cs / 4);
+    const unsigned nblk = (unsigned)((nq + 255) / 256);
+    typedef void (*fn_t)(const float*, const float*, int, const float*, int, float*, long long, int, int, int, int);
+    static const fn_t fns[3] = {fuse_up_add_k<0>, fuse_up_add_k<1>, fuse_up_add_k<2>};
+    hipLaunchKernelGGL(fns[dt], dim3(nblk), dim3(256), 0, (hipStream_t)stream, base, t1, sh1, t2, sh2, out, nq, h, w, cs / 4, act);
+    I2R_CHECK_LAUNCH("i2r_fuse_up_add");
+    return I2R_OK;
+}
 
 extern "C" int i2r_stem_conv(const float* in_nchw, const float* w, const float* bias, float* out_nhwc, int32_t n_img,
                              int32_t cin, int32_t in_h, int32_t in_w, int32_t cout, int32_t out_cs, int32_t n_src, int32_t n_valid,

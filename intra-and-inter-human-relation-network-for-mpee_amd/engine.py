@@ -738,6 +738,17 @@ class Program:
         self.ops.append((cabi.OP_UPSAMPLE, lane, a))
         return out
 
+    def fuse_up_add(self, base, terms, out, relu=True, lane=0):
+        """out = act((base + up(t1)) + up(t2)): nearest-neighbour up-sampled low-resolution terms added in one HBM-bound pass
+        (i2r_fuse_up_add); terms: 1 or 2 Acts whose maps are base's divided by a power of two"""
+        assert 1 <= len(terms) <= 2 and all(t.cs == base.cs == out.cs and t.dt == base.dt == out.dt and t.n == base.n for t in terms)
+        sc = [base.h // t.h for t in terms]
+        assert all(t.h * s == base.h and t.w * s == base.w for t, s in zip(terms, sc))
+        a = cabi.FuseUpArgs(base.ptr, terms[0].ptr, terms[1].ptr if len(terms) > 1 else None, out.ptr, base.n, base.h, base.w, base.cs,
+                            sc[0], sc[1] if len(terms) > 1 else 1, int(relu), base.dt)
+        self.ops.append((cabi.OP_FUSE_UP, lane, a))
+        return out
+
     def head(self, x, hd, out_ptr=0, lane=0):
         assert x.dt == 0, "fp32 kernel: the producer must store fp32 (conv(..., out_dt=0))"
         self.keep.append(hd)
@@ -947,56 +958,78 @@ class HRNetW48:
                 P.flush_group(grp)
         if uniform:
             P.conv_chain(layers)
-        # fuse: per output i an ordered chain of launches ((src, pc, kwargs) steps); y = ((t_0 + t_1) + ...) in the
-        # reference's order, identity terms folded into a neighbouring conv's residual inputs, running sum in place in y
-        chains = []
+        # fuse (interformer_pureMulti.py:392-410): y_i = ReLU(sum_j f_ij(x_j)), f_ii = identity, summed left to right.
+        #  * down-sampling terms (j < i, chains of stride-2 convs) are evaluated level by level, one grouped launch per level: every
+        #    chain advances one conv per level while, per output, at most one term whose source is ready is ACCUMULATED into y_i
+        #    (running sum in place; the identity x_i rides as a residual of the first term).  Terms are taken shortest chain first,
+        #    so a two-conv chain runs beside the other terms' sums: 2 levels for three branches.
+        #  * up-sampling terms (j > i: 1x1 conv + BN, nearest up-sampling) write their small low-resolution maps t_ij in the LAST of
+        #    those grouped launches (plain epilogues), and one HBM-bound closing pass per output adds them:
+        #    y_i = ReLU((base + up(t_i,a)) + up(t_i,b)) (i2r_fuse_up_add), base = x_i or the down-sampling partial sum.  Before, the
+        #    conv epilogues scattered s x s read-modify-writes per conv pixel (load -> add -> store, serialised per destination:
+        #    those launches ran at 21 TFLOP/s).
+        #  The down-sampling terms all precede the identity and the up-sampling terms in the reference's j order, so only the order
+        #  WITHIN the down-sampling part differs from it (three-term sums of output 2: rounding only).
+        terms, ups = [], []
         for i in range(nb):
-            steps, acc, j = [], None, 0
-            y = None
-            while j < nb:
-                if j == i:
-                    assert acc is None
-                    acc = "x"
-                    j += 1
-                    continue
-                chain, up = ([mod["fuse"][(i, j)]], 2 ** (j - i)) if j > i else (mod["fuse"][(i, j)], 1)
-                for pc in chain[:-1]:
-                    steps.append(("mid", j, pc))
-                res = [acc] if acc is not None else []
-                if j + 1 == i:
-                    res.append("x")
-                jn = j + 2 if j + 1 == i else j + 1
-                steps.append(("sum", j, chain[-1], res, up, jn >= nb))
-                acc, j = "y", jn
-            chains.append(steps)
+            ts = []
+            for j in range(i):
+                chain = mod["fuse"][(i, j)]
+                ts.append(dict(j=j, mids=list(chain[:-1]), last=chain[-1], cur=None))
+            ts.sort(key=lambda t: (len(t["mids"]), t["j"]))
+            terms.append(ts)
+            ups.append([(j, mod["fuse"][(i, j)]) for j in range(i + 1, nb)])
+        n_up = sum(len(u) for u in ups)
         ys = [None] * nb
-        cur = [None] * nb      # running intermediate of a down-sampling chain
-        pos = [0] * nb
-        while any(pos[i] < len(chains[i]) for i in range(nb)):
+        n_sum = [0] * nb
+        tmaps = [[] for _ in range(nb)]
+        levels_left = max([1 + len(t["mids"]) for ts in terms for t in ts] + [1 if n_up else 0])
+        while levels_left > 0:
+            levels_left -= 1
             grp, rel = [], []
             for i in range(nb):
-                if pos[i] >= len(chains[i]):
-                    continue
-                st = chains[i][pos[i]]
-                pos[i] += 1
-                src = cur[i] if cur[i] is not None else xs[st[1]]
-                if st[0] == "mid":
-                    nxt = P.conv(src, st[2], relu=True, group=grp)
-                    if cur[i] is not None:
-                        rel.append(cur[i])
-                    cur[i] = nxt
-                else:
-                    _, j, pc, res, up, final = st
+                ready = [t for t in terms[i] if not t["mids"]]  # (as of the start of this level)
+                for t in terms[i]:
+                    if t["mids"]:
+                        src = t["cur"] if t["cur"] is not None else xs[t["j"]]
+                        nxt = P.conv(src, t["mids"].pop(0), relu=True, group=grp)
+                        if t["cur"] is not None:
+                            rel.append(t["cur"])
+                        t["cur"] = nxt
+                if ready:
+                    t = ready[0]
+                    terms[i].remove(t)
+                    src = t["cur"] if t["cur"] is not None else xs[t["j"]]
                     if ys[i] is None:
                         ys[i] = P.alloc(xs[i].n, xs[i].h, xs[i].w, xs[i].c, xs[i].dt)
-                    rr = [xs[i] if r == "x" else ys[i] for r in res]
-                    P.conv(src, pc, relu=final, res1=rr[0] if rr else None, res2=rr[1] if len(rr) > 1 else None,
-                           up=up, out=ys[i], group=grp)
-                    if cur[i] is not None:
-                        rel.append(cur[i])
-                        cur[i] = None
+                    # ReLU here only if nothing else is added afterwards (no further down-sampling term, no up-sampling term)
+                    P.conv(src, t["last"], relu=(not terms[i] and not ups[i]), res1=xs[i] if n_sum[i] == 0 else ys[i], out=ys[i], group=grp)
+                    n_sum[i] += 1
+                    if t["cur"] is not None:
+                        rel.append(t["cur"])
+            if levels_left == 0 and n_up:  # the 1x1 convs of the up-sampling terms: small maps, plain epilogues
+                cands = [(i, j, pc) for i in range(nb) for j, pc in ups[i]]
+                if len(grp) + len(cands) > cabi.MAX_GROUP:  # (too many members for one launch: the 1x1 convs go out on their own)
+                    P.flush_group(grp)
+                for i, j, pc in cands:
+                    tmaps[i].append(P.conv(xs[j], pc, group=grp))
+                    if len(grp) == cabi.MAX_GROUP:
+                        P.flush_group(grp)
             P.flush_group(grp)
             P.release(*rel)
+        assert not any(terms)
+        for i in range(nb):
+            if not tmaps[i]:
+                continue
+            base = xs[i] if ys[i] is None else ys[i]
+            if ys[i] is None:
+                ys[i] = P.alloc(xs[i].n, xs[i].h, xs[i].w, xs[i].c, xs[i].dt)
+            pend = list(tmaps[i])
+            while pend:  # (two terms per pass; HRNet-W48-S has at most two lower branches)
+                now, pend = pend[:2], pend[2:]
+                P.fuse_up_add(base, now, ys[i], relu=not pend)
+                base = ys[i]
+            P.release(*tmaps[i])
         P.release(*xs)
         return ys
 

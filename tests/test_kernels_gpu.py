@@ -146,6 +146,33 @@ def test_maxpool_and_head():
     assert (out.cpu() - F.conv2d(x2[:, :78], sd["f.weight"], sd["f.bias"])).abs().max().item() < 1e-4
 
 
+@pytest.mark.parametrize("dt,tol", [(0, 0.0), (1, 0.05), (2, 0.006)])
+def test_fuse_up_add(dt, tol):
+    """i2r_fuse_up_add = ReLU((base + nearest_up(t1)) + nearest_up(t2)) (the closing pass of an HRNet fuse sum,
+    interformer_pureMulti.py:392-410), one and two terms, in place and out of place; fp32 bit-exact, 16-bit storage within rounding"""
+    base = _rand((3, 48, 16, 12), "fb")
+    t1, t2 = _rand((3, 48, 8, 6), "f1"), _rand((3, 48, 4, 3), "f2")
+    P = engine.Program(torch.device(DEV))
+    ba, a1, a2 = to_act(P, base, dt), to_act(P, t1, dt), to_act(P, t2, dt)
+    bq, q1, q2 = from_act(ba), from_act(a1), from_act(a2)  # (what the storage type holds)
+    out = P.alloc(3, 16, 12, 48, dt)
+    P.fuse_up_add(ba, [a1, a2], out, relu=True)
+    one = P.alloc(3, 16, 12, 48, dt)
+    P.fuse_up_add(ba, [a1], one, relu=False)
+    run(P)
+    up = lambda t, s: F.interpolate(t, scale_factor=s, mode="nearest")
+    ref2 = F.relu((bq + up(q1, 2)) + up(q2, 4))
+    ref1 = bq + up(q1, 2)
+    e2, e1 = (from_act(out) - ref2).abs().max().item(), (from_act(one) - ref1).abs().max().item()
+    assert e2 <= tol and e1 <= tol, (e2, e1)
+    assert torch.isfinite(out.t).all()
+    P = engine.Program(torch.device(DEV))  # in place (base aliases out)
+    ba, a1 = to_act(P, base, dt), to_act(P, t1, dt)
+    P.fuse_up_add(ba, [a1], ba, relu=True)
+    run(P)
+    assert (from_act(ba) - F.relu(ref1)).abs().max().item() <= tol
+
+
 def _chain_case(use_chain, n_img=9):
     """two BasicBlocks (4 dependent 3x3 convs, residuals) on two branches, the way HRNetW48._emit_module emits them"""
     os.environ["I2R_CONV_CHAIN"] = "1" if use_chain else "0"
