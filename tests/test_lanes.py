@@ -1,0 +1,145 @@
+"""CPU: memory safety of the stream-lane schedule of a launch program (engine.Program fork / join / xsync + the arena's buffer reuse).
+The HRFormer tower's program is built on the host (nothing is launched) and replayed symbolically: every op reads / writes byte ranges
+of arena buffers on its lane; two accesses to overlapping ranges of which at least one is a write must be ordered by the happens-before
+relation the fork / join / xsync ops create (vector clocks per lane).  A race here would not necessarily show up in a parity test."""
+import ctypes as C
+
+import pytest
+import torch
+
+import i2r_amd  # noqa: F401
+from i2r_amd import arch, cabi, config, engine, synth
+
+
+def _ranges_of(program):
+    """sorted (start, end) of every arena buffer of the program, to map raw pointers back to buffers"""
+    rs = sorted((t.data_ptr(), t.data_ptr() + t.numel() * 4) for t in program.keep if isinstance(t, torch.Tensor) and t.dtype == torch.float32)
+    return rs
+
+
+def _accesses(kind, st):
+    """(reads, writes) as lists of raw pointers of one op"""
+    g = lambda name: getattr(st, name)
+    if kind == cabi.OP_CONV:
+        return [p for p in (st.in_, st.in2, st.res1, st.res2, st.res_post) if p], [st.out]
+    if kind == cabi.OP_CONV_GROUP:
+        r, w = [], []
+        for i in range(st.n):
+            d = st.d[i].contents
+            r += [p for p in (d.in_, d.in2, d.res1, d.res2, d.res_post) if p]
+            w.append(d.out)
+        return r, w
+    if kind == cabi.OP_STEM:
+        return [], [g("out")]
+    if kind in (cabi.OP_HRT_ATTN, cabi.OP_HRT_MLP):
+        return [g("x")], [g("out")]
+    if kind == cabi.OP_LAYERNORM:
+        return [g("in_")], [g("out")]
+    if kind == cabi.OP_WINATTN:
+        return [g("qkv")], [g("out")]
+    if kind == cabi.OP_DWCONV:
+        return [g("in_")], [g("out")]
+    if kind == cabi.OP_UPSAMPLE:
+        return [g("low"), g("res")], [g("out")]
+    if kind == cabi.OP_FUSE_UP:
+        return [p for p in (g("base"), g("t1"), g("t2")) if p], [g("out")]
+    if kind == cabi.OP_MAXPOOL:
+        return [g("in_")], [g("out")]
+    raise AssertionError("op kind %d not modelled" % kind)
+
+
+def _field_names(st):
+    return [f[0] for f in st._fields_]
+
+
+def check_program(program):
+    """-> number of cross-lane ordered conflicts verified; raises on a race"""
+    import bisect
+    rs = _ranges_of(program)
+    starts = [a for a, _ in rs]
+
+    def buf(ptr):
+        i = bisect.bisect_right(starts, ptr) - 1
+        return i if i >= 0 and ptr < rs[i][1] else None  # weights / tables are read-only: not arena buffers
+
+    clock = [[0, 0, 0, 0] for _ in range(4)]   # vector clock of each lane
+    last_w = {}   # buffer -> (lane, clock snapshot) of the last write
+    reads = {}    # buffer -> list of (lane, snapshot) since the last write
+    checked = 0
+
+    def hb(snap, lane_from, lane_to):  # the access with snapshot `snap` on lane_from happens before the current point of lane_to
+        return lane_from == lane_to or clock[lane_to][lane_from] >= snap[lane_from]
+
+    for kind, lane, st in program.ops:
+        if kind == cabi.OP_FORK:   # lanes of the mask see everything of lane 0
+            for l in range(1, 4):
+                if lane & (1 << l):
+                    clock[l] = [max(a, b) for a, b in zip(clock[l], clock[0])]
+            continue
+        if kind == cabi.OP_JOIN:   # lane 0 sees everything of the lanes of the mask
+            for l in range(1, 4):
+                if lane & (1 << l):
+                    clock[0] = [max(a, b) for a, b in zip(clock[0], clock[l])]
+            continue
+        if kind == cabi.OP_XSYNC:  # all-to-all among the lanes of the mask
+            ls = [l for l in range(4) if lane & (1 << l)]
+            m = [max(clock[l][i] for l in ls) for i in range(4)]
+            for l in ls:
+                clock[l] = list(m)
+            continue
+        clock[lane][lane] += 1
+        snap = list(clock[lane])
+        r, w = _accesses(kind, st)
+        for ptr in r:
+            b = buf(ptr)
+            if b is None:
+                continue
+            if b in last_w:
+                wl, ws = last_w[b]
+                assert hb(ws, wl, lane), "read on lane %d races with the write on lane %d (op kind %d)" % (lane, wl, kind)
+                checked += wl != lane
+            reads.setdefault(b, []).append((lane, snap))
+        for ptr in w:
+            b = buf(ptr)
+            assert b is not None, "op kind %d writes outside the arena" % kind
+            if b in last_w:
+                wl, ws = last_w[b]
+                assert hb(ws, wl, lane), "write on lane %d races with the write on lane %d (op kind %d)" % (lane, wl, kind)
+                checked += wl != lane
+            for rl, rsnap in reads.get(b, []):
+                assert hb(rsnap, rl, lane), "write on lane %d races with a read on lane %d (op kind %d): buffer reused too early" % (lane, rl, kind)
+                checked += rl != lane
+            last_w[b] = (lane, snap)
+            reads[b] = []
+    return checked
+
+
+@pytest.mark.parametrize("cname,precision,n,h,w", [("hrt_192_p4_b4", "bf16", 3, 256, 192), ("hrt_192_p4_b4", "fp32", 2, 256, 192),
+                                                   ("coco_hrt_288_p2_b4", "fp16", 2, 384, 288)])
+def test_hrformer_lane_schedule_has_no_race(cname, precision, n, h, w):
+    cfg = config.load_config(cname)
+    sd = synth.make_state_dict(arch.param_spec(cfg))
+    dev = torch.device("cpu")
+    pk = engine.Packer(sd, dev, precision)
+    tower = engine.HRFormerB(pk, "singleformer.")
+    P = engine.Program(dev)
+    P.store_dt = pk.dtype
+    ys, _ = tower.emit(P, n, h, w)
+    kinds = [k for k, _, _ in P.ops]
+    assert kinds.count(cabi.OP_XSYNC) == 7 and kinds.count(cabi.OP_FORK) == 3 and kinds.count(cabi.OP_JOIN) == 3  # 7 modules, 3 stages
+    assert {lane for k, lane, _ in P.ops if k not in cabi.SYNC_OPS} == {0, 1, 2, 3}
+    assert check_program(P) > 100
+
+
+def test_checker_catches_a_missing_sync():
+    """the same program with its xsyncs removed must be reported as racy (the checker is not vacuous)"""
+    cfg = config.load_config("hrt_192_p4_b4")
+    sd = synth.make_state_dict(arch.param_spec(cfg))
+    dev = torch.device("cpu")
+    pk = engine.Packer(sd, dev, "bf16")
+    P = engine.Program(dev)
+    P.store_dt = pk.dtype
+    engine.HRFormerB(pk, "singleformer.").emit(P, 2, 256, 192)
+    P.ops = [op for op in P.ops if op[0] != cabi.OP_XSYNC]
+    with pytest.raises(AssertionError, match="races"):
+        check_program(P)
