@@ -5,10 +5,13 @@
 namespace {
 
 // 3x3 stride-2 pad-1 conv with tiny cin (3 = RGB crop, 1 = person box mask) + folded BN + ReLU.
-// thread = one output pixel x 16 output channels; the G = cout/16 threads of a pixel are adjacent lanes and own the channel
-// quadruples f = i G + cg (i = 0..3) -- INTERLEAVED, so that store instruction i of a wave writes, per pixel, G x 16 contiguous
-// bytes from G adjacent lanes (cout = 64: the four lanes of a quad fill one 64-byte segment, the texture addresser's fast case;
-// with 16 consecutive channels per lane every lane of a store hit its own segment and the kernel ran at 1.8 TB/s).  w: [9][CIN][cout].
+// thread = one output pixel x 16 output channels; the G = cout/16 threads of a pixel are adjacent lanes and own INTERLEAVED 16-byte
+// pieces of the pixel's channel row, so that every store instruction of a wave writes, per pixel, G x 16 contiguous bytes from G
+// adjacent lanes (cout = 64: the four lanes of a quad fill one 64-byte segment, the texture addresser's fast case; with 16
+// consecutive channels per lane every lane of a store hit its own segment and the kernel ran at 1.8 TB/s):
+//   fp32 output:   lane cg owns the channel quadruples i G + cg, i = 0..3 (four 16-byte stores);
+//   16-bit output: lane cg owns the channel octets i G + cg, i = 0..1 (two 16-byte stores of 8 packed values).
+// w: [9][CIN][cout].
 template <int CIN, int ODT>
 __global__ __launch_bounds__(256) void stem_conv_k(const float* __restrict__ in, const float* __restrict__ w,
                                                    const float* __restrict__ bias, float* __restrict__ out, int n_img,
@@ -46,18 +49,20 @@ __global__ __launch_bounds__(256) void stem_conv_k(const float* __restrict__ in,
         }
     }
     float acc[16];
+    // float4 index (within a [cout] row) of register quadruple q of this lane
+    auto f4 = [&](int q) { return ODT == 0 ? q * groups + cg : ((q >> 1) * groups + cg) * 2 + (q & 1); };
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
-        const f32x4 bv = *reinterpret_cast<const f32x4*>(wl + 9 * CIN * cout + (q * groups + cg) * 4);
+        const f32x4 bv = *reinterpret_cast<const f32x4*>(wl + 9 * CIN * cout + f4(q) * 4);
         acc[q * 4] = bv[0]; acc[q * 4 + 1] = bv[1]; acc[q * 4 + 2] = bv[2]; acc[q * 4 + 3] = bv[3];
     }
 #pragma unroll 3
     for (int t = 0; t < 9 * CIN; ++t) {
         const float x = xin[t];
-        const f32x4* wr = reinterpret_cast<const f32x4*>(wl + t * cout) + cg;
+        const f32x4* wr = reinterpret_cast<const f32x4*>(wl + t * cout);
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
-            const f32x4 wv = wr[q * groups];
+            const f32x4 wv = wr[f4(q)];
             acc[q * 4 + 0] = fmaf(x, wv[0], acc[q * 4 + 0]);
             acc[q * 4 + 1] = fmaf(x, wv[1], acc[q * 4 + 1]);
             acc[q * 4 + 2] = fmaf(x, wv[2], acc[q * 4 + 2]);
@@ -65,10 +70,27 @@ __global__ __launch_bounds__(256) void stem_conv_k(const float* __restrict__ in,
         }
     }
     if (!valid) return;
+    if constexpr (ODT == 0) {
 #pragma unroll
-    for (int q = 0; q < 4; ++q)  // ODT != 0: the tower keeps its activations in 16 bit (bf16 / f16), element offsets are the same
-        st_act4<ODT>(out, (size_t)pix * out_cs + (q * groups + cg) * 4,
-                     (f32x4){fmaxf(acc[q * 4], 0.f), fmaxf(acc[q * 4 + 1], 0.f), fmaxf(acc[q * 4 + 2], 0.f), fmaxf(acc[q * 4 + 3], 0.f)}, ODT != 0);
+        for (int q = 0; q < 4; ++q)
+            st_act4<0>(out, (size_t)pix * out_cs + f4(q) * 4,
+                       (f32x4){fmaxf(acc[q * 4], 0.f), fmaxf(acc[q * 4 + 1], 0.f), fmaxf(acc[q * 4 + 2], 0.f), fmaxf(acc[q * 4 + 3], 0.f)}, false);
+    } else {  // the tower keeps its activations in 16 bit (bf16 / f16): 8 values = 16 bytes per store
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            unsigned short h[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const float v = fmaxf(acc[i * 8 + e], 0.f);
+                if constexpr (ODT == 1) h[e] = __builtin_bit_cast(unsigned short, (__bf16)v);
+                else h[e] = __builtin_bit_cast(unsigned short, (_Float16)v);
+            }
+            uint4 u;
+            u.x = h[0] | ((unsigned)h[1] << 16); u.y = h[2] | ((unsigned)h[3] << 16);
+            u.z = h[4] | ((unsigned)h[5] << 16); u.w = h[6] | ((unsigned)h[7] << 16);
+            *reinterpret_cast<uint4*>(reinterpret_cast<unsigned short*>(out) + (size_t)pix * out_cs + (i * groups + cg) * 8) = u;
+        }
+    }
 }
 
 // PositionEmbeddingImage mode 'res' front end (position_embedding.py:14-17,93-95): conv_pre (1 -> 3, 3x3, pad 1, no bias) followed

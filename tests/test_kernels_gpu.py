@@ -118,6 +118,28 @@ def test_stem_conv(cin, cout):
     assert (from_act(out) - ref).abs().max().item() < 1e-4
 
 
+@pytest.mark.parametrize("cin,dt,tol", [(3, 1, 0.04), (3, 2, 0.005), (1, 1, 0.04)])
+def test_stem_conv_16bit_output(cin, dt, tol):
+    """the stem writing bf16 / f16 activations (16-bit towers): same values as the fp32 stem, rounded once to the storage type"""
+    cout = 64
+    sd = {"c.weight": _rand((cout, cin, 3, 3), "sw%d" % cin, 0.4), "b.weight": _rand((cout,), "sg", 0.5) + 1.0,
+          "b.bias": _rand((cout,), "sb", 0.3), "b.running_mean": _rand((cout,), "sm", 0.3),
+          "b.running_var": _rand((cout,), "sv", 0.4) + 1.0}
+    x = _rand((2, cin, 64, 48), "sx%d" % cin)
+    ref = F.relu(F.batch_norm(F.conv2d(x, sd["c.weight"], None, 2, 1), sd["b.running_mean"], sd["b.running_var"],
+                              sd["b.weight"], sd["b.bias"], False, 0.0, 1e-5))
+    P = engine.Program(torch.device(DEV))
+    st = engine.Packer(sd, torch.device(DEV)).stem("c", "b")
+    xd = x.to(DEV)
+    o32, _ = P.stem(st, 2, 64, 48, in_ptr=xd.data_ptr())
+    o16, _ = P.stem(st, 2, 64, 48, in_ptr=xd.data_ptr(), out_dt=dt)
+    run(P)
+    assert (from_act(o32) - ref).abs().max().item() < 1e-4
+    tdt = torch.bfloat16 if dt == 1 else torch.float16
+    assert torch.equal(from_act(o16), from_act(o32).to(tdt).float())  # bit-exact: one rounding of the same fp32 value
+    assert (from_act(o16) - ref).abs().max().item() < tol * ref.abs().max().item()
+
+
 def test_maxpool_and_head():
     x = _rand((2, 96, 64, 48), "px")
     P = engine.Program(torch.device(DEV))
