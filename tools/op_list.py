@@ -1,0 +1,47 @@
+"""GPU tuning aid: every launch of one workload's program IN PROGRAM ORDER with its stand-alone time (event pair per launch, 3 reps) --
+shows runs of small dependent / independent launches that emission-level changes (grouping, lanes) can act on.
+usage: python tools/op_list.py [workload] [precision]"""
+import os, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import ctypes as C
+import torch
+import bench
+import i2r_amd  # noqa
+from i2r_amd import config, synth, arch, engine, cabi
+DEV = torch.device("cuda:0")
+name = sys.argv[1] if len(sys.argv) > 1 else "w48_pure_en6"
+wl = bench.WORKLOADS[name]
+cfg = config.load_config(name)
+sd = synth.make_state_dict(arch.param_spec(cfg))
+eng = engine.Engine(cfg, sd, DEV, precision=sys.argv[2] if len(sys.argv) > 2 else wl["precision"])
+length = wl["length"]
+x, pm, _ = synth.make_inputs(length, cfg.MODEL.IMAGE_SIZE[1], cfg.MODEL.IMAGE_SIZE[0], 0)
+eng.forward(x.to(DEV), pm.to(DEV), length)
+P = next(iter(eng.programs.values()))[0]
+L = cabi.lib()
+cur = torch.cuda.current_stream().cuda_stream
+streams = (C.c_void_p * 4)(cur, cur, cur, cur)
+tot = 0.0
+for i, (kind, lane, st) in enumerate(P.ops):
+    if kind in cabi.SYNC_OPS:
+        print("%4d  lane %s  -- sync op %d" % (i, lane, kind))
+        continue
+    ms = 0.0
+    for rep in range(4):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        cabi.check(L.i2r_run_program(C.cast(C.byref(P._c_ops, i * C.sizeof(cabi.Op)), C.POINTER(cabi.Op)), 1, streams, None), "op")
+        e1.record()
+        torch.cuda.synchronize()
+        if rep:
+            ms += e0.elapsed_time(e1) / 3
+    nm, fl = bench._op_name_flop(kind, st)
+    shp = ""
+    if kind in (cabi.OP_CONV, cabi.OP_CONV_GROUP):
+        ms_ = [st] if kind == cabi.OP_CONV else [st.d[j].contents for j in range(st.n)]
+        shp = " + ".join("%d->%d k%d s%d @%dx%d%s%s" % (m.cin, m.cout, m.ntaps, m.stride, m.conv_h, m.conv_w, " up%d" % m.rep if m.rep > 1 else "",
+                                                        " res" if m.res1 else "") for m in ms_)
+    tot += ms
+    print("%4d  lane %s  %7.1f us  %6.1f TF  %-30s %s" % (i, lane, ms * 1e3, fl / ms / 1e9 if ms else 0, nm, shp))
+print("sum of stand-alone launch times: %.3f ms" % tot)
