@@ -120,6 +120,40 @@ class Packer:
         pad = kh // 2
         return self._pc(w_taps, self._dev(bias.float()), cin, cout, taps, -pad, -pad, stride, kh)
 
+    def conv_cat(self, parts, eps=1e-5):
+        """Sum of 1x1 convs (+BN each) over DIFFERENT inputs as ONE 1x1 conv over the channel concatenation of those inputs:
+        weights concatenated along cin (in the order of `parts`: (conv_key, bn_key)), folded biases added.  Used for the first
+        Bottleneck of layer1: relu(bn3(conv3(t2)) + bn_d(downsample(x))) = relu([W3' | Wd'] . [t2 ; x] + b3' + bd')."""
+        mats, bias_sum, cins = [], None, []
+        for conv_key, bn_key in parts:
+            w = self.sd[conv_key + ".weight"]
+            cout, cin, kh, kw = w.shape
+            assert kh == 1 and kw == 1
+            wf, bf = fold_bn(w, self._bn(bn_key), self.sd.get(conv_key + ".bias"), eps)
+            mats.append(wf.reshape(cout, cin).t())  # [cin, cout]
+            bias_sum = bf if bias_sum is None else bias_sum + bf
+            cins.append(cin)
+        assert all(c % 16 == 0 for c in cins), "concatenated inputs must keep whole 16-channel steps"
+        w_taps = torch.cat(mats, 0).unsqueeze(0)  # [1, sum cin, cout]
+        cout = w_taps.shape[2]
+        bias = torch.zeros(_r16(cout), dtype=torch.float64)
+        bias[:cout] = bias_sum
+        return self._pc(w_taps, self._dev(bias.float()), sum(cins), cout, [(0, 0)], 0, 0, 1, 1)
+
+    def bottlenecks(self, prefix, n):
+        """layer1 of HRNet / HRFormer: n Bottleneck blocks (reference hrnet.py / hrformer.py `Bottleneck`, expansion 4); the first one
+        carries a 1x1 downsample on its identity path, folded into its conv3 (conv_cat)."""
+        blocks = []
+        for b in range(n):
+            q = "%s.%d" % (prefix, b)
+            blk = dict(c1=self.conv(q + ".conv1", q + ".bn1"), c2=self.conv(q + ".conv2", q + ".bn2"))
+            if (q + ".downsample.0.weight") in self.sd:
+                blk["c3ds"] = self.conv_cat([(q + ".downsample.0", q + ".downsample.1"), (q + ".conv3", q + ".bn3")])
+            else:
+                blk["c3"] = self.conv(q + ".conv3", q + ".bn3")
+            blocks.append(blk)
+        return blocks
+
     def linear_as_conv(self, w, b):
         """[out, in] matrix + bias -> 1x1 PackedConv."""
         cout, cin = w.shape
@@ -668,6 +702,38 @@ class Program:
         self.ops.append((cabi.OP_CONV_GROUP, lane, a))
         del group[:]
 
+    def channel_slice(self, a, c0, c):
+        """channels c0 .. c0+c of buffer `a` as an Act of its own (same pixel stride): lets one conv write, and another read, a part
+        of a concatenated map.  Never release a slice -- release the parent."""
+        assert c0 % 16 == 0 and c0 + c <= a.cs
+        words = c0 // 2 if a.dt else c0  # float32 words of storage per channel offset (16-bit maps: two channels per word)
+        return Act(a.t[words:], a.n, a.h, a.w, c, a.cs, a.dt)
+
+    def stem_conv2_layer1(self, a, conv2, blocks):
+        """Second stem conv + layer1's Bottlenecks (hrnet.py:419-427 / hrformer.py forward).  The first Bottleneck's identity path is a
+        1x1 conv + BN of the block input x; its sum with conv3(t2) is ONE 1x1 conv over the concatenation [x ; t2] (Packer.conv_cat):
+        conv2 and the block's 3x3 conv write the two halves of one buffer, so the 256-channel downsample map is neither written nor
+        read back (one launch and 2 x 3.1 MB per crop less)."""
+        first = blocks[0]
+        assert "c3ds" in first, "layer1.0 carries the downsample"
+        cx, cm = conv2.cout, first["c2"].cout
+        cat = self.alloc(a.n, (a.h - 1) // 2 + 1, (a.w - 1) // 2 + 1, cx + cm, a.dt)
+        x, t2 = self.channel_slice(cat, 0, cx), self.channel_slice(cat, cx, cm)
+        self.conv(a, conv2, relu=True, out=x)
+        self.release(a)
+        t1 = self.conv(x, first["c1"], relu=True)
+        self.conv(t1, first["c2"], relu=True, out=t2)
+        y = self.conv(cat, first["c3ds"], relu=True)
+        self.release(t1, cat)
+        x = y
+        for blk in blocks[1:]:
+            t1 = self.conv(x, blk["c1"], relu=True)
+            t2 = self.conv(t1, blk["c2"], relu=True)
+            y = self.conv(t2, blk["c3"], relu=True, res1=x)
+            self.release(t1, t2, x)
+            x = y
+        return x
+
     def deconv(self, x, pcs, relu=True, res_post=None, lane=0):
         """ConvTranspose(k4,s2,p1)+BN(+ReLU)(+post-ReLU residual) as four parity convs writing the interleaved 2x output."""
         out = self.alloc(x.n, 2 * x.h, 2 * x.w, pcs[(0, 0)].cout, x.dt)
@@ -901,14 +967,7 @@ class HRNetW48:
         s2, s3 = extra["STAGE2"], extra["STAGE3"]
         self.stem1 = pk.stem(p + "conv1", p + "bn1")
         self.conv2 = pk.conv(p + "conv2", p + "bn2", stride=2)
-        self.layer1 = []
-        for b in range(4):
-            q = "%slayer1.%d" % (p, b)
-            blk = dict(c1=pk.conv(q + ".conv1", q + ".bn1"), c2=pk.conv(q + ".conv2", q + ".bn2"),
-                       c3=pk.conv(q + ".conv3", q + ".bn3"))
-            if (q + ".downsample.0.weight") in pk.sd:
-                blk["ds"] = pk.conv(q + ".downsample.0", q + ".downsample.1")
-            self.layer1.append(blk)
+        self.layer1 = pk.bottlenecks(p + "layer1", 4)
         self.t1 = [pk.conv(p + "transition1.0.0", p + "transition1.0.1"),
                    pk.conv(p + "transition1.1.0.0", p + "transition1.1.0.1", stride=2)]
         self.stage2 = [self._module(pk, "%sstage2.%d" % (p, m), s2) for m in range(s2["NUM_MODULES"])]
@@ -1040,18 +1099,7 @@ class HRNetW48:
     def emit(self, P, n, h, w, n_src=None):
         """-> (list of branch Acts, stem StemArgs to patch the input pointer into)."""
         a, stem_args = P.stem(self.stem1, n, h, w, n_src=n_src, out_dt=P.store_dt)  # 16-bit modes: the whole tower stores 16 bit
-        b = P.conv(a, self.conv2, relu=True)
-        P.release(a)
-        x = b
-        for blk in self.layer1:
-            t1 = P.conv(x, blk["c1"], relu=True)
-            t2 = P.conv(t1, blk["c2"], relu=True)
-            res = P.conv(x, blk["ds"]) if "ds" in blk else x
-            y = P.conv(t2, blk["c3"], relu=True, res1=res)
-            P.release(t1, t2, x)
-            if res is not x:
-                P.release(res)
-            x = y
+        x = P.stem_conv2_layer1(a, self.conv2, self.layer1)
         xs = [P.conv(x, self.t1[0], relu=True), P.conv(x, self.t1[1], relu=True)]
         P.release(x)
         for mod in self.stage2:
@@ -1071,13 +1119,7 @@ class HRFormerB:
         b = p + "backbone."
         self.stem1 = pk.stem(b + "conv1", b + "bn1")
         self.conv2 = pk.conv(b + "conv2", b + "bn2", stride=2)
-        self.layer1 = []
-        for blk in range(2):
-            q = "%slayer1.%d" % (b, blk)
-            d = dict(c1=pk.conv(q + ".conv1", q + ".bn1"), c2=pk.conv(q + ".conv2", q + ".bn2"), c3=pk.conv(q + ".conv3", q + ".bn3"))
-            if (q + ".downsample.0.weight") in pk.sd:
-                d["ds"] = pk.conv(q + ".downsample.0", q + ".downsample.1")
-            self.layer1.append(d)
+        self.layer1 = pk.bottlenecks(b + "layer1", 2)
         self.stages = []
         pre = [256]
         for sname, tname in (("stage2", "transition1"), ("stage3", "transition2"), ("stage4", "transition3")):
@@ -1213,17 +1255,7 @@ class HRFormerB:
 
     def emit(self, P, n, h, w, n_src=None):
         a, stem_args = P.stem(self.stem1, n, h, w, n_src=n_src)
-        x = P.conv(a, self.conv2, relu=True)
-        P.release(a)
-        for blk in self.layer1:
-            t1 = P.conv(x, blk["c1"], relu=True)
-            t2 = P.conv(t1, blk["c2"], relu=True)
-            res = P.conv(x, blk["ds"]) if "ds" in blk else x
-            y = P.conv(t2, blk["c3"], relu=True, res1=res)
-            P.release(t1, t2, x)
-            if res is not x:
-                P.release(res)
-            x = y
+        x = P.stem_conv2_layer1(a, self.conv2, self.layer1)
         ys = [x]
         for st in self.stages:
             xs = []
