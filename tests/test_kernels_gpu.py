@@ -84,6 +84,53 @@ def test_conv_without_bn_and_channel_padding():
     assert (from_act(out) - ref).abs().max().item() < 2e-4
 
 
+@pytest.mark.parametrize("precision,dt,tol", [("fp32", 0, 2e-4), ("bf16", 1, 0.08), ("fp16", 2, 0.01)])
+def test_stem_conv2_and_layer1_bottlenecks(precision, dt, tol):
+    """Program.stem_conv2_layer1: conv2 (3x3 s2) + two Bottlenecks, the first with its downsample folded into conv3 as ONE 1x1 conv
+    over the concatenated buffer [x ; t2] (Packer.conv_cat + Program.channel_slice), against the torch modules it replaces
+    (reference hrnet.py Bottleneck.forward: out = relu(bn3(conv3(.)) + downsample(x)))."""
+    def bn(p, c):
+        return {p + ".weight": _rand((c,), p + "g", 0.5) + 1.0, p + ".bias": _rand((c,), p + "b", 0.3),
+                p + ".running_mean": _rand((c,), p + "m", 0.3), p + ".running_var": _rand((c,), p + "v", 0.4) + 1.0}
+
+    def cbr(x, sd, c, b, stride=1, relu=True):
+        w = sd[c + ".weight"]
+        y = F.conv2d(x, w, None, stride=stride, padding=w.shape[2] // 2)
+        y = F.batch_norm(y, sd[b + ".running_mean"], sd[b + ".running_var"], sd[b + ".weight"], sd[b + ".bias"], False, 0.0, 1e-5)
+        return F.relu(y) if relu else y
+
+    sd = {"conv2.weight": _rand((64, 64, 3, 3), "l1c2", (6.0 / 576) ** 0.5)}
+    sd.update(bn("bn2", 64))
+    for b, cin in ((0, 64), (1, 256)):
+        q = "layer1.%d" % b
+        sd[q + ".conv1.weight"] = _rand((64, cin, 1, 1), q + "w1", (6.0 / cin) ** 0.5)
+        sd[q + ".conv2.weight"] = _rand((64, 64, 3, 3), q + "w2", (6.0 / 576) ** 0.5)
+        sd[q + ".conv3.weight"] = _rand((256, 64, 1, 1), q + "w3", (6.0 / 64) ** 0.5)
+        for i, c in ((1, 64), (2, 64), (3, 256)):
+            sd.update(bn("%s.bn%d" % (q, i), c))
+    sd["layer1.0.downsample.0.weight"] = _rand((256, 64, 1, 1), "l1ds", (6.0 / 64) ** 0.5)
+    sd.update(bn("layer1.0.downsample.1", 256))
+    a = _rand((2, 64, 34, 26), "l1a").abs()
+    x = cbr(a, sd, "conv2", "bn2", stride=2)
+    for b in range(2):
+        q = "layer1.%d" % b
+        t = cbr(cbr(x, sd, q + ".conv1", q + ".bn1"), sd, q + ".conv2", q + ".bn2")
+        idn = cbr(x, sd, q + ".downsample.0", q + ".downsample.1", relu=False) if b == 0 else x
+        x = F.relu(cbr(t, sd, q + ".conv3", q + ".bn3", relu=False) + idn)
+    P = engine.Program(torch.device(DEV))
+    pk = engine.Packer(sd, torch.device(DEV), precision)
+    blocks = pk.bottlenecks("layer1", 2)
+    assert "c3ds" in blocks[0] and blocks[0]["c3ds"].cin == 128 and "c3" in blocks[1]
+    out = P.stem_conv2_layer1(to_act(P, a, dt), pk.conv("conv2", "bn2", stride=2), blocks)
+    n_launch = len(P.ops)
+    run(P)
+    assert n_launch == 1 + 3 + 3, "conv2 + 3 launches per Bottleneck (no separate downsample launch)"
+    got = from_act(out)
+    assert got.shape == x.shape
+    err = (got - x).abs().max().item() / max(1.0, x.abs().max().item())
+    assert err < tol, "%s layer1 relative max-abs %.3e" % (precision, err)
+
+
 def test_deconv_matches_conv_transpose():
     sd = {"d.weight": _rand((96, 96, 4, 4), "dw", 0.08), "b.weight": _rand((96,), "dg", 0.5) + 1.0,
           "b.bias": _rand((96,), "db", 0.3), "b.running_mean": _rand((96,), "dm", 0.3),

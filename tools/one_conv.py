@@ -16,9 +16,16 @@ DEV = torch.device("cuda:0")
 S = int(sys.argv[1]) if len(sys.argv) > 1 else 32
 N = int(sys.argv[2]) if len(sys.argv) > 2 else 10
 mode = sys.argv[3] if len(sys.argv) > 3 else "group"
+# mode "group2" / "group2:<mt>": the two-branch stage-2 launch, optionally with the M blocking forced (tile-model experiments)
+BR = [(48, 64, 48), (96, 32, 24), (192, 16, 12)]
+if mode.startswith("group2"):
+    BR = BR[:2]
+    if ":" in mode:
+        engine._MT_EFF[int(mode.split(":")[1])] = 9.9  # the cost model then picks this mt for the group
+    mode = "group"
 P = engine.Program(DEV)
 grp = []
-for (c, h, w) in [(48, 64, 48), (96, 32, 24), (192, 16, 12)]:
+for (c, h, w) in BR:
     sd = {"c.weight": torch.from_numpy(synth._sym(1, "w%d" % c, (c, c, 3, 3), 0.05))}
     pc = engine.Packer(sd, DEV).conv("c", None)
     P.keep.append(pc)
@@ -40,5 +47,8 @@ for _ in range(N):
 e1.record()
 torch.cuda.synchronize()
 ms = e0.elapsed_time(e1) / N
-flop = sum(2.0 * S * h * w * c * c * 9 for (c, h, w) in [(48, 64, 48), (96, 32, 24), (192, 16, 12)])
+flop = sum(2.0 * S * h * w * c * c * 9 for (c, h, w) in BR)
+for kind, lane, st in P.ops:
+    if kind == cabi.OP_CONV_GROUP:
+        print("tiles/mt:", [(st.d[j].contents.tile_h, st.d[j].contents.tile_w, st.d[j].contents.mt) for j in range(st.n)])
 print("%s S=%d: %.1f us per program  %.1f TF" % (mode, S, ms * 1e3, flop / ms / 1e9))
