@@ -84,6 +84,27 @@ def conv_flop(d):
     return 2.0 * d.n_img * d.conv_h * d.conv_w * d.cout * d.cin * d.ntaps
 
 
+def conv_bytes(d):
+    """ALGORITHMIC HBM bytes of one conv launch member (SURVEY 8d convention: every operand element once): input map(s), packed
+    weights, output, and each residual map that is present, in their storage types (fp32, or 16 bit in the bf16 / fp16 modes)."""
+    e_in, e_out = (2 if d.in_f16 else 4), (2 if d.out_f16 else 4)
+    b = d.n_img * d.in_h * d.in_w * d.cin * e_in * (2 if d.in2 else 1)
+    b += d.ntaps * d.cin * d.cout * (4 if d.dtype == 0 else 2)
+    o = d.n_img * d.conv_h * d.conv_w * d.rep * d.rep * d.cout * e_out
+    return float(b + o * (1 + sum(1 for r in (d.res1, d.res2, d.res_post) if r)))
+
+
+def _op_bytes(kind, st):
+    if kind == cabi.OP_CONV:
+        return conv_bytes(st)
+    if kind == cabi.OP_CONV_GROUP:
+        return sum(conv_bytes(st.d[i].contents) for i in range(st.n))
+    return 0.0
+
+
+HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E ~8 TB/s
+
+
 def _op_name_flop(kind, st):
     if kind == cabi.OP_CONV:
         return conv_kernel_name([st]), conv_flop(st)
@@ -111,19 +132,20 @@ def per_launch_timing(program, reps=3):
     cur = torch.cuda.current_stream().cuda_stream
     streams = (C.c_void_p * 4)(cur, cur, cur, cur)
     ops = [(i, kind, st) for i, (kind, lane, st) in enumerate(program.ops) if kind not in cabi.SYNC_OPS]
-    named = [(i,) + _op_name_flop(kind, st) for i, kind, st in ops]  # single-stream pass: lanes collapse onto the current stream
-    runs = []  # [name, [op indices], flop]
-    for i, name, flop in named:
+    named = [(i,) + _op_name_flop(kind, st) + (_op_bytes(kind, st),) for i, kind, st in ops]  # single-stream pass: lanes collapse onto the current stream
+    runs = []  # [name, [op indices], flop, bytes]
+    for i, name, flop, nbytes in named:
         if runs and runs[-1][0] == name:
             runs[-1][1].append(i)
             runs[-1][2] += flop
+            runs[-1][3] += nbytes
         else:
-            runs.append([name, [i], flop])
+            runs.append([name, [i], flop, nbytes])
     stats = {}
     for rep in range(reps + 1):
         evs = [torch.cuda.Event(enable_timing=True) for _ in range(len(runs) + 1)]
         evs[0].record()
-        for r, (name, idx, flop) in enumerate(runs):
+        for r, (name, idx, flop, nbytes) in enumerate(runs):
             for i in idx:
                 cabi.check(L.i2r_run_program(C.cast(C.byref(program._c_ops, i * C.sizeof(cabi.Op)), C.POINTER(cabi.Op)), 1,
                                              streams, None), "op %d" % i)
@@ -131,11 +153,12 @@ def per_launch_timing(program, reps=3):
         torch.cuda.synchronize()
         if rep == 0:
             continue  # warm-up pass
-        for r, (name, idx, flop) in enumerate(runs):
-            s = stats.setdefault(name, [0, 0.0, 0.0])
+        for r, (name, idx, flop, nbytes) in enumerate(runs):
+            s = stats.setdefault(name, [0, 0.0, 0.0, 0.0])
             s[0] += len(idx)
             s[1] += evs[r].elapsed_time(evs[r + 1])
             s[2] += flop
+            s[3] += nbytes
     return stats, reps
 
 
@@ -420,7 +443,7 @@ def main():
             stats, reps = per_launch_timing(prog)
             total_ms = sum(s[1] for s in stats.values())
             dom = max((k for k in stats if k.startswith("conv_")), key=lambda k: stats[k][1])
-            cnt, ms, flop = stats[dom]
+            cnt, ms, flop, nbytes = stats[dom]
             ach = flop / (ms * 1e-3) / 1e12
             conv_ms = sum(s[1] for k, s in stats.items() if k.startswith("conv_"))
             conv_flop_ = sum(s[2] for k, s in stats.items() if k.startswith("conv_"))
@@ -435,6 +458,19 @@ def main():
                 "all_conv_tflops": round(conv_flop_ / (conv_ms * 1e-3) / 1e12, 2),
                 "per_kernel_ms_per_step": {k: round(s[1] / reps, 3) for k, s in sorted(stats.items(), key=lambda kv: -kv[1][1])},
             }
+            # which roof bounds the dominant kernel: its arithmetic intensity (algorithmic FLOP / algorithmic HBM byte, both per
+            # launch) against the machine balance peak FLOP/s : 8 TB/s.  fp32 convs sit far above it (MFMA-bound); with 16-bit
+            # operands the matrix peak is 16x higher and the same launches fall BELOW it: their roof is HBM.
+            r = out["roofline"]
+            gbs = nbytes / (ms * 1e-3) / 1e9
+            ai, balance = flop / nbytes, peak * 1e12 / (HBM_PEAK_GBS * 1e9)
+            r["gbytes_per_launch"] = round(nbytes / cnt / 1e9, 4)
+            r["intensity_flop_per_byte"], r["machine_balance_flop_per_byte"] = round(ai, 1), round(balance, 1)
+            if ai < balance:
+                r["mfma_view"] = {"achieved": r["achieved"], "peak": peak, "unit": "TFLOP/s", "frac": r["frac"]}
+                r.update({"bound": "hbm", "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(gbs / HBM_PEAK_GBS, 4)})
+            else:
+                r["hbm_view"] = {"achieved": round(gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(gbs / HBM_PEAK_GBS, 4)}
             att_flop = attention_flop(prog)
             att_k = sorted(k for k in stats if k.startswith("enc_"))
             att_ms = stack_timing(prog)  # (each encoder stack timed as one unit; the per-kernel split stays in per_kernel_ms_per_step)
