@@ -2,6 +2,10 @@
 // element-wise-class work (a few % of the forward); written for coalesced 16-byte accesses.
 #include "i2r_conv.h"  // (st_act4: fp32 / bf16 / f16 activation stores)
 
+#ifndef I2R_STEM_FR
+#define I2R_STEM_FR 2
+#endif
+
 namespace {
 
 // 3x3 stride-2 pad-1 conv with tiny cin (3 = RGB crop, 1 = person box mask) + folded BN + ReLU.
@@ -89,6 +93,82 @@ __global__ __launch_bounds__(256) void stem_conv_k(const float* __restrict__ in,
             u.x = h[0] | ((unsigned)h[1] << 16); u.y = h[2] | ((unsigned)h[3] << 16);
             u.z = h[4] | ((unsigned)h[5] << 16); u.w = h[6] | ((unsigned)h[7] << 16);
             *reinterpret_cast<uint4*>(reinterpret_cast<unsigned short*>(out) + (size_t)pix * out_cs + (i * groups + cg) * 8) = u;
+        }
+    }
+}
+
+// The same stem on the fp32 matrix pipe, for cout == 64 (every stem of the shipped models).  GEMM view: M = output pixels (16 per
+// fragment, consecutive in the linear [img][oy][ox] order), N = 64 channels, K = 9 * CIN taps-times-channels padded to whole
+// 4-wide MFMA steps (CIN = 3: 27 -> 28, CIN = 1: 9 -> 12).
+//  * A: lane (m = l & 15, g = l >> 4) of step s supplies input value k = 4 s + g = (tap, channel) of pixel m: ONE scalar load per
+//    lane and step straight from the NCHW boundary tensor (28 loads per pixel instead of the 108 of the VALU kernel).
+//  * B: the weights of a wave live in 4 * KS registers, loaded once and reused over FR fragments.  The COLUMN of fragment nt that
+//    lane n = l & 15 feeds is chosen as channel 4 n + nt -- so after the MFMAs lane (n, g) holds, for each of its four pixels
+//    4 g + r, the four CONSECUTIVE channels 4 n .. 4 n + 3 in acc[0..3][r]: the NHWC store is one 16-byte (fp32) / 8-byte (16-bit)
+//    access per pixel row with no transpose at all, the 16 lanes of a group writing one pixel's whole 256 / 128 contiguous bytes.
+//  * 28 MFMAs per 16 pixels: 9 us of matrix-pipe time for 32 crops; the kernel is bound by its 3.1 MB per crop of output.
+template <int CIN, int ODT, int FR>
+__global__ __launch_bounds__(256) void stem_mfma_k(const float* __restrict__ in, const float* __restrict__ w,
+                                                   const float* __restrict__ bias, float* __restrict__ out, int n_img,
+                                                   int in_h, int in_w, int out_h, int out_w, int out_cs, int n_src, int n_valid) {
+    constexpr int K = 9 * CIN, KS = (K + 3) / 4, COUT = 64;
+    const int lane = threadIdx.x & 63, n = lane & 15, g = lane >> 4;
+    const int wave = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int total = n_img * out_h * out_w;  // (< 2^31: checked by the launcher; 32-bit index arithmetic throughout)
+    const int pw = wave * (FR * 16);          // first pixel of this wave's FR fragments
+    if (pw >= total) return;
+    // (tap, channel) of this lane's k = 4 s + g in every step
+    int kdy[KS], kdx[KS], kci[KS];
+#pragma unroll
+    for (int s = 0; s < KS; ++s) {
+        const int k = min(4 * s + g, K - 1), tap = k / CIN;
+        kci[s] = k - tap * CIN;
+        kdy[s] = tap / 3 - 1;
+        kdx[s] = tap % 3 - 1;
+    }
+    // A side first: the input values of ALL FR fragments are in flight together (one memory latency per wave, not per fragment)
+    float a[FR][KS];
+#pragma unroll
+    for (int f = 0; f < FR; ++f) {
+        const int p = pw + f * 16 + n;
+        const bool a_ok = p < total;
+        const int pa = a_ok ? p : total - 1;
+        const int row = pa / out_w, ox = pa - row * out_w, img = row / out_h, oy = row - img * out_h;
+        // images >= n_src: horizontally mirrored copies (flip test); slots n_valid .. n_src - 1: capacity padding (see stem_conv_k)
+        const int simg = min(img % n_src, n_valid - 1);
+        const bool mirror = img >= n_src;
+#pragma unroll
+        for (int s = 0; s < KS; ++s) {
+            const int iy = oy * 2 + kdy[s], ix = ox * 2 + kdx[s];
+            const bool ok = a_ok && 4 * s + g < K && iy >= 0 && iy < in_h && ix >= 0 && ix < in_w;
+            a[f][s] = ok ? in[((size_t)(simg * CIN + kci[s]) * in_h + iy) * in_w + (mirror ? in_w - 1 - ix : ix)] : 0.f;
+        }
+    }
+    // this lane's weight column of every step (k = 4 s + g) and fragment (channel 4 n + nt); rows k >= K are padding
+    float b[KS][4];
+#pragma unroll
+    for (int s = 0; s < KS; ++s) {
+        const int k = 4 * s + g;
+        const f32x4 wv = k < K ? *reinterpret_cast<const f32x4*>(w + k * COUT + 4 * n) : (f32x4){0.f, 0.f, 0.f, 0.f};
+        b[s][0] = wv[0]; b[s][1] = wv[1]; b[s][2] = wv[2]; b[s][3] = wv[3];
+    }
+    const f32x4 bv = *reinterpret_cast<const f32x4*>(bias + 4 * n);
+#pragma unroll
+    for (int f = 0; f < FR; ++f) {
+        f32x4 acc[4];
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt) acc[nt] = (f32x4){bv[nt], bv[nt], bv[nt], bv[nt]};
+#pragma unroll
+        for (int s = 0; s < KS; ++s)
+#pragma unroll
+            for (int nt = 0; nt < 4; ++nt) acc[nt] = mfma16(a[f][s], b[s][nt], acc[nt]);
+        // D side: pixels 4 g + r of the fragment, channels 4 n .. 4 n + 3
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int pd = pw + f * 16 + 4 * g + r;
+            if (pd >= total) continue;
+            const f32x4 v = {fmaxf(acc[0][r], 0.f), fmaxf(acc[1][r], 0.f), fmaxf(acc[2][r], 0.f), fmaxf(acc[3][r], 0.f)};
+            st_act4<ODT>(out, (size_t)pd * out_cs + 4 * n, v, ODT != 0);
         }
     }
 }
@@ -310,6 +390,19 @@ extern "C" int i2r_stem_conv(const float* in_nchw, const float* w, const float* 
     const int out_h = (in_h - 1) / 2 + 1, out_w = (in_w - 1) / 2 + 1;
     const long long nthr = (long long)n_img * out_h * out_w * (cout / 16);
     const unsigned nblk = (unsigned)((nthr + 255) / 256);
+    if (cout == 64) {  // matrix-pipe stem (every shipped model); other widths keep the VALU kernel below
+        typedef void (*mfma_fn)(const float*, const float*, const float*, float*, int, int, int, int, int, int, int, int);
+        constexpr int FR = I2R_STEM_FR;  // fragments (16 pixels each) per wave
+        static const mfma_fn mf[2][3] = {{stem_mfma_k<1, 0, FR>, stem_mfma_k<1, 1, FR>, stem_mfma_k<1, 2, FR>},
+                                         {stem_mfma_k<3, 0, FR>, stem_mfma_k<3, 1, FR>, stem_mfma_k<3, 2, FR>}};
+        const long long frags = ((long long)n_img * out_h * out_w + 15) / 16;
+        const long long nb = (frags + 4 * FR - 1) / (4 * FR);
+        I2R_CHECK_ARG(nb > 0 && frags * 16 + 64 * FR < (1ll << 31), "i2r_stem_conv: grid");
+        hipLaunchKernelGGL(mf[cin == 3][out_dt], dim3((unsigned)nb), dim3(256), 0, (hipStream_t)stream, in_nchw, w, bias, out_nhwc, n_img,
+                           in_h, in_w, out_h, out_w, out_cs, n_src, n_valid);
+        I2R_CHECK_LAUNCH("i2r_stem_conv");
+        return I2R_OK;
+    }
     typedef void (*stem_fn)(const float*, const float*, const float*, float*, int, int, int, int, int, int, int, int, int);
     static const stem_fn fns[2][3] = {{stem_conv_k<1, 0>, stem_conv_k<1, 1>, stem_conv_k<1, 2>}, {stem_conv_k<3, 0>, stem_conv_k<3, 1>, stem_conv_k<3, 2>}};
     hipLaunchKernelGGL(fns[cin == 3][out_dt], dim3(nblk), dim3(256), (size_t)(9 * cin + 1) * cout * sizeof(float), (hipStream_t)stream, in_nchw, w,
