@@ -5,8 +5,8 @@ f = glob.glob(sys.argv[1] + "/*/*_kernel_trace.csv")[0]
 rows = [r for r in csv.DictReader(open(f))]
 ev = [(int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Kernel_Name"].replace("void ", "").replace("(anonymous namespace)::", "").split("(")[0][:40]) for r in rows]
 ev.sort()
-# last step: from the last stem_conv_k<3> launch to the end
-starts = [i for i, e in enumerate(ev) if e[2].startswith("stem_conv_k<3")]
+# last step: from the last RGB stem launch (stem_mfma_k<3, ...> or stem_conv_k<3, ...>) to the end
+starts = [i for i, e in enumerate(ev) if e[2].startswith(("stem_conv_k<3", "stem_mfma_k<3"))]
 lo = starts[-2] if len(starts) > 1 else 0
 hi = starts[-1] if len(starts) > 1 else len(ev)
 step = ev[lo:hi]
