@@ -165,6 +165,34 @@ def test_stem_conv(cin, cout):
     assert (from_act(out) - ref).abs().max().item() < 1e-4
 
 
+@pytest.mark.parametrize("cin,n,h,w,n_src,n_valid", [(3, 3, 37, 29, 3, 3),    # odd sizes: 3 x 19 x 15 = 855 pixels, partial last fragment
+                                                     (1, 1, 9, 7, 1, 1),       # fewer pixels (20) than one wave's two fragments
+                                                     (3, 6, 38, 30, 3, 3),     # flip test: crops 3..5 are the mirrored 0..2
+                                                     (3, 8, 21, 33, 4, 3)])    # capacity padding: slot 3 (and its mirror 7) re-reads crop 2
+def test_stem_conv_matrix_pipe_edges(cin, n, h, w, n_src, n_valid):
+    """stem_mfma_k (cout 64): fragments that run past the last pixel, odd input sizes (the stride-2 pad-1 border), mirrored crops
+    and padded program slots -- against F.conv2d on the crops the slots stand for."""
+    cout = 64
+    sd = {"c.weight": _rand((cout, cin, 3, 3), "ew%d" % cin, 0.4), "b.weight": _rand((cout,), "eg", 0.5) + 1.0,
+          "b.bias": _rand((cout,), "eb", 0.3), "b.running_mean": _rand((cout,), "em", 0.3),
+          "b.running_var": _rand((cout,), "ev", 0.4) + 1.0}
+    x = _rand((n_valid, cin, h, w), "ex%d_%d" % (cin, h))
+    src = [min(i % n_src, n_valid - 1) for i in range(n)]
+    xs = torch.stack([x[j].flip(-1) if i >= n_src else x[j] for i, j in enumerate(src)])
+    ref = F.relu(F.batch_norm(F.conv2d(xs, sd["c.weight"], None, 2, 1), sd["b.running_mean"], sd["b.running_var"],
+                              sd["b.weight"], sd["b.bias"], False, 0.0, 1e-5))
+    P = engine.Program(torch.device(DEV))
+    st = engine.Packer(sd, torch.device(DEV)).stem("c", "b")
+    xd = x.to(DEV)
+    out, args = P.stem(st, n, h, w, in_ptr=xd.data_ptr(), n_src=n_src)
+    args.n_valid = n_valid
+    run(P)
+    got = from_act(out)
+    assert got.shape == ref.shape
+    assert (got - ref).abs().max().item() < 1e-4
+    assert torch.isfinite(out.t).all()
+
+
 @pytest.mark.parametrize("cin,dt,tol", [(3, 1, 0.04), (3, 2, 0.005), (1, 1, 0.04)])
 def test_stem_conv_16bit_output(cin, dt, tol):
     """the stem writing bf16 / f16 activations (16-bit towers): same values as the fp32 stem, rounded once to the storage type"""
