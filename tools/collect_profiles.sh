@@ -25,3 +25,7 @@ for c in tph_192_p6_b4 hrt_192_p4_b4 coco_hrt_288_p2_b4; do
 done
 python bench.py --pipeline --no-cpu-baseline > $O/bench_pipeline.json 2> $O/bench_pipeline.err
 find $O -name "*.csv" | head -60
+# HBM traffic of the dominant 16-bit conv launch inside the real forward of config 3 (counters only, short run)
+for c in FETCH_SIZE WRITE_SIZE; do
+  rocprofv3 --pmc $c --kernel-trace --output-format csv -d $O/prof_pmc_tph_$c -- python bench.py --config tph_192_p6_b4 --steps 2 --warmup 1 --no-cpu-baseline --no-roofline --no-parity > $O/pmc_tph_$c.log 2>&1
+done

@@ -123,3 +123,18 @@ if enc:
     print(json.dumps(enc, indent=1))
 print(json.dumps(hbm, indent=1))
 print(json.dumps(sq, indent=1))
+
+# config 3 (16-bit): HBM traffic of its dominant conv instantiation inside the real forward (prof_pmc_tph_* passes)
+DOM_TPH = "conv_igemm_lp<3, 3, 8, 1>"
+ft, wt = counters_of("prof_pmc_tph_FETCH_SIZE", DOM_TPH), counters_of("prof_pmc_tph_WRITE_SIZE", DOM_TPH)
+if ft and wt and "FETCH_SIZE" in ft and "WRITE_SIZE" in wt:
+    json.dump({
+        "FETCH_SIZE_KB_per_launch": ft["FETCH_SIZE"], "WRITE_SIZE_KB_per_launch": wt["WRITE_SIZE"],
+        "launch": "average over the %s launches (bf16 operands, bf16 activation storage) of bench.py --config tph_192_p6_b4 "
+                  "(57 crops): the grouped stage-2 / stage-3 convs and the grouped 32x24 deconv" % DOM_TPH,
+        "hbm_bytes_per_launch": (2 * ft["FETCH_SIZE"] + wt["WRITE_SIZE"]) * 1024,
+        "note": "separate rocprofv3 --pmc passes over a short bench run; FETCH_SIZE doubled per MI355X_MICROARCH.md (the staging loads are "
+                "16 B per lane; the 8 B residual loads are counted with the same factor: upper bound); WRITE_SIZE uncalibrated and equal to "
+                "the algorithmic output bytes. bench.py's algorithmic figure for the same launches is 74 MB: reads are ~1.27x "
+                "(halo of the 3x3 patches), writes 1.0x.",
+    }, open(os.path.join(P, tag + "_hbm_traffic_tph_192_p6_b4.json"), "w"), indent=1)
