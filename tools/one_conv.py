@@ -18,8 +18,9 @@ N = int(sys.argv[2]) if len(sys.argv) > 2 else 10
 mode = sys.argv[3] if len(sys.argv) > 3 else "group"
 # mode "group2" / "group2:<mt>": the two-branch stage-2 launch, optionally with the M blocking forced (tile-model experiments)
 BR = [(48, 64, 48), (96, 32, 24), (192, 16, 12)]
-if mode.startswith("group2"):
-    BR = BR[:2]
+if mode.startswith("group"):
+    if mode.startswith("group2"):
+        BR = BR[:2]
     if ":" in mode:
         engine._MT_EFF[int(mode.split(":")[1])] = 9.9  # the cost model then picks this mt for the group
     mode = "group"
