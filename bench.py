@@ -117,7 +117,7 @@ def _op_name_flop(kind, st):
     if kind in (cabi.OP_ENC_KV, cabi.OP_ENC_LAYER):
         lp = st.dtype != 0
         return {cabi.OP_ENC_KV: "enc_kv_lp_k" if lp else "enc_kv_k", cabi.OP_ENC_LAYER: "enc_layer_lp_k" if lp else "enc_layer4_k"}[kind], 0.0
-    name = {cabi.OP_STEM: "stem_mfma_k", cabi.OP_MAXPOOL: "maxpool_k", cabi.OP_HEAD: "head_k", cabi.OP_LAYERNORM: "layernorm_k",
+    name = {cabi.OP_STEM: "stem_mfma_k", cabi.OP_MAXPOOL: "maxpool_k", cabi.OP_HEAD: "head_mfma_k", cabi.OP_LAYERNORM: "layernorm_k",
             cabi.OP_WINATTN: "window_attn_k", cabi.OP_DWCONV: "dwconv3x3_k", cabi.OP_UPSAMPLE: "upsample_add_k",
             cabi.OP_PE_RES_STEM: "pe_res_stem_k", cabi.OP_HRT_ATTN: "hrt_attn_block_k", cabi.OP_HRT_MLP: "hrt_mlp_block_k", cabi.OP_FUSE_UP: "fuse_up_add_k"}.get(kind, "op%d" % kind)
     return name, 0.0

@@ -330,6 +330,76 @@ __global__ __launch_bounds__(256) void head_k(const float* __restrict__ in, cons
     }
 }
 
+// The same head on the fp32 matrix pipe (cin a multiple of 16, <= 128).  M = 16 consecutive pixels per fragment, N = joints (one or
+// two 16-wide fragments), K = cin with the conv kernel's k-permutation: lane (m = l & 15, g = l >> 4) loads the 16 bytes
+// in[pixel m][16 j + 4 g .. + 3] and feeds them to four consecutive MFMAs, the weight fragment of lane (n, g) being
+// w[joint n][16 j + 4 g + s] -- so a pixel row is read with cin / 16 sixteen-byte loads per lane, ALL of a wave's FR fragments in
+// flight together, and no LDS / shuffle reduction is left.  D: lane (n, g) holds joint n of pixels 4 g .. 4 g + 3 -- four
+// consecutive floats of the joint's NCHW plane: one 16-byte store.
+template <int NF, int FR>
+__global__ __launch_bounds__(256) void head_mfma_k(const float* __restrict__ in, const float* __restrict__ w,
+                                                   const float* __restrict__ bias, float* __restrict__ out, int total, int hw,
+                                                   int cin, int in_cs, int cout) {
+    constexpr int CJ = 8;  // 16-channel steps provided for (cin <= 128)
+    const int lane = threadIdx.x & 63, n = lane & 15, g = lane >> 4;
+    const int wave = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int pw = wave * (FR * 16);
+    if (pw >= total) return;
+    const int cj = cin >> 4;
+    f32x4 va[FR][CJ];
+#pragma unroll
+    for (int f = 0; f < FR; ++f) {
+        const int p = pw + f * 16 + n;
+        const bool ok = p < total;
+        const f32x4* x = reinterpret_cast<const f32x4*>(in + (size_t)(ok ? p : total - 1) * in_cs) + g;
+#pragma unroll
+        for (int j = 0; j < CJ; ++j) va[f][j] = (ok && j < cj) ? x[j * 4] : (f32x4){0.f, 0.f, 0.f, 0.f};
+    }
+    f32x4 wb[NF][CJ];
+    float bj[NF];
+#pragma unroll
+    for (int nf = 0; nf < NF; ++nf) {
+        const int jn = nf * 16 + n;
+        bj[nf] = jn < cout ? bias[jn] : 0.f;
+#pragma unroll
+        for (int j = 0; j < CJ; ++j)
+            wb[nf][j] = (jn < cout && j < cj) ? *reinterpret_cast<const f32x4*>(w + (size_t)jn * cin + j * 16 + g * 4) : (f32x4){0.f, 0.f, 0.f, 0.f};
+    }
+    const bool vec = (hw & 3) == 0;  // then a lane's four pixels lie in one image and are 16-byte aligned in the joint's plane
+#pragma unroll
+    for (int f = 0; f < FR; ++f) {
+        f32x4 acc[NF];
+#pragma unroll
+        for (int nf = 0; nf < NF; ++nf) acc[nf] = (f32x4){bj[nf], bj[nf], bj[nf], bj[nf]};
+#pragma unroll
+        for (int j = 0; j < CJ; ++j)
+            if (j < cj) {
+#pragma unroll
+                for (int s = 0; s < 4; ++s)
+#pragma unroll
+                    for (int nf = 0; nf < NF; ++nf) acc[nf] = mfma16(va[f][j][s], wb[nf][j][s], acc[nf]);
+            }
+        const int pd = pw + f * 16 + 4 * g;
+#pragma unroll
+        for (int nf = 0; nf < NF; ++nf) {
+            const int jn = nf * 16 + n;
+            if (jn >= cout || pd >= total) continue;
+            if (vec && pd + 3 < total) {
+                const int img = pd / hw, p = pd - img * hw;
+                *reinterpret_cast<f32x4*>(out + ((size_t)img * cout + jn) * hw + p) = acc[nf];
+            } else {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int q = pd + r;
+                    if (q >= total) break;
+                    const int img = q / hw, p = q - img * hw;
+                    out[((size_t)img * cout + jn) * hw + p] = acc[nf][r];
+                }
+            }
+        }
+    }
+}
+
 // closing pass of an HRNet fuse sum: out = act((base + up(t1)) + up(t2)), nearest-neighbour up-sampling by 2^k.  thread = 4 channels
 // of one output pixel (consecutive lanes = consecutive channel quadruples of a pixel, then the next pixel: fully coalesced);
 // HBM-bound: reads base once, writes out once, the low-resolution maps come from L2.
@@ -444,6 +514,16 @@ extern "C" int i2r_head(const float* in, const float* w, const float* bias, floa
     I2R_CHECK_ARG(in && w && bias && out_nchw, "i2r_head: null pointer");
     I2R_CHECK_ARG(cin % 4 == 0 && in_cs % 4 == 0 && cin <= in_cs && cout >= 1 && cout <= 32, "i2r_head: cin=%d cout=%d", cin, cout);
     const long long npix = (long long)n_img * h * w_;
+    if (cin % 16 == 0 && cin <= 128 && npix + 256 < (1ll << 31)) {  // matrix-pipe head (every shipped model); else the VALU kernel below
+        constexpr int FR = 2;
+        typedef void (*mfma_fn)(const float*, const float*, const float*, float*, int, int, int, int, int);
+        const mfma_fn mf = cout <= 16 ? head_mfma_k<1, FR> : head_mfma_k<2, FR>;
+        const long long waves = (npix + 16 * FR - 1) / (16 * FR);
+        hipLaunchKernelGGL(mf, dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, (hipStream_t)stream, in, w, bias, out_nchw, (int)npix, h * w_, cin,
+                           in_cs, cout);
+        I2R_CHECK_LAUNCH("i2r_head");
+        return I2R_OK;
+    }
     const unsigned nblk = (unsigned)((npix * 4 + 255) / 256);  // 4 lanes per pixel
     typedef void (*head_fn)(const float*, const float*, const float*, float*, int, int, int, int, int);
     const int jp = cout <= 16 ? 16 : cout <= 20 ? 20 : 32;

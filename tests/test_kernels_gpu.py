@@ -243,6 +243,24 @@ def test_maxpool_and_head():
     assert (out.cpu() - F.conv2d(x2[:, :78], sd["f.weight"], sd["f.bias"])).abs().max().item() < 1e-4
 
 
+@pytest.mark.parametrize("n,cin,cout,h,w", [(3, 78, 17, 9, 7),      # 63 pixels per image: a lane's four pixels straddle images (scalar stores)
+                                            (1, 96, 14, 6, 6),       # 36 pixels: 16-byte stores, second fragment of the wave partial
+                                            (5, 32, 17, 4, 4),       # two joint fragments, one 16-channel pair of steps
+                                            (2, 128, 32, 8, 12),     # the widest case the matrix-pipe head takes
+                                            (2, 132, 17, 8, 6)])     # padded cin 144 > 128: the VALU kernel (head_k)
+def test_head_edges(n, cin, cout, h, w):
+    """i2r_head (head_mfma_k / head_k): NHWC features -> NCHW heat maps, against F.conv2d"""
+    x = _rand((n, cin, h, w), "hx%d_%d" % (cin, h))
+    sd = {"f.weight": _rand((cout, cin, 1, 1), "hw%d_%d" % (cin, cout), 0.2), "f.bias": _rand((cout,), "hb%d" % cout, 0.2)}
+    P = engine.Program(torch.device(DEV))
+    xa = to_act(P, x)
+    hd = engine.Packer(sd, torch.device(DEV)).head("f")
+    out = torch.full((n, cout, h, w), float("nan"), device=DEV)
+    P.head(xa, hd, out_ptr=out.data_ptr())
+    run(P)
+    assert (out.cpu() - F.conv2d(x, sd["f.weight"], sd["f.bias"])).abs().max().item() < 1e-4
+
+
 @pytest.mark.parametrize("dt,tol", [(0, 0.0), (1, 0.05), (2, 0.006)])
 def test_fuse_up_add(dt, tol):
     """i2r_fuse_up_add = ReLU((base + nearest_up(t1)) + nearest_up(t2)) (the closing pass of an HRNet fuse sum,
