@@ -179,3 +179,29 @@ def test_validate_config_refuses_unshipped_combinations():
     for opts in (["MODEL.N_HEAD", "8"], ["MODEL.MULTI_POS_EMBEDDING", "cat_vec"], ["MODEL.NORMALIZE_BEFORE", "True"]):
         with pytest.raises(NotImplementedError):
             engine.validate_config(config.load_config("w48_pure_en6", opts))
+
+
+def test_conv_cat_folds_the_downsample_into_conv3():
+    """Packer.conv_cat (CPU): the packed 'k4' weights of the concatenated 1x1 conv, unpacked again, reproduce
+    bn3(conv3(t2)) + bn_d(downsample(x)) of the reference's first Bottleneck (hrnet.py Bottleneck.forward) on [x ; t2]."""
+    import torch.nn.functional as F
+    from i2r_amd import engine
+
+    def rnd(shape, key, scale=1.0):
+        return torch.from_numpy(synth._sym(11, key, tuple(shape), scale))
+
+    sd = {"ds.0.weight": rnd((256, 64, 1, 1), "dsw", 0.2), "c3.weight": rnd((256, 64, 1, 1), "c3w", 0.2)}
+    for p in ("ds.1", "bn3"):
+        sd.update({p + ".weight": rnd((256,), p + "g", 0.5) + 1.0, p + ".bias": rnd((256,), p + "b", 0.3),
+                   p + ".running_mean": rnd((256,), p + "m", 0.3), p + ".running_var": rnd((256,), p + "v", 0.4) + 1.0})
+    pc = engine.Packer(sd, torch.device("cpu")).conv_cat([("ds.0", "ds.1"), ("c3", "bn3")])
+    assert (pc.cin, pc.cout, pc.ksize, pc.stride) == (128, 256, 1, 1)
+    w = pc.w.view(1, 128 // 4, 256, 4).permute(0, 1, 3, 2).reshape(128, 256)  # undo pack_k4: [cin, cout]
+    x, t2 = rnd((2, 64, 5, 3), "x"), rnd((2, 64, 5, 3), "t2")
+
+    def bn(y, p):
+        return F.batch_norm(y, sd[p + ".running_mean"], sd[p + ".running_var"], sd[p + ".weight"], sd[p + ".bias"], False, 0.0, 1e-5)
+
+    ref = bn(F.conv2d(t2, sd["c3.weight"]), "bn3") + bn(F.conv2d(x, sd["ds.0.weight"]), "ds.1")
+    got = torch.einsum("nkhw,kc->nchw", torch.cat([x, t2], 1), w) + pc.bias[:256].view(1, -1, 1, 1)
+    assert (got - ref).abs().max().item() < 1e-5
