@@ -1,7 +1,7 @@
 """GPU tuning aid: host time of ONE forward's enqueue (Program.run / Engine.forward) measured against an EMPTY queue -- a loop of
 un-synchronised forwards (tools/host_launch_time.py) blocks on the full hardware queue and reports the GPU time instead."""
 import os, sys, time
-sys.path.insert(0, "/root/repo")
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch, bench
 import i2r_amd
 from i2r_amd import config, synth, arch, engine
