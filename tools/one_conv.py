@@ -12,6 +12,32 @@ if os.environ.get("I2R_TOOL_LIB"):  # a tuning build (tools/ab/build_tuning.sh)
     cabi._LIB = cabi.load_library(os.path.join(ROOT, os.environ["I2R_TOOL_LIB"]))
 from i2r_amd import engine, synth
 
+# TOOL_LPT=<variant>: dispatch-plan experiments for the three-branch group (members sorted heaviest first: 0 = 192 ch / 4 units,
+# 1 = 96 ch / 2 units, 2 = 48 ch / 1 unit per workgroup).  Each variant lists, per CU class, the workgroups of a CU in dispatch order.
+_PLANS = {"a42": ([0, 1], [1, 2, 2, 2, 2]), "b2121": ([0, 2, 2], [1, 2, 1, 2]), "b1212": ([0, 2, 2], [2, 1, 2, 1]),
+          "a141": ([2, 0, 2], [1, 1, 2, 2]), "b2112": ([0, 2, 2], [1, 2, 2, 1]), "b1221": ([0, 2, 2], [2, 1, 1, 2])}
+if os.environ.get("TOOL_LPT"):
+    def _plan_order(counts, works, n_cu=256, stagger=None, plan=_PLANS[os.environ["TOOL_LPT"]]):
+        pa, pb = plan
+        na = counts[0]  # one 4-unit workgroup per class-A CU
+        nxt = [0] * len(counts)
+        bins = []
+        for b in range(n_cu):
+            items = []
+            for g in (pa if b < na else pb):
+                if nxt[g] < counts[g]:
+                    items.append((g << 24) | nxt[g])
+                    nxt[g] += 1
+            bins.append(items)
+        assert nxt == list(counts), (nxt, counts)
+        out, r = [], 0
+        while len(out) < sum(counts):
+            for b in range(n_cu):
+                if r < len(bins[b]):
+                    out.append(bins[b][r])
+            r += 1
+        return out
+    engine.lpt_block_order = _plan_order
 DEV = torch.device("cuda:0")
 S = int(sys.argv[1]) if len(sys.argv) > 1 else 32
 N = int(sys.argv[2]) if len(sys.argv) > 2 else 10
