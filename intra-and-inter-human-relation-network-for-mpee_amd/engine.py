@@ -1330,6 +1330,7 @@ class Engine:
             self.device = torch.device("cuda", torch.cuda.current_device())
         cabi.require_gfx950(self.device.index)
         self.programs = {}
+        self.n_builds = 0  # programs built so far (bench.py --ragged-stream reports them)
         self.multi_lane = False  # (grouped launches replaced per-branch stream lanes)
         self.side_streams = [torch.cuda.Stream(device=self.device) for _ in range(3)]
         M = cfg["MODEL"]
@@ -1584,6 +1585,7 @@ class Engine:
             while len(self.programs) >= self.MAX_PROGRAMS:
                 self.programs.pop(next(iter(self.programs)))
             self.programs[key] = self._build(cap, H, W, list(length) + [1] * (cap - S), flip)
+            self.n_builds += 1
         P, patch = self.programs[key]
         glen = list(length) + [1] * (cap - S)
         if flip:
