@@ -1,0 +1,345 @@
+// HRFormer-B transformer block, MLP half, FUSED for the 16-bit modes (BASELINE configs 4-5):
+//     x2 = x1 + GELU(BN3(fc2( GELU(BN2(DW3x3( GELU(BN1(fc1( LayerNorm2(x1) ))) ))) )))
+// (reference lib/models/hrformer.py:1237 + MlpDWBN.forward :1094-1119; the BatchNorms are folded into the conv weights by the host)
+// in ONE launch per block, without the 4C-wide hidden tensor (the largest map of the block) ever reaching HBM.
+//
+// The kernel is bound by the VALU (three GELUs + nine depth-wise FMAs per hidden element against 2 x 16 MFMA k-steps), i.e. by issue
+// slots and by how well a wave hides its own latencies -- not by the matrix pipe and not by HBM.  Structure (round 3):
+//
+//   * One workgroup = one 8 x 6 sub-tile of output pixels (three 16-pixel fragments) + its halo of 1: 10 x 8 = 80 pixels = exactly five
+//     fragments for fc1 (1.67x recompute; every map of the HRFormer-B pyramid is a multiple of 8 x 6).
+//   * The hidden dimension (4C padded to HBT = 4 CB blocks of 16 channels) is split over the NBG waves of the workgroup: wave w owns
+//     blocks w, w + NBG, ...  A depth-wise conv never mixes channels, so for ITS blocks a wave does everything itself -- fc1 on the
+//     five halo fragments (A = weight fragment, B = LayerNorm-ed pixel columns held in registers), + bias, GELU, fp32 to a wave-PRIVATE
+//     LDS tile H[channel quad][halo row][halo column][4]; depth-wise 3x3 + bias + GELU for the three output pixels of each lane (a
+//     horizontal strip: 15 LDS reads for 27 taps); packed, that is the B operand (k = hidden channel) of fc2, accumulated into
+//     3 x CB fragments.  No workgroup barrier inside the loop: waves drift apart and fill each other's stalls.
+//   * The loop is software-pipelined inside a wave: fc1's MFMAs of block b+1 are issued before the depth-wise phase of block b, the weight
+//     fragments of block b+2 / b+1 are fetched right behind the MFMAs that free their registers.
+//   * The waves' partial fc2 sums meet once, through LDS, in a fixed order (bit-identical replays): output block ob is finished by wave
+//     ob % NBG: + bias, GELU, + x1 (fp32 residual), fp32 store.
+// LDS layout of H (floats): quad g at g*448, halo row hy at hy*40, halo column hx at hx*4: the 16-lane groups of ds_read_b128 /
+// the 8-lane groups of ds_write_b128 then hit 64 distinct banks for every tap (checked exhaustively, tools/lds_layout.py).
+// x / out are the fp32 residual stream [n, h, w, cs]; operands bf16 / f16 (v_mfma_f32_16x16x16), accumulation fp32.
+#include "i2r_common.h"
+
+namespace {
+
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+typedef _Float16 h16x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 b16x4 __attribute__((ext_vector_type(4)));
+
+template <int DT>
+__device__ __forceinline__ f32x4 mfma16(uint2 a, uint2 b, f32x4 c) {  // D = A(16x16) B(16x16) + C
+    if constexpr (DT == 1)
+        return __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(__builtin_bit_cast(s16x4, a), __builtin_bit_cast(s16x4, b), c, 0, 0, 0);
+    else
+        return __builtin_amdgcn_mfma_f32_16x16x16f16(__builtin_bit_cast(h16x4, a), __builtin_bit_cast(h16x4, b), c, 0, 0, 0);
+}
+template <int DT>
+__device__ __forceinline__ uint2 pack4(f32x4 v) {
+    if constexpr (DT == 1) {
+        const b16x4 b = {(__bf16)v[0], (__bf16)v[1], (__bf16)v[2], (__bf16)v[3]};
+        return __builtin_bit_cast(uint2, b);
+    } else {
+        const h16x4 h = {(_Float16)v[0], (_Float16)v[1], (_Float16)v[2], (_Float16)v[3]};
+        return __builtin_bit_cast(uint2, h);
+    }
+}
+__device__ __forceinline__ float xsum4(float v) {  // over the 4 lanes that share l & 15
+    v += __shfl_xor(v, 16);
+    v += __shfl_xor(v, 32);
+    return v;
+}
+
+struct MlpK {
+    const float* x; float* out;
+    const float* ln_w; const float* ln_b;
+    const uint2* w1; const float* b1;     // fc1 (+BN1): fragments [hidden block][CB][64 lanes]; bias [hidden_pad]
+    const float* wdw; const float* bdw;   // depth-wise 3x3 (+BN2): [9][hidden_pad] tap-major; bias [hidden_pad]
+    const uint2* w2; const float* b2;     // fc2 (+BN3): fragments [CB out blocks][hidden blocks][64 lanes]; bias [cs]
+    int n_img, h, w, c, tiles_y, tiles_x;
+    float eps;
+};
+
+// exact-erf GELU (nn.GELU, hrformer.py:1197) with ONE transcendental:  GELU(x) = max(x, 0) - |x| Phi(-|x|), and the normal tail
+// Phi(-a) = erfc(a / sqrt 2) / 2 = 2^-Q(a), Q(0) = 1, Q a polynomial in a = min(|x|, 8) evaluated by Horner (minimax fit of the error of
+// the GELU VALUE, tools/fit_gelu.py; beyond 8 the tail term is below 1e-14 |x|, so the clamped a also serves as |x| in the product).
+// DEG 4: |error| < 9e-6 (hidden activations: two orders below one bf16 / f16 rounding); DEG 5: |error| < 1e-6 (the block output, added to
+// the fp32 residual stream).  The VALU retires one wave64 instruction per 4 cycles, packed fp32 ones (v_pk_fma_f32) included, so the
+// Horner steps and the final product run on PAIRS: 5.5 (6) issue slots per element: min, exp2, max + 5 (6) packed FMAs per pair.
+// The fp32 parity kernels keep libm's erff.
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+struct GeluC {  // the coefficients as opaque SGPR pairs: literals would make the compiler pick scalar fmaak / fmamk over the packed FMAs
+    f32x2 c1, c2, c3, c4, d1, d2, d3, d4, d5, one;
+    __device__ __forceinline__ GeluC() {
+        auto splat = [](float v) { f32x2 r = {v, v}; asm("" : "+s"(r)); return r; };
+        c1 = splat(1.14955728e+00f); c2 = splat(4.64952799e-01f); c3 = splat(4.57202931e-02f); c4 = splat(-4.15856780e-03f);
+        d1 = splat(1.15100107e+00f); d2 = splat(4.59593681e-01f); d3 = splat(5.21493605e-02f); d4 = splat(-7.20005350e-03f);
+        d5 = splat(4.88322604e-04f); one = splat(1.f);
+    }
+};
+template <int DEG>
+__device__ __forceinline__ f32x2 gelu2(f32x2 x, const GeluC& k) {
+    // (v_med3_f32: clamp without the NaN-canonicalising v_max the IEEE fminf / fmaxf forms cost)
+    const f32x2 a = {__builtin_amdgcn_fmed3f(__builtin_fabsf(x[0]), 0.f, 8.f), __builtin_amdgcn_fmed3f(__builtin_fabsf(x[1]), 0.f, 8.f)};
+    f32x2 t;
+    if constexpr (DEG == 4) {
+        t = a * k.c4 + k.c3;
+        t = t * a + k.c2;
+        t = t * a + k.c1;
+    } else {
+        t = a * k.d5 + k.d4;
+        t = t * a + k.d3;
+        t = t * a + k.d2;
+        t = t * a + k.d1;
+    }
+    const f32x2 q = t * a + k.one;
+    const f32x2 e = {__builtin_amdgcn_exp2f(-q[0]), __builtin_amdgcn_exp2f(-q[1])};
+    const f32x2 r = {__builtin_amdgcn_fmed3f(x[0], 0.f, 3.0e38f), __builtin_amdgcn_fmed3f(x[1], 0.f, 3.0e38f)};
+    return r - a * e;
+}
+template <int DEG>
+__device__ __forceinline__ f32x4 gelu4(f32x4 v, const GeluC& k) {
+    const f32x2 lo = gelu2<DEG>(v.xy, k), hi = gelu2<DEG>(v.zw, k);
+    return (f32x4){lo[0], lo[1], hi[0], hi[1]};
+}
+
+constexpr int TY = 8, TX = 6;                    // output sub-tile (rows x columns)
+constexpr int HY = TY + 2, HX = TX + 2;          // halo grid 10 x 8 = 80 pixels = 5 fragments (two halo rows each)
+constexpr int NF = HY * HX / 16, NPF = TY * TX / 16;
+constexpr int H_ROW = 40, H_QUAD = 448;          // LDS strides of H in floats (see the header)
+static_assert(NF == 5 && NPF == 3, "sub-tile geometry");
+
+template <int DT, int CB, int NBG>
+__global__ __launch_bounds__(NBG * 64, NBG == 2 ? 2 : 1) void hrt_mlp_block_k(const MlpK p) {
+    constexpr int cs = CB * 16, HBT = 4 * CB, HID = HBT * 16, NB = HBT / NBG;  // NB hidden blocks per wave
+    static_assert(HBT % NBG == 0, "even split of the hidden blocks");
+    constexpr int WD_WAVE = NB * 160;                           // floats: per block [10 = 9 taps + bias][16 channels]
+    constexpr int H_WAVE = 4 * H_QUAD;                          // floats
+    constexpr int X_FLOATS = NF * CB * 64 * 2;                  // packed pixel columns, uint2 per lane
+    constexpr int R1 = X_FLOATS > NBG * H_WAVE ? X_FLOATS : NBG * H_WAVE;
+    constexpr int RED_FLOATS = (NBG == 2 ? CB : (CB + 1) / 2) * (NBG - 1) * NPF * 64 * 4;  // partial fc2 sums handed to the finishing wave
+    constexpr int SMEM = NBG * WD_WAVE + R1 > RED_FLOATS ? NBG * WD_WAVE + R1 : RED_FLOATS;
+    __shared__ __attribute__((aligned(16))) float smem[SMEM];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, li = lane & 15, g = lane >> 4;
+    float* const Wd = smem + wave * WD_WAVE;                    // this wave's depth-wise weights
+    float* const Hs = smem + NBG * WD_WAVE + wave * H_WAVE;     // this wave's hidden tile
+    uint2* const Xs = reinterpret_cast<uint2*>(smem + NBG * WD_WAVE);  // (prologue only; aliases the H tiles)
+    int bid = blockIdx.x;
+    const int sx = bid % p.tiles_x; bid /= p.tiles_x;
+    const int sy = bid % p.tiles_y;
+    const int img = bid / p.tiles_y;
+    const int y0 = sy * TY - 1, x0 = sx * TX - 1;               // image coordinate of halo pixel (0, 0)
+
+    // ---- depth-wise weights + bias of this wave's blocks -> its LDS region: [block i][tap][16] ----
+    for (int i = lane; i < NB * 40; i += 64) {
+        const int blk = i / 40, r = i - blk * 40, tap = r >> 2, q = r & 3;
+        const int hb = wave + NBG * blk;
+        const f32x4 v = tap < 9 ? *reinterpret_cast<const f32x4*>(p.wdw + tap * HID + hb * 16 + 4 * q)
+                                : *reinterpret_cast<const f32x4*>(p.bdw + hb * 16 + 4 * q);
+        *reinterpret_cast<f32x4*>(Wd + blk * 160 + tap * 16 + 4 * q) = v;
+    }
+    // ---- LayerNorm 2 of halo fragments wave, wave + NBG, ...: packed B operands -> Xs[fragment][c][lane] ----
+    float hinf[NF];  // 1 = halo pixel (16 f + li) lies inside the image
+#pragma unroll
+    for (int f = 0; f < NF; ++f) {
+        const int y = y0 + 2 * f + (li >> 3), x = x0 + (li & 7);
+        hinf[f] = (y >= 0 && y < p.h && x >= 0 && x < p.w) ? 1.f : 0.f;
+    }
+#pragma unroll
+    for (int f = 0; f < NF; ++f) {
+        if (f % NBG != wave) continue;  // (wave-uniform)
+        const int y = y0 + 2 * f + (li >> 3), x = x0 + (li & 7);
+        const bool in = hinf[f] != 0.f;
+        const float* row = p.x + (((size_t)img * p.h + (in ? y : 0)) * p.w + (in ? x : 0)) * cs;
+        f32x4 xr[CB];
+        float s = 0.f;
+#pragma unroll
+        for (int c = 0; c < CB; ++c) {
+            xr[c] = *reinterpret_cast<const f32x4*>(row + 16 * c + 4 * g);
+            s += (xr[c][0] + xr[c][1]) + (xr[c][2] + xr[c][3]);
+        }
+        const float mean = xsum4(s) / (float)p.c;
+        float q2 = 0.f;
+#pragma unroll
+        for (int c = 0; c < CB; ++c)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float d = (16 * c + 4 * g + r < p.c) ? xr[c][r] - mean : 0.f;
+                q2 += d * d;
+            }
+        const float rstd = in ? rsqrtf(xsum4(q2) / (float)p.c + p.eps) : 0.f;  // outside the image: zero columns
+#pragma unroll
+        for (int c = 0; c < CB; ++c) {
+            const f32x4 wv = *reinterpret_cast<const f32x4*>(p.ln_w + 16 * c + 4 * g), bv = *reinterpret_cast<const f32x4*>(p.ln_b + 16 * c + 4 * g);
+            const f32x4 v = (xr[c] - mean) * rstd * wv + bv * hinf[f];
+            Xs[(f * CB + c) * 64 + lane] = pack4<DT>(v);
+        }
+    }
+    __syncthreads();
+    uint2 xn[NF][CB];
+#pragma unroll
+    for (int f = 0; f < NF; ++f)
+#pragma unroll
+        for (int c = 0; c < CB; ++c) xn[f][c] = Xs[(f * CB + c) * 64 + lane];
+    __syncthreads();  // everyone holds the pixel columns in registers: the region becomes the H tiles
+
+    // this lane's three output pixels: row oy, columns 3 xb .. 3 xb + 2 of the sub-tile
+    const int oy = li & 7, xb = li >> 3;
+    float* const hwr = Hs + g * H_QUAD + (li >> 3) * H_ROW + (li & 7) * 4;   // fc1 result of halo fragment 0 (fragment f: + 2 f rows)
+    const float* const hrd = Hs + g * H_QUAD + oy * H_ROW + (3 * xb) * 4;    // top-left tap of the strip
+    const float* const wrd = Wd + 4 * g;
+
+    const GeluC gk;
+    f32x4 acc[NPF][CB];
+#pragma unroll
+    for (int pf = 0; pf < NPF; ++pf)
+#pragma unroll
+        for (int ob = 0; ob < CB; ++ob) acc[pf][ob] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    uint2 w1f[CB], w2f[CB];
+    f32x4 b1v;
+    auto fetch1 = [&](int hb) {
+#pragma unroll
+        for (int c = 0; c < CB; ++c) w1f[c] = p.w1[(hb * CB + c) * 64 + lane];
+        b1v = *reinterpret_cast<const f32x4*>(p.b1 + hb * 16 + 4 * g);
+    };
+    auto fetch2 = [&](int hb) {
+#pragma unroll
+        for (int ob = 0; ob < CB; ++ob) w2f[ob] = p.w2[(ob * HBT + hb) * 64 + lane];
+    };
+    f32x4 a[NF];
+    auto fc1 = [&]() {  // hidden block in w1f / b1v, all five halo fragments (interleaved dependency chains)
+#pragma unroll
+        for (int f = 0; f < NF; ++f) a[f] = b1v * hinf[f];
+#pragma unroll
+        for (int c = 0; c < CB; ++c)
+#pragma unroll
+            for (int f = 0; f < NF; ++f) a[f] = mfma16<DT>(w1f[c], xn[f][c], a[f]);
+    };
+    auto store_h = [&]() {
+#pragma unroll
+        for (int f = 0; f < NF; ++f) *reinterpret_cast<f32x4*>(hwr + 2 * f * H_ROW) = gelu4<4>(a[f], gk);
+    };
+
+    // depth-wise 3x3 + bias + GELU of block i (three output pixels x 4 channels per lane), then its fc2 partial products
+    auto dw_fc2 = [&](int i) {
+        const float* const wch = wrd + i * 160;
+        f32x4 d[NPF];
+        {
+            const f32x4 bias = *reinterpret_cast<const f32x4*>(wch + 9 * 16);
+#pragma unroll
+            for (int pf = 0; pf < NPF; ++pf) d[pf] = bias;
+        }
+#pragma unroll
+        for (int ky = 0; ky < 3; ++ky) {
+            f32x4 t[5], wv[3];
+#pragma unroll
+            for (int j = 0; j < 5; ++j) t[j] = *reinterpret_cast<const f32x4*>(hrd + ky * H_ROW + j * 4);
+#pragma unroll
+            for (int kx = 0; kx < 3; ++kx) wv[kx] = *reinterpret_cast<const f32x4*>(wch + (ky * 3 + kx) * 16);
+#pragma unroll
+            for (int pf = 0; pf < NPF; ++pf)
+#pragma unroll
+                for (int kx = 0; kx < 3; ++kx) d[pf] = t[pf + kx] * wv[kx] + d[pf];
+        }
+        uint2 dB[NPF];
+#pragma unroll
+        for (int pf = 0; pf < NPF; ++pf) dB[pf] = pack4<DT>(gelu4<4>(d[pf], gk));
+#pragma unroll
+        for (int ob = 0; ob < CB; ++ob)
+#pragma unroll
+            for (int pf = 0; pf < NPF; ++pf) acc[pf][ob] = mfma16<DT>(w2f[ob], dB[pf], acc[pf][ob]);
+    };
+
+    fetch1(wave);
+    fetch2(wave);
+    fc1();
+    fetch1(wave + NBG * (NB > 1 ? 1 : 0));
+    store_h();
+    for (int i = 0; i + 1 < NB; ++i) {
+        const int hb = wave + NBG * i;
+        __builtin_amdgcn_wave_barrier();  // (H of block i is complete in program order; LDS executes a wave's accesses in order)
+        fc1();  // block i + 1 goes to the matrix pipe first; its results are only needed after this block's depth-wise phase
+        fetch1(i + 2 < NB ? hb + 2 * NBG : hb);  // (last round: a harmless re-fetch instead of a branch)
+        dw_fc2(i);
+        fetch2(hb + NBG);
+        store_h();  // block i + 1's hidden tile (block i's taps have all been read: LDS keeps a wave's accesses in order)
+    }
+    __builtin_amdgcn_wave_barrier();
+    dw_fc2(NB - 1);
+
+    // ---- the waves' partial sums meet: output block ob is finished by wave ob % NBG ----
+    const int gy = sy * TY + oy;
+    const bool rowin = gy < p.h;
+    size_t prow[NPF];
+    bool oin[NPF];
+#pragma unroll
+    for (int pf = 0; pf < NPF; ++pf) {
+        const int gx = sx * TX + 3 * xb + pf;
+        oin[pf] = rowin && gx < p.w;
+        prow[pf] = (((size_t)img * p.h + (rowin ? gy : 0)) * p.w + (gx < p.w ? gx : 0)) * cs;
+    }
+    // (partials of OBC output blocks at a time, so the exchange area fits the loop's LDS footprint)
+    constexpr int OBC = NBG == 2 ? CB : (CB + 1) / 2;
+    static_assert(OBC * (NBG - 1) * NPF * 64 * 4 <= SMEM, "exchange area");
+    f32x4* const Red = reinterpret_cast<f32x4*>(smem);
+#pragma unroll
+    for (int ob0 = 0; ob0 < CB; ob0 += OBC) {
+        __syncthreads();  // every wave is done with its H tile and weights / with the previous chunk: the buffer is the exchange area
+#pragma unroll
+        for (int ob = ob0; ob < ob0 + OBC && ob < CB; ++ob) {
+            const int owner = ob % NBG;
+            if (owner == wave) continue;  // (wave-uniform)
+            const int slot = (wave - owner - 1 + NBG) % NBG;  // 0 .. NBG-2
+#pragma unroll
+            for (int pf = 0; pf < NPF; ++pf) Red[(((ob - ob0) * (NBG - 1) + slot) * NPF + pf) * 64 + lane] = acc[pf][ob];
+        }
+        __syncthreads();
+#pragma unroll
+        for (int ob = ob0; ob < ob0 + OBC && ob < CB; ++ob) {
+            if (ob % NBG != wave) continue;
+            const f32x4 b = *reinterpret_cast<const f32x4*>(p.b2 + 16 * ob + 4 * g);
+#pragma unroll
+            for (int pf = 0; pf < NPF; ++pf) {
+                f32x4 v = acc[pf][ob];
+#pragma unroll
+                for (int s = 1; s < NBG; ++s)  // fixed order: waves owner + 1, owner + 2, ... (mod NBG)
+                    v += Red[(((ob - ob0) * (NBG - 1) + (s - 1)) * NPF + pf) * 64 + lane];
+                if (!oin[pf]) continue;
+                const f32x4 xres = *reinterpret_cast<const f32x4*>(p.x + prow[pf] + 16 * ob + 4 * g);
+                f32x4 o = gelu4<5>(v + b, gk) + xres;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) o[r] = (16 * ob + 4 * g + r < p.c) ? o[r] : 0.f;
+                *reinterpret_cast<f32x4*>(p.out + prow[pf] + 16 * ob + 4 * g) = o;
+            }
+        }
+    }
+}
+
+}  // namespace
+
+extern "C" int i2r_hrt_mlp_block(const float* x, float* out, const float* ln_w, const float* ln_b, const void* w1, const float* b1,
+                                 const float* wdw, const float* bdw, const void* w2, const float* b2, int32_t n_img, int32_t h, int32_t w,
+                                 int32_t c, int32_t cs, int32_t hidden_pad, float eps, int32_t dtype, void* stream) {
+    I2R_CHECK_ARG(x && out && x != out && ln_w && ln_b && w1 && b1 && wdw && bdw && w2 && b2, "i2r_hrt_mlp_block: null pointer / out aliases x");
+    I2R_CHECK_ARG(dtype == 1 || dtype == 2, "i2r_hrt_mlp_block: dtype %d (1 bf16, 2 f16; the fp32 path is i2r_layernorm + i2r_conv + i2r_dwconv3x3)", dtype);
+    I2R_CHECK_ARG((cs == 80 || cs == 160) && c <= cs && c > cs - 16 && hidden_pad >= 4 * c && hidden_pad == 4 * cs,
+                  "i2r_hrt_mlp_block: c=%d cs=%d hidden_pad=%d (built for the two high-resolution HRFormer-B branches; hidden padded to 4 cs)", c, cs, hidden_pad);
+    MlpK k;
+    k.x = x; k.out = out; k.ln_w = ln_w; k.ln_b = ln_b; k.w1 = (const uint2*)w1; k.b1 = b1; k.wdw = wdw; k.bdw = bdw; k.w2 = (const uint2*)w2; k.b2 = b2;
+    k.n_img = n_img; k.h = h; k.w = w; k.c = c; k.eps = eps;
+    k.tiles_y = (h + TY - 1) / TY; k.tiles_x = (w + TX - 1) / TX;
+    const long long nblk = (long long)n_img * k.tiles_y * k.tiles_x;
+    I2R_CHECK_ARG(nblk > 0 && nblk < (1ll << 31), "i2r_hrt_mlp_block: grid");
+    const dim3 grid((unsigned)nblk);
+    if (dtype == 1) {
+        if (cs == 80) hipLaunchKernelGGL((hrt_mlp_block_k<1, 5, 2>), grid, dim3(128), 0, (hipStream_t)stream, k);
+        else hipLaunchKernelGGL((hrt_mlp_block_k<1, 10, 4>), grid, dim3(256), 0, (hipStream_t)stream, k);
+    } else {
+        if (cs == 80) hipLaunchKernelGGL((hrt_mlp_block_k<2, 5, 2>), grid, dim3(128), 0, (hipStream_t)stream, k);
+        else hipLaunchKernelGGL((hrt_mlp_block_k<2, 10, 4>), grid, dim3(256), 0, (hipStream_t)stream, k);
+    }
+    I2R_CHECK_LAUNCH("i2r_hrt_mlp_block");
+    return I2R_OK;
+}

@@ -23,6 +23,7 @@ L = cabi.lib()
 cur = torch.cuda.current_stream().cuda_stream
 streams = (C.c_void_p * 4)(cur, cur, cur, cur)
 tot = 0.0
+per_lane, per_name = {}, {}
 for i, (kind, lane, st) in enumerate(P.ops):
     if kind in cabi.SYNC_OPS:
         print("%4d  lane %s  -- sync op %d" % (i, lane, kind))
@@ -36,12 +37,27 @@ for i, (kind, lane, st) in enumerate(P.ops):
         torch.cuda.synchronize()
         if rep:
             ms += e0.elapsed_time(e1) / 3
-    nm, fl = bench._op_name_flop(kind, st)
+    nm, fl, _, _ = bench.op_model(kind, st, eng.precision)
     shp = ""
     if kind in (cabi.OP_CONV, cabi.OP_CONV_GROUP):
         ms_ = [st] if kind == cabi.OP_CONV else [st.d[j].contents for j in range(st.n)]
         shp = " + ".join("%d->%d k%d s%d @%dx%d%s%s" % (m.cin, m.cout, m.ntaps, m.stride, m.conv_h, m.conv_w, " up%d" % m.rep if m.rep > 1 else "",
                                                         " res" if m.res1 else "") for m in ms_)
     tot += ms
+    if kind == cabi.OP_HRT_ATTN or kind == cabi.OP_HRT_MLP:
+        shp = "C=%d @%dx%d" % (st.c, st.h, st.w_)
+    elif kind in (cabi.OP_LAYERNORM,):
+        shp = "C=%d npix=%d" % (st.c, st.npix)
+    elif kind in (cabi.OP_WINATTN,):
+        shp = "C=%d @%dx%d" % (st.c, st.h, st.w_)
+    elif kind in (cabi.OP_DWCONV,):
+        shp = "C=%d @%dx%d s%d" % (st.c, st.in_h, st.in_w, st.stride)
+    per_lane[lane] = per_lane.get(lane, 0.0) + ms
+    per_name[(lane, nm)] = per_name.get((lane, nm), 0.0) + ms
     print("%4d  lane %s  %7.1f us  %6.1f TF  %-30s %s" % (i, lane, ms * 1e3, fl / ms / 1e9 if ms else 0, nm, shp))
 print("sum of stand-alone launch times: %.3f ms" % tot)
+for lane in sorted(per_lane):
+    print("lane %d: %.3f ms" % (lane, per_lane[lane]))
+    for (l, nm), v in sorted(per_name.items(), key=lambda kv: -kv[1]):
+        if l == lane and v > 0.01:
+            print("      %-34s %.3f ms" % (nm, v))

@@ -17,7 +17,7 @@ def collect(dirs, subs):
                     name = r["Kernel_Name"]
                     if subs and not any(s in name for s in subs):
                         continue
-                    short = name.split("(")[0].replace("void (anonymous namespace)::", "").replace("(anonymous namespace)::", "")
+                    short = name.replace("void (anonymous namespace)::", "").replace("(anonymous namespace)::", "").split("(")[0]
                     k = acc.setdefault(short, {"grid": r["Grid_Size"], "wg": r.get("Workgroup_Size"), "lds": r["LDS_Block_Size"], "vgpr": r["VGPR_Count"],
                                                "agpr": r["Accum_VGPR_Count"], "sgpr": r.get("SGPR_Count"), "c": {}})
                     k["c"].setdefault(r["Counter_Name"], []).append(float(r["Counter_Value"]))
