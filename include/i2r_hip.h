@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define I2R_ABI_VERSION 3
+#define I2R_ABI_VERSION 4
 
 #define I2R_OK 0
 #define I2R_E_ARG (-1)      /* bad argument (shape / alignment / unsupported combination) */
@@ -83,6 +83,11 @@ typedef struct i2r_conv_desc {
     int32_t in_f16, out_f16;       /* dtype != 0 only: activation STORAGE of `in` / of `out`, res1, res2 and res_post -- 0 fp32,
                                       1 = 16 bit of the operand type (bf16 / f16; the pointers then address 2-byte elements, all strides
                                       and offsets stay in elements).  The conv towers of the 16-bit modes keep their maps in 16 bit. */
+    int32_t algo;                  /* 0 = direct implicit GEMM.  1 = Winograd F(2x2, 3x3): dtype 0, dense 3x3 taps with iy0 = ix0 = -1, stride 1,
+                                      rep = out_step = 1, no in2; `w` then holds the TRANSFORMED weights U = G g G^T in the k4 layout with the 16
+                                      Winograd positions (row-major 4x4) in place of the taps: float w[16][cin/4][cout_pad][4].  tile_w selects the
+                                      fragment shape (16 Winograd tiles = 64 output pixels): 16, 8 or 4 pixels wide (0 = choose); mt = fragments per
+                                      workgroup (1 or 2, 0 = 2).  2.25x fewer matrix-pipe operations than algo 0 for the same sum. */
 } i2r_conv_desc;
 
 int i2r_conv(const i2r_conv_desc* d, void* stream);
@@ -334,7 +339,8 @@ typedef struct i2r_encoder_desc {
     /* fp32 mode, optional: scratch of the "partial key split".  A launch with between one and two 16-query tiles per CU (256 < n_qtiles16
      * < 512) handles just enough tiles with TWO workgroups (each over half of the group's keys) that every CU carries two workgroups
      * (csrc/i2r_encoder.hip).  split_ws: 256 * 2 * 1792 floats; split_cnt: 256 int32, zero before the first launch (the kernel leaves
-     * them zero).  Both null = one workgroup per tile. */
+     * them zero; a launch that faults half-way may not -- re-zero them before the next one).  Launches that share a scratch pair must be
+     * stream-ordered, never concurrent.  Both null = one workgroup per tile. */
     float* split_ws; int32_t* split_cnt;
 } i2r_encoder_desc;
 

@@ -14,7 +14,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libi2r_hip.so")
 
 MAX_TAPS = 9
-ABI_VERSION = 3  # I2R_ABI_VERSION of include/i2r_hip.h
+ABI_VERSION = 4  # I2R_ABI_VERSION of include/i2r_hip.h
 OP_CONV, OP_STEM, OP_MAXPOOL, OP_HEAD, OP_ENC_KV, OP_ENC_LAYER, OP_FORK, OP_JOIN, OP_CONV_GROUP = 1, 2, 3, 4, 5, 6, 7, 8, 9
 MAX_GROUP = 4
 OP_LAYERNORM, OP_WINATTN, OP_DWCONV, OP_UPSAMPLE = 10, 11, 12, 13
@@ -39,7 +39,7 @@ class ConvDesc(C.Structure):
         ("dy", _i32 * MAX_TAPS), ("dx", _i32 * MAX_TAPS),
         ("out_step", _i32), ("out_off_y", _i32), ("out_off_x", _i32), ("rep", _i32), ("relu", _i32),
         ("tile_h", _i32), ("tile_w", _i32), ("ck", _i32), ("wn", _i32), ("mt", _i32), ("dtype", _i32),
-        ("in_f16", _i32), ("out_f16", _i32),
+        ("in_f16", _i32), ("out_f16", _i32), ("algo", _i32),
     ]
 
 

@@ -34,6 +34,9 @@ struct ConvK {
     int dtype;          // 0 fp32 MFMA, 1 bf16, 2 f16 (fp32 accumulate)
     int in16, out16;    // 16-bit modes: activation storage of the input / of out + res1 + res2 + res_post (0 = fp32, 1 = 16-bit of `dtype`)
     int dbg;            // ablation switches (env I2R_CONV_DBG; tuning only): 1 no epilogue, 2 no staging loads, 4 no weight loads
+    // Winograd F(2x2, 3x3) kernels (i2r_conv_wino.hip; algo == 1): tiles_y / tiles_x count FRAGMENTS (16 Winograd tiles, 2^w_fwlog across)
+    // per crop, ph / pw / plane describe one fragment's raw patch, whose rows have w_pitch slots with the odd columns at + w_half
+    int algo, w_fwlog, w_pitch, w_half, w_nfrag;
 };
 
 constexpr int kMaxPP = 5;  // patch pixels per thread (256 threads) -> patches up to 1280 pixels
@@ -206,3 +209,6 @@ typedef void (*conv_fn)(const ConvGroupK);
 // kernel pickers of the 16-bit translation units (one per operand type, so the three conv files compile in parallel); null = no such variant
 void* i2r_pick_conv_bf16(int nt, int mt, int cap, int pf);
 void* i2r_pick_conv_f16(int nt, int mt, int cap, int pf);
+// Winograd F(2x2, 3x3) fp32 kernels (i2r_conv_wino.hip): MT fragments x NT channel fragments per workgroup; LDS bytes of a workgroup
+void* i2r_pick_conv_wino(int nt, int mt);
+size_t i2r_conv_wino_lds(int nt, int mt, int plane);

@@ -387,6 +387,66 @@ inline int cdiv(int a, int b) { return (a + b - 1) / b; }
 
 }  // namespace
 
+static void copy_desc(const i2r_conv_desc* d, ConvK& k) {
+    k.in = d->in; k.in2 = d->in2; k.w = d->w; k.bias = d->bias; k.res1 = d->res1; k.res2 = d->res2; k.res_post = d->res_post; k.out = d->out;
+    k.n_img = d->n_img; k.in_h = d->in_h; k.in_w = d->in_w; k.in_cs = d->in_cs; k.cin = d->cin;
+    k.conv_h = d->conv_h; k.conv_w = d->conv_w; k.out_h = d->out_h; k.out_w = d->out_w; k.out_cs = d->out_cs;
+    k.cout = d->cout; k.cout_pad = d->cout_pad; k.stride = d->stride; k.iy0 = d->iy0; k.ix0 = d->ix0;
+    k.ntaps = d->ntaps;
+    k.out_step = d->out_step; k.out_off_y = d->out_off_y; k.out_off_x = d->out_off_x; k.rep = d->rep; k.relu = d->relu;
+    k.dtype = d->dtype;
+    k.in16 = d->in_f16; k.out16 = d->out_f16;
+    k.algo = d->algo; k.w_fwlog = k.w_pitch = k.w_half = k.w_nfrag = 0;
+    k.dbg = 0;
+}
+
+// Winograd F(2x2, 3x3) launch geometry (i2r_conv_wino.hip): fragment shape, patch layout in LDS, workgroup count
+static int prepare_wino(const i2r_conv_desc* d, int force_mt, ConvK& k, int* nt_out, int* mt_out, int* cap_out, int* pf_out, size_t* lds_out,
+                        long long* nblk_out) {
+    I2R_CHECK_ARG(d->dtype == 0 && !d->in_f16 && !d->out_f16, "i2r_conv: the Winograd kernels are fp32");
+    I2R_CHECK_ARG(d->stride == 1 && d->ntaps == 9 && d->iy0 == -1 && d->ix0 == -1 && d->rep == 1 && d->out_step == 1 && d->out_off_y == 0 &&
+                      d->out_off_x == 0 && d->in2 == nullptr,
+                  "i2r_conv: algo 1 (Winograd) needs a plain 3x3 stride-1 pad-1 convolution");
+    for (int t = 0; t < 9; ++t) I2R_CHECK_ARG(d->dy[t] == t / 3 && d->dx[t] == t % 3, "i2r_conv: algo 1 needs row-major 3x3 taps");
+    I2R_CHECK_ARG(d->conv_h == d->in_h && d->conv_w == d->in_w && d->out_h == d->conv_h && d->out_w == d->conv_w, "i2r_conv: algo 1 geometry");
+    const int nfrag = d->cout_pad / 16;
+    const int nt = nfrag % 3 == 0 ? 3 : (nfrag % 4 == 0 ? 4 : 0);
+    I2R_CHECK_ARG(nt != 0, "i2r_conv: algo 1 needs cout_pad=%d to be a multiple of 48 or 64", d->cout_pad);
+    const int mt = force_mt ? force_mt : (d->mt ? d->mt : 2);
+    I2R_CHECK_ARG(mt == 1 || mt == 2, "i2r_conv: algo 1 takes mt 1 or 2 (got %d)", mt);
+    int fw = 0;  // Winograd tiles across a fragment of 16 (64 output pixels): the shape that covers the map with the fewest fragments
+    if (d->tile_w) {
+        I2R_CHECK_ARG(d->tile_w == 16 || d->tile_w == 8 || d->tile_w == 4, "i2r_conv: algo 1 fragment width %d (16, 8, 4)", d->tile_w);
+        fw = d->tile_w / 2;
+    } else {
+        long long best = -1;
+        for (int cand : {8, 4, 2}) {
+            const long long n = (long long)cdiv(d->conv_w, 2 * cand) * cdiv(d->conv_h, 32 / cand);
+            if (best < 0 || n < best) { best = n; fw = cand; }
+        }
+    }
+    copy_desc(d, k);
+    k.w_fwlog = fw == 8 ? 3 : (fw == 4 ? 2 : 1);
+    k.tile_w = 2 * fw; k.tile_h = 32 / fw;
+    k.tiles_x = cdiv(d->conv_w, k.tile_w); k.tiles_y = cdiv(d->conv_h, k.tile_h);
+    k.n_cblk = nfrag / nt;
+    k.ph = k.tile_h + 2; k.pw = k.tile_w + 2;
+    // row pitch (16-byte slots): odd columns sit at + half; 2 * pitch = 8 / 4 / 2 (mod 16) for fw = 8 / 4 / 2, so the 16 tiles of a
+    // fragment (fw across) gather 16 distinct slots modulo 16 for every (row, column) of their 4x4 patches
+    k.w_half = fw + 1;
+    k.w_pitch = fw == 8 ? 20 : (fw == 4 ? 10 : 9);
+    k.plane = cdiv(k.ph * k.w_pitch, 16) * 16;
+    k.tap_kw = k.tap_kh = 3;
+    k.ck = 16; k.wn = 1;
+    const long long nf = (long long)d->n_img * k.tiles_y * k.tiles_x;
+    I2R_CHECK_ARG(nf > 0 && nf < (1ll << 28), "i2r_conv: grid");
+    k.w_nfrag = (int)nf;
+    *nt_out = nt; *mt_out = mt; *cap_out = 0; *pf_out = 100;
+    *lds_out = i2r_conv_wino_lds(nt, mt, k.plane);
+    *nblk_out = (nf + mt - 1) / mt * k.n_cblk;
+    return I2R_OK;
+}
+
 // validate one descriptor and derive its launch geometry; *nt_out/*mt_out: fragment blocking, *lds_out: LDS bytes
 static int prepare(const i2r_conv_desc* d, int force_mt, int force_cap, int force_pf, ConvK& k, int* nt_out, int* mt_out, int* cap_out,
                    int* pf_out, size_t* lds_out, long long* nblk_out) {
@@ -406,6 +466,8 @@ static int prepare(const i2r_conv_desc* d, int force_mt, int force_cap, int forc
                       (d->conv_w - 1) * d->out_step + d->out_off_x + d->rep <= d->out_w,
                   "i2r_conv: destination grid exceeds out tensor");
     I2R_CHECK_ARG(d->in2 != (const float*)d->out && d->in != (const float*)d->out, "i2r_conv: out aliases in");
+    I2R_CHECK_ARG(d->algo == 0 || d->algo == 1, "i2r_conv: algo %d", d->algo);
+    if (d->algo == 1) return prepare_wino(d, force_mt, k, nt_out, mt_out, cap_out, pf_out, lds_out, nblk_out);
 
     int max_dy = 0, max_dx = 0;
     for (int t = 0; t < d->ntaps; ++t) {
@@ -442,12 +504,7 @@ static int prepare(const i2r_conv_desc* d, int force_mt, int force_cap, int forc
     if (mt == 0) mt = cdiv(th * tw, wm * 16);
     I2R_CHECK_ARG(mt >= 1 && mt <= 4 && th * tw <= wm * mt * 16, "i2r_conv: tile %dx%d does not fit wm=%d mt=%d", th, tw, wm, mt);
 
-    k.in = d->in; k.in2 = d->in2; k.w = d->w; k.bias = d->bias; k.res1 = d->res1; k.res2 = d->res2; k.res_post = d->res_post; k.out = d->out;
-    k.n_img = d->n_img; k.in_h = d->in_h; k.in_w = d->in_w; k.in_cs = d->in_cs; k.cin = d->cin;
-    k.conv_h = d->conv_h; k.conv_w = d->conv_w; k.out_h = d->out_h; k.out_w = d->out_w; k.out_cs = d->out_cs;
-    k.cout = d->cout; k.cout_pad = d->cout_pad; k.stride = d->stride; k.iy0 = d->iy0; k.ix0 = d->ix0;
-    k.ntaps = d->ntaps;
-    k.out_step = d->out_step; k.out_off_y = d->out_off_y; k.out_off_x = d->out_off_x; k.rep = d->rep; k.relu = d->relu;
+    copy_desc(d, k);
     k.tile_h = th; k.tile_w = tw;
     k.tiles_y = cdiv(d->conv_h, th); k.tiles_x = cdiv(d->conv_w, tw);
     k.n_cblk = nfrag / (nt * wn);
@@ -522,15 +579,11 @@ static int prepare(const i2r_conv_desc* d, int force_mt, int force_cap, int forc
     k.ck = ck;
     I2R_CHECK_ARG(lds_bytes <= 160 * 1024, "i2r_conv: LDS %zu B", lds_bytes);
     k.wn = wn;
-    k.dtype = d->dtype;
-    k.in16 = d->in_f16; k.out16 = d->out_f16;
 #ifdef I2R_TUNING
     {
         static const int dbg = getenv("I2R_CONV_DBG") ? atoi(getenv("I2R_CONV_DBG")) : 0;
         k.dbg = dbg;
     }
-#else
-    k.dbg = 0;
 #endif
     const long long nblk = (long long)d->n_img * k.tiles_y * k.tiles_x * k.n_cblk;
     I2R_CHECK_ARG(nblk > 0 && nblk < (1ll << 30), "i2r_conv: grid");
@@ -544,7 +597,8 @@ static int resolve(const i2r_conv_desc* const* descs, int32_t n, ConvGroupK& grp
     int nt0 = 0, mt0 = 0, pf0 = -1, cap0 = 4;
     size_t lds_max = 0;
     long long total = 0;
-    if (n > 1) {  // members must share the staging variant: the most general one any member needs
+    for (int i = 0; i < n; ++i) I2R_CHECK_ARG(descs[i] && descs[i]->algo == descs[0]->algo, "i2r_conv_grouped: members mix algorithms");
+    if (n > 1 && descs[0]->algo == 0) {  // members must share the staging variant: the most general one any member needs
         pf0 = 0;
         cap0 = 4;
         bool all_pf = true;
@@ -594,7 +648,8 @@ extern "C" int i2r_conv_grouped(const i2r_conv_desc* const* descs, int32_t n, co
     if (rc) return rc;
     grp.blk_map = block_map;
     I2R_CHECK_ARG(block_map == nullptr || map_len == (int32_t)total, "i2r_conv_grouped: block_map has %d entries, grid has %lld", map_len, total);
-    conv_fn fn = descs[0]->dtype == 0 ? pick_kernel(nt0, mt0, cap0, pf0)
+    conv_fn fn = descs[0]->algo == 1 ? reinterpret_cast<conv_fn>(i2r_pick_conv_wino(nt0, mt0))
+                 : descs[0]->dtype == 0 ? pick_kernel(nt0, mt0, cap0, pf0)
                                       : reinterpret_cast<conv_fn>(descs[0]->dtype == 1 ? i2r_pick_conv_bf16(nt0, mt0, cap0, pf0) : i2r_pick_conv_f16(nt0, mt0, cap0, pf0));
     I2R_CHECK_ARG(fn != nullptr, "i2r_conv: no kernel for nt=%d mt=%d cap=%d pf=%d dtype=%d", nt0, mt0, cap0, pf0, descs[0]->dtype);
     if (lds_max > 64 * 1024)
@@ -707,7 +762,9 @@ extern "C" int i2r_conv_kernel_name(const i2r_conv_desc* const* descs, int32_t n
     int rc = resolve(descs, n, grp, &nt0, &mt0, &cap0, &pf0, &lds_max, &total);
     if (rc) return rc;
     I2R_CHECK_ARG(buf && buflen > 0, "i2r_conv_kernel_name: buffer");
-    if (descs[0]->dtype)
+    if (descs[0]->algo == 1)
+        snprintf(buf, (size_t)buflen, "conv_wino_f32<%d, %d>", mt0, nt0);
+    else if (descs[0]->dtype)
         snprintf(buf, (size_t)buflen, "conv_igemm_lp<%d, %d, %d, %d>/%s", mt0, nt0, cap0, pf0, descs[0]->dtype == 1 ? "bf16" : "f16");
     else
         snprintf(buf, (size_t)buflen, "conv_igemm_f32<%d, %d, %d, %d>", mt0, nt0, cap0, pf0);

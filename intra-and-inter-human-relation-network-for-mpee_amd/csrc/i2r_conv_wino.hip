@@ -1,0 +1,279 @@
+// 3x3 stride-1 convolution as Winograd F(2x2, 3x3) on the fp32 matrix pipe (v_mfma_f32_16x16x4_f32), gfx950.
+//
+// Why: the fp32 MFMA runs at the fp32 VECTOR rate (157 TFLOP/s, 1/16 of the 16-bit pipe) and the direct implicit-GEMM kernel
+// (i2r_conv.hip) is bound by exactly that pipe; its HBM side sits at 9 % of the roof.  F(2x2, 3x3) computes a 2x2 output tile from
+// a 4x4 input tile with 16 multiplies per (cin, cout) pair instead of 36:  Y = A^T [ (G g G^T) . (B^T d B) ] A  -- 2.25x fewer
+// MFMAs for the same result (exact in exact arithmetic; in fp32 the rounding differs from the direct sum by a few ulp of the
+// partial sums, far inside the 1e-3 parity bar -- tests/test_kernels_gpu.py).  The weights U = G g G^T are transformed once at
+// pack time in float64 (engine.Packer.conv) and stored "k4" with the 16 Winograd positions in place of the 9 taps.
+//
+// Decomposition (one 4-wave workgroup):
+//  * M = Winograd tiles.  A FRAGMENT is 16 tiles = 64 output pixels laid out FW x (16/FW) tiles (FW = 8, 4 or 2, chosen per map so
+//    that fragments cover the map without waste: 64x48 -> 16x4 px, 32x24 -> 8x8 px, 16x12 -> 4x16 px); a workgroup owns MT
+//    consecutive fragments of the flattened (crop, fy, fx) list and NT x 16 output channels.  Every fragment stages its own
+//    (2 FH + 2) x (2 FW + 2) input patch, so fragments of a workgroup may belong to different crops.
+//  * wave i (0..3) owns ROW i of the 4x4 Winograd positions: positions (i, 0..3) x MT fragments x NT channel fragments =
+//    4 MT NT accumulator tiles.  Row i of  B^T d B  needs only two rows of d: the wave reads 2 x 4 patch pixels per tile from the RAW
+//    patch in LDS and does the input transform in registers (8 ds_read_b128 + 32 VALU per fragment and 16-channel step, next to
+//    48 MT MFMAs) -- the transformed tensor (3.2x the patch) never exists in LDS.
+//  * LDS holds the raw patch of a 16-channel chunk, double-buffered, the next chunk fetched into registers under the current
+//    chunk's MFMAs (as in i2r_conv.hip).  Columns are de-interleaved by parity (slot = row * pitch + (x & 1) * half + (x >> 1)) and
+//    the pitch is chosen per FW so that the stride-2 tile gathers of a 16-lane ds_read_b128 group hit 16 distinct 16-byte slots.
+//  * B operands (U, k-permuted k4 packing) stream from L2 straight into registers one position ahead, as in the direct kernel.
+//  * epilogue: the column half of the output transform (over j) is in-lane; the row half (over i) crosses the four waves: each
+//    wave writes its two partial tiles T_i[b] to LDS as [i][b][tile][cout] and every thread then owns (pixel, 4 channels) pieces:
+//    three 16-byte LDS reads, bias / residuals / ReLU, one 16-byte store (a quad of lanes = 64 contiguous bytes of one pixel).
+#include "i2r_conv.h"
+
+namespace {
+
+constexpr int kWinoPatchMax = 108;  // patch pixels of a fragment: 6 x 18 (FW = 8 or 2), 10 x 10 (FW = 4)
+
+template <int MT, int NT>
+__device__ __forceinline__ void wino_body(const ConvK& p, int bid, f32x4* lds) {
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wi = __builtin_amdgcn_readfirstlane(tid >> 6);  // Winograd row of this wave
+    const int li = lane & 15, g = lane >> 4;
+    const int cb = bid % p.n_cblk;
+    const int wg = bid / p.n_cblk;
+    const int fwl = p.w_fwlog, FW = 1 << fwl;  // tiles across a fragment
+    const int PC = p.pw, PP = p.ph * p.pw;
+    const int per_img = p.tiles_y * p.tiles_x;
+    const int pitch = p.w_pitch, half = p.w_half, plane = p.plane;
+
+    int f_img[MT], f_oy[MT], f_ox[MT];
+    bool f_ok[MT];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) {
+        int fid = wg * MT + mt;
+        f_ok[mt] = fid < p.w_nfrag;
+        if (!f_ok[mt]) fid = 0;
+        f_img[mt] = fid / per_img;
+        const int rem = fid - f_img[mt] * per_img;
+        const int fy = rem / p.tiles_x;
+        f_oy[mt] = fy * (32 >> fwl);
+        f_ox[mt] = (rem - fy * p.tiles_x) * (2 * FW);
+    }
+
+    // ---- staging assignment: item = (fragment, patch pixel, channel group of the 16-channel chunk); the four lanes of a quad
+    //      fetch the 64 contiguous bytes of one pixel (quad rule of the texture addresser, see i2r_conv.hip) ----
+    constexpr int NIT = (MT * kWinoPatchMax * 4 + 255) / 256;
+    int goff[NIT], lslot[NIT];
+    bool gval[NIT];
+#pragma unroll
+    for (int k = 0; k < NIT; ++k) {
+        const int it = tid + k * 256;
+        const int cg = it & 3, pix = it >> 2;
+        const int f = pix / PP, pp = pix - f * PP;
+        const int row = pp / PC, col = pp - row * PC;
+        goff[k] = 0;
+        gval[k] = false;
+        lslot[k] = -1;
+        if (f < MT) {
+            int img = f_img[0], oy = f_oy[0], ox = f_ox[0];
+            bool ok = f_ok[0];
+#pragma unroll
+            for (int m = 1; m < MT; ++m)
+                if (f == m) { img = f_img[m]; oy = f_oy[m]; ox = f_ox[m]; ok = f_ok[m]; }
+            const int iy = oy - 1 + row, ix = ox - 1 + col;
+            lslot[k] = (f * 4 + cg) * plane + row * pitch + (col & 1) * half + (col >> 1);
+            if (ok && iy >= 0 && iy < p.in_h && ix >= 0 && ix < p.in_w) {
+                goff[k] = ((img * p.in_h + iy) * p.in_w + ix) * p.in_cs + cg * 4;
+                gval[k] = true;
+            }
+        }
+    }
+    f32x4 v[NIT];
+    auto stage_load = [&](int c0) {
+#pragma unroll
+        for (int k = 0; k < NIT; ++k)
+            v[k] = gval[k] ? *reinterpret_cast<const f32x4*>(p.in + goff[k] + c0) : (f32x4){0.f, 0.f, 0.f, 0.f};
+    };
+    auto stage_store = [&](f32x4* buf) {
+#pragma unroll
+        for (int k = 0; k < NIT; ++k)
+            if (lslot[k] >= 0) buf[lslot[k]] = v[k];
+    };
+
+    // ---- A operand: lane (tile li, channel group g) gathers rows ra, rb of its tile's 4x4 patch and forms row i of B^T d B ----
+    //      i = 0: d0 - d2,  1: d1 + d2,  2: d2 - d1,  3: d1 - d3
+    const int ra = wi == 0 ? 0 : (wi == 2 ? 2 : 1);
+    const int rb = wi == 0 ? 2 : (wi == 1 ? 2 : (wi == 2 ? 1 : 3));
+    const float sg = wi == 1 ? 1.f : -1.f;
+    const int ty = li >> fwl, tx = li & (FW - 1);
+    const int abase = g * plane + 2 * ty * pitch + tx;
+    const int oa = ra * pitch, ob = rb * pitch;
+    auto load_a = [&](const f32x4* buf, f32x4 (&a)[MT][4]) {
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) {
+            const f32x4* q = buf + mt * 4 * plane + abase;
+            f32x4 R[4];
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                const int oc = (c & 1) * half + (c >> 1);
+                const f32x4 xa = q[oa + oc], xb = q[ob + oc];
+                R[c] = xa + sg * xb;
+            }
+            a[mt][0] = R[0] - R[2];
+            a[mt][1] = R[1] + R[2];
+            a[mt][2] = R[2] - R[1];
+            a[mt][3] = R[1] - R[3];
+        }
+    };
+
+    // ---- B operand: U[pos = 4 i + j][cin / 4][cout_pad][4], lane (cout li, g) takes channels 4g..4g+3 of the 16-channel step ----
+    const int n_base = cb * NT * 16;
+    const int cin4 = p.cin >> 2;
+    const f32x4* const wq = reinterpret_cast<const f32x4*>(p.w) + n_base + li;
+    auto fetch_b = [&](f32x4 (&b)[NT], int pass, int j) {
+        const f32x4* wp = wq + (size_t)((wi * 4 + j) * cin4 + pass * 4 + g) * p.cout_pad;
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) b[nt] = wp[nt * 16];
+    };
+
+    f32x4 acc[4][MT][NT];
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) acc[j][mt][nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    const int npass = p.cin >> 4;
+    const int bufsz = MT * 4 * plane;
+    f32x4 a[MT][4], b0[NT], b1[NT];
+#define WINO_MMA(J, B)                                                                                          \
+    _Pragma("unroll") for (int s = 0; s < 4; ++s) _Pragma("unroll") for (int mt = 0; mt < MT; ++mt)             \
+        _Pragma("unroll") for (int nt = 0; nt < NT; ++nt) acc[J][mt][nt] = mfma16(a[mt][J][s], B[nt][s], acc[J][mt][nt]);
+    stage_load(0);
+    fetch_b(b0, 0, 0);
+    stage_store(lds);
+    __syncthreads();
+    for (int pass = 0; pass < npass; ++pass) {
+        f32x4* cur = lds + (pass & 1) * bufsz;
+        f32x4* nxt = lds + ((pass + 1) & 1) * bufsz;
+        const bool more = pass + 1 < npass;
+        if (more) stage_load((pass + 1) * 16);
+        load_a(cur, a);
+        fetch_b(b1, pass, 1);
+        WINO_MMA(0, b0)
+        fetch_b(b0, pass, 2);
+        WINO_MMA(1, b1)
+        fetch_b(b1, pass, 3);
+        WINO_MMA(2, b0)
+        fetch_b(b0, more ? pass + 1 : 0, 0);  // (wraps after the last pass: stays in bounds, keeps the waits counted)
+        WINO_MMA(3, b1)
+        if (more) stage_store(nxt);
+        __syncthreads();
+    }
+#undef WINO_MMA
+
+    // ---- output transform.  Over j in registers:  T[0] = m0 + m1 + m2,  T[1] = m1 - m2 - m3 ----
+    float* const Tl = reinterpret_cast<float*>(lds);
+    constexpr int TW = NT * 16;           // floats per tile row of the exchange buffer
+    constexpr int TPL = MT * 16 * TW;     // floats per (i, b) plane
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) {
+            const f32x4 t0 = acc[0][mt][nt] + acc[1][mt][nt] + acc[2][mt][nt];
+            const f32x4 t1 = acc[1][mt][nt] - acc[2][mt][nt] - acc[3][mt][nt];
+            float* q = Tl + (size_t)(wi * 2) * TPL + (mt * 16 + 4 * g) * TW + nt * 16 + li;  // D layout: rows 4g + r, column li
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                q[r * TW] = t0[r];
+                q[TPL + r * TW] = t1[r];
+            }
+        }
+    // ---- over i across the waves:  Y[0][b] = T0 + T1 + T2,  Y[1][b] = T1 - T2 - T3;  thread = (pixel, 4 channels) ----
+    constexpr int C4 = NT * 4;                         // 16-byte channel pieces per pixel
+    constexpr int NOUT = MT * 64 * C4 / 256;           // pieces per thread
+    size_t ooff[NOUT];
+    bool oval[NOUT];
+    f32x4 r[NOUT];
+    int lrd[NOUT];
+    bool hi[NOUT];
+#pragma unroll
+    for (int k = 0; k < NOUT; ++k) {
+        const int idx = tid + k * 256;
+        const int c4 = idx % C4, pix = idx / C4;
+        const int tile = pix >> 2, ay = (pix >> 1) & 1, bx = pix & 1;
+        const int f = tile >> 4, t = tile & 15;
+        int img = f_img[0], oy = f_oy[0], ox = f_ox[0];
+        bool ok = f_ok[0];
+#pragma unroll
+        for (int m = 1; m < MT; ++m)
+            if (f == m) { img = f_img[m]; oy = f_oy[m]; ox = f_ox[m]; ok = f_ok[m]; }
+        oy += 2 * (t >> fwl) + ay;
+        ox += 2 * (t & (FW - 1)) + bx;
+        const int n = n_base + c4 * 4;
+        oval[k] = ok && oy < p.conv_h && ox < p.conv_w && n < p.cout_pad && (n + 4 <= p.cout || n + 4 <= p.out_cs);
+        ooff[k] = ((size_t)(img * p.out_h + oy) * p.out_w + ox) * p.out_cs + n;
+        lrd[k] = bx * TPL + tile * TW + c4 * 4;
+        hi[k] = ay != 0;
+        r[k] = n < p.cout_pad ? *reinterpret_cast<const f32x4*>(p.bias + n) : (f32x4){0.f, 0.f, 0.f, 0.f};
+        if (oval[k]) {
+            if (p.res1) r[k] += *reinterpret_cast<const f32x4*>(p.res1 + ooff[k]);
+            if (p.res2) r[k] += *reinterpret_cast<const f32x4*>(p.res2 + ooff[k]);
+        }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < NOUT; ++k) {
+        const float* q = Tl + lrd[k];
+        const f32x4 u1 = *reinterpret_cast<const f32x4*>(q + 2 * TPL);   // T1
+        const f32x4 u2 = *reinterpret_cast<const f32x4*>(q + 4 * TPL);   // T2
+        const f32x4 u0 = *reinterpret_cast<const f32x4*>(q + (hi[k] ? 6 * TPL : 0));  // T3 or T0
+        f32x4 y = hi[k] ? (u1 - u2 - u0) : (u0 + u1 + u2);
+        if (!oval[k]) continue;
+        y += r[k];
+        if (p.relu == 1) {
+            y[0] = fmaxf(y[0], 0.f); y[1] = fmaxf(y[1], 0.f); y[2] = fmaxf(y[2], 0.f); y[3] = fmaxf(y[3], 0.f);
+        } else if (p.relu == 2) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) y[e] = 0.5f * y[e] * (1.f + erff(y[e] * 0.70710678118654752f));
+        }
+        if (p.res_post) y += *reinterpret_cast<const f32x4*>(p.res_post + ooff[k]);
+        const int n = n_base + (int)((tid + k * 256) % C4) * 4;
+        if (n + 4 > p.cout) {  // channels >= cout are padding: keep them exactly zero
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+                if (n + e >= p.cout) y[e] = 0.f;
+        }
+        *reinterpret_cast<f32x4*>(p.out + ooff[k]) = y;
+    }
+}
+
+template <int MT, int NT>
+__global__ __launch_bounds__(256) void conv_wino_f32(const ConvGroupK grp) {
+    extern __shared__ __attribute__((aligned(16))) f32x4 lds[];
+    int bid = blockIdx.x, gi = 0, start = 0;
+    if (grp.blk_map) {
+        const int v = grp.blk_map[bid];
+        gi = v >> 24;
+        bid = v & 0xFFFFFF;
+    } else {
+#pragma unroll
+        for (int i = 0; i < kMaxGroups - 1; ++i)
+            if (i + 1 < grp.n && bid >= grp.blk_end[i]) { gi = i + 1; start = grp.blk_end[i]; }
+    }
+    wino_body<MT, NT>(grp.g[gi], bid - start, lds);
+}
+
+}  // namespace
+
+void* i2r_pick_conv_wino(int nt, int mt) {
+    conv_fn fn = nullptr;
+    if (mt == 2 && nt == 3) fn = conv_wino_f32<2, 3>;
+    if (mt == 2 && nt == 4) fn = conv_wino_f32<2, 4>;
+    if (mt == 1 && nt == 3) fn = conv_wino_f32<1, 3>;
+    if (mt == 1 && nt == 4) fn = conv_wino_f32<1, 4>;
+    return reinterpret_cast<void*>(fn);
+}
+
+// LDS bytes of a Winograd workgroup: two raw-patch chunk buffers, re-used by the cross-wave exchange of the output transform
+size_t i2r_conv_wino_lds(int nt, int mt, int plane) {
+    const size_t stage = (size_t)2 * mt * 4 * plane * 16;
+    const size_t xchg = (size_t)4 * 2 * mt * 16 * nt * 16 * 4;
+    return stage > xchg ? stage : xchg;
+}

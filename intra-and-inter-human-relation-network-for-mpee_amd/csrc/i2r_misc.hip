@@ -404,8 +404,8 @@ __global__ __launch_bounds__(256) void head_mfma_k(const float* __restrict__ in,
 // of one output pixel (consecutive lanes = consecutive channel quadruples of a pixel, then the next pixel: fully coalesced);
 // HBM-bound: reads base once, writes out once, the low-resolution maps come from L2.
 template <int DT>
-__global__ __launch_bounds__(256) void fuse_up_add_k(const float* __restrict__ base, const float* __restrict__ t1, int sh1,
-                                                     const float* __restrict__ t2, int sh2, float* __restrict__ out, long long nq, int h,
+__global__ __launch_bounds__(256) void fuse_up_add_k(const float* base, const float* __restrict__ t1, int sh1,  // (base may alias out)
+                                                     const float* __restrict__ t2, int sh2, float* out, long long nq, int h,
                                                      int w, int cs4, int act) {
     const long long gid = (long long)blockIdx.x * 256 + threadIdx.x;
     if (gid >= nq) return;

@@ -72,8 +72,30 @@ def pack_k8(w_taps, cin_pad, cout_pad, tdtype):
     return full.float().to(tdtype).view(nt, g8_pad, 8, cout_pad).permute(0, 1, 3, 2).contiguous()
 
 
+def winograd_weights(wf):
+    """[cout, cin, 3, 3] float64 -> U = G g G^T per (cout, cin) as [16, cin, cout] (position p = 4 i + j), the weight side of
+    Winograd F(2x2, 3x3) (csrc/i2r_conv_wino.hip); done in float64 and rounded once to fp32 by pack_k4"""
+    G = torch.tensor([[1.0, 0.0, 0.0], [0.5, 0.5, 0.5], [0.5, -0.5, 0.5], [0.0, 0.0, 1.0]], dtype=torch.float64)
+    U = torch.einsum("ia,ocab,jb->ijco", G, wf.double(), G)
+    return U.reshape(16, wf.shape[1], wf.shape[0])
+
+
+def wino_fragment(conv_h, conv_w):
+    """(fragment width, height) in output pixels of the Winograd kernels for a map: 16 tiles as 8x2, 4x4 or 2x8 -- the shape that
+    covers the map with the fewest fragments (same rule as prepare_wino in csrc/i2r_conv.hip)"""
+    best = None
+    for fw in (8, 4, 2):
+        n = -(-conv_w // (2 * fw)) * -(-conv_h // (32 // fw))
+        if best is None or n < best[0]:
+            best = (n, 2 * fw, 32 // fw)
+    return best[1], best[2]
+
+
+WINOGRAD = os.environ.get("I2R_WINOGRAD", "1") != "0"  # fp32 3x3 stride-1 convs on the Winograd F(2x2, 3x3) kernels (A/B switch for tools/)
+
+
 class PackedConv:
-    __slots__ = ("w", "bias", "cin", "cin_pad", "cout", "cout_pad", "taps", "iy0", "ix0", "stride", "ksize", "dtype")
+    __slots__ = ("w", "bias", "cin", "cin_pad", "cout", "cout_pad", "taps", "iy0", "ix0", "stride", "ksize", "dtype", "w_wino")
 
     def __init__(self, w, bias, cin, cout, taps, iy0, ix0, stride, ksize, cin_pad=None, dtype=0):
         self.w, self.bias = w, bias
@@ -81,6 +103,7 @@ class PackedConv:
         self.cout, self.cout_pad = cout, w.shape[2]
         self.taps, self.iy0, self.ix0, self.stride, self.ksize = taps, iy0, ix0, stride, ksize
         self.dtype = dtype
+        self.w_wino = None  # fp32 3x3 stride-1 convs: the Winograd-domain weights [16][cin/4][cout_pad][4] (Packer.conv)
 
 
 class Packer:
@@ -118,7 +141,11 @@ class Packer:
         bias = torch.zeros(cout_pad, dtype=torch.float64)
         bias[:cout] = bf
         pad = kh // 2
-        return self._pc(w_taps, self._dev(bias.float()), cin, cout, taps, -pad, -pad, stride, kh)
+        pc = self._pc(w_taps, self._dev(bias.float()), cin, cout, taps, -pad, -pad, stride, kh)
+        nfrag = cout_pad // 16
+        if self.dtype == 0 and kh == 3 and stride == 1 and (nfrag % 3 == 0 or nfrag % 4 == 0):
+            pc.w_wino = self._dev(pack_k4(winograd_weights(wf), _r16(cin), cout_pad))
+        return pc
 
     def conv_cat(self, parts, eps=1e-5):
         """Sum of 1x1 convs (+BN each) over DIFFERENT inputs as ONE 1x1 conv over the channel concatenation of those inputs:
@@ -482,6 +509,7 @@ class Program:
         self.lane_ctx = 0    # lane whose ops are being emitted (set by the emitters inside a fork region)
         self.groupings = []  # (grouping, tokens per crop) of encoders whose groups follow `length` (set_groups)
         self.enc_stacks = []
+        self.split_counters = []  # hand-off counters of the encoder stacks (zero between launches; re-zeroed when a run fails)
         self.store_dt = 0    # storage type the conv TOWER keeps its maps in (set by the engine in the 16-bit modes: 1 bf16, 2 f16)
         self.in_fork = False
         self.nbytes = 0
@@ -568,15 +596,31 @@ class Program:
             d.dy[i], d.dx[i] = dy, dx
         d.out_step, d.out_off_y, d.out_off_x, d.rep = out_step, out_off[0], out_off[1], up
         d.relu = int(relu) if act is None else act  # 0 none, 1 ReLU, 2 GELU
-        nt, wn = conv_split(pc.cout_pad)
-        n_cblk = (pc.cout_pad // 16) // (nt * wn)
-        max_d = max(max(t) for t in pc.taps)
-        th, tw, mt = choose_tile(conv_h, conv_w, 4 // wn, pc.stride, max_d, x.n, n_cblk)
-        d.tile_h, d.tile_w, d.mt, d.wn, d.ck = th, tw, mt, wn, 0
         d.dtype = pc.dtype
         d.in_f16, d.out_f16 = int(x.dt != 0), int(out.dt != 0)
+        wino = (WINOGRAD and pc.w_wino is not None and pc.dtype == 0 and in2 is None and up == 1 and out_step == 1 and tuple(out_off) == (0, 0)
+                and (out.h, out.w) == (conv_h, conv_w))
+        if wino:
+            # Winograd F(2x2, 3x3): 2.25x fewer matrix-pipe operations (csrc/i2r_conv_wino.hip); NT 3 or 4, two fragments per workgroup
+            nfrag = pc.cout_pad // 16
+            nt = 3 if nfrag % 3 == 0 else 4
+            fw, fh = wino_fragment(conv_h, conv_w)
+            d.algo, d.w = 1, pc.w_wino.data_ptr()
+            mt = 2 if nt == 3 else 1  # (NT = 4 with two fragments needs 265 registers: one wave per SIMD)
+            d.tile_h, d.tile_w, d.mt, d.wn, d.ck = fh, fw, mt, 1, 0
+            n_frag = x.n * -(-conv_h // fh) * -(-conv_w // fw)
+            geo = ("wino", -(-n_frag // mt) * (nfrag // nt))
+            key = ("wino", nt, mt)
+        else:
+            nt, wn = conv_split(pc.cout_pad)
+            n_cblk = (pc.cout_pad // 16) // (nt * wn)
+            max_d = max(max(t) for t in pc.taps)
+            th, tw, mt = choose_tile(conv_h, conv_w, 4 // wn, pc.stride, max_d, x.n, n_cblk)
+            d.tile_h, d.tile_w, d.mt, d.wn, d.ck = th, tw, mt, wn, 0
+            geo = (conv_h, conv_w, 4 // wn, pc.stride, max_d, x.n, n_cblk)
+            key = nt
         if group is not None:
-            group.append((d, (conv_h, conv_w, 4 // wn, pc.stride, max_d, x.n, n_cblk), nt))
+            group.append((d, geo, key))
         else:
             self.ops.append((cabi.OP_CONV, lane, d))
         return out
@@ -611,7 +655,8 @@ class Program:
         7.9 ms/step against 7.2 ms with per-layer launches -- the per-item cache invalidation that makes the
         producer's data visible costs more than the layer barriers it removes.  Returns True if the chain launch was used."""
         G = len(layers[0])
-        ok = G <= cabi.MAX_GROUP and all(len(g) == G for g in layers) and len({m[2] for g in layers for m in g}) == 1
+        ok = (G <= cabi.MAX_GROUP and all(len(g) == G for g in layers) and len({m[2] for g in layers for m in g}) == 1
+              and not any(m[0].algo for g in layers for m in g))
         if not ok or os.environ.get("I2R_CONV_CHAIN", "0") != "1":
             for g in layers:
                 self.flush_group(g, lane)
@@ -678,21 +723,28 @@ class Program:
             return
         nts = {g[2] for g in group}
         if len(group) == 1 or len(nts) != 1 or len(group) > cabi.MAX_GROUP:
+            # (no common fragment blocking, or more members than a launch holds: sequential launches.  The shipped HRNet towers have
+            #  <= 3 branches, whose levels stay within MAX_GROUP; a 4-branch module would land here for its 6-member fuse level)
             for d, _, _ in group:
                 self.ops.append((cabi.OP_CONV, lane, d))
             del group[:]
             return
-        mt, tiles = self._group_tiles(group)
+        wino = group[0][0].algo == 1  # (the group key keeps the two algorithms apart)
+        if not wino:
+            mt, tiles = self._group_tiles(group)
         order = sorted(range(len(group)), key=lambda i: -(group[i][0].cin * group[i][0].ntaps))
         a = cabi.ConvGroupArgs()
         counts, works = [], []
         for slot, i in enumerate(order):
             d, geo, _ = group[i]
-            d.tile_h, d.tile_w, d.mt = tiles[i][1], tiles[i][2], mt
             a.d[slot] = C.pointer(d)
             self.keep.append(d)
-            conv_h, conv_w, wm, stride, max_d, n_img, n_cblk = geo
-            counts.append(-(-conv_h // d.tile_h) * -(-conv_w // d.tile_w) * n_img * n_cblk)
+            if wino:
+                counts.append(geo[1])
+            else:
+                d.tile_h, d.tile_w, d.mt = tiles[i][1], tiles[i][2], mt
+                conv_h, conv_w, wm, stride, max_d, n_img, n_cblk = geo
+                counts.append(-(-conv_h // d.tile_h) * -(-conv_w // d.tile_w) * n_img * n_cblk)
             works.append(d.cin * d.ntaps)
         a.n = len(group)
         if len(set(works)) > 1:
@@ -848,6 +900,7 @@ class Program:
         split_ws = torch.empty(256 * 2 * 1792, dtype=torch.float32, device=self.device)
         split_cnt = torch.zeros(256, dtype=torch.int32, device=self.device)
         self.keep += kbufs + vbufs + [goff, split_ws, split_cnt]
+        self.split_counters.append(split_cnt)
         cur = x
         self.keep.append(layers)
         descs = []
@@ -934,7 +987,8 @@ class Program:
         self.uses_lanes = any(lane != 0 or kind in cabi.SYNC_OPS for kind, lane, _ in self.ops)
 
     def run(self, side_streams=None, events=None):
-        """side_streams: 3 torch.cuda.Stream for lanes 1..3 (None -> everything on the current stream)."""
+        """side_streams: 3 torch.cuda.Stream for lanes 1..3 (None -> everything on the current stream).  A Program owns its
+        activation arena and hand-off counters: never replay one Program concurrently on two streams."""
         L = cabi.lib()
         cur = torch.cuda.current_stream(self.device).cuda_stream
         if side_streams is None:
@@ -946,7 +1000,14 @@ class Program:
             if events is None:
                 events = self._own_events()
             evs = (C.c_void_p * 8)(*[e.cuda_event for e in events])
-        cabi.check(L.i2r_run_program(self._c_ops, len(self.ops), streams, evs), "i2r_run_program")
+        try:
+            cabi.check(L.i2r_run_program(self._c_ops, len(self.ops), streams, evs), "i2r_run_program")
+        except Exception:
+            # a launch list that stopped half-way may leave hand-off counters of the encoder's partial key split non-zero; the
+            # kernels rely on finding them zero (include/i2r_hip.h: split_cnt)
+            for t in self.split_counters:
+                t.zero_()
+            raise
 
     def _own_events(self):
         if not hasattr(self, "_events"):
@@ -1019,7 +1080,7 @@ class HRNetW48:
                 layers.append(grp)
             else:
                 P.flush_group(grp)
-        if uniform:
+        if uniform and layers:
             P.conv_chain(layers)
         # fuse (interformer_pureMulti.py:392-410): y_i = ReLU(sum_j f_ij(x_j)), f_ii = identity, summed left to right.
         #  * down-sampling terms (j < i, chains of stride-2 convs) are evaluated level by level, one grouped launch per level: every
@@ -1256,16 +1317,18 @@ class HRFormerB:
         return outs
 
     def emit(self, P, n, h, w, n_src=None):
-        a, stem_args = P.stem(self.stem1, n, h, w, n_src=n_src)
+        # 16-bit modes: stem and layer1 (the 64- / 256-channel maps at 1/4 resolution, the largest of the forward) store 16 bit like the
+        # HRNet tower; the transition convs hand the transformer blocks their fp32 residual stream
+        a, stem_args = P.stem(self.stem1, n, h, w, n_src=n_src, out_dt=P.store_dt)
         x = P.stem_conv2_layer1(a, self.conv2, self.layer1)
         ys = [x]
         for st in self.stages:
             xs, grp = [], []  # the transition convs of a stage are independent: one grouped launch when their blocking agrees
             for i, pc in enumerate(st["trans"]):
                 if i < st["n_pre"]:
-                    xs.append(P.conv(ys[i], pc, relu=True, group=grp) if pc is not None else ys[i])
+                    xs.append(P.conv(ys[i], pc, relu=True, group=grp, out_dt=0) if pc is not None else ys[i])
                 else:
-                    xs.append(P.conv(ys[-1], pc, relu=True, group=grp))
+                    xs.append(P.conv(ys[-1], pc, relu=True, group=grp, out_dt=0))
             P.flush_group(grp)
             for i, pc in enumerate(st["trans"]):  # inputs replaced by a transition conv are dead now
                 if i < st["n_pre"] and pc is not None and not any(ys[i] is x_ for x_ in xs):

@@ -70,7 +70,8 @@ class I2RModule(nn.Module):
     # ---- engine lifecycle ----
     def set_precision(self, precision):
         """'fp32' (default: exact-fp32 MFMA, the 1e-3 parity mode), 'bf16' or 'fp16' (BASELINE configs 3-5: 16-bit MFMA
-        operands, fp32 accumulation and fp32 activations in HBM)."""
+        operands, fp32 accumulation; the conv towers store their maps in 16 bit, token rows and the transformer blocks' residual
+        stream stay fp32 in HBM)."""
         from ..engine import PRECISIONS
         assert precision in PRECISIONS, precision
         self.precision = precision

@@ -71,6 +71,55 @@ def test_conv_matches_torch(cin, cout, k, stride, n, h, w, relu, nres, up):
     _conv_case(cin, cout, k, stride, n, h, w, relu, nres, up, tag="%d_%d_%d_%d_%d_%d" % (cin, cout, k, stride, h, up))
 
 
+@pytest.mark.parametrize("cin,cout,n,h,w,relu,nres", [
+    (48, 48, 3, 64, 48, True, 1),     # 16x4-pixel fragments; 3 crops x 48 fragments
+    (96, 96, 3, 32, 24, True, 2),     # 8x8-pixel fragments, two residual inputs
+    (192, 192, 3, 16, 12, False, 0),  # 4x16-pixel fragments: 9 fragments, the workgroups' fragment pairs straddle crops
+    (64, 64, 2, 64, 48, True, 0),     # NT = 4 (layer1's 3x3 convs)
+    (16, 48, 1, 7, 5, True, 1),       # one chunk, odd map smaller than a fragment
+    (48, 96, 5, 23, 17, False, 1),    # odd sizes: partial fragments on both edges, odd fragment count
+    (78, 78, 1, 24, 18, True, 0),     # padded channels stay zero (cs 80 -> 5 fragments: not eligible, stays on the direct kernel)
+])
+def test_conv_winograd_matches_torch_and_direct(cin, cout, n, h, w, relu, nres):
+    """3x3 stride-1 convs run as Winograd F(2x2, 3x3) (csrc/i2r_conv_wino.hip): against torch in float64 at fp32-rounding tolerance,
+    and against the direct implicit-GEMM kernel on the same packed weights"""
+    tag = "wg%d_%d_%d_%d" % (cin, cout, h, w)
+    sd = {"c.weight": _rand((cout, cin, 3, 3), "w" + tag, (6.0 / (cin * 9)) ** 0.5),
+          "b.weight": _rand((cout,), "g" + tag, 0.5) + 1.0, "b.bias": _rand((cout,), "b" + tag, 0.3),
+          "b.running_mean": _rand((cout,), "m" + tag, 0.3), "b.running_var": _rand((cout,), "v" + tag, 0.4) + 1.0}
+    x = _rand((n, cin, h, w), "x" + tag)
+    ref = F.conv2d(x.double(), sd["c.weight"].double(), None, padding=1)
+    ref = F.batch_norm(ref, sd["b.running_mean"].double(), sd["b.running_var"].double(), sd["b.weight"].double(), sd["b.bias"].double(), False, 0.0, 1e-5)
+    res = [_rand(tuple(ref.shape), "r%d%s" % (i, tag)) for i in range(nres)]
+    for r in res:
+        ref = ref + r.double()
+    if relu:
+        ref = F.relu(ref)
+    outs = {}
+    for wino in (True, False):
+        saved = engine.WINOGRAD
+        engine.WINOGRAD = wino
+        try:
+            P = engine.Program(torch.device(DEV))
+            pc = engine.Packer(sd, torch.device(DEV)).conv("c", "b")
+            xa = to_act(P, x)
+            ra = [to_act(P, r) for r in res]
+            out = P.conv(xa, pc, relu=relu, res1=ra[0] if nres > 0 else None, res2=ra[1] if nres > 1 else None)
+            algo = [st.algo for k, _, st in P.ops if k == engine.cabi.OP_CONV]
+            run(P)
+        finally:
+            engine.WINOGRAD = saved
+        eligible = (cout + 15) // 16 % 3 == 0 or (cout + 15) // 16 % 4 == 0
+        assert algo == [1 if (wino and eligible) else 0]
+        outs[wino] = from_act(out).double()
+        assert torch.isfinite(out.t).all()
+        if out.cs > cout:
+            assert out.view()[..., cout:].abs().max().item() == 0.0, "padding channels must stay zero"
+        err = (outs[wino] - ref).abs().max().item()
+        assert err < 2e-5 * max(1.0, ref.abs().max().item()), "%s algo %r: max-abs %.3e" % (tag, algo, err)
+    assert (outs[True] - outs[False]).abs().max().item() < 2e-5 * max(1.0, ref.abs().max().item())
+
+
 def test_conv_without_bn_and_channel_padding():
     _conv_case(192, 96, 1, 1, 2, 16, 12, False, 0, bn=False, tag="nobn")
     # cin 78 (padded to 80 in the activation), cout 78
@@ -288,9 +337,70 @@ def test_fuse_up_add(dt, tol):
     assert (from_act(ba) - F.relu(ref1)).abs().max().item() <= tol
 
 
+@pytest.mark.parametrize("nb", [2, 3])
+def test_hrnet_fuse_module_matches_torch(nb):
+    """the fuse layers of one HighResolutionModule (interformer_pureMulti.py:332-410) as HRNetW48._emit_module schedules them --
+    down-sampling chains level by level in grouped launches, up-sampling terms through i2r_fuse_up_add -- against the torch modules
+    evaluated in float64 (the level scheduling changes the summation order inside the down-sampling part only: rounding)"""
+    chans, sizes, n = [48, 96, 192][:nb], [(32, 24), (16, 12), (8, 6)][:nb], 5
+    sd, q = {}, "m"
+
+    def conv_bn(key_c, key_b, cin, cout, k):
+        sd[key_c + ".weight"] = _rand((cout, cin, k, k), key_c, (3.0 / (cin * k * k)) ** 0.5)
+        sd[key_b + ".weight"] = _rand((cout,), key_b + "g", 0.5) + 1.0
+        sd[key_b + ".bias"] = _rand((cout,), key_b + "b", 0.3)
+        sd[key_b + ".running_mean"] = _rand((cout,), key_b + "m", 0.3)
+        sd[key_b + ".running_var"] = _rand((cout,), key_b + "v", 0.4) + 1.0
+
+    for i in range(nb):
+        for j in range(nb):
+            if j > i:
+                conv_bn("%s.fuse_layers.%d.%d.0" % (q, i, j), "%s.fuse_layers.%d.%d.1" % (q, i, j), chans[j], chans[i], 1)
+            elif j < i:
+                for k in range(i - j):
+                    cout = chans[i] if k == i - j - 1 else chans[j]
+                    conv_bn("%s.fuse_layers.%d.%d.%d.0" % (q, i, j, k), "%s.fuse_layers.%d.%d.%d.1" % (q, i, j, k), chans[j], cout, 3)
+    xs = [_rand((n, c, h, w), "fx%d" % i) for i, (c, (h, w)) in enumerate(zip(chans, sizes))]
+
+    def cb(x, key_c, key_b, stride, pad):
+        y = F.conv2d(x, sd[key_c + ".weight"].double(), None, stride=stride, padding=pad)
+        return F.batch_norm(y, sd[key_b + ".running_mean"].double(), sd[key_b + ".running_var"].double(), sd[key_b + ".weight"].double(),
+                            sd[key_b + ".bias"].double(), False, 0.0, 1e-5)
+
+    refs = []
+    for i in range(nb):
+        acc = None
+        for j in range(nb):
+            if j == i:
+                t = xs[j].double()
+            elif j > i:
+                t = cb(xs[j].double(), "%s.fuse_layers.%d.%d.0" % (q, i, j), "%s.fuse_layers.%d.%d.1" % (q, i, j), 1, 0)
+                t = F.interpolate(t, scale_factor=2 ** (j - i), mode="nearest")
+            else:
+                t = xs[j].double()
+                for k in range(i - j):
+                    t = cb(t, "%s.fuse_layers.%d.%d.%d.0" % (q, i, j, k), "%s.fuse_layers.%d.%d.%d.1" % (q, i, j, k), 2, 1)
+                    if k < i - j - 1:
+                        t = F.relu(t)
+            acc = t if acc is None else acc + t
+        refs.append(F.relu(acc))
+    P = engine.Program(torch.device(DEV))
+    pk = engine.Packer(sd, torch.device(DEV))
+    mod = engine.HRNetW48._module(pk, q, dict(NUM_BRANCHES=nb, NUM_BLOCKS=[0] * nb))
+    ys = engine.HRNetW48._emit_module(P, mod, [to_act(P, x) for x in xs])
+    assert sum(1 for k, _, _ in P.ops if k in (engine.cabi.OP_CONV, engine.cabi.OP_CONV_GROUP)) <= 2, "two grouped conv levels for <= 3 branches"
+    run(P)
+    for i in range(nb):
+        got = from_act(ys[i]).double()
+        assert got.shape == refs[i].shape
+        err = (got - refs[i]).abs().max().item()
+        assert err < 1e-5 * max(1.0, refs[i].abs().max().item()), "fuse output %d: max-abs %.3e" % (i, err)
+
+
 def _chain_case(use_chain, n_img=9):
     """two BasicBlocks (4 dependent 3x3 convs, residuals) on two branches, the way HRNetW48._emit_module emits them"""
     os.environ["I2R_CONV_CHAIN"] = "1" if use_chain else "0"
+    saved_wino, engine.WINOGRAD = engine.WINOGRAD, False  # (the experimental chain launch drives the direct kernel)
     try:
         P = engine.Program(torch.device(DEV))
         pk_sd, xs = {}, []
@@ -321,6 +431,7 @@ def _chain_case(use_chain, n_img=9):
         return used, [from_act(t) for t in cur], errs
     finally:
         os.environ.pop("I2R_CONV_CHAIN", None)
+        engine.WINOGRAD = saved_wino
 
 
 def test_conv_chain_matches_per_layer_launches():

@@ -196,6 +196,7 @@ def test_full_size_batch_properties():
 #                                          fp16: max-abs <= 1 % of max|ref| and rms error <= 0.3 % of rms(ref)
 # (measured on MI355X, tools/lp_error.py: bf16 0.4-3.1 % / 0.4-1.1 %, fp16 0.05-0.4 % / 0.05-0.14 %).
 LP_TOL = {"bf16": (5e-2, 2e-2), "fp16": (1e-2, 3e-3)}
+HRFORMER_FUSED_WIDTHS = (78, 156)  # branches whose transformer blocks run as one attention + one MLP launch in the 16-bit modes
 
 
 @pytest.mark.parametrize("tag,precision", [("tph_l21", "bf16"), ("hrt_l21", "bf16"), ("hrt288_l2", "fp16"), ("w48_l213", "bf16")])
@@ -290,6 +291,47 @@ def test_config5_twelve_persons_384x288():
     d = yh - ref["multi"]
     assert d.abs().max().item() <= tol_max * ref["multi"].abs().max().item()
     assert d.pow(2).mean().sqrt().item() <= tol_rms * ref["multi"].pow(2).mean().sqrt().item()
+
+
+def test_config4_real_batch_bf16_fused_blocks():
+    """BASELINE config 4 at its own batch: 4 images x 4 persons = 16 crops of the HRFormer-B 2-stage model in bf16.  Image 2 against
+    the fp32 oracle within the stated tolerance, image permutation permutes the rows, and the program really runs the fused 16-bit
+    transformer-block kernels on the branches the packer fuses (one attention + one MLP launch per block), the 16-bit inter-human
+    encoder (d = 78) and a 16-bit stem / layer1."""
+    import bench
+    from i2r_amd import synth
+    from i2r_amd.arch_hrformer import STAGES
+    length = bench.WORKLOADS["hrt_192_p4_b4"]["length"]
+    assert length == [4] * 4
+    cfg, sd, _, _, _, _ = setup("hrt_l21")
+    net = _net(cfg, sd, "hrt_192_p4_b4")
+    x, m, length = synth.make_inputs(length, 256, 192, seed=6)
+    try:
+        net.set_precision("bf16")
+        y = net(x.cuda(), m.cuda(), length)
+        ym = y["multi"].cpu()
+        perm = [2, 0, 3, 1]
+        idx = torch.cat([torch.arange(4 * p, 4 * p + 4) for p in perm])
+        yp = net(x[idx].cuda(), m[idx].cuda(), length)["multi"].cpu()
+        var = _variants(net)
+        progs = [P for P, _ in net.engine().programs.values()]
+    finally:
+        net.set_precision("fp32")
+    assert ym.shape == (16, 14, 64, 48) and torch.isfinite(ym).all()
+    assert (yp - ym[idx]).abs().max().item() < 1e-4 * max(1.0, ym.abs().max().item())
+    assert var and all(d == 78 and dt == 1 for d, dt in var), "bf16 mode must run the 16-bit inter-human encoder: %r" % (var,)
+    fused_c = HRFORMER_FUSED_WIDTHS
+    want = sum(st["num_modules"] * st["num_blocks"][i] for st in STAGES.values() for i, c in enumerate(st["num_channels"]) if c in fused_c)
+    for P in progs:
+        kinds = [k for k, _, _ in P.ops]
+        assert kinds.count(cabi.OP_HRT_ATTN) == want and kinds.count(cabi.OP_HRT_MLP) == want, (kinds.count(cabi.OP_HRT_ATTN), kinds.count(cabi.OP_HRT_MLP), want)
+        stem = [st for k, _, st in P.ops if k == cabi.OP_STEM][0]
+        assert stem.out_dt == 1, "bf16 mode: the HRFormer stem stores bf16"
+    ref = i2r_cpu.forward(sd, cfg, x[8:12], m[8:12], [4])["multi"]
+    tol_max, tol_rms = LP_TOL["bf16"]
+    d = ym[8:12] - ref
+    assert d.abs().max().item() <= tol_max * ref.abs().max().item(), d.abs().max().item() / ref.abs().max().item()
+    assert d.pow(2).mean().sqrt().item() <= tol_rms * ref.pow(2).mean().sqrt().item()
 
 
 def test_regrouping_same_crop_count_reuses_program():
