@@ -309,6 +309,12 @@ def _kernel_view(name, s, reps, total_ms, precision):
     # which roof bounds the kernel: its arithmetic intensity (algorithmic FLOP / algorithmic HBM byte) against the machine balance
     # peak FLOP/s : 8 TB/s of the pipe it computes on.  fp32 convs sit far above it (MFMA-bound); with 16-bit operands the matrix
     # peak is 16x higher and the same launches can fall BELOW it: their roof is HBM.  Kernels without matrix work: HBM.
+    if name.startswith("conv_wino"):
+        # Winograd F(2x2, 3x3) (csrc/i2r_conv_wino.hip): `achieved` keeps counting the ALGORITHMIC FLOPs of the direct convolution
+        # (2 pixels cout cin 9), but the kernel issues 16 multiply-adds per 2x2 output tile and (cin, cout) pair instead of
+        # 36 -- so `frac` is work delivered per peak pipe-second and may exceed 1; `executed` is what the matrix pipe really ran
+        out["algorithm"] = "winograd F(2x2,3x3): 2.25x fewer matrix-pipe operations than the algorithmic (direct-convolution) FLOPs counted in achieved"
+        out["executed"] = {"achieved": round(tf / 2.25, 2), "peak": peak, "unit": "TFLOP/s", "frac": round(tf / 2.25 / peak, 4)}
     if peak and ai >= balance:
         out.update(bound="mfma", **mfma)
         out["hbm_view"] = hbm
@@ -348,7 +354,7 @@ def roofline_report(prog, precision, cname):
     return r
 
 
-LP_TOL = {"bf16": 3e-2, "fp16": 1e-2}  # tests/test_model_gpu.py LP_TOL: max-abs error as a fraction of max|ref|
+LP_TOL = {"bf16": 4e-2, "fp16": 6e-3}  # tests/test_model_gpu.py LP_TOL: max-abs error as a fraction of max|ref|
 
 
 def oracle_parity(cfg, sd, x, m, length, y, precision):

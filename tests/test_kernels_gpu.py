@@ -105,7 +105,8 @@ def test_conv_winograd_matches_torch_and_direct(cin, cout, n, h, w, relu, nres):
             xa = to_act(P, x)
             ra = [to_act(P, r) for r in res]
             out = P.conv(xa, pc, relu=relu, res1=ra[0] if nres > 0 else None, res2=ra[1] if nres > 1 else None)
-            algo = [st.algo for k, _, st in P.ops if k == engine.cabi.OP_CONV]
+            algo = [st.algo for k, _, st in P.ops if k == engine.cabi.OP_CONV] + \
+                   [st.d[0].contents.algo for k, _, st in P.ops if k == engine.cabi.OP_CONV_GROUP]  # (Winograd: a persistent one-member group)
             run(P)
         finally:
             engine.WINOGRAD = saved

@@ -192,10 +192,11 @@ def test_full_size_batch_properties():
 
 
 # 16-bit MFMA modes (BASELINE configs 3-5).  BASELINE defines 1e-3 for fp32 only; the tolerances stated here are relative to
-# the fp32 CPU oracle on the same inputs:  bf16: max-abs <= 5 % of max|ref| and rms error <= 2 % of rms(ref);
-#                                          fp16: max-abs <= 1 % of max|ref| and rms error <= 0.3 % of rms(ref)
-# (measured on MI355X, tools/lp_error.py: bf16 0.4-3.1 % / 0.4-1.1 %, fp16 0.05-0.4 % / 0.05-0.14 %).
-LP_TOL = {"bf16": (5e-2, 2e-2), "fp16": (1e-2, 3e-3)}
+# the fp32 CPU oracle on the same inputs:  bf16: max-abs <= 4 % of max|ref| and rms error <= 1.5 % of rms(ref);
+#                                          fp16: max-abs <= 0.6 % of max|ref| and rms error <= 0.2 % of rms(ref)
+# (measured on MI355X, tools/lp_error.py, round 3: bf16 0.8-3.1 % / 0.7-1.2 % -- the 3.1 % is the first-stage `single` head of the
+#  3-crop HRFormer case, the `multi` outputs stay below 1.9 %; fp16 0.14-0.39 % / 0.10-0.15 %).
+LP_TOL = {"bf16": (4e-2, 1.5e-2), "fp16": (6e-3, 2e-3)}
 HRFORMER_FUSED_WIDTHS = (78, 156)  # branches whose transformer blocks run as one attention + one MLP launch in the 16-bit modes
 
 
