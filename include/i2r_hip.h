@@ -102,14 +102,6 @@ int i2r_conv(const i2r_conv_desc* d, void* stream);
  * (sum over members of n_img * ceil(conv_h/tile_h) * ceil(conv_w/tile_w) * cout_blocks). */
 int i2r_conv_grouped(const i2r_conv_desc* const* descs, int32_t n, const int32_t* block_map, int32_t map_len,
                      void* stream);
-/* Winograd members (algo 1) as PERSISTENT workgroups: n_bins workgroups are launched and workgroup b processes the items
- * table[r * n_bins + b], r = 0 .. n_rounds - 1 (device int32; entry = (member << 24) | item index within the member, -1 = none; an
- * item = mt fragments x one output-channel block, numbered fragment-block-major: index = fragment_block * cout_blocks + cout_block),
- * fetching the next item's first chunk under the current item's last pass.  Every item must appear exactly once.  Size n_bins by
- * i2r_conv_grouped_occupancy (resident workgroups per CU x CUs) so that all workgroups run at once. */
-int i2r_conv_grouped_bins(const i2r_conv_desc* const* descs, int32_t n, const int32_t* table, int32_t n_bins, int32_t n_rounds,
-                          void* stream);
-int i2r_conv_grouped_occupancy(const i2r_conv_desc* const* descs, int32_t n, int32_t* wg_per_cu, int32_t* n_cu);
 
 /* i2r_conv_chain (EXPERIMENTAL: correct and tested, but measured slower than one i2r_conv_grouped per layer on MI355X at 32 crops;
  * the host side keeps it behind I2R_CONV_CHAIN=1) -- n_layers DEPENDENT stride-1 convolutions (layer l of member g reads layer l-1's output of member g) for up to
@@ -431,8 +423,6 @@ typedef struct i2r_conv_group_args {
     const int32_t* block_map;
     int32_t n;
     int32_t map_len;
-    int32_t n_bins;        /* > 0: i2r_conv_grouped_bins with block_map as its table of map_len / n_bins rounds */
-    int32_t reserved;
 } i2r_conv_group_args;
 
 typedef struct i2r_op {

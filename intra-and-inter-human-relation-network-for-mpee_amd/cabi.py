@@ -114,7 +114,7 @@ class FuseUpArgs(C.Structure):
 
 
 class ConvGroupArgs(C.Structure):
-    _fields_ = [("d", C.POINTER(ConvDesc) * MAX_GROUP), ("block_map", _fp), ("n", _i32), ("map_len", _i32), ("n_bins", _i32), ("reserved", _i32)]
+    _fields_ = [("d", C.POINTER(ConvDesc) * MAX_GROUP), ("block_map", _fp), ("n", _i32), ("map_len", _i32)]
 
 
 class ConvChainArgs(C.Structure):
@@ -129,7 +129,7 @@ class Op(C.Structure):
 
 
 # every symbol include/i2r_hip.h declares (tests/test_host.py::test_cabi_library_exports_every_declared_symbol checks the built library exports them all)
-EXPORTS = ("i2r_conv", "i2r_conv_grouped", "i2r_conv_grouped_bins", "i2r_conv_grouped_occupancy", "i2r_conv_kernel_name", "i2r_stem_conv", "i2r_pe_res_stem", "i2r_maxpool3x3s2", "i2r_head", "i2r_layernorm", "i2r_window_attn", "i2r_hrt_attn_block", "i2r_hrt_mlp_block", "i2r_dwconv3x3",
+EXPORTS = ("i2r_conv", "i2r_conv_grouped", "i2r_conv_kernel_name", "i2r_stem_conv", "i2r_pe_res_stem", "i2r_maxpool3x3s2", "i2r_head", "i2r_layernorm", "i2r_window_attn", "i2r_hrt_attn_block", "i2r_hrt_mlp_block", "i2r_dwconv3x3",
            "i2r_upsample_bilinear_add", "i2r_fuse_up_add", "i2r_flip_merge", "i2r_decode", "i2r_crop_affine", "i2r_box_mask", "i2r_crop_affine_cv2", "i2r_box_mask_cv2", "i2r_conv_chain_pack", "i2r_conv_chain", "i2r_encoder_kv", "i2r_encoder_layer",
            "i2r_run_program", "i2r_abi_version", "i2r_last_error", "i2r_device_check")
 
@@ -149,8 +149,6 @@ def load_library(path=LIB_PATH):
     L = C.CDLL(path)
     L.i2r_conv.argtypes = [C.POINTER(ConvDesc), C.c_void_p]
     L.i2r_conv_grouped.argtypes = [C.POINTER(C.POINTER(ConvDesc)), _i32, _fp, _i32, C.c_void_p]
-    L.i2r_conv_grouped_bins.argtypes = [C.POINTER(C.POINTER(ConvDesc)), _i32, _fp, _i32, _i32, C.c_void_p]
-    L.i2r_conv_grouped_occupancy.argtypes = [C.POINTER(C.POINTER(ConvDesc)), _i32, C.POINTER(_i32), C.POINTER(_i32)]
     L.i2r_conv_chain_pack.argtypes = [C.POINTER(ConvChainArgs), C.c_void_p, C.c_int64]
     L.i2r_conv_chain.argtypes = [C.POINTER(ConvChainArgs), C.c_void_p]
     L.i2r_conv_kernel_name.argtypes = [C.POINTER(C.POINTER(ConvDesc)), _i32, C.c_char_p, _i32]

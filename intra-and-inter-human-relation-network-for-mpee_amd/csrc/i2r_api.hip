@@ -91,8 +91,7 @@ extern "C" int i2r_run_program(const i2r_op* ops, int32_t n_ops, void* const* st
             case I2R_OP_CONV: rc = i2r_conv((const i2r_conv_desc*)op.args, st); break;
             case I2R_OP_CONV_GROUP: {
                 const i2r_conv_group_args* a = (const i2r_conv_group_args*)op.args;
-                rc = a->n_bins > 0 ? i2r_conv_grouped_bins(a->d, a->n, a->block_map, a->n_bins, a->map_len / a->n_bins, st)
-                                   : i2r_conv_grouped(a->d, a->n, a->block_map, a->map_len, st);
+                rc = i2r_conv_grouped(a->d, a->n, a->block_map, a->map_len, st);
                 break;
             }
             case I2R_OP_STEM: {

@@ -37,6 +37,7 @@ struct ConvK {
     // Winograd F(2x2, 3x3) kernels (i2r_conv_wino.hip; algo == 1): tiles_y / tiles_x count FRAGMENTS (16 Winograd tiles, 2^w_fwlog across)
     // per crop, ph / pw / plane describe one fragment's raw patch, whose rows have w_pitch slots with the odd columns at + w_half
     int algo, w_fwlog, w_pitch, w_half, w_nfrag, w_rcp;  // w_rcp = ceil(65536 / pw): patch row of a pixel index without a division
+    unsigned w_m_cblk, w_m_img, w_m_tx;                  // ceil(2^32 / d) for d = n_cblk, fragments per crop, fragments per row (item decode)
 };
 
 constexpr int kMaxPP = 5;  // patch pixels per thread (256 threads) -> patches up to 1280 pixels
@@ -47,7 +48,6 @@ struct ConvGroupK {
     int blk_end[kMaxGroups];  // exclusive prefix sums of workgroups per group
     int n;
     const int* blk_map;       // optional dispatch-order table: entry = (group << 24) | workgroup index within the group
-    int n_rounds;             // Winograd kernels (persistent workgroups): blk_map is a table [n_rounds][gridDim.x], -1 = no item
 };
 
 // 4 consecutive channels of an activation tensor at ELEMENT offset `off`: fp32 (16 bytes) or, in the 16-bit kernels when h16 is set,

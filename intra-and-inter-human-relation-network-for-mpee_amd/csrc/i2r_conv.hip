@@ -397,6 +397,7 @@ static void copy_desc(const i2r_conv_desc* d, ConvK& k) {
     k.dtype = d->dtype;
     k.in16 = d->in_f16; k.out16 = d->out_f16;
     k.algo = d->algo; k.w_fwlog = k.w_pitch = k.w_half = k.w_nfrag = k.w_rcp = 0;
+    k.w_m_cblk = k.w_m_img = k.w_m_tx = 0;
     k.dbg = 0;
 }
 
@@ -440,10 +441,13 @@ static int prepare_wino(const i2r_conv_desc* d, int force_mt, ConvK& k, int* nt_
     k.w_pitch = fw == 8 ? 20 : (fw == 4 ? 10 : 9);
     k.plane = cdiv(k.ph * k.w_pitch, 16) * 16;
     k.w_rcp = (65536 + k.pw - 1) / k.pw;  // exact for pixel indices < 256 and pw in {6, 10, 18}
+    // item decode without integer divisions: n / d = mulhi(n, ceil(2^32 / d)) is exact for n < 2^20 and d < 2^11
+    auto magic = [](int d) { return d == 1 ? 0u : (unsigned)(((1ull << 32) + d - 1) / d); };
+    k.w_m_cblk = magic(k.n_cblk); k.w_m_img = magic(k.tiles_y * k.tiles_x); k.w_m_tx = magic(k.tiles_x);
     k.tap_kw = k.tap_kh = 3;
     k.ck = 16; k.wn = 1;
     const long long nf = (long long)d->n_img * k.tiles_y * k.tiles_x;
-    I2R_CHECK_ARG(nf > 0 && nf < (1ll << 28), "i2r_conv: grid");
+    I2R_CHECK_ARG(nf > 0 && nf * k.n_cblk < (1ll << 20) && k.tiles_y * k.tiles_x < 2048 && k.n_cblk < 2048, "i2r_conv: algo 1 grid (%lld fragments)", nf);
     k.w_nfrag = (int)nf;
 #ifdef I2R_TUNING
     {
@@ -657,8 +661,6 @@ extern "C" int i2r_conv_grouped(const i2r_conv_desc* const* descs, int32_t n, co
     int rc = resolve(descs, n, grp, &nt0, &mt0, &cap0, &pf0, &lds_max, &total);
     if (rc) return rc;
     grp.blk_map = block_map;
-    grp.n_rounds = 0;
-    I2R_CHECK_ARG(descs[0]->algo == 0 || block_map == nullptr, "i2r_conv_grouped: Winograd members take their table through i2r_conv_grouped_bins");
     I2R_CHECK_ARG(block_map == nullptr || map_len == (int32_t)total, "i2r_conv_grouped: block_map has %d entries, grid has %lld", map_len, total);
     conv_fn fn = descs[0]->algo == 1 ? reinterpret_cast<conv_fn>(i2r_pick_conv_wino(nt0, mt0))
                  : descs[0]->dtype == 0 ? pick_kernel(nt0, mt0, cap0, pf0)
@@ -673,56 +675,6 @@ extern "C" int i2r_conv_grouped(const i2r_conv_desc* const* descs, int32_t n, co
 }
 
 extern "C" int i2r_conv(const i2r_conv_desc* d, void* stream) { return i2r_conv_grouped(&d, 1, nullptr, 0, stream); }
-
-// ---- Winograd members as persistent workgroups (see i2r_conv_wino.hip) ----
-extern "C" int i2r_conv_grouped_bins(const i2r_conv_desc* const* descs, int32_t n, const int32_t* table, int32_t n_bins, int32_t n_rounds,
-                                     void* stream) {
-    ConvGroupK grp;
-    int nt0, mt0, cap0, pf0;
-    size_t lds_max;
-    long long total;
-    int rc = resolve(descs, n, grp, &nt0, &mt0, &cap0, &pf0, &lds_max, &total);
-    if (rc) return rc;
-    I2R_CHECK_ARG(descs[0]->algo == 1, "i2r_conv_grouped_bins: Winograd members only (algo 1)");
-    I2R_CHECK_ARG(table && n_bins >= 1 && n_rounds >= 1 && (long long)n_bins * n_rounds >= total,
-                  "i2r_conv_grouped_bins: table of %d x %d entries for %lld items", n_rounds, n_bins, total);
-    grp.blk_map = table;
-    grp.n_rounds = n_rounds;
-    conv_fn fn = reinterpret_cast<conv_fn>(i2r_pick_conv_wino(nt0, mt0));
-    I2R_CHECK_ARG(fn != nullptr, "i2r_conv: no Winograd kernel for nt=%d mt=%d", nt0, mt0);
-    if (lds_max > 64 * 1024)
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_max);
-    hipLaunchKernelGGL(fn, dim3((unsigned)n_bins), dim3(256), lds_max, (hipStream_t)stream, grp);
-    I2R_CHECK_LAUNCH("i2r_conv_grouped_bins");
-    return I2R_OK;
-}
-
-extern "C" int i2r_conv_grouped_occupancy(const i2r_conv_desc* const* descs, int32_t n, int32_t* wg_per_cu, int32_t* n_cu) {
-    ConvGroupK grp;
-    int nt0, mt0, cap0, pf0;
-    size_t lds_max;
-    long long total;
-    int rc = resolve(descs, n, grp, &nt0, &mt0, &cap0, &pf0, &lds_max, &total);
-    if (rc) return rc;
-    I2R_CHECK_ARG(wg_per_cu && n_cu, "i2r_conv_grouped_occupancy: null pointer");
-    conv_fn fn = descs[0]->algo == 1 ? reinterpret_cast<conv_fn>(i2r_pick_conv_wino(nt0, mt0))
-                 : descs[0]->dtype == 0 ? pick_kernel(nt0, mt0, cap0, pf0)
-                                      : reinterpret_cast<conv_fn>(descs[0]->dtype == 1 ? i2r_pick_conv_bf16(nt0, mt0, cap0, pf0) : i2r_pick_conv_f16(nt0, mt0, cap0, pf0));
-    I2R_CHECK_ARG(fn != nullptr, "i2r_conv_grouped_occupancy: no kernel");
-    if (lds_max > 64 * 1024)
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_max);
-    int per_cu = 0, dev = 0;
-    hipDeviceProp_t prop;
-    if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess ||
-        hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, reinterpret_cast<const void*>(fn), 256, lds_max) != hipSuccess) {
-        (void)hipGetLastError();
-        i2r_set_error("i2r_conv_grouped_occupancy: no device");
-        return I2R_E_NODEV;
-    }
-    *wg_per_cu = per_cu;
-    *n_cu = prop.multiProcessorCount;
-    return I2R_OK;
-}
 
 // ---- chain launches (see conv_chain_f32) ----
 namespace {

@@ -91,8 +91,6 @@ def wino_fragment(conv_h, conv_w):
     return best[1], best[2]
 
 
-_WINO_BINS = os.environ.get("I2R_WINO_BINS", "all")  # "all" = one workgroup per item in LPT order (default); "resident" = persistent workgroups (tools/ A/B: no gain)
-_WINO_BINS_F = float(os.environ.get("I2R_WINO_BINS_F", "1"))  # tools/ A/B switch: workgroups launched per resident slot
 _WINO_MT = int(os.environ.get("I2R_WINO_MT", "0"))  # tools/ A/B switch: fragments per Winograd workgroup
 WINOGRAD = os.environ.get("I2R_WINOGRAD", "1") != "0"  # fp32 3x3 stride-1 convs on the Winograd F(2x2, 3x3) kernels (A/B switch for tools/)
 
@@ -492,25 +490,6 @@ def lpt_block_order(counts, works, n_cu=256):
     return out
 
 
-def lpt_bin_table(counts, works, n_bins):
-    """Item table of a persistent-workgroup launch (i2r_conv_grouped_bins): longest-processing-time packing of all items onto n_bins
-    workgroups -> flat [n_rounds][n_bins] list, entry = member << 24 | item index, -1 = none.  Every bin runs its items heaviest first."""
-    import heapq
-    items = sorted(((w, g, i) for g, (c, w) in enumerate(zip(counts, works)) for i in range(c)), key=lambda t: (-t[0], t[1], t[2]))
-    n_bins = max(1, min(n_bins, len(items)))
-    heap = [(0, b) for b in range(n_bins)]
-    bins = [[] for _ in range(n_bins)]
-    for w, g, i in items:
-        load, b = heapq.heappop(heap)
-        bins[b].append((g << 24) | i)
-        heapq.heappush(heap, (load + w, b))
-    rounds = max(len(b) for b in bins)
-    return [bins[b][r] if r < len(bins[b]) else -1 for r in range(rounds) for b in range(n_bins)], n_bins
-
-
-_WINO_OCC = {}  # (nt, mt, LDS-relevant shape) -> (resident workgroups per CU, CUs) of the Winograd kernel, queried once
-
-
 def conv_split(cout_pad):
     nfrag = cout_pad // 16
     nt = next(c for c in (3, 4, 5) if nfrag % c == 0)  # same rule as csrc/i2r_conv.hip
@@ -645,7 +624,7 @@ class Program:
             key = nt
         if group is not None:
             group.append((d, geo, key))
-        elif wino:  # (a Winograd conv always goes out as a persistent-workgroup launch with its item table)
+        elif wino:  # (a Winograd conv always goes out with its LPT dispatch table: one-member group)
             self.flush_group([(d, geo, key)], lane=lane)
         else:
             self.ops.append((cabi.OP_CONV, lane, d))
@@ -776,20 +755,7 @@ class Program:
                 counts.append(-(-conv_h // d.tile_h) * -(-conv_w // d.tile_w) * n_img * n_cblk)
             works.append(d.cin * d.ntaps)
         a.n = len(group)
-        if wino:
-            # item table of the launch: one workgroup per item in LPT order (or persistent workgroups, see _WINO_BINS)
-            okey = (group[0][2], tuple(sorted({m[0].tile_w for m in group})))  # (LDS bytes follow NT, MT and the widest fragment patch)
-            if okey not in _WINO_OCC:
-                per_cu, n_cu = C.c_int32(0), C.c_int32(0)
-                ptrs = (C.POINTER(cabi.ConvDesc) * len(group))(*[a.d[i] for i in range(len(group))])
-                cabi.check(cabi.lib().i2r_conv_grouped_occupancy(ptrs, len(group), C.byref(per_cu), C.byref(n_cu)), "i2r_conv_grouped_occupancy")
-                _WINO_OCC[okey] = (per_cu.value, n_cu.value)
-            per_cu, n_cu = _WINO_OCC[okey]
-            table, n_bins = lpt_bin_table(counts, works, sum(counts) if _WINO_BINS == "all" else int(per_cu * n_cu * _WINO_BINS_F))
-            bm = torch.tensor(table, dtype=torch.int32, device=self.device)
-            self.keep.append(bm)
-            a.block_map, a.map_len, a.n_bins = bm.data_ptr(), bm.numel(), n_bins
-        elif len(set(works)) > 1:
+        if wino or len(set(works)) > 1:  # dispatch order: heaviest items first, balanced over the CUs (a Winograd item is small: always)
             bm = torch.tensor(lpt_block_order(counts, works), dtype=torch.int32, device=self.device)
             self.keep.append(bm)
             a.block_map, a.map_len = bm.data_ptr(), bm.numel()
