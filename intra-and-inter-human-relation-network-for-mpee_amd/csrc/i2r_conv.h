@@ -34,11 +34,19 @@ struct ConvK {
     int dtype;          // 0 fp32 MFMA, 1 bf16, 2 f16 (fp32 accumulate)
     int in16, out16;    // 16-bit modes: activation storage of the input / of out + res1 + res2 + res_post (0 = fp32, 1 = 16-bit of `dtype`)
     int dbg;            // ablation switches (env I2R_CONV_DBG; tuning only): 1 no epilogue, 2 no staging loads, 4 no weight loads
+    // index decode without integer divisions (a runtime division is ~35 vector-ALU instructions; a workgroup's prologue had a dozen):
+    // ceil(2^32 / d) for d = n_cblk, tiles_x, tiles_y, pw, tile_w (div_m below); wn_log = log2(wn); npass = channel chunks per workgroup
+    unsigned m_cblk, m_tx, m_ty, m_pw, m_tw;
+    int wn_log, npass;
     // Winograd F(2x2, 3x3) kernels (i2r_conv_wino.hip; algo == 1): tiles_y / tiles_x count FRAGMENTS (16 Winograd tiles, 2^w_fwlog across)
     // per crop, ph / pw / plane describe one fragment's raw patch, whose rows have w_pitch slots with the odd columns at + w_half
     int algo, w_fwlog, w_pitch, w_half, w_nfrag, w_rcp;  // w_rcp = ceil(65536 / pw): patch row of a pixel index without a division
     unsigned w_m_cblk, w_m_img, w_m_tx;                  // ceil(2^32 / d) for d = n_cblk, fragments per crop, fragments per row (item decode)
 };
+
+// n / d through m = ceil(2^32 / d): exact while n * (m * d - 2^32) < 2^32, i.e. for every n < 2^32 / d (prepare() checks the ranges);
+// d == 1 has no 32-bit reciprocal
+__device__ __forceinline__ int div_m(int n, int d, unsigned m) { return d == 1 ? n : (int)__umulhi((unsigned)n, m); }
 
 constexpr int kMaxPP = 5;  // patch pixels per thread (256 threads) -> patches up to 1280 pixels
 
@@ -147,7 +155,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvK& p, f32x4 (&acc)[MT][N
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt) {
             const int m = (wm * MT + mt) * 16 + g * 4 + pj;
-            const int ty = m / p.tile_w, tx = m - ty * p.tile_w;
+            const int ty = div_m(m, p.tile_w, p.m_tw), tx = m - ty * p.tile_w;
             const int oy = oy0 + ty, ox = ox0 + tx;
             pv[mt] = m < tile_px && oy < p.conv_h && ox < p.conv_w;
             off[mt] = ((size_t)(img * p.out_h + oy * p.out_step + p.out_off_y) * p.out_w + ox * p.out_step + p.out_off_x) * p.out_cs;
@@ -180,7 +188,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvK& p, f32x4 (&acc)[MT][N
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt) {
         const int m = (wm * MT + mt) * 16 + g * 4 + pj;
-        const int ty = m / p.tile_w, tx = m - ty * p.tile_w;
+        const int ty = div_m(m, p.tile_w, p.m_tw), tx = m - ty * p.tile_w;
         const int oy = oy0 + ty, ox = ox0 + tx;
         const bool pvalid = m < tile_px && oy < p.conv_h && ox < p.conv_w;
         const int by = oy * p.out_step + p.out_off_y, bx = ox * p.out_step + p.out_off_x;

@@ -34,15 +34,17 @@ __device__ __forceinline__ void conv_body(const ConvK& p, int bid, f32x4* lds) {
     if (stamp) ts0 = __builtin_amdgcn_s_memtime();
     const int lane = tid & 63, wave = tid >> 6;
     const int WN = p.wn;
-    const int wm = wave / WN, wn = wave % WN;
+    const int wm = wave >> p.wn_log, wn = wave & (WN - 1);
     const int li = lane & 15, g = lane >> 4;
 
-    const int cb = bid % p.n_cblk;
-    bid /= p.n_cblk;
-    const int tile_x = bid % p.tiles_x;
-    bid /= p.tiles_x;
-    const int tile_y = bid % p.tiles_y;
-    const int img = bid / p.tiles_y;
+    int q = div_m(bid, p.n_cblk, p.m_cblk);  // (host-made reciprocals: no integer division in the prologue)
+    const int cb = bid - q * p.n_cblk;
+    bid = q;
+    q = div_m(bid, p.tiles_x, p.m_tx);
+    const int tile_x = bid - q * p.tiles_x;
+    bid = q;
+    const int img = div_m(bid, p.tiles_y, p.m_ty);
+    const int tile_y = bid - img * p.tiles_y;
     const int oy0 = tile_y * p.tile_h, ox0 = tile_x * p.tile_w;
     const int py0 = oy0 * p.stride + p.iy0, px0 = ox0 * p.stride + p.ix0;
     const int phw = p.ph * p.pw;
@@ -65,7 +67,7 @@ __device__ __forceinline__ void conv_body(const ConvK& p, int bid, f32x4* lds) {
         goff[j] = 0;
         gval[j] = false;
         if (pp < phw) {
-            const int py = pp / p.pw, px = pp - py * p.pw;
+            const int py = div_m(pp, p.pw, p.m_pw), px = pp - py * p.pw;
             const int iy = py0 + py, ix = px0 + px;
             if (iy >= 0 && iy < p.in_h && ix >= 0 && ix < p.in_w) {
                 goff[j] = ((img * p.in_h + iy) * p.in_w + ix) * p.in_cs;
@@ -82,7 +84,7 @@ __device__ __forceinline__ void conv_body(const ConvK& p, int bid, f32x4* lds) {
     for (int mt = 0; mt < MT; ++mt) {
         int m = (wm * MT + mt) * 16 + li;
         if (m >= tile_px) m = 0;  // padded rows compute garbage-free duplicates; masked at the store
-        const int ty = m / p.tile_w, tx = m - ty * p.tile_w;
+        const int ty = div_m(m, p.tile_w, p.m_tw), tx = m - ty * p.tile_w;
         ppix[mt] = ty * p.stride * p.pw + tx * p.stride;
     }
 
@@ -185,7 +187,7 @@ __device__ __forceinline__ void conv_body(const ConvK& p, int bid, f32x4* lds) {
                     }
                 }
         };
-        const int npass = p.cin / p.ck;
+        const int npass = p.npass;
         stage_load(0);
         stage_store(lds);
         __syncthreads();
@@ -398,6 +400,7 @@ static void copy_desc(const i2r_conv_desc* d, ConvK& k) {
     k.in16 = d->in_f16; k.out16 = d->out_f16;
     k.algo = d->algo; k.w_fwlog = k.w_pitch = k.w_half = k.w_nfrag = k.w_rcp = 0;
     k.w_m_cblk = k.w_m_img = k.w_m_tx = 0;
+    k.m_cblk = k.m_tx = k.m_ty = k.m_pw = k.m_tw = 0; k.wn_log = 0; k.npass = 0;
     k.dbg = 0;
 }
 
@@ -593,6 +596,13 @@ static int prepare(const i2r_conv_desc* d, int force_mt, int force_cap, int forc
     k.ck = ck;
     I2R_CHECK_ARG(lds_bytes <= 160 * 1024, "i2r_conv: LDS %zu B", lds_bytes);
     k.wn = wn;
+    {
+        auto magic = [](int d) { return d == 1 ? 0u : (unsigned)(((1ull << 32) + d - 1) / d); };
+        k.m_cblk = magic(k.n_cblk); k.m_tx = magic(k.tiles_x); k.m_ty = magic(k.tiles_y); k.m_pw = magic(k.pw); k.m_tw = magic(k.tile_w);
+        k.wn_log = wn == 4 ? 2 : (wn == 2 ? 1 : 0);
+        // chunks per workgroup: fp32 cin / ck; 16-bit: padded 8-channel groups / groups per chunk (the double-buffered variants use it)
+        k.npass = d->dtype == 0 ? d->cin / ck : ((d->cin / 8 + 3) / 4 * 4) / (ck / 8);
+    }
 #ifdef I2R_TUNING
     {
         static const int dbg = getenv("I2R_CONV_DBG") ? atoi(getenv("I2R_CONV_DBG")) : 0;
@@ -601,6 +611,9 @@ static int prepare(const i2r_conv_desc* d, int force_mt, int force_cap, int forc
 #endif
     const long long nblk = (long long)d->n_img * k.tiles_y * k.tiles_x * k.n_cblk;
     I2R_CHECK_ARG(nblk > 0 && nblk < (1ll << 30), "i2r_conv: grid");
+    // ranges of the reciprocal divisions in the kernels (div_m): n < 2^32 / d
+    I2R_CHECK_ARG(nblk * std::max(k.n_cblk, std::max(k.tiles_x, k.tiles_y)) < (1ll << 32) && (long long)kMaxPP * 256 * k.pw < (1ll << 32),
+                  "i2r_conv: grid of %lld workgroups exceeds the index-decode range", nblk);
     *nt_out = nt; *mt_out = mt; *cap_out = cap; *pf_out = pf; *lds_out = lds_bytes; *nblk_out = nblk;
     return I2R_OK;
 }

@@ -38,9 +38,6 @@ namespace {
 
 constexpr int kWinoPatchMax = 108;  // patch pixels of a fragment: 6 x 18 (FW = 8 or 2), 10 x 10 (FW = 4)
 
-// n / d for n < 2^20, d < 2^11 through m = ceil(2^32 / d) (exact in that range; d == 1 has no 32-bit reciprocal)
-__device__ __forceinline__ int div_magic(int n, int d, unsigned m) { return d == 1 ? n : (int)__umulhi((unsigned)n, m); }
-
 template <int MT, int NT>
 __global__ __launch_bounds__(256, (MT == 1 ? (NT == 3 ? 4 : 3) : 2)) void conv_wino_f32(const ConvGroupK grp) {
     extern __shared__ __attribute__((aligned(16))) f32x4 lds[];
@@ -69,7 +66,7 @@ __global__ __launch_bounds__(256, (MT == 1 ? (NT == 3 ? 4 : 3) : 2)) void conv_w
     if (stamp) ts0 = __builtin_amdgcn_s_memtime();
     const float* const res2 = stamp ? nullptr : p.res2;
 
-    const int wg = div_magic(bid, p.n_cblk, p.w_m_cblk), cb = bid - wg * p.n_cblk;
+    const int wg = div_m(bid, p.n_cblk, p.w_m_cblk), cb = bid - wg * p.n_cblk;
     const int fwl = p.w_fwlog, FW = 1 << fwl;  // tiles across a fragment
     const int PC = p.pw, PP = p.ph * p.pw;
     const int per_img = p.tiles_y * p.tiles_x;
@@ -82,9 +79,9 @@ __global__ __launch_bounds__(256, (MT == 1 ? (NT == 3 ? 4 : 3) : 2)) void conv_w
         int fid = wg * MT + mt;
         f_ok[mt] = fid < p.w_nfrag;
         if (!f_ok[mt]) fid = 0;
-        f_img[mt] = div_magic(fid, per_img, p.w_m_img);
+        f_img[mt] = div_m(fid, per_img, p.w_m_img);
         const int rem = fid - f_img[mt] * per_img;
-        const int fy = div_magic(rem, p.tiles_x, p.w_m_tx);
+        const int fy = div_m(rem, p.tiles_x, p.w_m_tx);
         f_oy[mt] = fy * (32 >> fwl);
         f_ox[mt] = (rem - fy * p.tiles_x) * (2 * FW);
     }
