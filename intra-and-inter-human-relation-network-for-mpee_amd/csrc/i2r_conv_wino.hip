@@ -225,6 +225,8 @@ __global__ __launch_bounds__(256, (MT == 1 ? (NT == 3 ? 4 : 3) : 2)) void conv_w
     const int q4 = tid & 3, px = tid >> 2;  // pixel px of the fragment: tile px >> 2, output row parity (px >> 1) & 1, column parity px & 1
     const bool hi = (px & 2) != 0;
     const int n0 = n_base + q4 * 4;  // (+ 16 k < cout_pad: a channel block never reaches past the padded width)
+    const bool tail = n_base + NT * 16 > p.cout || n_base + NT * 16 > p.out_cs;  // (uniform) the block holds padding channels
+    const bool has_res = (p.res1 != nullptr || res2 != nullptr) && !(I2R_DBG(p) & 1);
     f32x4 r[MT][NT];
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt) {
@@ -234,9 +236,12 @@ __global__ __launch_bounds__(256, (MT == 1 ? (NT == 3 ? 4 : 3) : 2)) void conv_w
         const bool ok = f_ok[mt] && oy < p.conv_h && ox < p.conv_w;
         obase[mt] = ok ? ((f_img[mt] * p.out_h + oy) * p.out_w + ox) * p.out_cs + n0 : -1;
 #pragma unroll
-        for (int k = 0; k < NT; ++k) {
-            r[mt][k] = *reinterpret_cast<const f32x4*>(p.bias + n0 + 16 * k);
-            if (ok && !(I2R_DBG(p) & 1)) {
+        for (int k = 0; k < NT; ++k) r[mt][k] = *reinterpret_cast<const f32x4*>(p.bias + n0 + 16 * k);
+        // (one exec region per pixel: its NT pieces share the validity; a tail block re-checks per piece below)
+        if (has_res && ok) {
+#pragma unroll
+            for (int k = 0; k < NT; ++k) {
+                if (tail && !(n0 + 16 * k + 4 <= p.cout || n0 + 16 * k + 4 <= p.out_cs)) continue;
                 if (p.res1) r[mt][k] += *reinterpret_cast<const f32x4*>(p.res1 + obase[mt] + 16 * k);
                 if (res2) r[mt][k] += *reinterpret_cast<const f32x4*>(res2 + obase[mt] + 16 * k);
             }
@@ -245,27 +250,33 @@ __global__ __launch_bounds__(256, (MT == 1 ? (NT == 3 ? 4 : 3) : 2)) void conv_w
     __syncthreads();
     // T0[b] (even output rows) or T1[b] (odd rows) is the first of the three terms; the others follow two planes apart
     const float* const tq = Tl + ((px & 1) + (hi ? 2 : 0)) * TPL + (px >> 2) * TW + q4 * 4;
-    const bool tail = n_base + NT * 16 > p.cout || n_base + NT * 16 > p.out_cs;  // (uniform) the block holds padding channels
+    const float sgn = hi ? -1.f : 1.f;  // Y = u0 + sgn (u1 + u2)
 #pragma unroll
-    for (int mt = 0; mt < MT; ++mt)
+    for (int mt = 0; mt < MT; ++mt) {
+        f32x4 y[NT];
 #pragma unroll
         for (int k = 0; k < NT; ++k) {
             const float* q = tq + mt * 16 * TW + 16 * k;
             const f32x4 u0 = *reinterpret_cast<const f32x4*>(q);             // T0 | T1
             const f32x4 u1 = *reinterpret_cast<const f32x4*>(q + 2 * TPL);   // T1 | T2
             const f32x4 u2 = *reinterpret_cast<const f32x4*>(q + 4 * TPL);   // T2 | T3
-            f32x4 y = (hi ? (u0 - u1 - u2) : (u0 + u1 + u2)) + r[mt][k];
-            if (p.relu) { y[0] = fmaxf(y[0], 0.f); y[1] = fmaxf(y[1], 0.f); y[2] = fmaxf(y[2], 0.f); y[3] = fmaxf(y[3], 0.f); }
+            y[k] = u0 + sgn * (u1 + u2) + r[mt][k];
+            if (p.relu) { y[k][0] = fmaxf(y[k][0], 0.f); y[k][1] = fmaxf(y[k][1], 0.f); y[k][2] = fmaxf(y[k][2], 0.f); y[k][3] = fmaxf(y[k][3], 0.f); }
+        }
+        if (obase[mt] < 0) continue;
+#pragma unroll
+        for (int k = 0; k < NT; ++k) {
             const int n = n0 + 16 * k;
-            if (obase[mt] < 0 || (tail && !(n + 4 <= p.cout || n + 4 <= p.out_cs))) continue;
-            if (p.res_post) y += *reinterpret_cast<const f32x4*>(p.res_post + obase[mt] + 16 * k);
+            if (tail && !(n + 4 <= p.cout || n + 4 <= p.out_cs)) continue;
+            if (p.res_post) y[k] += *reinterpret_cast<const f32x4*>(p.res_post + obase[mt] + 16 * k);
             if (tail) {
 #pragma unroll
                 for (int e = 0; e < 4; ++e)
-                    if (n + e >= p.cout) y[e] = 0.f;  // channels >= cout are padding: keep them exactly zero
+                    if (n + e >= p.cout) y[k][e] = 0.f;  // channels >= cout are padding: keep them exactly zero
             }
-            if (!(I2R_DBG(p) & 1) || y[0] == 12345.678f) *reinterpret_cast<f32x4*>(p.out + obase[mt] + 16 * k) = y;
+            if (!(I2R_DBG(p) & 1) || y[k][0] == 12345.678f) *reinterpret_cast<f32x4*>(p.out + obase[mt] + 16 * k) = y[k];
         }
+    }
     if (stamp) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         const unsigned long long ts3 = __builtin_amdgcn_s_memtime();
