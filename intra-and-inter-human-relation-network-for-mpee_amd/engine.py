@@ -468,6 +468,22 @@ def choose_tile(conv_h, conv_w, wm, stride, max_d, n_img, n_cblk, force_mt=0, wa
     return best[1], best[2], best[3]
 
 
+_LPT_CACHE = {}  # (counts, works, n_cu) -> dispatch order (a stage's modules repeat the same signature; a table costs ~25 ms of Python)
+_LPT_DEV = {}    # (device, counts, works) -> the table as a device tensor, shared by every program of the device
+
+
+def lpt_block_table(device, counts, works):
+    """device int32 tensor of lpt_block_order(counts, works), built once per signature and device"""
+    key = (str(device), tuple(counts), tuple(works))
+    t = _LPT_DEV.get(key)
+    if t is None:
+        ck = (tuple(counts), tuple(works), 256)
+        if ck not in _LPT_CACHE:
+            _LPT_CACHE[ck] = lpt_block_order(counts, works)
+        t = _LPT_DEV[key] = torch.tensor(_LPT_CACHE[ck], dtype=torch.int32, device=device)
+    return t
+
+
 def lpt_block_order(counts, works, n_cu=256):
     """Dispatch order for a grouped launch whose members have different per-workgroup work (K): longest-processing-
     time packing of all workgroups onto n_cu bins, emitted round by round (bin0[r], bin1[r], ...), so the first n_cu
@@ -756,7 +772,7 @@ class Program:
             works.append(d.cin * d.ntaps)
         a.n = len(group)
         if wino or len(set(works)) > 1:  # dispatch order: heaviest items first, balanced over the CUs (a Winograd item is small: always)
-            bm = torch.tensor(lpt_block_order(counts, works), dtype=torch.int32, device=self.device)
+            bm = lpt_block_table(self.device, counts, works)
             self.keep.append(bm)
             a.block_map, a.map_len = bm.data_ptr(), bm.numel()
         self.ops.append((cabi.OP_CONV_GROUP, lane, a))
