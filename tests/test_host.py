@@ -205,3 +205,29 @@ def test_conv_cat_folds_the_downsample_into_conv3():
     ref = bn(F.conv2d(t2, sd["c3.weight"]), "bn3") + bn(F.conv2d(x, sd["ds.0.weight"]), "ds.1")
     got = torch.einsum("nkhw,kc->nchw", torch.cat([x, t2], 1), w) + pc.bias[:256].view(1, -1, 1, 1)
     assert (got - ref).abs().max().item() < 1e-5
+
+
+def test_winograd_weight_transform_and_fragment_choice():
+    """host side of the Winograd F(2x2, 3x3) kernels (engine.winograd_weights / wino_fragment): Y = A^T[(G g G^T) . (B^T d B)]A with
+    the packed U reproduces the direct 3x3 convolution of a 4x4 tile; fragments cover the shipped maps without waste"""
+    import numpy as np
+    import torch
+    from i2r_amd import engine
+    rng = np.random.default_rng(0)
+    w = torch.from_numpy(rng.standard_normal((5, 7, 3, 3)))          # [cout, cin, 3, 3]
+    U = engine.winograd_weights(w).numpy().reshape(4, 4, 7, 5)       # [i, j, cin, cout]
+    d = rng.standard_normal((7, 4, 4))                               # one 4x4 input tile per input channel
+    BT = np.array([[1, 0, -1, 0], [0, 1, 1, 0], [0, -1, 1, 0], [0, 1, 0, -1]], float)
+    AT = np.array([[1, 1, 1, 0], [0, 1, -1, -1]], float)
+    V = np.einsum("ia,cab,jb->ijc", BT, d, BT)                       # B^T d B per channel
+    M = np.einsum("ijc,ijco->ijo", V, U)                             # the 16 GEMMs
+    Y = np.einsum("ai,ijo,bj->abo", AT, M, AT)                       # [2, 2, cout]
+    ref = np.array([[[(d[:, a:a + 3, b:b + 3] * w[o].numpy()).sum() for o in range(5)] for b in range(2)] for a in range(2)])
+    assert np.abs(Y - ref).max() < 1e-12
+    packed = engine.pack_k4(engine.winograd_weights(w), 16, 16)      # k4 layout with the 16 positions in place of the taps
+    assert tuple(packed.shape) == (16, 4, 16, 4) and packed.dtype == torch.float32
+    assert abs(packed[5, 1, 3, 2].item() - U[1, 1, 6, 3]) < 1e-6     # [pos = 4 i + j][cin / 4][cout][cin % 4]
+    for (h, w_), want in (((64, 48), (16, 4)), ((32, 24), (8, 8)), ((16, 12), (4, 16)), ((96, 72), (8, 8)), ((48, 36), (4, 16))):
+        fw, fh = engine.wino_fragment(h, w_)
+        assert (fw, fh) == want and fw * fh == 64
+        assert -(-h // fh) * fh * -(-w_ // fw) * fw == h * w_, "fragments cover the map without waste"

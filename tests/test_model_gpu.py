@@ -48,6 +48,33 @@ def test_heatmaps_match_reference_golden(tag):
             assert err_ref < TOL, "%s/%s vs reference golden max-abs %.3e" % (tag, k, err_ref)
 
 
+def test_direct_conv_path_still_matches_reference():
+    """fp32 3x3 stride-1 convs run on the Winograd kernel by default; the direct implicit-GEMM kernel they ran on until round 2 stays a
+    supported path (engine.WINOGRAD = False): same golden heat maps, and the two paths agree far inside the parity bar"""
+    from i2r_amd import engine
+    cfg, sd, x, m, length, g = setup("w48_l31")
+    y_wino = _net(cfg, sd, CASES["w48_l31"])(x.cuda(), m.cuda(), length).cpu()
+    saved = engine.WINOGRAD
+    engine.WINOGRAD = False
+    try:
+        net = eval("models." + cfg.MODEL.NAME + ".get_pose_net")(cfg, is_train=False)
+        net.load_state_dict(sd, strict=True)
+        net = net.cuda()
+        y_dir = net(x.cuda(), m.cuda(), length).cpu()
+        progs = [P for P, _ in net.engine().programs.values()]
+    finally:
+        engine.WINOGRAD = saved
+    for P in progs:  # no Winograd launch in the direct program
+        for k, _, st in P.ops:
+            if k == cabi.OP_CONV:
+                assert st.algo == 0
+            elif k == cabi.OP_CONV_GROUP:
+                assert all(st.d[i].contents.algo == 0 for i in range(st.n))
+    assert np.abs(y_dir.numpy() - g["out_multi"]).max() < TOL
+    assert np.abs(y_wino.numpy() - g["out_multi"]).max() < TOL
+    assert (y_dir - y_wino).abs().max().item() < 1e-4
+
+
 def test_standalone_hrnet_backbone_module():
     """models.hrnet.get_pose_net / models.backbone.build_backbone (reference lib/models/hrnet.py:419-446, backbone.py:9-20): the bare
     tower + reduce, fed with the `backbone.body.*` weights of the bare-backbone interformer case."""
