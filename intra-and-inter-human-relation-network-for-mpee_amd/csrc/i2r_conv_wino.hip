@@ -89,7 +89,13 @@ __global__ __launch_bounds__(256, (MT == 1 ? (NT == 3 ? 4 : 3) : 2)) void conv_w
     // ---- staging assignment: item = (fragment, patch pixel, channel group of the 16-channel chunk); the four lanes of a quad
     //      fetch the 64 contiguous bytes of one pixel (quad rule of the texture addresser, see i2r_conv.hip) ----
     constexpr int NIT = (MT * kWinoPatchMax * 4 + 255) / 256;
-    int goff[NIT], lslot[NIT];  // global element offset of (pixel, channel group) or -1 (outside the image: zero), LDS slot or -1 (no item)
+    // Global accesses go through buffer instructions: a 32-bit per-lane byte offset + a scalar offset that walks the channel chunks,
+    // no 64-bit address arithmetic on the vector ALU, and a lane whose offset lies beyond the descriptor's range reads zeros -- which
+    // is how the halo outside the image and the unused items are zero-filled without a select per load.
+    const __amdgpu_buffer_rsrc_t rs_in = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.in), 0, p.w_in_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_w = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.w), 0, p.w_w_bytes, 0x00020000);
+    unsigned goff[NIT];  // byte offset of (pixel, channel group) in `in`, 0xFFFFFFFF (out of range: reads zeros) outside the image
+    int lslot[NIT];      // LDS slot, -1 = no item
 #pragma unroll
     for (int k = 0; k < NIT; ++k) {
         const int it = tid + k * 256;
@@ -99,7 +105,7 @@ __global__ __launch_bounds__(256, (MT == 1 ? (NT == 3 ? 4 : 3) : 2)) void conv_w
         for (int m = 1; m <= MT; ++m)
             if (pix >= m * PP) { f = m; pp = pix - m * PP; }
         const int row = (pp * p.w_rcp) >> 16, col = pp - row * PC;
-        goff[k] = -1;
+        goff[k] = 0xFFFFFFFFu;
         lslot[k] = -1;
         if (f < MT) {
             int img = f_img[0], oy = f_oy[0], ox = f_ox[0];
@@ -109,14 +115,15 @@ __global__ __launch_bounds__(256, (MT == 1 ? (NT == 3 ? 4 : 3) : 2)) void conv_w
                 if (f == m) { img = f_img[m]; oy = f_oy[m]; ox = f_ox[m]; ok = f_ok[m]; }
             const int iy = oy - 1 + row, ix = ox - 1 + col;
             lslot[k] = (f * 4 + cg) * plane + row * pitch + (col & 1) * half + (col >> 1);
-            if (ok && iy >= 0 && iy < p.in_h && ix >= 0 && ix < p.in_w) goff[k] = ((img * p.in_h + iy) * p.in_w + ix) * p.in_cs + cg * 4;
+            if (ok && iy >= 0 && iy < p.in_h && ix >= 0 && ix < p.in_w) goff[k] = (unsigned)(((img * p.in_h + iy) * p.in_w + ix) * p.in_cs + cg * 4) * 4u;
         }
     }
     f32x4 v[NIT];
     auto stage_load = [&](int c0) {
 #pragma unroll
         for (int k = 0; k < NIT; ++k)
-            v[k] = (goff[k] >= 0 && !(I2R_DBG(p) & 2)) ? *reinterpret_cast<const f32x4*>(p.in + goff[k] + c0) : (f32x4){0.f, 0.f, 0.f, 0.f};
+            v[k] = (I2R_DBG(p) & 2) ? (f32x4){0.f, 0.f, 0.f, 0.f}
+                                    : __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_in, goff[k], c0 * 4, 0));
     };
     auto stage_store = [&](f32x4* buf) {
 #pragma unroll
@@ -153,12 +160,14 @@ __global__ __launch_bounds__(256, (MT == 1 ? (NT == 3 ? 4 : 3) : 2)) void conv_w
     // ---- B operand: U[pos = 4 i + j][cin / 4][cout_pad][4], lane (cout li, g) takes channels 4g..4g+3 of the 16-channel step;
     //      the pointer walks j (stride cin4 * cout_pad slots) and wraps to the next chunk after j = 3 ----
     const int cin4 = p.cin >> 2;
-    const f32x4* wp = reinterpret_cast<const f32x4*>(p.w) + n_base + li + (size_t)(wi * 4 * cin4 + g) * p.cout_pad;
-    const int inc_j = cin4 * p.cout_pad;
-    const int inc_wrap = (4 - 3 * cin4) * p.cout_pad;  // from (pass, j = 3) to (pass + 1, j = 0)
+    const unsigned wlane = (unsigned)(n_base + li + g * p.cout_pad) * 16u;   // per-lane byte offset (constant)
+    int wp = wi * 4 * cin4 * p.cout_pad * 16;                                   // scalar byte offset of (position 4 i + j, chunk)
+    const int inc_j = cin4 * p.cout_pad * 16;
+    const int inc_wrap = (4 - 3 * cin4) * p.cout_pad * 16;  // from (pass, j = 3) to (pass + 1, j = 0)
     auto fetch_b = [&](f32x4 (&b)[NT]) {
 #pragma unroll
-        for (int nt = 0; nt < NT; ++nt) b[nt] = (I2R_DBG(p) & 4) ? wp[0] : wp[nt * 16];
+        for (int nt = 0; nt < NT; ++nt)
+            b[nt] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_w, wlane + nt * 256u, (I2R_DBG(p) & 4) ? 0 : wp, 0));
     };
 
     f32x4 acc[4][MT][NT];
