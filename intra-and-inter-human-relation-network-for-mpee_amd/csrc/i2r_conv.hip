@@ -399,7 +399,7 @@ static void copy_desc(const i2r_conv_desc* d, ConvK& k) {
     k.dtype = d->dtype;
     k.in16 = d->in_f16; k.out16 = d->out_f16;
     k.algo = d->algo; k.w_fwlog = k.w_pitch = k.w_half = k.w_nfrag = k.w_rcp = 0;
-    k.w_m_cblk = k.w_m_img = k.w_m_tx = 0; k.w_in_bytes = k.w_w_bytes = 0;
+    k.w_m_cblk = k.w_m_img = k.w_m_tx = 0; k.w_in_bytes = k.w_w_bytes = k.w_out_bytes = 0;
     k.m_cblk = k.m_tx = k.m_ty = k.m_pw = k.m_tw = 0; k.wn_log = 0; k.npass = 0;
     k.dbg = 0;
 }
@@ -413,9 +413,9 @@ static int prepare_wino(const i2r_conv_desc* d, int force_mt, ConvK& k, int* nt_
                   "i2r_conv: algo 1 (Winograd) needs a plain 3x3 stride-1 pad-1 convolution");
     for (int t = 0; t < 9; ++t) I2R_CHECK_ARG(d->dy[t] == t / 3 && d->dx[t] == t % 3, "i2r_conv: algo 1 needs row-major 3x3 taps");
     I2R_CHECK_ARG(d->relu == 0 || d->relu == 1, "i2r_conv: algo 1 has no GELU epilogue");
-    I2R_CHECK_ARG((long long)d->n_img * d->in_h * d->in_w * d->in_cs < (1ll << 30) && (long long)d->n_img * d->out_h * d->out_w * d->out_cs < (1ll << 31) &&
-                      (long long)16 * d->cin * d->cout_pad < (1ll << 30),
-                  "i2r_conv: algo 1 addresses tensors with 32-bit offsets");
+    I2R_CHECK_ARG((long long)d->n_img * d->in_h * d->in_w * d->in_cs < (1ll << 29) && (long long)d->n_img * d->out_h * d->out_w * d->out_cs < (1ll << 29) &&
+                      (long long)16 * d->cin * d->cout_pad < (1ll << 29),
+                  "i2r_conv: algo 1 addresses its tensors through buffer descriptors of < 2 GiB");
     I2R_CHECK_ARG(d->conv_h == d->in_h && d->conv_w == d->in_w && d->out_h == d->conv_h && d->out_w == d->conv_w, "i2r_conv: algo 1 geometry");
     const int nfrag = d->cout_pad / 16;
     const int nt = nfrag % 3 == 0 ? 3 : (nfrag % 4 == 0 ? 4 : 0);
@@ -447,6 +447,7 @@ static int prepare_wino(const i2r_conv_desc* d, int force_mt, ConvK& k, int* nt_
     k.w_rcp = (65536 + k.pw - 1) / k.pw;  // exact for pixel indices < 256 and pw in {6, 10, 18}
     k.w_in_bytes = (unsigned)((long long)d->n_img * d->in_h * d->in_w * d->in_cs * 4);
     k.w_w_bytes = (unsigned)((long long)16 * d->cin * d->cout_pad * 4);
+    k.w_out_bytes = (unsigned)((long long)d->n_img * d->out_h * d->out_w * d->out_cs * 4);
     // item decode without integer divisions: n / d = mulhi(n, ceil(2^32 / d)) is exact for n < 2^20 and d < 2^11
     auto magic = [](int d) { return d == 1 ? 0u : (unsigned)(((1ull << 32) + d - 1) / d); };
     k.w_m_cblk = magic(k.n_cblk); k.w_m_img = magic(k.tiles_y * k.tiles_x); k.w_m_tx = magic(k.tiles_x);

@@ -36,6 +36,10 @@
 
 namespace {
 
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+// lane offset that lies beyond every buffer this kernel describes (tensors are < 2 GiB, checked by the host) and stays there when a
+// chunk / piece offset of a few KiB is added: such a lane reads zeros and its stores are dropped
+constexpr unsigned kOOB = 0x80000000u;
 constexpr int kWinoPatchMax = 108;  // patch pixels of a fragment: 6 x 18 (FW = 8 or 2), 10 x 10 (FW = 4)
 
 template <int MT, int NT>
@@ -94,7 +98,7 @@ __global__ __launch_bounds__(256, (MT == 1 ? (NT == 3 ? 4 : 3) : 2)) void conv_w
     // is how the halo outside the image and the unused items are zero-filled without a select per load.
     const __amdgpu_buffer_rsrc_t rs_in = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.in), 0, p.w_in_bytes, 0x00020000);
     const __amdgpu_buffer_rsrc_t rs_w = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.w), 0, p.w_w_bytes, 0x00020000);
-    unsigned goff[NIT];  // byte offset of (pixel, channel group) in `in`, 0xFFFFFFFF (out of range: reads zeros) outside the image
+    unsigned goff[NIT];  // byte offset of (pixel, channel group) in `in`, kOOB (out of range: reads zeros) outside the image
     int lslot[NIT];      // LDS slot, -1 = no item
 #pragma unroll
     for (int k = 0; k < NIT; ++k) {
@@ -105,7 +109,7 @@ __global__ __launch_bounds__(256, (MT == 1 ? (NT == 3 ? 4 : 3) : 2)) void conv_w
         for (int m = 1; m <= MT; ++m)
             if (pix >= m * PP) { f = m; pp = pix - m * PP; }
         const int row = (pp * p.w_rcp) >> 16, col = pp - row * PC;
-        goff[k] = 0xFFFFFFFFu;
+        goff[k] = kOOB;
         lslot[k] = -1;
         if (f < MT) {
             int img = f_img[0], oy = f_oy[0], ox = f_ox[0];
@@ -230,12 +234,19 @@ __global__ __launch_bounds__(256, (MT == 1 ? (NT == 3 ? 4 : 3) : 2)) void conv_w
     // ---- over i across the waves:  Y[0][b] = T0 + T1 + T2,  Y[1][b] = T1 - T2 - T3.  A thread owns one output pixel per fragment and
     //      every fourth 16-byte channel piece of it (piece q + 4 k, q = tid & 3: the four lanes of a quad write 64 contiguous bytes), so
     //      the pixel's index math is done once for its NT pieces ----
-    int obase[MT];  // element offset of the pixel's channel n_base in out / res*, -1 = nothing to write
+    // (buffer instructions here too: a pixel outside the map, or a piece in the padding of a tail block, gets the out-of-range offset --
+    //  its loads return zeros and its stores are dropped, so the epilogue has no divergent branches)
+    unsigned obase[MT];  // byte offset of the pixel's channel n0 in out / res*
     const int q4 = tid & 3, px = tid >> 2;  // pixel px of the fragment: tile px >> 2, output row parity (px >> 1) & 1, column parity px & 1
     const bool hi = (px & 2) != 0;
     const int n0 = n_base + q4 * 4;  // (+ 16 k < cout_pad: a channel block never reaches past the padded width)
     const bool tail = n_base + NT * 16 > p.cout || n_base + NT * 16 > p.out_cs;  // (uniform) the block holds padding channels
-    const bool has_res = (p.res1 != nullptr || res2 != nullptr) && !(I2R_DBG(p) & 1);
+    const unsigned out_bytes = p.w_out_bytes;
+    const __amdgpu_buffer_rsrc_t rs_out = __builtin_amdgcn_make_buffer_rsrc(p.out, 0, out_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_r1 = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.res1), 0, p.res1 ? out_bytes : 0, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_r2 = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(res2), 0, res2 ? out_bytes : 0, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_rp = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.res_post), 0, p.res_post ? out_bytes : 0, 0x00020000);
+    auto ldb = [](const __amdgpu_buffer_rsrc_t& rs, unsigned off) { return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, off, 0, 0)); };
     f32x4 r[MT][NT];
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt) {
@@ -243,16 +254,13 @@ __global__ __launch_bounds__(256, (MT == 1 ? (NT == 3 ? 4 : 3) : 2)) void conv_w
         const int oy = f_oy[mt] + 2 * (t >> fwl) + (hi ? 1 : 0);
         const int ox = f_ox[mt] + 2 * (t & (FW - 1)) + (px & 1);
         const bool ok = f_ok[mt] && oy < p.conv_h && ox < p.conv_w;
-        obase[mt] = ok ? ((f_img[mt] * p.out_h + oy) * p.out_w + ox) * p.out_cs + n0 : -1;
+        obase[mt] = ok ? (unsigned)(((f_img[mt] * p.out_h + oy) * p.out_w + ox) * p.out_cs + n0) * 4u : kOOB;
 #pragma unroll
-        for (int k = 0; k < NT; ++k) r[mt][k] = *reinterpret_cast<const f32x4*>(p.bias + n0 + 16 * k);
-        // (one exec region per pixel: its NT pieces share the validity; a tail block re-checks per piece below)
-        if (has_res && ok) {
-#pragma unroll
-            for (int k = 0; k < NT; ++k) {
-                if (tail && !(n0 + 16 * k + 4 <= p.cout || n0 + 16 * k + 4 <= p.out_cs)) continue;
-                if (p.res1) r[mt][k] += *reinterpret_cast<const f32x4*>(p.res1 + obase[mt] + 16 * k);
-                if (res2) r[mt][k] += *reinterpret_cast<const f32x4*>(res2 + obase[mt] + 16 * k);
+        for (int k = 0; k < NT; ++k) {
+            r[mt][k] = *reinterpret_cast<const f32x4*>(p.bias + n0 + 16 * k);
+            if (!(I2R_DBG(p) & 1)) {
+                if (p.res1) r[mt][k] += ldb(rs_r1, obase[mt] + 64u * k);
+                if (res2) r[mt][k] += ldb(rs_r2, obase[mt] + 64u * k);
             }
         }
     }
@@ -261,31 +269,26 @@ __global__ __launch_bounds__(256, (MT == 1 ? (NT == 3 ? 4 : 3) : 2)) void conv_w
     const float* const tq = Tl + ((px & 1) + (hi ? 2 : 0)) * TPL + (px >> 2) * TW + q4 * 4;
     const float sgn = hi ? -1.f : 1.f;  // Y = u0 + sgn (u1 + u2)
 #pragma unroll
-    for (int mt = 0; mt < MT; ++mt) {
-        f32x4 y[NT];
+    for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
         for (int k = 0; k < NT; ++k) {
             const float* q = tq + mt * 16 * TW + 16 * k;
             const f32x4 u0 = *reinterpret_cast<const f32x4*>(q);             // T0 | T1
             const f32x4 u1 = *reinterpret_cast<const f32x4*>(q + 2 * TPL);   // T1 | T2
             const f32x4 u2 = *reinterpret_cast<const f32x4*>(q + 4 * TPL);   // T2 | T3
-            y[k] = u0 + sgn * (u1 + u2) + r[mt][k];
-            if (p.relu) { y[k][0] = fmaxf(y[k][0], 0.f); y[k][1] = fmaxf(y[k][1], 0.f); y[k][2] = fmaxf(y[k][2], 0.f); y[k][3] = fmaxf(y[k][3], 0.f); }
-        }
-        if (obase[mt] < 0) continue;
-#pragma unroll
-        for (int k = 0; k < NT; ++k) {
-            const int n = n0 + 16 * k;
-            if (tail && !(n + 4 <= p.cout || n + 4 <= p.out_cs)) continue;
-            if (p.res_post) y[k] += *reinterpret_cast<const f32x4*>(p.res_post + obase[mt] + 16 * k);
-            if (tail) {
+            f32x4 y = u0 + sgn * (u1 + u2) + r[mt][k];
+            if (p.relu) { y[0] = fmaxf(y[0], 0.f); y[1] = fmaxf(y[1], 0.f); y[2] = fmaxf(y[2], 0.f); y[3] = fmaxf(y[3], 0.f); }
+            unsigned off = obase[mt] + 64u * k;
+            if (p.res_post) y += ldb(rs_rp, off);
+            if (tail) {  // (uniform) channels >= cout are padding: keep them exactly zero; pieces beyond the row are not written
+                const int n = n0 + 16 * k;
+                if (!(n + 4 <= p.cout || n + 4 <= p.out_cs)) off = kOOB;
 #pragma unroll
                 for (int e = 0; e < 4; ++e)
-                    if (n + e >= p.cout) y[k][e] = 0.f;  // channels >= cout are padding: keep them exactly zero
+                    if (n + e >= p.cout) y[e] = 0.f;
             }
-            if (!(I2R_DBG(p) & 1) || y[k][0] == 12345.678f) *reinterpret_cast<f32x4*>(p.out + obase[mt] + 16 * k) = y[k];
+            if (!(I2R_DBG(p) & 1) || y[0] == 12345.678f) __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, y), rs_out, off, 0, 0);
         }
-    }
     if (stamp) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         const unsigned long long ts3 = __builtin_amdgcn_s_memtime();
