@@ -37,18 +37,31 @@ struct ConvK {
     // index decode without integer divisions (a runtime division is ~35 vector-ALU instructions; a workgroup's prologue had a dozen):
     // ceil(2^32 / d) for d = n_cblk, tiles_x, tiles_y, pw, tile_w (div_m below); wn_log = log2(wn); npass = channel chunks per workgroup
     unsigned m_cblk, m_tx, m_ty, m_pw, m_tw;
+    // byte sizes of in (= in2), the packed weights and out (= res1 / res2 / res_post) for the buffer descriptors of the kernels: global
+    // accesses are buffer instructions with 32-bit lane offsets, a lane at kOOB reads zeros and its stores are dropped
+    unsigned in_bytes, w_bytes, out_bytes;
     int wn_log, npass;
     // Winograd F(2x2, 3x3) kernels (i2r_conv_wino.hip; algo == 1): tiles_y / tiles_x count FRAGMENTS (16 Winograd tiles, 2^w_fwlog across)
     // per crop, ph / pw / plane describe one fragment's raw patch, whose rows have w_pitch slots with the odd columns at + w_half
     int algo, w_fwlog, w_pitch, w_half, w_nfrag, w_rcp;  // w_rcp = ceil(65536 / pw): patch row of a pixel index without a division
-    unsigned w_out_bytes;                                // size of out (= of res1 / res2 / res_post)
-    unsigned w_in_bytes, w_w_bytes;                      // sizes of `in` and of the transformed weights (buffer descriptors: reads beyond them return zeros)
     unsigned w_m_cblk, w_m_img, w_m_tx;                  // ceil(2^32 / d) for d = n_cblk, fragments per crop, fragments per row (item decode)
 };
 
 // n / d through m = ceil(2^32 / d): exact while n * (m * d - 2^32) < 2^32, i.e. for every n < 2^32 / d (prepare() checks the ranges);
 // d == 1 has no 32-bit reciprocal
 __device__ __forceinline__ int div_m(int n, int d, unsigned m) { return d == 1 ? n : (int)__umulhi((unsigned)n, m); }
+
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+// lane offset beyond every buffer the conv kernels describe (tensors are < 2 GiB: checked by the host) that stays there when a chunk /
+// piece offset of a few KiB is added
+constexpr unsigned kOOB = 0x80000000u;
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void* base, unsigned bytes) {
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, base ? bytes : 0, 0x00020000);
+}
+__device__ __forceinline__ f32x4 buf_ld16(const __amdgpu_buffer_rsrc_t& rs, unsigned voff, int soff) {
+    return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, voff, soff, 0));
+}
 
 constexpr int kMaxPP = 5;  // patch pixels per thread (256 threads) -> patches up to 1280 pixels
 
@@ -99,6 +112,44 @@ __device__ __forceinline__ void st_act4(float* base, size_t off, f32x4 v, bool h
     *reinterpret_cast<f32x4*>(base + off) = v;
 }
 
+// the same through a buffer descriptor at BYTE offset voff (a lane at kOOB: loads return zeros, stores are dropped)
+template <int DT>
+__device__ __forceinline__ f32x4 buf_ld_act4(const __amdgpu_buffer_rsrc_t& rs, unsigned voff, bool h16) {
+    if constexpr (DT != 0) {
+        if (h16) {
+            const u32x2 u = __builtin_amdgcn_raw_buffer_load_b64(rs, voff, 0, 0);
+            if constexpr (DT == 1)
+                return (f32x4){__uint_as_float(u.x << 16), __uint_as_float(u.x & 0xFFFF0000u), __uint_as_float(u.y << 16), __uint_as_float(u.y & 0xFFFF0000u)};
+            else {
+                typedef _Float16 h4 __attribute__((ext_vector_type(4)));
+                const h4 h = __builtin_bit_cast(h4, u);
+                return (f32x4){(float)h[0], (float)h[1], (float)h[2], (float)h[3]};
+            }
+        }
+    }
+    return buf_ld16(rs, voff, 0);
+}
+template <int DT>
+__device__ __forceinline__ void buf_st_act4(const __amdgpu_buffer_rsrc_t& rs, unsigned voff, f32x4 v, bool h16) {
+    if constexpr (DT != 0) {
+        if (h16) {
+            u32x2 u;
+            if constexpr (DT == 1) {
+                typedef __bf16 b4 __attribute__((ext_vector_type(4)));
+                const b4 b = {(__bf16)v[0], (__bf16)v[1], (__bf16)v[2], (__bf16)v[3]};
+                u = __builtin_bit_cast(u32x2, b);
+            } else {
+                typedef _Float16 h4 __attribute__((ext_vector_type(4)));
+                const h4 h = {(_Float16)v[0], (_Float16)v[1], (_Float16)v[2], (_Float16)v[3]};
+                u = __builtin_bit_cast(u32x2, h);
+            }
+            __builtin_amdgcn_raw_buffer_store_b64(u, rs, voff, 0, 0);
+            return;
+        }
+    }
+    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), rs, voff, 0, 0);
+}
+
 // ---- epilogue (shared by the fp32 and the bf16/f16 MFMA bodies: the C/D register layout is dtype independent) ----
 // D layout: lane (li = l&15, g) holds channel n = nt*16 + li of pixels 4g + r (r = 0..3).  A 4x4 transpose inside each
 // lane quad (two DPP butterfly stages, no LDS) turns that into: lane (q = li>>2, j = li&3, g) holds channels
@@ -125,14 +176,19 @@ __device__ __forceinline__ void conv_epilogue(const ConvK& p, f32x4 (&acc)[MT][N
         return v;
     };
     const bool h16 = DT != 0 && p.out16;
-    auto finish = [&](f32x4 t, int n, bool full, bool res_post_at, size_t res_post_off) {
+    const unsigned esz = h16 ? 2u : 4u;
+    // destination / residual tensors through buffer descriptors: pixels outside the map and channel pieces beyond the row get the
+    // out-of-range offset -- their loads return zeros, their stores are dropped -- so nothing below branches on validity
+    const __amdgpu_buffer_rsrc_t rs_out = make_rsrc(p.out, p.out_bytes), rs_r1 = make_rsrc(p.res1, p.out_bytes),
+                                 rs_r2 = make_rsrc(p.res2, p.out_bytes), rs_rp = make_rsrc(p.res_post, p.out_bytes);
+    auto finish = [&](f32x4 t, int n, bool full, unsigned voff) {
         if (p.relu == 1) {
             t[0] = fmaxf(t[0], 0.f); t[1] = fmaxf(t[1], 0.f); t[2] = fmaxf(t[2], 0.f); t[3] = fmaxf(t[3], 0.f);
         } else if (p.relu == 2) {  // exact-erf GELU (HRFormer MlpDWBN, hrformer.py:1197)
 #pragma unroll
             for (int e = 0; e < 4; ++e) t[e] = 0.5f * t[e] * (1.f + erff(t[e] * 0.70710678118654752f));
         }
-        if (res_post_at) t += ld_act4<DT>(p.res_post, res_post_off, h16);
+        if (p.res_post) t += buf_ld_act4<DT>(rs_rp, voff, h16);
         if (!full) {  // channels >= cout are padding: keep them exactly zero
 #pragma unroll
             for (int e = 0; e < 4; ++e)
@@ -142,37 +198,38 @@ __device__ __forceinline__ void conv_epilogue(const ConvK& p, f32x4 (&acc)[MT][N
     };
     // per-lane channel piece of every N fragment: bias fetched once, up front
     f32x4 bias[NT];
-    bool nok[NT];
+    unsigned noff[NT];  // byte offset of the piece inside a pixel's row, kOOB when the piece does not exist in the destination
+    const bool tail = n_base + NT * 16 > p.cout || n_base + NT * 16 > p.out_cs;  // (wave-uniform)
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt) {
         const int n = n_base + nt * 16 + pq * 4;
-        nok[nt] = n < p.cout_pad && (n + 4 <= p.cout || n + 4 <= p.out_cs);
+        const bool nok = n < p.cout_pad && (n + 4 <= p.cout || n + 4 <= p.out_cs);
+        noff[nt] = nok ? (unsigned)n * esz : kOOB;
         bias[nt] = n < p.cout_pad ? *reinterpret_cast<const f32x4*>(p.bias + n) : (f32x4){0.f, 0.f, 0.f, 0.f};
     }
     if (p.rep == 1 && !(I2R_DBG(p) & 16)) {
         // ---- every output pixel written once: issue ALL residual loads of the tile first (one memory latency instead of
         //      MT x NT dependent load -> add -> store round trips), then transform and store ----
-        size_t off[MT];
-        bool pv[MT];
+        unsigned off[MT];
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt) {
             const int m = (wm * MT + mt) * 16 + g * 4 + pj;
             const int ty = div_m(m, p.tile_w, p.m_tw), tx = m - ty * p.tile_w;
             const int oy = oy0 + ty, ox = ox0 + tx;
-            pv[mt] = m < tile_px && oy < p.conv_h && ox < p.conv_w;
-            off[mt] = ((size_t)(img * p.out_h + oy * p.out_step + p.out_off_y) * p.out_w + ox * p.out_step + p.out_off_x) * p.out_cs;
+            const bool pv = m < tile_px && oy < p.conv_h && ox < p.conv_w;
+            off[mt] = pv ? (unsigned)(((img * p.out_h + oy * p.out_step + p.out_off_y) * p.out_w + ox * p.out_step + p.out_off_x) * p.out_cs) * esz : kOOB;
         }
+        // byte offset of piece (mt, nt): pixel + piece; only a TAIL block (uniform: the wave's channels reach past cout / the row) has
+        // pieces that do not exist -- elsewhere the plain sum is right, and a pixel at kOOB stays out of range with a piece offset added
+        auto at = [&](int mt, int nt) { return (tail && noff[nt] == kOOB) ? kOOB : off[mt] + noff[nt]; };
         f32x4 r[MT][NT];
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
             for (int nt = 0; nt < NT; ++nt) {
-                const size_t o = off[mt] + n_base + nt * 16 + pq * 4;
                 r[mt][nt] = bias[nt];
-                if (pv[mt] && nok[nt]) {
-                    if (p.res1) r[mt][nt] += ld_act4<DT>(p.res1, o, h16);
-                    if (p.res2) r[mt][nt] += ld_act4<DT>(p.res2, o, h16);
-                }
+                if (p.res1) r[mt][nt] += buf_ld_act4<DT>(rs_r1, at(mt, nt), h16);
+                if (p.res2) r[mt][nt] += buf_ld_act4<DT>(rs_r2, at(mt, nt), h16);
             }
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt)
@@ -180,9 +237,8 @@ __device__ __forceinline__ void conv_epilogue(const ConvK& p, f32x4 (&acc)[MT][N
             for (int nt = 0; nt < NT; ++nt) {
                 const f32x4 v = to_pixel_major(acc[mt][nt]);
                 const int n = n_base + nt * 16 + pq * 4;
-                if (!pv[mt] || !nok[nt]) continue;
-                const size_t o = off[mt] + n;
-                st_act4<DT>(p.out, o, finish(v + r[mt][nt], n, n + 4 <= p.cout, p.res_post != nullptr, o), h16);
+                const unsigned o = at(mt, nt);
+                buf_st_act4<DT>(rs_out, o, finish(v + r[mt][nt], n, !tail || n + 4 <= p.cout, o), h16);
             }
         return;
     }
@@ -198,14 +254,14 @@ __device__ __forceinline__ void conv_epilogue(const ConvK& p, f32x4 (&acc)[MT][N
         for (int nt = 0; nt < NT; ++nt) {
             const f32x4 v = to_pixel_major(acc[mt][nt]) + bias[nt];
             const int n = n_base + nt * 16 + pq * 4;
-            if (!pvalid || !nok[nt]) continue;
+            if (!pvalid || noff[nt] == kOOB) continue;
             for (int ry = 0; ry < p.rep; ++ry)
                 for (int rx = 0; rx < p.rep; ++rx) {
-                    const size_t o = ((size_t)(img * p.out_h + by + ry) * p.out_w + bx + rx) * p.out_cs + n;
+                    const unsigned o = (unsigned)(((img * p.out_h + by + ry) * p.out_w + bx + rx) * p.out_cs) * esz + noff[nt];
                     f32x4 t = v;
-                    if (p.res1) t += ld_act4<DT>(p.res1, o, h16);
-                    if (p.res2) t += ld_act4<DT>(p.res2, o, h16);
-                    st_act4<DT>(p.out, o, finish(t, n, n + 4 <= p.cout, p.res_post != nullptr, o), h16);
+                    if (p.res1) t += buf_ld_act4<DT>(rs_r1, o, h16);
+                    if (p.res2) t += buf_ld_act4<DT>(rs_r2, o, h16);
+                    buf_st_act4<DT>(rs_out, o, finish(t, n, n + 4 <= p.cout, o), h16);
                 }
         }
     }

@@ -57,22 +57,20 @@ __device__ __forceinline__ void conv_body(const ConvK& p, int bid, f32x4* lds) {
     // channel independent, so computed once
     // (the synchronous variant PF == 0 serves patches of up to 1280 pixels: it keeps one pixel per lane, 20 offsets per thread
     // would cost a wave of occupancy)
+    // (global accesses are buffer instructions: 32-bit lane byte offsets + scalar chunk offsets, no 64-bit address arithmetic on the
+    //  vector ALU; a lane at kOOB -- halo outside the image, unused slots -- reads zeros without a select per load)
     constexpr int NPP = PF > 0 ? 4 * PF : kMaxPP;
     const int ul = tid & 3;
-    int goff[NPP];
-    bool gval[NPP];
+    const __amdgpu_buffer_rsrc_t rs_in = make_rsrc(p.in, p.in_bytes), rs_in2 = make_rsrc(p.in2, p.in_bytes), rs_w = make_rsrc(p.w, p.w_bytes);
+    unsigned goff[NPP];  // byte offset of the patch pixel's channel 0, kOOB outside the image
 #pragma unroll
     for (int j = 0; j < NPP; ++j) {
         const int pp = PF > 0 ? (tid >> 2) + j * 64 : tid + j * 256;
-        goff[j] = 0;
-        gval[j] = false;
+        goff[j] = kOOB;
         if (pp < phw) {
             const int py = div_m(pp, p.pw, p.m_pw), px = pp - py * p.pw;
             const int iy = py0 + py, ix = px0 + px;
-            if (iy >= 0 && iy < p.in_h && ix >= 0 && ix < p.in_w) {
-                goff[j] = ((img * p.in_h + iy) * p.in_w + ix) * p.in_cs;
-                gval[j] = true;
-            }
+            if (iy >= 0 && iy < p.in_h && ix >= 0 && ix < p.in_w) goff[j] = (unsigned)(((img * p.in_h + iy) * p.in_w + ix) * p.in_cs) * 4u;
         }
     }
     const int npp = (phw + 255) >> 8;  // PF == 0: patch pixels per thread actually in use (wave-uniform)
@@ -96,8 +94,8 @@ __device__ __forceinline__ void conv_body(const ConvK& p, int bid, f32x4* lds) {
 
     const int n_base = (cb * WN + wn) * NT * 16;
     const int cin4 = p.cin >> 2;
-    // lane's weight pointer: float4 index ((tap*cin4 + cg) * cout_pad + n)
-    const f32x4* wq = reinterpret_cast<const f32x4*>(p.w) + n_base + li;
+    // lane's weight offset: float4 index ((tap*cin4 + cg) * cout_pad + n): the lane part (n, g) is constant, the rest walks on the scalar ALU
+    const unsigned wlane = (unsigned)(n_base + li + g * p.cout_pad) * 16u;
 
     // ---- one channel chunk: K loop over (tap, 16-channel step) reading the staged patch `buf`, software-pipelined
     //      one step ahead with two named register sets (no register copies, so the compiler's vmcnt/lgkmcnt waits land
@@ -105,14 +103,14 @@ __device__ __forceinline__ void conv_body(const ConvK& p, int bid, f32x4* lds) {
     auto run_chunk = [&](const f32x4* buf, int c0, int ckc, auto&& mid) {
         const int ncs = ckc >> 4;
         const int nit = p.ntaps * ncs;
-        const f32x4* const wp0 = wq + (size_t)((c0 >> 2) + g) * p.cout_pad;  // step (tap 0, cs 0) of this chunk
-        const f32x4* wp = wp0;
-        const size_t inc_cs = (size_t)4 * p.cout_pad;
-        const size_t inc_tap = (size_t)(cin4 - (ncs - 1) * 4) * p.cout_pad;
+        const int wp0 = (c0 >> 2) * p.cout_pad * 16;  // step (tap 0, cs 0) of this chunk (scalar byte offset)
+        int wp = wp0;
+        const int inc_cs = 4 * p.cout_pad * 16;
+        const int inc_tap = (cin4 - (ncs - 1) * 4) * p.cout_pad * 16;
         int cs_n = 0, tx_n = 0, ty_n = 0;  // position of the next step to fetch
         auto fetch = [&](f32x4(&a)[MT], f32x4(&b)[NT]) {
 #pragma unroll
-            for (int nt = 0; nt < NT; ++nt) b[nt] = (I2R_DBG(p) & 4) ? wp0[nt * 16] : wp[nt * 16];
+            for (int nt = 0; nt < NT; ++nt) b[nt] = buf_ld16(rs_w, wlane + nt * 256u, (I2R_DBG(p) & 4) ? wp0 : wp);
             const int abase = (cs_n * 4 + g) * p.plane + ty_n * p.pw + tx_n;
 #pragma unroll
             for (int mt = 0; mt < MT; ++mt) a[mt] = buf[abase + ppix[mt]];
@@ -163,8 +161,7 @@ __device__ __forceinline__ void conv_body(const ConvK& p, int bid, f32x4* lds) {
                     for (int j = 0; j < PJ; ++j)
                         // (predicated on the pixel lying inside the image: halo pixels outside cost no memory access -- and the
                         //  exec-masked loads keep this block of loads together: with unconditional loads the same kernel measured 8 % slower)
-                        v[uq][j] = (gval[j] && !(I2R_DBG(p) & 2)) ? *reinterpret_cast<const f32x4*>(p.in + goff[j] + c0 + (uq * 4 + ul) * 4)
-                                                                  : (f32x4){0.f, 0.f, 0.f, 0.f};
+                        v[uq][j] = (I2R_DBG(p) & 2) ? (f32x4){0.f, 0.f, 0.f, 0.f} : buf_ld16(rs_in, goff[j] + (uq * 4 + ul) * 16u, c0 * 4);
                 }
             if (p.in2) {
 #pragma unroll
@@ -172,7 +169,7 @@ __device__ __forceinline__ void conv_body(const ConvK& p, int bid, f32x4* lds) {
                     if (uq * 4 < ckg) {
 #pragma unroll
                         for (int j = 0; j < PJ; ++j)
-                            if (gval[j]) v[uq][j] += *reinterpret_cast<const f32x4*>(p.in2 + goff[j] + c0 + (uq * 4 + ul) * 4);
+                            v[uq][j] += buf_ld16(rs_in2, goff[j] + (uq * 4 + ul) * 16u, c0 * 4);
                     }
             }
         };
@@ -213,14 +210,13 @@ __device__ __forceinline__ void conv_body(const ConvK& p, int bid, f32x4* lds) {
                 for (int u = 0; u < 4; ++u)
 #pragma unroll
                     for (int j = 0; j < kMaxPP; ++j)
-                        v[u][j] = (j < npp && gval[j] && !(I2R_DBG(p) & 2)) ? *reinterpret_cast<const f32x4*>(p.in + goff[j] + c0 + (cg0 + u) * 4)
-                                                                             : (f32x4){0.f, 0.f, 0.f, 0.f};
+                        v[u][j] = (j < npp && !(I2R_DBG(p) & 2)) ? buf_ld16(rs_in, goff[j] + u * 16u, (c0 + cg0 * 4) * 4) : (f32x4){0.f, 0.f, 0.f, 0.f};
                 if (p.in2) {
 #pragma unroll
                     for (int u = 0; u < 4; ++u)
 #pragma unroll
                         for (int j = 0; j < kMaxPP; ++j)
-                            if (j < npp && gval[j]) v[u][j] += *reinterpret_cast<const f32x4*>(p.in2 + goff[j] + c0 + (cg0 + u) * 4);
+                            if (j < npp) v[u][j] += buf_ld16(rs_in2, goff[j] + u * 16u, (c0 + cg0 * 4) * 4);
                 }
 #pragma unroll
                 for (int u = 0; u < 4; ++u)
@@ -266,7 +262,7 @@ __global__ __launch_bounds__(256) void conv_igemm_f32(const ConvGroupK grp) {
     if (grp.blk_map) {
         // host-chosen dispatch order (longest-processing-time packing over the CUs): members of a group have very
         // different K, and with every workgroup resident from the start the hardware cannot rebalance later
-        const int v = grp.blk_map[bid];
+        const int v = __builtin_amdgcn_readfirstlane(grp.blk_map[bid]);  // (uniform: keeps the member's fields and buffer descriptors in SGPRs)
         gi = v >> 24;
         bid = v & 0xFFFFFF;
     } else {
@@ -399,7 +395,7 @@ static void copy_desc(const i2r_conv_desc* d, ConvK& k) {
     k.dtype = d->dtype;
     k.in16 = d->in_f16; k.out16 = d->out_f16;
     k.algo = d->algo; k.w_fwlog = k.w_pitch = k.w_half = k.w_nfrag = k.w_rcp = 0;
-    k.w_m_cblk = k.w_m_img = k.w_m_tx = 0; k.w_in_bytes = k.w_w_bytes = k.w_out_bytes = 0;
+    k.w_m_cblk = k.w_m_img = k.w_m_tx = 0; k.in_bytes = k.w_bytes = k.out_bytes = 0;
     k.m_cblk = k.m_tx = k.m_ty = k.m_pw = k.m_tw = 0; k.wn_log = 0; k.npass = 0;
     k.dbg = 0;
 }
@@ -445,9 +441,9 @@ static int prepare_wino(const i2r_conv_desc* d, int force_mt, ConvK& k, int* nt_
     k.w_pitch = fw == 8 ? 20 : (fw == 4 ? 10 : 9);
     k.plane = cdiv(k.ph * k.w_pitch, 16) * 16;
     k.w_rcp = (65536 + k.pw - 1) / k.pw;  // exact for pixel indices < 256 and pw in {6, 10, 18}
-    k.w_in_bytes = (unsigned)((long long)d->n_img * d->in_h * d->in_w * d->in_cs * 4);
-    k.w_w_bytes = (unsigned)((long long)16 * d->cin * d->cout_pad * 4);
-    k.w_out_bytes = (unsigned)((long long)d->n_img * d->out_h * d->out_w * d->out_cs * 4);
+    k.in_bytes = (unsigned)((long long)d->n_img * d->in_h * d->in_w * d->in_cs * 4);
+    k.w_bytes = (unsigned)((long long)16 * d->cin * d->cout_pad * 4);
+    k.out_bytes = (unsigned)((long long)d->n_img * d->out_h * d->out_w * d->out_cs * 4);
     // item decode without integer divisions: n / d = mulhi(n, ceil(2^32 / d)) is exact for n < 2^20 and d < 2^11
     auto magic = [](int d) { return d == 1 ? 0u : (unsigned)(((1ull << 32) + d - 1) / d); };
     k.w_m_cblk = magic(k.n_cblk); k.w_m_img = magic(k.tiles_y * k.tiles_x); k.w_m_tx = magic(k.tiles_x);
@@ -601,6 +597,12 @@ static int prepare(const i2r_conv_desc* d, int force_mt, int force_cap, int forc
     I2R_CHECK_ARG(lds_bytes <= 160 * 1024, "i2r_conv: LDS %zu B", lds_bytes);
     k.wn = wn;
     {
+        // buffer descriptors of the kernels (in / weights / out): every tensor stays below 2 GiB so that kOOB lies beyond all of them
+        const long long esz_in = d->in_f16 ? 2 : 4, esz_out = d->out_f16 ? 2 : 4;
+        const long long inb = (long long)d->n_img * d->in_h * d->in_w * d->in_cs * esz_in, outb = (long long)d->n_img * d->out_h * d->out_w * d->out_cs * esz_out;
+        const long long wb = d->dtype == 0 ? (long long)d->ntaps * d->cin * d->cout_pad * 4 : (long long)d->ntaps * ((d->cin / 8 + 3) / 4 * 4) * 8 * d->cout_pad * 2;
+        I2R_CHECK_ARG(inb < (1ll << 31) && outb < (1ll << 31) && wb < (1ll << 31), "i2r_conv: tensors of 2 GiB and more are not supported (in %lld, out %lld, weights %lld bytes)", inb, outb, wb);
+        k.in_bytes = (unsigned)inb; k.out_bytes = (unsigned)outb; k.w_bytes = (unsigned)wb;
         auto magic = [](int d) { return d == 1 ? 0u : (unsigned)(((1ull << 32) + d - 1) / d); };
         k.m_cblk = magic(k.n_cblk); k.m_tx = magic(k.tiles_x); k.m_ty = magic(k.tiles_y); k.m_pw = magic(k.pw); k.m_tw = magic(k.tile_w);
         k.wn_log = wn == 4 ? 2 : (wn == 2 ? 1 : 0);

@@ -36,10 +36,6 @@
 
 namespace {
 
-typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
-// lane offset that lies beyond every buffer this kernel describes (tensors are < 2 GiB, checked by the host) and stays there when a
-// chunk / piece offset of a few KiB is added: such a lane reads zeros and its stores are dropped
-constexpr unsigned kOOB = 0x80000000u;
 constexpr int kWinoPatchMax = 108;  // patch pixels of a fragment: 6 x 18 (FW = 8 or 2), 10 x 10 (FW = 4)
 
 template <int MT, int NT>
@@ -96,8 +92,8 @@ __global__ __launch_bounds__(256, (MT == 1 ? (NT == 3 ? 4 : 3) : 2)) void conv_w
     // Global accesses go through buffer instructions: a 32-bit per-lane byte offset + a scalar offset that walks the channel chunks,
     // no 64-bit address arithmetic on the vector ALU, and a lane whose offset lies beyond the descriptor's range reads zeros -- which
     // is how the halo outside the image and the unused items are zero-filled without a select per load.
-    const __amdgpu_buffer_rsrc_t rs_in = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.in), 0, p.w_in_bytes, 0x00020000);
-    const __amdgpu_buffer_rsrc_t rs_w = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.w), 0, p.w_w_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_in = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.in), 0, p.in_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_w = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.w), 0, p.w_bytes, 0x00020000);
     unsigned goff[NIT];  // byte offset of (pixel, channel group) in `in`, kOOB (out of range: reads zeros) outside the image
     int lslot[NIT];      // LDS slot, -1 = no item
 #pragma unroll
@@ -241,7 +237,7 @@ __global__ __launch_bounds__(256, (MT == 1 ? (NT == 3 ? 4 : 3) : 2)) void conv_w
     const bool hi = (px & 2) != 0;
     const int n0 = n_base + q4 * 4;  // (+ 16 k < cout_pad: a channel block never reaches past the padded width)
     const bool tail = n_base + NT * 16 > p.cout || n_base + NT * 16 > p.out_cs;  // (uniform) the block holds padding channels
-    const unsigned out_bytes = p.w_out_bytes;
+    const unsigned out_bytes = p.out_bytes;
     const __amdgpu_buffer_rsrc_t rs_out = __builtin_amdgcn_make_buffer_rsrc(p.out, 0, out_bytes, 0x00020000);
     const __amdgpu_buffer_rsrc_t rs_r1 = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.res1), 0, p.res1 ? out_bytes : 0, 0x00020000);
     const __amdgpu_buffer_rsrc_t rs_r2 = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(res2), 0, res2 ? out_bytes : 0, 0x00020000);
