@@ -91,6 +91,7 @@ def wino_fragment(conv_h, conv_w):
     return best[1], best[2]
 
 
+_WINO_TABLE = os.environ.get("I2R_WINO_TABLE", "0") == "1"  # tools/ A/B switch: LPT dispatch table for Winograd launches (default: members heaviest first)
 _WINO_MT = int(os.environ.get("I2R_WINO_MT", "0"))  # tools/ A/B switch: fragments per Winograd workgroup
 WINOGRAD = os.environ.get("I2R_WINOGRAD", "1") != "0"  # fp32 3x3 stride-1 convs on the Winograd F(2x2, 3x3) kernels (A/B switch for tools/)
 
@@ -771,7 +772,7 @@ class Program:
                 counts.append(-(-conv_h // d.tile_h) * -(-conv_w // d.tile_w) * n_img * n_cblk)
             works.append(d.cin * d.ntaps)
         a.n = len(group)
-        if wino or len(set(works)) > 1:  # dispatch order: heaviest items first, balanced over the CUs (a Winograd item is small: always)
+        if (wino and _WINO_TABLE) or (not wino and len(set(works)) > 1):  # dispatch order: heaviest items first, balanced over the CUs
             bm = lpt_block_table(self.device, counts, works)
             self.keep.append(bm)
             a.block_map, a.map_len = bm.data_ptr(), bm.numel()
