@@ -969,7 +969,9 @@ class Program:
         lens = [offs[i + 1] - offs[i] for i in range(len(offs) - 1)]
         assert all(l > 0 for l in lens)
         nq, nq16, nq64 = (sum(-(-l // t) for l in lens) for t in (32, 16, 64))
-        grouping["goff"][:len(offs)].copy_(torch.tensor(offs, dtype=torch.int32))
+        # (pinned staging + stream-ordered copy: a pageable source would make every regroup of the validate() loop a blocking copy; torch's
+        #  caching host allocator keeps the pinned block alive until the copy has run)
+        grouping["goff"][:len(offs)].copy_(torch.tensor(offs, dtype=torch.int32).pin_memory(), non_blocking=True)
         for d, dt in grouping["descs"]:
             d.n_grp, d.n_qtiles32, d.n_qtiles16, d.n_qtiles64 = len(offs) - 1, nq, nq16, nq64
             d.dtype = dt  # (both kernel families take any group offsets: K / V blocks are numbered group by group)
@@ -1636,17 +1638,17 @@ class Engine:
 
     @staticmethod
     def capacity(S):
-        """Crop capacity of the program that serves a batch of S crops: exact up to 8, then the next multiple of 4 (<= 64) or 8.
+        """Crop capacity of the program that serves a batch of S crops: exact up to 8, then the next multiple of 2 (<= 32), 4 (<= 64) or 8.
         In the reference's validate() loop S = sum(length) changes with nearly every batch (persons per image vary); building a
         program costs tens of ms (arena, block maps, descriptors), so programs are built per CAPACITY and a batch runs in the
-        smallest one that holds it -- the unused slots are extra single-person groups whose heat maps are dropped (<= 3 / 7 wasted
-        crops, i.e. <= 11 % above 32 crops)."""
+        smallest one that holds it -- the unused slots are extra single-person groups whose heat maps are dropped (<= 1 / 3 / 7 wasted
+        crops, i.e. <= 11 % at any size)."""
         if S <= 8:
             return S
-        step = 4 if S <= 64 else 8
+        step = 2 if S <= 32 else (4 if S <= 64 else 8)
         return -(-S // step) * step
 
-    MAX_PROGRAMS = 12  # least-recently-used programs beyond this are dropped (each owns ~20 MB of activations per crop)
+    MAX_PROGRAMS = 16  # least-recently-used programs beyond this are dropped (each owns ~20 MB of activations per crop)
 
     def forward(self, x, pos_mask, length, flip_joint_map=None):
         """flip_joint_map (device int32 [J], see caller.joint_map): run the flip test in the same forward and return the merged

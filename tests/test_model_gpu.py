@@ -155,11 +155,11 @@ def test_ragged_batches_and_program_cache():
 
 
 def test_capacity_padded_programs():
-    """S = 9 crops run in the capacity-12 program (Engine.capacity): the 3 unused slots re-read the last crop as extra single-person
-    groups and are dropped; batches of 9..12 crops share that one program; the flip-test batch pads both halves"""
+    """S = 9 crops run in the capacity-10 program (Engine.capacity): the unused slot re-reads the last crop as an extra single-person
+    group and is dropped; batches of 9..10 crops share that one program; the flip-test batch pads both halves"""
     from i2r_amd import caller, synth
     from i2r_amd.engine import Engine
-    assert [Engine.capacity(s) for s in (1, 7, 8, 9, 12, 13, 33, 64, 65)] == [1, 7, 8, 12, 12, 16, 36, 64, 72]
+    assert [Engine.capacity(s) for s in (1, 7, 8, 9, 12, 13, 32, 33, 64, 65)] == [1, 7, 8, 10, 12, 14, 32, 36, 64, 72]
     cfg, sd, _, _, _, _ = setup("w48_l1")
     net = _net(cfg, sd, "w48_pure_en6")
     eng = net.engine()
@@ -172,11 +172,11 @@ def test_capacity_padded_programs():
         alone = net(x[o:o + n].cuda(), m[o:o + n].cuda(), [n]).cpu()
         assert (alone - y[o:o + n]).abs().max().item() < 1e-4
         o += n
-    x2, m2, l2 = synth.make_inputs([5, 6], 256, 192, seed=12)
+    x2, m2, l2 = synth.make_inputs([4, 6], 256, 192, seed=12)
     y2 = net(x2.cuda(), m2.cuda(), l2).cpu()
-    assert sum(1 for k in eng.programs if k[0] == 12 and not k[3]) == 1
-    ref = i2r_cpu.forward(sd, cfg, x2[:5], m2[:5], [5])
-    assert (y2[:5] - ref).abs().max().item() < TOL
+    assert sum(1 for k in eng.programs if k[0] == 10 and not k[3]) == 1
+    ref = i2r_cpu.forward(sd, cfg, x2[:4], m2[:4], [4])
+    assert (y2[:4] - ref).abs().max().item() < TOL
     jm = caller.FLIP_PAIRS["crowdpose"]
     f9 = net.forward_flip(x.cuda(), m.cuda(), length, jm).cpu()
     f4 = net.forward_flip(x[5:].cuda(), m[5:].cuda(), [4], jm).cpu()
