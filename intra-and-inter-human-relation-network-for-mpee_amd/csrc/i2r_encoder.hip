@@ -835,15 +835,21 @@ __global__ __launch_bounds__(64) void enc_layer_lp_k(const EncK p) {
     }
 
     // ---- flash attention over the group's 32-key blocks; K rows / V^T blocks stream from L2 into registers, one block ahead ----
-    f32x4 o[QF][DC];
-    float m_run[QF], l_run[QF];
+    // The loop is bound by the vector ALU, not by the matrix pipe (the 16-bit MFMA is 16x the fp32 rate; round 2: ~50 VALU instructions
+    // per 12 MFMAs), so the softmax is arranged to need as few VALU instructions per score as possible:
+    //  * the running reference m is folded into the S accumulator (acc starts at -m instead of 0): no subtraction per score;
+    //  * the row sums l come out of the matrix pipe: one extra A fragment whose row 0 is all ones makes  ol = 1^T P  next to O = V^T P;
+    f32x4 o[QF][DC], ol[QF], negm[QF];
 #pragma unroll
     for (int qf = 0; qf < QF; ++qf) {
-        m_run[qf] = -__builtin_inff();
-        l_run[qf] = 0.f;
+        negm[qf] = ol[qf] = (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int nt = 0; nt < DC; ++nt) o[qf][nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
     }
+    const f32x4 one4 = (f32x4){1.f, 1.f, 1.f, 1.f};
+    const f32x4 onesA = li == 0 ? pack8<DT>(one4, one4) : (f32x4){0.f, 0.f, 0.f, 0.f};  // A fragment: row 0 = ones over the block's 32 keys
+    // (plain fmaxf: an inline-asm v_max3 on MFMA results gets no hazard wait states from the compiler -- NaNs under -amdgpu-mfma-vgpr-form)
+    auto max3 = [](float x, float y, float z) { return fmaxf(fmaxf(x, y), z); };
     auto fetch_kv = [&](int k0, f32x4(&ka)[2][KC], f32x4(&va)[DC]) {  // fragment-packed images of the group's block (k0 - gs) / 32
         const size_t blk = (size_t)(base32 + ((k0 - gs) >> 5));
 #pragma unroll
@@ -853,19 +859,20 @@ __global__ __launch_bounds__(64) void enc_layer_lp_k(const EncK p) {
 #pragma unroll
         for (int nt = 0; nt < DC; ++nt) va[nt] = ld16(p.vbuf, ((blk * DC + nt) * 64 + lane) * 8);
     };
-    // online softmax in base 2 with the lazy reference of the fp32 kernel: m is raised (and O, l rescaled) only when a score
-    // exceeds it by more than 2^10 -- the common path has no cross-lane max and no O rescale, which is what bounds this kernel
-    // (the 12 MFMAs of a 32-key block take ~200 cycles, the eager softmax took more)
+    // online softmax in base 2 with a lazy reference: m (kept as -m in every lane of a query's column) is raised -- and O, l rescaled --
+    // only when a score exceeds it by more than 2^10; the first block always sets it (scores far below 0 must not underflow).  The
+    // common path has no cross-lane traffic and no O rescale.
     auto attend = [&](int k0, const f32x4(&ka)[2][KC], const f32x4(&va)[DC]) {
         const bool ragged = k0 + 32 > ge;  // (wave-uniform)
+        const bool first = k0 == gs;
 #pragma unroll
         for (int qf = 0; qf < QF; ++qf) {
             f32x4 st[2];
 #pragma unroll
             for (int kf = 0; kf < 2; ++kf) {
-                f32x4 a = (f32x4){0.f, 0.f, 0.f, 0.f};
+                f32x4 a = negm[qf];
 #pragma unroll
-                for (int c = 0; c < KC; ++c) a = mfma32_lp<DT>(ka[kf][c], qB[qf][c], a);  // S^T[key 16kf+4g+r][query li]
+                for (int c = 0; c < KC; ++c) a = mfma32_lp<DT>(ka[kf][c], qB[qf][c], a);  // S^T[key 16kf+4g+r][query li] - m
                 if (ragged) {
 #pragma unroll
                     for (int r = 0; r < 4; ++r)
@@ -873,26 +880,28 @@ __global__ __launch_bounds__(64) void enc_layer_lp_k(const EncK p) {
                 }
                 st[kf] = a;
             }
-            const float mx = fmaxf(fmaxf(fmaxf(st[0][0], st[0][1]), fmaxf(st[0][2], st[0][3])),
-                                   fmaxf(fmaxf(st[1][0], st[1][1]), fmaxf(st[1][2], st[1][3])));
-            if (__any(mx > m_run[qf] + 10.f)) {
-                const float m_new = fmaxf(m_run[qf], xmax(mx));
-                const float alpha = __builtin_amdgcn_exp2f(m_run[qf] - m_new);
-                l_run[qf] *= alpha;
+            const float mx = max3(max3(max3(st[0][0], st[0][1], st[0][2]), st[0][3], st[1][0]), max3(st[1][1], st[1][2], st[1][3]), st[1][1]);
+            if (first || __any(mx > 10.f)) {
+                float d = xmax(mx);             // how far the block's maximum lies above the reference
+                if (!first) d = fmaxf(d, 0.f);  // (the reference only rises afterwards)
+                if (!first) {
+                    const float alpha = __builtin_amdgcn_exp2f(-d);
+                    ol[qf] *= alpha;
 #pragma unroll
-                for (int nt = 0; nt < DC; ++nt) o[qf][nt] *= alpha;
-                m_run[qf] = m_new;
+                    for (int nt = 0; nt < DC; ++nt) o[qf][nt] *= alpha;
+                }
+                negm[qf] -= d;
+                st[0] -= d;
+                st[1] -= d;
             }
 #pragma unroll
             for (int kf = 0; kf < 2; ++kf)
 #pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    st[kf][r] = __builtin_amdgcn_exp2f(st[kf][r] - m_run[qf]);
-                    l_run[qf] += st[kf][r];
-                }
+                for (int r = 0; r < 4; ++r) st[kf][r] = __builtin_amdgcn_exp2f(st[kf][r]);
             const f32x4 pB = pack8<DT>(st[0], st[1]);  // keys {4g+r} U {16+4g+r} of the block: the order V^T blocks are stored in
 #pragma unroll
             for (int nt = 0; nt < DC; ++nt) o[qf][nt] = mfma32_lp<DT>(va[nt], pB, o[qf][nt]);
+            ol[qf] = mfma32_lp<DT>(onesA, pB, ol[qf]);  // row 0: l[query li] += sum of the block's (16-bit rounded) weights
         }
     };
     {
@@ -917,7 +926,7 @@ __global__ __launch_bounds__(64) void enc_layer_lp_k(const EncK p) {
     f32x4 oB[QF][KC];
 #pragma unroll
     for (int qf = 0; qf < QF; ++qf) {
-        const float inv = 1.f / xsum(l_run[qf]);
+        const float inv = 1.f / xsum(ol[qf][0]);  // l sits in row 0 of the ones tile (lane g = 0, register 0); rows 4g of g > 0 are zero
 #pragma unroll
         for (int c = 0; c < KC; ++c) oB[qf][c] = pack8<DT>(o[qf][2 * c] * inv, o[qf][2 * c + 1] * inv);
     }

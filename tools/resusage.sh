@@ -4,7 +4,7 @@
 R=$(cd $(dirname $0)/.. && pwd)
 C=$R/intra-and-inter-human-relation-network-for-mpee_amd/csrc
 f=$1; shift
-/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -I $R/include -I $C --cuda-device-only -c $C/$f.hip -o /tmp/$f.dev.o -Rpass-analysis=kernel-resource-usage "$@" 2>&1 |
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -mllvm -amdgpu-mfma-vgpr-form -I $R/include -I $C --cuda-device-only -c $C/$f.hip -o /tmp/$f.dev.o -Rpass-analysis=kernel-resource-usage "$@" 2>&1 |
   python3 -c '
 import sys, re, subprocess
 cur = {}
