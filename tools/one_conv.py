@@ -50,16 +50,18 @@ if mode.startswith("group"):
     if ":" in mode:
         engine._MT_EFF[int(mode.split(":")[1])] = 9.9  # the cost model then picks this mt for the group
     mode = "group"
+PREC = sys.argv[4] if len(sys.argv) > 4 else "fp32"  # 16-bit: bf16 | fp16 operands and activation storage
+DT = engine.PRECISIONS[PREC]
 P = engine.Program(DEV)
 grp = []
 for (c, h, w) in BR:
     sd = {"c.weight": torch.from_numpy(synth._sym(1, "w%d" % c, (c, c, 3, 3), 0.05))}
-    pc = engine.Packer(sd, DEV).conv("c", None)
+    pc = engine.Packer(sd, DEV, PREC).conv("c", None)
     P.keep.append(pc)
-    x = P.alloc(S, h, w, c)
-    x.t.normal_()
-    r = P.alloc(S, h, w, c)
-    r.t.normal_()
+    x = P.alloc(S, h, w, c, DT)
+    x.t.normal_() if DT == 0 else x.view().normal_()
+    r = P.alloc(S, h, w, c, DT)
+    r.t.normal_() if DT == 0 else r.view().normal_()
     P.conv(x, pc, relu=True, res1=r, group=grp if mode == "group" else None)
 if mode == "group":
     P.flush_group(grp)
@@ -78,4 +80,4 @@ flop = sum(2.0 * S * h * w * c * c * 9 for (c, h, w) in BR)
 for kind, lane, st in P.ops:
     if kind == cabi.OP_CONV_GROUP:
         print("tiles/mt:", [(st.d[j].contents.tile_h, st.d[j].contents.tile_w, st.d[j].contents.mt) for j in range(st.n)])
-print("%s S=%d: %.1f us per program  %.1f TF" % (mode, S, ms * 1e3, flop / ms / 1e9))
+print("%s %s S=%d: %.1f us per program  %.1f TF" % (mode, PREC, S, ms * 1e3, flop / ms / 1e9))
