@@ -178,6 +178,10 @@ def op_model(kind, st, precision, enc_lens=None):
         n_out = st.n_img * st.h * st.w
         low = n_out // (st.s1 * st.s1) + (n_out // (st.s2 * st.s2) if st.t2 else 0)
         return "fuse_up_add_k", (2.0 if st.t2 else 1.0) * n_out * st.cs, float((2 * n_out + low) * st.cs * _esz(st.dt)), None
+    if kind == cabi.OP_CONV1X1_PAIR:
+        n = st.n_pix
+        return ("conv1x1_pair_k<%d, %d, %d>" % (st.k_a // 16, st.cb_out // 16, st.mt or 2), 2.0 * n * st.ca_out * (st.k_a + st.cb_out),
+                float(n * (st.x_cs + st.y_cs * (2 if st.res else 1) + st.cb_out) * 4 + st.ca_out * (st.k_a + st.cb_out) * 4), "fp32")
     return "op%d" % kind, 0.0, 0.0, None
 
 

@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define I2R_ABI_VERSION 4
+#define I2R_ABI_VERSION 5
 
 #define I2R_OK 0
 #define I2R_E_ARG (-1)      /* bad argument (shape / alignment / unsupported combination) */
@@ -275,6 +275,21 @@ int i2r_upsample_bilinear_add(const float* low, const float* res, float* out, in
 int i2r_fuse_up_add(const float* base, const float* t1, int32_t s1, const float* t2, int32_t s2, float* out, int32_t n_img,
                     int32_t h, int32_t w, int32_t cs, int32_t act, int32_t dt, void* stream);
 
+/* i2r_conv1x1_pair -- two chained 1x1 convolutions over NHWC rows in one launch (fp32):
+ *     y = act_a(W_a x + b_a [+ res])     written out, [n_pix, y_cs]
+ *     z = act_b(W_b y + b_b)             optional (cb_out = 0: only y), [n_pix, z_cs]
+ * Replaces conv3 + bn3 + residual + ReLU of one Bottleneck together with conv1 + bn1 + ReLU of the next (reference lib/models/hrnet.py
+ * Bottleneck.forward as used by layer1, interformer_pureMulti.py:69-107, :462-476 _make_layer): y stays in registers between the two
+ * GEMMs instead of being written and read back.  w_a / w_b are fragment-packed ([cout / 16][cin / 16][64 lanes][4], engine.pack_frag)
+ * with eval BatchNorm folded, b_* the folded biases.  res (optional) is laid out like y.  k_a in {64, 128}; ca_out % 32 == 0;
+ * cb_out in {0, 64}; channel strides are multiples of 4 floats.  mt: 16-pixel tiles per wave (1, 2, 4; 0 = default). */
+typedef struct i2r_conv1x1_pair_args {
+    const float* x; const float* w_a; const float* b_a; const float* res; float* y;
+    const float* w_b; const float* b_b; float* z;
+    int32_t n_pix, k_a, ca_out, cb_out, x_cs, y_cs, z_cs, relu_a, relu_b, mt;
+} i2r_conv1x1_pair_args;
+int i2r_conv1x1_pair(const i2r_conv1x1_pair_args* a, void* stream);
+
 /* ------------------------------------------------------------------------------------------------
  * i2r_encoder_desc -- one DETR-style post-norm encoder layer over variable-length token groups
  * (persons of one image attend to each other; no padding, no mask tensor).
@@ -359,7 +374,8 @@ enum {
     I2R_OP_CONV = 1, I2R_OP_STEM = 2, I2R_OP_MAXPOOL = 3, I2R_OP_HEAD = 4,
     I2R_OP_ENC_KV = 5, I2R_OP_ENC_LAYER = 6, I2R_OP_FORK = 7, I2R_OP_JOIN = 8, I2R_OP_CONV_GROUP = 9,
     I2R_OP_LAYERNORM = 10, I2R_OP_WINATTN = 11, I2R_OP_DWCONV = 12, I2R_OP_UPSAMPLE = 13, I2R_OP_CONV_CHAIN = 14,
-    I2R_OP_PE_RES_STEM = 15, I2R_OP_HRT_ATTN = 16, I2R_OP_HRT_MLP = 17, I2R_OP_XSYNC = 18, I2R_OP_FUSE_UP = 19
+    I2R_OP_PE_RES_STEM = 15, I2R_OP_HRT_ATTN = 16, I2R_OP_HRT_MLP = 17, I2R_OP_XSYNC = 18, I2R_OP_FUSE_UP = 19,
+    I2R_OP_CONV1X1_PAIR = 20
 };
 
 typedef struct i2r_stem_args {

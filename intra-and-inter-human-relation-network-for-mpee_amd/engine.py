@@ -93,11 +93,13 @@ def wino_fragment(conv_h, conv_w):
 
 _WINO_TABLE = os.environ.get("I2R_WINO_TABLE", "0") == "1"  # tools/ A/B switch: LPT dispatch table for Winograd launches (default: members heaviest first)
 _WINO_MT = int(os.environ.get("I2R_WINO_MT", "0"))  # tools/ A/B switch: fragments per Winograd workgroup
+PAIR1X1 = os.environ.get("I2R_PAIR1X1", "1") != "0"  # layer1's conv3 + next conv1 as one i2r_conv1x1_pair launch (fp32; A/B switch for tools/)
+_PAIR_MT = int(os.environ.get("I2R_PAIR_MT", "0"))  # tools/ A/B switch: 16-pixel tiles per wave of that kernel
 WINOGRAD = os.environ.get("I2R_WINOGRAD", "1") != "0"  # fp32 3x3 stride-1 convs on the Winograd F(2x2, 3x3) kernels (A/B switch for tools/)
 
 
 class PackedConv:
-    __slots__ = ("w", "bias", "cin", "cin_pad", "cout", "cout_pad", "taps", "iy0", "ix0", "stride", "ksize", "dtype", "w_wino")
+    __slots__ = ("w", "bias", "cin", "cin_pad", "cout", "cout_pad", "taps", "iy0", "ix0", "stride", "ksize", "dtype", "w_wino", "w_frag")
 
     def __init__(self, w, bias, cin, cout, taps, iy0, ix0, stride, ksize, cin_pad=None, dtype=0):
         self.w, self.bias = w, bias
@@ -106,6 +108,7 @@ class PackedConv:
         self.taps, self.iy0, self.ix0, self.stride, self.ksize = taps, iy0, ix0, stride, ksize
         self.dtype = dtype
         self.w_wino = None  # fp32 3x3 stride-1 convs: the Winograd-domain weights [16][cin/4][cout_pad][4] (Packer.conv)
+        self.w_frag = None  # fp32 1x1 convs of layer1: the [cout, cin] matrix as MFMA A-operand fragments (pack_frag) for i2r_conv1x1_pair
 
 
 class Packer:
@@ -167,7 +170,16 @@ class Packer:
         cout = w_taps.shape[2]
         bias = torch.zeros(_r16(cout), dtype=torch.float64)
         bias[:cout] = bias_sum
-        return self._pc(w_taps, self._dev(bias.float()), sum(cins), cout, [(0, 0)], 0, 0, 1, 1)
+        pc = self._pc(w_taps, self._dev(bias.float()), sum(cins), cout, [(0, 0)], 0, 0, 1, 1)
+        pc.w_frag = self._frag(w_taps)
+        return pc
+
+    def _frag(self, w_taps):
+        """fragment-packed [cout, cin] image of a 1x1 conv for i2r_conv1x1_pair (fp32, whole 16-channel fragments), else None"""
+        _, cin, cout = w_taps.shape
+        if self.dtype != 0 or w_taps.shape[0] != 1 or cin % 16 or cout % 16:
+            return None
+        return self._dev(pack_frag(w_taps[0].t().contiguous()).float())
 
     def bottlenecks(self, prefix, n):
         """layer1 of HRNet / HRFormer: n Bottleneck blocks (reference hrnet.py / hrformer.py `Bottleneck`, expansion 4); the first one
@@ -180,6 +192,11 @@ class Packer:
                 blk["c3ds"] = self.conv_cat([(q + ".downsample.0", q + ".downsample.1"), (q + ".conv3", q + ".bn3")])
             else:
                 blk["c3"] = self.conv(q + ".conv3", q + ".bn3")
+            for key in ("c1", "c3"):
+                if key in blk:
+                    w = self.sd[q + ".conv%s.weight" % key[1]]
+                    wf, _ = fold_bn(w, self._bn(q + ".bn%s" % key[1]), None, 1e-5)
+                    blk[key].w_frag = self._frag(wf.reshape(1, w.shape[0], w.shape[1]).permute(0, 2, 1))
             blocks.append(blk)
         return blocks
 
@@ -800,6 +817,19 @@ class Program:
         self.release(a)
         t1 = self.conv(x, first["c1"], relu=True)
         self.conv(t1, first["c2"], relu=True, out=t2)
+        if PAIR1X1 and a.dt == 0 and first["c3ds"].w_frag is not None and all(b["c1"].w_frag is not None and b["c3"].w_frag is not None for b in blocks[1:]):
+            # conv3 (+ residual + ReLU) of a block and conv1 (+ ReLU) of the next one in ONE launch: the 256-channel map is written once
+            # (it is the next residual) and not read back by conv1
+            self.release(t1)
+            y, t1 = self.conv1x1_pair(cat, first["c3ds"], None, blocks[1]["c1"] if len(blocks) > 1 else None)
+            self.release(cat)
+            for i, blk in enumerate(blocks[1:], 1):
+                t2 = self.conv(t1, blk["c2"], relu=True)
+                self.release(t1)
+                yn, t1 = self.conv1x1_pair(t2, blk["c3"], y, blocks[i + 1]["c1"] if i + 1 < len(blocks) else None)
+                self.release(t2, y)
+                y = yn
+            return y
         y = self.conv(cat, first["c3ds"], relu=True)
         self.release(t1, cat)
         x = y
@@ -884,6 +914,20 @@ class Program:
         a = cabi.UpArgs(low.ptr, res.ptr, out.ptr, low.n, low.h, low.w, scale, low.c, low.cs, act)
         self.ops.append((cabi.OP_UPSAMPLE, lane, a))
         return out
+
+    def conv1x1_pair(self, x, pa, res, pb, lane=0):
+        """y = ReLU(conv1x1_a(x) [+ res]) and, with pb, z = ReLU(conv1x1_b(y)) in one launch (i2r_conv1x1_pair) -> (y, z | None)"""
+        assert x.dt == 0 and pa.w_frag is not None and pa.ksize == 1 and pa.cin == x.cs and (pb is None or (pb.w_frag is not None and pb.cin == pa.cout))
+        y = self.alloc(x.n, x.h, x.w, pa.cout)
+        z = self.alloc(x.n, x.h, x.w, pb.cout) if pb is not None else None
+        assert res is None or (res.cs == y.cs and res.dt == 0 and res.n * res.h * res.w == y.n * y.h * y.w)
+        self.keep.extend([pa, pb])
+        a = cabi.Conv1x1PairArgs(x.ptr, pa.w_frag.data_ptr(), pa.bias.data_ptr(), res.ptr if res is not None else None, y.ptr,
+                                 pb.w_frag.data_ptr() if pb is not None else None, pb.bias.data_ptr() if pb is not None else None,
+                                 z.ptr if z is not None else None, x.n * x.h * x.w, pa.cin, pa.cout, pb.cout if pb is not None else 0,
+                                 x.cs, y.cs, z.cs if z is not None else 0, 1, 1, _PAIR_MT)
+        self.ops.append((cabi.OP_CONV1X1_PAIR, lane, a))
+        return y, z
 
     def fuse_up_add(self, base, terms, out, relu=True, lane=0):
         """out = act((base + up(t1)) + up(t2)): nearest-neighbour up-sampled low-resolution terms added in one HBM-bound pass

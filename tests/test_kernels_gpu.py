@@ -134,11 +134,13 @@ def test_conv_without_bn_and_channel_padding():
     assert (from_act(out) - ref).abs().max().item() < 2e-4
 
 
-@pytest.mark.parametrize("precision,dt,tol", [("fp32", 0, 2e-4), ("bf16", 1, 0.08), ("fp16", 2, 0.01)])
-def test_stem_conv2_and_layer1_bottlenecks(precision, dt, tol):
-    """Program.stem_conv2_layer1: conv2 (3x3 s2) + two Bottlenecks, the first with its downsample folded into conv3 as ONE 1x1 conv
+@pytest.mark.parametrize("precision,dt,tol,pair", [("fp32", 0, 2e-4, True), ("fp32", 0, 2e-4, False), ("bf16", 1, 0.08, False), ("fp16", 2, 0.01, False)])
+def test_stem_conv2_and_layer1_bottlenecks(precision, dt, tol, pair):
+    """Program.stem_conv2_layer1: conv2 (3x3 s2) + three Bottlenecks, the first with its downsample folded into conv3 as ONE 1x1 conv
     over the concatenated buffer [x ; t2] (Packer.conv_cat + Program.channel_slice), against the torch modules it replaces
-    (reference hrnet.py Bottleneck.forward: out = relu(bn3(conv3(.)) + downsample(x)))."""
+    (reference hrnet.py Bottleneck.forward: out = relu(bn3(conv3(.)) + downsample(x))).  pair: conv3 of a block and conv1 of the next
+    one as ONE i2r_conv1x1_pair launch (fp32; 442 pixels: the last 16-pixel tile is partial)."""
+    NB = 3
     def bn(p, c):
         return {p + ".weight": _rand((c,), p + "g", 0.5) + 1.0, p + ".bias": _rand((c,), p + "b", 0.3),
                 p + ".running_mean": _rand((c,), p + "m", 0.3), p + ".running_var": _rand((c,), p + "v", 0.4) + 1.0}
@@ -151,7 +153,7 @@ def test_stem_conv2_and_layer1_bottlenecks(precision, dt, tol):
 
     sd = {"conv2.weight": _rand((64, 64, 3, 3), "l1c2", (6.0 / 576) ** 0.5)}
     sd.update(bn("bn2", 64))
-    for b, cin in ((0, 64), (1, 256)):
+    for b, cin in ((0, 64), (1, 256), (2, 256)):
         q = "layer1.%d" % b
         sd[q + ".conv1.weight"] = _rand((64, cin, 1, 1), q + "w1", (6.0 / cin) ** 0.5)
         sd[q + ".conv2.weight"] = _rand((64, 64, 3, 3), q + "w2", (6.0 / 576) ** 0.5)
@@ -162,19 +164,28 @@ def test_stem_conv2_and_layer1_bottlenecks(precision, dt, tol):
     sd.update(bn("layer1.0.downsample.1", 256))
     a = _rand((2, 64, 34, 26), "l1a").abs()
     x = cbr(a, sd, "conv2", "bn2", stride=2)
-    for b in range(2):
+    for b in range(NB):
         q = "layer1.%d" % b
         t = cbr(cbr(x, sd, q + ".conv1", q + ".bn1"), sd, q + ".conv2", q + ".bn2")
         idn = cbr(x, sd, q + ".downsample.0", q + ".downsample.1", relu=False) if b == 0 else x
         x = F.relu(cbr(t, sd, q + ".conv3", q + ".bn3", relu=False) + idn)
     P = engine.Program(torch.device(DEV))
     pk = engine.Packer(sd, torch.device(DEV), precision)
-    blocks = pk.bottlenecks("layer1", 2)
+    blocks = pk.bottlenecks("layer1", NB)
     assert "c3ds" in blocks[0] and blocks[0]["c3ds"].cin == 128 and "c3" in blocks[1]
-    out = P.stem_conv2_layer1(to_act(P, a, dt), pk.conv("conv2", "bn2", stride=2), blocks)
+    saved = engine.PAIR1X1
+    engine.PAIR1X1 = pair
+    try:
+        out = P.stem_conv2_layer1(to_act(P, a, dt), pk.conv("conv2", "bn2", stride=2), blocks)
+    finally:
+        engine.PAIR1X1 = saved
     n_launch = len(P.ops)
+    n_pair = sum(k == engine.cabi.OP_CONV1X1_PAIR for k, _, _ in P.ops)
     run(P)
-    assert n_launch == 1 + 3 + 3, "conv2 + 3 launches per Bottleneck (no separate downsample launch)"
+    if pair:
+        assert n_pair == NB and n_launch == 1 + 2 + NB + (NB - 1), "conv2, conv1 of the first block, one 3x3 conv and one pair launch per block"
+    else:
+        assert n_pair == 0 and n_launch == 1 + 3 * NB, "conv2 + 3 launches per Bottleneck (no separate downsample launch)"
     got = from_act(out)
     assert got.shape == x.shape
     err = (got - x).abs().max().item() / max(1.0, x.abs().max().item())

@@ -2,14 +2,10 @@
 cd /tmp && export TMPDIR=/tmp
 R=${GRAFT_REPO_ROOT:-/root/repo}
 O=$R/gpurun_out/j27
-mkdir -p $O
+rm -rf $O; mkdir -p $O
 cd $R
-for mt in 0 1 2 3 4; do
-  m=group; [ $mt != 0 ] && m=group:$mt
-  timeout 120 python tools/one_conv.py 57 20 $m bf16 2>&1 | tail -n 2 | tr '\n' ' ' >> $O/ab.log; echo >> $O/ab.log
+timeout 600 python -m pytest tests/test_kernels_gpu.py -x -q -m gpu -k "layer1_bottlenecks" 2>&1 | tail -n 5 > $O/test.log
+for mt in 1 2 4; do
+  I2R_PAIR_MT=$mt timeout 300 python tools/op_list.py w48_pure_en6 fp32 2>&1 | grep pair | sed "s/^/mt=$mt /" >> $O/oplist.log
 done
-for mt in 0 2 3 4; do
-  m=group2; [ $mt != 0 ] && m=group2:$mt
-  timeout 120 python tools/one_conv.py 57 20 $m bf16 2>&1 | tail -n 2 | tr '\n' ' ' >> $O/ab.log; echo >> $O/ab.log
-done
-cat $O/ab.log
+cat $O/test.log $O/oplist.log
