@@ -904,16 +904,72 @@ __global__ __launch_bounds__(64) void enc_layer_lp_k(const EncK p) {
             ol[qf] = mfma32_lp<DT>(onesA, pB, ol[qf]);  // row 0: l[query li] += sum of the block's (16-bit rounded) weights
         }
     };
+    // The same for a block that is neither a group's first nor ragged -- every block of the main loop -- as ONE basic block: the scores of
+    // all QF fragments first, ONE (rarely taken) branch for the reference update of all of them, then exp / pack / O = V^T P.  With a
+    // branch per fragment (attend above) the scheduler cannot place a fragment's softmax beside the next fragment's MFMAs, and the wave is
+    // alone on its SIMD: whatever it does not overlap itself is idle matrix-pipe time (same box: 1.57 -> 1.45 ms per 6-layer stack).
+    auto attend_fast = [&](const f32x4(&ka)[2][KC], const f32x4(&va)[DC]) {
+        f32x4 st[QF][2];
+        float mx[QF];
+#pragma unroll
+        for (int qf = 0; qf < QF; ++qf) {
+#pragma unroll
+            for (int kf = 0; kf < 2; ++kf) {
+                f32x4 a = negm[qf];
+#pragma unroll
+                for (int c = 0; c < KC; ++c) a = mfma32_lp<DT>(ka[kf][c], qB[qf][c], a);
+                st[qf][kf] = a;
+            }
+        }
+        float mxa = -__builtin_inff();
+#pragma unroll
+        for (int qf = 0; qf < QF; ++qf) {
+            mx[qf] = max3(max3(max3(st[qf][0][0], st[qf][0][1], st[qf][0][2]), st[qf][0][3], st[qf][1][0]), max3(st[qf][1][1], st[qf][1][2], st[qf][1][3]), st[qf][1][1]);
+            mxa = fmaxf(mxa, mx[qf]);
+        }
+        if (__any(mxa > 10.f)) {
+#pragma unroll
+            for (int qf = 0; qf < QF; ++qf) {
+                if (!__any(mx[qf] > 10.f)) continue;  // (exactly the fragments attend would have touched)
+                const float d = fmaxf(xmax(mx[qf]), 0.f);
+                const float alpha = __builtin_amdgcn_exp2f(-d);
+                ol[qf] *= alpha;
+#pragma unroll
+                for (int nt = 0; nt < DC; ++nt) o[qf][nt] *= alpha;
+                negm[qf] -= d;
+                st[qf][0] -= d;
+                st[qf][1] -= d;
+            }
+        }
+#pragma unroll
+        for (int qf = 0; qf < QF; ++qf) {
+#pragma unroll
+            for (int kf = 0; kf < 2; ++kf)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) st[qf][kf][r] = __builtin_amdgcn_exp2f(st[qf][kf][r]);
+            const f32x4 pB = pack8<DT>(st[qf][0], st[qf][1]);
+#pragma unroll
+            for (int nt = 0; nt < DC; ++nt) o[qf][nt] = mfma32_lp<DT>(va[nt], pB, o[qf][nt]);
+            ol[qf] = mfma32_lp<DT>(onesA, pB, ol[qf]);
+        }
+    };
     {
         f32x4 ka0[2][KC], va0[DC], ka1[2][KC], va1[DC];
         fetch_kv(gs, ka0, va0);
         const int last = gs + (((ge - 1 - gs) >> 5) << 5);  // first key of the group's last block
         int k0 = gs;
-        for (; k0 + 64 <= ge; k0 += 64) {
+        if (k0 + 64 <= ge) {  // the group's first block sets the reference: general path
             fetch_kv(k0 + 32, ka1, va1);
             attend(k0, ka0, va0);
+            fetch_kv(min(k0 + 64, last), ka0, va0);
+            attend_fast(ka1, va1);
+            k0 += 64;
+        }
+        for (; k0 + 64 <= ge; k0 += 64) {
+            fetch_kv(k0 + 32, ka1, va1);
+            attend_fast(ka0, va0);
             fetch_kv(min(k0 + 64, last), ka0, va0);  // (look-ahead past the end re-reads the last block, unused)
-            attend(k0 + 32, ka1, va1);
+            attend_fast(ka1, va1);
         }
         if (k0 < ge) {
             if (k0 + 32 < ge) fetch_kv(k0 + 32, ka1, va1);
@@ -1040,6 +1096,14 @@ extern "C" int i2r_encoder_layer(const i2r_encoder_desc* d, void* stream) {
         const bool big = d->n_qtiles64 >= 512;
         const unsigned grid = (unsigned)(big ? d->n_qtiles64 : d->n_qtiles16);
         const bool c6 = d->cs == 96;
+#ifdef I2R_TUNING
+        static const int qf_env = getenv("I2R_ENC_QF") ? atoi(getenv("I2R_ENC_QF")) : 0;  // tuning switch: 2 = 32 queries per wave
+        if (qf_env == 2 && big) {
+            if (d->dtype == 1) launch_lp<2, 1>(k, c6, (unsigned)d->n_qtiles32, (hipStream_t)stream); else launch_lp<2, 2>(k, c6, (unsigned)d->n_qtiles32, (hipStream_t)stream);
+            I2R_CHECK_LAUNCH("i2r_encoder_layer");
+            return I2R_OK;
+        }
+#endif
         if (d->dtype == 1) {
             if (big) launch_lp<4, 1>(k, c6, grid, (hipStream_t)stream); else launch_lp<1, 1>(k, c6, grid, (hipStream_t)stream);
         } else {
