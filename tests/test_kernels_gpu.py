@@ -192,6 +192,55 @@ def test_stem_conv2_and_layer1_bottlenecks(precision, dt, tol, pair):
     assert err < tol, "%s layer1 relative max-abs %.3e" % (precision, err)
 
 
+@pytest.mark.parametrize("k_a,cb,res,relu_a,relu_b,n_pix,mt", [
+    (64, 64, True, 1, 1, 1000, 0),    # Bottleneck conv3 + residual + ReLU, then the next conv1 + ReLU; last 16-pixel tile partial
+    (128, 64, False, 1, 1, 777, 1),   # first Bottleneck: conv3 over [x ; t2] with the downsample folded in; one tile per wave
+    (64, 0, True, 1, 1, 4096, 4),     # last Bottleneck of layer1: only y; four tiles per wave
+    (64, 64, False, 0, 0, 48, 2),     # no activation on either conv, no residual
+    (128, 0, True, 0, 1, 17, 0),      # two pixels tiles, the second almost empty
+])
+def test_conv1x1_pair_through_the_c_abi(k_a, cb, res, relu_a, relu_b, n_pix, mt):
+    """i2r_conv1x1_pair called through the C-ABI with fragment-packed weights (engine.pack_frag) against the two torch GEMMs in
+    float64: y = act(W_a x + b_a [+ res]), z = act(W_b y + b_b); rows past n_pix of the outputs must stay untouched"""
+    import ctypes as C
+    from i2r_amd import cabi
+    tag = "pair%d_%d_%d" % (k_a, cb, n_pix)
+    ca = 256
+    x = _rand((n_pix, k_a), "x" + tag)
+    wa, ba = _rand((ca, k_a), "wa" + tag, (3.0 / k_a) ** 0.5), _rand((ca,), "ba" + tag, 0.3)
+    r = _rand((n_pix, ca), "r" + tag) if res else None
+    y_ref = x.double() @ wa.double().t() + ba.double()
+    if res:
+        y_ref = y_ref + r.double()
+    if relu_a:
+        y_ref = F.relu(y_ref)
+    dev = torch.device(DEV)
+    xd, wad, bad = x.to(dev), engine.pack_frag(wa.double()).float().to(dev), ba.to(dev)
+    rd = r.to(dev) if res else None
+    yd = torch.full((n_pix + 3, ca), 7.0, device=dev)
+    zd = wbd = bbd = None
+    if cb:
+        wb, bb = _rand((cb, ca), "wb" + tag, (3.0 / ca) ** 0.5), _rand((cb,), "bb" + tag, 0.3)
+        z_ref = y_ref @ wb.double().t() + bb.double()
+        if relu_b:
+            z_ref = F.relu(z_ref)
+        wbd, bbd = engine.pack_frag(wb.double()).float().to(dev), bb.to(dev)
+        zd = torch.full((n_pix + 3, cb), 7.0, device=dev)
+    ptr = lambda t: t.data_ptr() if t is not None else None
+    a = cabi.Conv1x1PairArgs(ptr(xd), ptr(wad), ptr(bad), ptr(rd), ptr(yd), ptr(wbd), ptr(bbd), ptr(zd), n_pix, k_a, ca, cb, k_a, ca, cb, relu_a, relu_b, mt)
+    cabi.check(cabi.lib().i2r_conv1x1_pair(C.byref(a), torch.cuda.current_stream().cuda_stream), "i2r_conv1x1_pair")
+    torch.cuda.synchronize()
+    tol = 2e-5 * max(1.0, y_ref.abs().max().item())
+    assert (yd[:n_pix].double().cpu() - y_ref).abs().max().item() < tol
+    assert (yd[n_pix:] == 7.0).all(), "rows past n_pix written"
+    if cb:
+        assert (zd[:n_pix].double().cpu() - z_ref).abs().max().item() < 2e-5 * max(1.0, z_ref.abs().max().item())
+        assert (zd[n_pix:] == 7.0).all()
+    # argument errors are reported, not launched
+    bad = cabi.Conv1x1PairArgs(ptr(xd), ptr(wad), ptr(bad), None, ptr(yd), None, None, None, n_pix, 48, ca, 0, k_a, ca, 0, 1, 1, 0)
+    assert cabi.lib().i2r_conv1x1_pair(C.byref(bad), None) != 0 and b"k_a" in cabi.lib().i2r_last_error()
+
+
 def test_deconv_matches_conv_transpose():
     sd = {"d.weight": _rand((96, 96, 4, 4), "dw", 0.08), "b.weight": _rand((96,), "dg", 0.5) + 1.0,
           "b.bias": _rand((96,), "db", 0.3), "b.running_mean": _rand((96,), "dm", 0.3),

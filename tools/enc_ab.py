@@ -29,4 +29,7 @@ e0.record()
 for _ in range(10):
     eng.forward(x.to(DEV), pm.to(DEV), length)
 e1.record(); torch.cuda.synchronize()
-print("%s %s: encoder stacks %.3f ms per forward, forward %.3f ms  (I2R_ENC_QT=%s)" % (name, prec, ms, e0.elapsed_time(e1) / 10, os.environ.get("I2R_ENC_QT", "-")))
+yy = y
+while not torch.is_tensor(yy):
+    yy = list(yy.values())[-1] if isinstance(yy, dict) else yy[-1]
+print("%s %s: encoder stacks %.3f ms per forward, forward %.3f ms  (I2R_ENC_QT=%s I2R_ENC_QF=%s)  output checksum %.6f max %.4f" % (name, prec, ms, e0.elapsed_time(e1) / 10, os.environ.get("I2R_ENC_QT", "-"), os.environ.get("I2R_ENC_QF", "-"), yy.float().abs().mean().item(), yy.float().abs().max().item()))

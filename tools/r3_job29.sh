@@ -5,8 +5,7 @@ O=$R/gpurun_out/j29
 rm -rf $O; mkdir -p $O
 cd $R
 for i in 1 2; do
-timeout 300 python tools/enc_ab.py tph_192_p6_b4 bf16 2>&1 | tail -n 1 | sed "s/^/fast QF4 /" >> $O/ab.log
-I2R_ENC_QF=2 I2R_TOOL_LIB=tools/ab/lib_enc_tun.so timeout 300 python tools/enc_ab.py tph_192_p6_b4 bf16 2>&1 | tail -n 1 | sed "s/^/fast QF2 /" >> $O/ab.log
-I2R_TOOL_LIB=tools/ab/lib_enc_base.so timeout 300 python tools/enc_ab.py tph_192_p6_b4 bf16 2>&1 | tail -n 1 | sed "s/^/base     /" >> $O/ab.log
+I2R_TOOL_LIB=tools/ab/lib_enc_tun.so timeout 300 python tools/enc_ab.py tph_192_p6_b4 bf16 2>&1 | tail -n 1 | sed "s/^/QF4 NW1 /" >> $O/ab.log
+I2R_ENC_QF=24 I2R_TOOL_LIB=tools/ab/lib_enc_tun.so timeout 300 python tools/enc_ab.py tph_192_p6_b4 bf16 2>&1 | tail -n 1 | sed "s/^/QF2 NW4 /" >> $O/ab.log
 done
 cat $O/ab.log
