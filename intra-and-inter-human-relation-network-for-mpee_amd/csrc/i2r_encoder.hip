@@ -447,12 +447,15 @@ __global__ __launch_bounds__(256, 2) void enc_layer4_k(const EncK p) {
     STAMP(2);
     // out-proj rows of this wave's slots + the residual pieces they need: in flight under the merge
     f32x4 wo[SD][DC], res[SD][QT];
+    auto fetch_wo = [&]() {
 #pragma unroll
-    for (int s = 0; s < SD; ++s) {
-        load_wrow<DC>(wo[s], p.w_out, min(wave + 4 * s, DC - 1), lane);
+        for (int s = 0; s < SD; ++s) {
+            load_wrow<DC>(wo[s], p.w_out, min(wave + 4 * s, DC - 1), lane);
 #pragma unroll
-        for (int u = 0; u < QT; ++u) res[s][u] = ld4(p.src + (size_t)qrow[u] * cs + 16 * min(wave + 4 * s, DC - 1) + 4 * g);
-    }
+            for (int u = 0; u < QT; ++u) res[s][u] = ld4(p.src + (size_t)qrow[u] * cs + 16 * min(wave + 4 * s, DC - 1) + 4 * g);
+        }
+    };
+    if constexpr (QT == 1) fetch_wo();
     __builtin_amdgcn_sched_barrier(0);
     // ---- merge the four partial softmax states ----
 #pragma unroll
@@ -536,10 +539,16 @@ __global__ __launch_bounds__(256, 2) void enc_layer4_k(const EncK p) {
     }
     STAMP(3);
     // ---- out-proj + residual (this wave's slots) -> LDS -> LayerNorm 1 on the full row in every wave ----
+    if constexpr (QT != 1) {
+        fetch_wo();
+        __builtin_amdgcn_sched_barrier(0);
+    }
     f32x4 w1r[SF][DC];
+    if constexpr (QT == 1) {
 #pragma unroll
-    for (int s = 0; s < SF; ++s) load_wrow<DC>(w1r[s], p.w1, min(wave + 4 * s, FC - 1), lane);  // FFN1 rows, one phase ahead
-    __builtin_amdgcn_sched_barrier(0);
+        for (int s = 0; s < SF; ++s) load_wrow<DC>(w1r[s], p.w1, min(wave + 4 * s, FC - 1), lane);  // FFN1 rows, one phase ahead
+        __builtin_amdgcn_sched_barrier(0);
+    }
 #pragma unroll
     for (int s = 0; s < SD; ++s) {
         const int nt = min(wave + 4 * s, DC - 1);
@@ -548,6 +557,11 @@ __global__ __launch_bounds__(256, 2) void enc_layer4_k(const EncK p) {
             const f32x4 a = frag_mm<DC>(wo[s], oc[u], ld4(Ps + P_BOUT + 16 * nt + 4 * g)) + res[s][u];
             if (wave + 4 * s < DC) Xs[(nt * QT + u) * 64 + lane] = a;
         }
+    }
+    if constexpr (QT != 1) {
+#pragma unroll
+        for (int s = 0; s < SF; ++s) load_wrow<DC>(w1r[s], p.w1, min(wave + 4 * s, FC - 1), lane);  // (two tiles in flight: after the out-proj has released its rows)
+        __builtin_amdgcn_sched_barrier(0);
     }
     __syncthreads();
     f32x4 x1[QT][DC];

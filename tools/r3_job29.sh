@@ -4,8 +4,9 @@ R=${GRAFT_REPO_ROOT:-/root/repo}
 O=$R/gpurun_out/j29
 rm -rf $O; mkdir -p $O
 cd $R
-for i in 1 2 3; do
-for v in 1 0; do
-I2R_POS_LANE=$v timeout 300 python tools/host_rate.py w48_pure_en6 fp32 2>&1 | tail -n 1 | sed "s/^/pos_lane=$v /" >> $O/ab.log
-done; done
-cat $O/ab.log
+timeout 900 python -m pytest tests -x -q -m gpu -k "encoder or config3 or tph or transpose" 2>&1 | tail -n 4 > $O/test.log
+for i in 1 2; do
+timeout 300 python tools/enc_ab.py tph_192_p6_b4 fp32 2>&1 | tail -n 1 | sed "s/^/new  /" >> $O/ab.log
+I2R_TOOL_LIB=tools/ab/lib_enc_base.so timeout 300 python tools/enc_ab.py tph_192_p6_b4 fp32 2>&1 | tail -n 1 | sed "s/^/base /" >> $O/ab.log
+done
+cat $O/test.log $O/ab.log
