@@ -4,9 +4,9 @@ R=${GRAFT_REPO_ROOT:-/root/repo}
 O=$R/gpurun_out/j29
 rm -rf $O; mkdir -p $O
 cd $R
-timeout 900 python -m pytest tests -x -q -m gpu -k "encoder or config3 or tph or transpose" 2>&1 | tail -n 4 > $O/test.log
+for w in tph_192_p6_b4 hrt_192_p4_b4 coco_hrt_288_p2_b4; do
 for i in 1 2; do
-timeout 300 python tools/enc_ab.py tph_192_p6_b4 fp32 2>&1 | tail -n 1 | sed "s/^/new  /" >> $O/ab.log
-I2R_TOOL_LIB=tools/ab/lib_enc_base.so timeout 300 python tools/enc_ab.py tph_192_p6_b4 fp32 2>&1 | tail -n 1 | sed "s/^/base /" >> $O/ab.log
-done
-cat $O/test.log $O/ab.log
+for lib in "" tools/ab/lib_lp_d1.so tools/ab/lib_lp_d3.so; do
+I2R_TOOL_LIB=$lib timeout 300 python tools/host_rate.py $w 2>&1 | tail -n 2 | tr '\n' ' ' | sed "s/host issue.*GPU/GPU/; s/, host incl.*//" >> $O/ab.log; echo >> $O/ab.log
+done; done; done
+cat $O/ab.log
