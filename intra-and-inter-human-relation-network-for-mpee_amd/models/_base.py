@@ -91,8 +91,25 @@ class I2RModule(nn.Module):
         self._invalidate()
         return out
 
+    def _tensors(self):
+        """name -> tensor of every parameter and persistent buffer (the state-dict keys).  Unlike state_dict() this also works on the
+        replicas nn.DataParallel makes for devices 1.. : torch.nn.parallel.replicate() empties their `_parameters` and keeps the
+        per-device copies as plain attributes, listed in `_former_parameters`."""
+        out = {}
+        for prefix, m in self.named_modules():
+            pre = prefix + "." if prefix else ""
+            src = dict(getattr(m, "_former_parameters", None) or {})
+            src.update({k: v for k, v in m._parameters.items() if v is not None})
+            for k, v in src.items():
+                out[pre + k] = v
+            for k, v in m._buffers.items():
+                if v is not None and k not in m._non_persistent_buffers_set:
+                    out[pre + k] = v
+        return out
+
     def engine(self):
-        dev = next(self.parameters()).device
+        tensors = self._tensors()
+        dev = next(iter(tensors.values())).device
         if dev.type != "cuda":
             raise RuntimeError(
                 "i2r_amd models run on an MI355X through the HIP extension only; move the module to the GPU "
@@ -102,7 +119,7 @@ class I2RModule(nn.Module):
         eng = self._engines.get(dev)
         if eng is None:
             from ..engine import Engine
-            eng = self._engines[dev] = Engine(self.cfg, self.state_dict(), dev, self.precision, name=self._engine_name())
+            eng = self._engines[dev] = Engine(self.cfg, tensors, dev, self.precision, name=self._engine_name())
         return eng
 
     def _engine_name(self):

@@ -231,3 +231,40 @@ def test_winograd_weight_transform_and_fragment_choice():
         fw, fh = engine.wino_fragment(h, w_)
         assert (fw, fh) == want and fw * fh == 64
         assert -(-h // fh) * fh * -(-w_ // fw) * fw == h * w_, "fragments cover the map without waste"
+
+
+def test_module_tensors_survive_dataparallel_replication():
+    """I2RModule._tensors() -- what the engine is packed from -- equals state_dict() on the module itself AND on a replica built the way
+    torch.nn.parallel.replicate() builds one (parameters emptied, per-device copies as plain attributes listed in
+    `_former_parameters`): nn.DataParallel over several devices re-creates such replicas on every forward (tools/test.py:118)."""
+    from collections import OrderedDict
+    from i2r_amd import models
+    cfg = config.load_config("w48_pure_en6")
+    net = models.interformer_pureMulti.get_pose_net(cfg, is_train=False)
+    sd = net.state_dict()
+    mine = net._tensors()
+    assert list(mine.keys()).sort() == list(sd.keys()).sort() and set(mine) == set(sd)
+    assert all(mine[k].data_ptr() == sd[k].data_ptr() for k in sd)
+    # replicate the tree (one replica, same device: the copies are clones)
+    mods = list(net.modules())
+    idx = {m: i for i, m in enumerate(mods)}
+    reps = []
+    for m in mods:
+        r = m._replicate_for_data_parallel()
+        r._former_parameters = OrderedDict()
+        reps.append(r)
+    for i, m in enumerate(mods):
+        for key, child in m._modules.items():
+            setattr(reps[i], key, reps[idx[child]])
+        for key, prm in m._parameters.items():
+            c = prm.detach().clone()
+            setattr(reps[i], key, c)
+            reps[i]._former_parameters[key] = c
+        for key, buf in m._buffers.items():
+            setattr(reps[i], key, buf.clone())
+    rep = reps[0]
+    assert len(list(rep.parameters())) == 0 and len(rep.state_dict()) < len(sd), "a replica exposes no parameters"
+    got = rep._tensors()
+    assert set(got) == set(sd)
+    assert all(torch.equal(got[k], sd[k]) and got[k].data_ptr() != sd[k].data_ptr() for k in sd)
+    assert rep._engines is net._engines, "replicas share the per-device engine table"
