@@ -182,6 +182,10 @@ def op_model(kind, st, precision, enc_lens=None):
         n = st.n_pix
         return ("conv1x1_pair_k<%d, %d, %d>" % (st.k_a // 16, st.cb_out // 16, st.mt or 2), 2.0 * n * st.ca_out * (st.k_a + st.cb_out),
                 float(n * (st.x_cs + st.y_cs * (2 if st.res else 1) + st.cb_out) * 4 + st.ca_out * (st.k_a + st.cb_out) * 4), "fp32")
+    if kind == cabi.OP_CONV1X1_LP:
+        n = st.n_pix
+        return ("conv1x1_lp_k", 2.0 * n * st.cin_pad * st.cout_pad,
+                float(n * (st.x_cs * _esz(st.in_16) + st.out_cs * _esz(st.out_16) * (1 + bool(st.res1) + bool(st.res_post))) + st.cin_pad * st.cout_pad * 2), precision)
     return "op%d" % kind, 0.0, 0.0, None
 
 

@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define I2R_ABI_VERSION 5
+#define I2R_ABI_VERSION 6
 
 #define I2R_OK 0
 #define I2R_E_ARG (-1)      /* bad argument (shape / alignment / unsupported combination) */
@@ -290,6 +290,20 @@ typedef struct i2r_conv1x1_pair_args {
 } i2r_conv1x1_pair_args;
 int i2r_conv1x1_pair(const i2r_conv1x1_pair_args* a, void* stream);
 
+/* i2r_conv1x1_lp -- 1x1 convolution (+ folded BN) over a small number of NHWC pixel rows on the 16-bit matrix pipe, operands straight
+ * from global memory, K split over the four waves of a workgroup:
+ *     out = act(W x + bias [+ res1]) [+ res_post]          act: 0 none, 1 ReLU, 2 exact-erf GELU
+ * Replaces the single 1x1 convs of the unfused HRFormer-B transformer blocks -- q|k|v and out projections (hrformer.py:1164-1180),
+ * MlpDWBN fc1 / fc2 (:1094-1119) -- and of the fuse layers (:1629-1704) where the pixel count is a few thousand and i2r_conv is bound
+ * by its per-chunk staging latency.  w: fragment-packed 16-bit [cout_pad / 16][cin_pad / 16][64 lanes][4] (engine.pack_frag); bias
+ * fp32 [cout_pad]; x fp32 (in_16 = 0, packed on load) or stored in the operand type; out, res1, res_post fp32 or 16 bit (out_16).
+ * cout_pad / 16 must be a multiple of 3, 4, 5 or 6; cin_pad >= 64.  res1 / res_post may alias out (in-place accumulation of a fuse sum).  mt: 16-pixel tiles per workgroup (1, 2; 0 = chosen from the grid size). */
+typedef struct i2r_conv1x1_lp_args {
+    const void* x; const void* w; const float* bias; const void* res1; const void* res_post; void* out;
+    int32_t n_pix, cin_pad, cout_pad, x_cs, out_cs, act, dtype, in_16, out_16, mt;
+} i2r_conv1x1_lp_args;
+int i2r_conv1x1_lp(const i2r_conv1x1_lp_args* a, void* stream);
+
 /* ------------------------------------------------------------------------------------------------
  * i2r_encoder_desc -- one DETR-style post-norm encoder layer over variable-length token groups
  * (persons of one image attend to each other; no padding, no mask tensor).
@@ -375,7 +389,7 @@ enum {
     I2R_OP_ENC_KV = 5, I2R_OP_ENC_LAYER = 6, I2R_OP_FORK = 7, I2R_OP_JOIN = 8, I2R_OP_CONV_GROUP = 9,
     I2R_OP_LAYERNORM = 10, I2R_OP_WINATTN = 11, I2R_OP_DWCONV = 12, I2R_OP_UPSAMPLE = 13, I2R_OP_CONV_CHAIN = 14,
     I2R_OP_PE_RES_STEM = 15, I2R_OP_HRT_ATTN = 16, I2R_OP_HRT_MLP = 17, I2R_OP_XSYNC = 18, I2R_OP_FUSE_UP = 19,
-    I2R_OP_CONV1X1_PAIR = 20
+    I2R_OP_CONV1X1_PAIR = 20, I2R_OP_CONV1X1_LP = 21
 };
 
 typedef struct i2r_stem_args {

@@ -14,7 +14,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libi2r_hip.so")
 
 MAX_TAPS = 9
-ABI_VERSION = 5  # I2R_ABI_VERSION of include/i2r_hip.h
+ABI_VERSION = 6  # I2R_ABI_VERSION of include/i2r_hip.h
 OP_CONV, OP_STEM, OP_MAXPOOL, OP_HEAD, OP_ENC_KV, OP_ENC_LAYER, OP_FORK, OP_JOIN, OP_CONV_GROUP = 1, 2, 3, 4, 5, 6, 7, 8, 9
 MAX_GROUP = 4
 OP_LAYERNORM, OP_WINATTN, OP_DWCONV, OP_UPSAMPLE = 10, 11, 12, 13
@@ -25,6 +25,7 @@ OP_HRT_MLP = 17
 OP_XSYNC = 18
 OP_FUSE_UP = 19
 OP_CONV1X1_PAIR = 20
+OP_CONV1X1_LP = 21
 SYNC_OPS = (OP_FORK, OP_JOIN, OP_XSYNC)  # ops whose `lane` field is a lane mask and that launch nothing
 
 _fp = C.c_void_p  # device pointers travel as integers
@@ -120,6 +121,12 @@ class Conv1x1PairArgs(C.Structure):
                 ("relu_a", _i32), ("relu_b", _i32), ("mt", _i32)]
 
 
+class Conv1x1LpArgs(C.Structure):
+    _fields_ = [("x", _fp), ("w", _fp), ("bias", _fp), ("res1", _fp), ("res_post", _fp), ("out", _fp),
+                ("n_pix", _i32), ("cin_pad", _i32), ("cout_pad", _i32), ("x_cs", _i32), ("out_cs", _i32), ("act", _i32), ("dtype", _i32),
+                ("in_16", _i32), ("out_16", _i32), ("mt", _i32)]
+
+
 class ConvGroupArgs(C.Structure):
     _fields_ = [("d", C.POINTER(ConvDesc) * MAX_GROUP), ("block_map", _fp), ("n", _i32), ("map_len", _i32)]
 
@@ -137,7 +144,7 @@ class Op(C.Structure):
 
 # every symbol include/i2r_hip.h declares (tests/test_host.py::test_cabi_library_exports_every_declared_symbol checks the built library exports them all)
 EXPORTS = ("i2r_conv", "i2r_conv_grouped", "i2r_conv_kernel_name", "i2r_stem_conv", "i2r_pe_res_stem", "i2r_maxpool3x3s2", "i2r_head", "i2r_layernorm", "i2r_window_attn", "i2r_hrt_attn_block", "i2r_hrt_mlp_block", "i2r_dwconv3x3",
-           "i2r_upsample_bilinear_add", "i2r_fuse_up_add", "i2r_conv1x1_pair", "i2r_flip_merge", "i2r_decode", "i2r_crop_affine", "i2r_box_mask", "i2r_crop_affine_cv2", "i2r_box_mask_cv2", "i2r_conv_chain_pack", "i2r_conv_chain", "i2r_encoder_kv", "i2r_encoder_layer",
+           "i2r_upsample_bilinear_add", "i2r_fuse_up_add", "i2r_conv1x1_pair", "i2r_conv1x1_lp", "i2r_flip_merge", "i2r_decode", "i2r_crop_affine", "i2r_box_mask", "i2r_crop_affine_cv2", "i2r_box_mask_cv2", "i2r_conv_chain_pack", "i2r_conv_chain", "i2r_encoder_kv", "i2r_encoder_layer",
            "i2r_run_program", "i2r_abi_version", "i2r_last_error", "i2r_device_check")
 
 _LIB = None
@@ -169,6 +176,7 @@ def load_library(path=LIB_PATH):
     L.i2r_box_mask_cv2.argtypes = [_fp, _i32, _i32, _fp, _i32, _i32, _i32, C.c_void_p]
     L.i2r_fuse_up_add.argtypes = [_fp, _fp, _i32, _fp, _i32, _fp, _i32, _i32, _i32, _i32, _i32, _i32, C.c_void_p]
     L.i2r_conv1x1_pair.argtypes = [C.POINTER(Conv1x1PairArgs), C.c_void_p]
+    L.i2r_conv1x1_lp.argtypes = [C.POINTER(Conv1x1LpArgs), C.c_void_p]
     L.i2r_maxpool3x3s2.argtypes = [_fp, _fp, _i32, _i32, _i32, _i32, _i32, _i32, C.c_void_p]
     L.i2r_head.argtypes = [_fp, _fp, _fp, _fp, _i32, _i32, _i32, _i32, _i32, _i32, C.c_void_p]
     L.i2r_layernorm.argtypes = [_fp, _fp, _fp, _fp, _i32, _i32, _i32, C.c_float, _i32, C.c_void_p]

@@ -93,13 +93,16 @@ def wino_fragment(conv_h, conv_w):
 
 _WINO_TABLE = os.environ.get("I2R_WINO_TABLE", "0") == "1"  # tools/ A/B switch: LPT dispatch table for Winograd launches (default: members heaviest first)
 _WINO_MT = int(os.environ.get("I2R_WINO_MT", "0"))  # tools/ A/B switch: fragments per Winograd workgroup
+LP1X1 = os.environ.get("I2R_LP1X1", "1") != "0"  # 16-bit modes: single 1x1 convs over few pixels on i2r_conv1x1_lp (A/B switch for tools/)
+LP1X1_MAX_PIX = int(os.environ.get("I2R_LP1X1_MAX_PIX", "16384"))  # beyond that the implicit-GEMM kernel has enough workgroups to hide its staging
+_LP1X1_MT = int(os.environ.get("I2R_LP1X1_MT", "0"))
 PAIR1X1 = os.environ.get("I2R_PAIR1X1", "1") != "0"  # layer1's conv3 + next conv1 as one i2r_conv1x1_pair launch (fp32; A/B switch for tools/)
 _PAIR_MT = int(os.environ.get("I2R_PAIR_MT", "0"))  # tools/ A/B switch: 16-pixel tiles per wave of that kernel
 WINOGRAD = os.environ.get("I2R_WINOGRAD", "1") != "0"  # fp32 3x3 stride-1 convs on the Winograd F(2x2, 3x3) kernels (A/B switch for tools/)
 
 
 class PackedConv:
-    __slots__ = ("w", "bias", "cin", "cin_pad", "cout", "cout_pad", "taps", "iy0", "ix0", "stride", "ksize", "dtype", "w_wino", "w_frag")
+    __slots__ = ("w", "bias", "cin", "cin_pad", "cout", "cout_pad", "taps", "iy0", "ix0", "stride", "ksize", "dtype", "w_wino", "w_frag", "w_lp1")
 
     def __init__(self, w, bias, cin, cout, taps, iy0, ix0, stride, ksize, cin_pad=None, dtype=0):
         self.w, self.bias = w, bias
@@ -108,6 +111,7 @@ class PackedConv:
         self.taps, self.iy0, self.ix0, self.stride, self.ksize = taps, iy0, ix0, stride, ksize
         self.dtype = dtype
         self.w_wino = None  # fp32 3x3 stride-1 convs: the Winograd-domain weights [16][cin/4][cout_pad][4] (Packer.conv)
+        self.w_lp1 = None   # 16-bit 1x1 stride-1 convs: the [cout_pad, cin_pad] matrix as 16-bit MFMA A-operand fragments for i2r_conv1x1_lp
         self.w_frag = None  # fp32 1x1 convs of layer1: the [cout, cin] matrix as MFMA A-operand fragments (pack_frag) for i2r_conv1x1_pair
 
 
@@ -124,7 +128,12 @@ class Packer:
             w = pack_k4(w_taps, cin_pad, cout_pad)
         else:
             w = pack_k8(w_taps, cin_pad, cout_pad, torch.bfloat16 if self.dtype == 1 else torch.float16)
-        return PackedConv(self._dev(w), bias, cin, cout, taps, iy0, ix0, stride, ksize, cin_pad=cin_pad, dtype=self.dtype)
+        pc = PackedConv(self._dev(w), bias, cin, cout, taps, iy0, ix0, stride, ksize, cin_pad=cin_pad, dtype=self.dtype)
+        if self.dtype != 0 and ksize == 1 and stride == 1 and w_taps.shape[0] == 1 and cin_pad >= 64 and any((cout_pad // 16) % k == 0 for k in (3, 4, 5, 6)):
+            full = torch.zeros(cout_pad, cin_pad, dtype=torch.float64)
+            full[:cout, :cin] = w_taps[0].t()
+            pc.w_lp1 = self._dev(pack_frag(full).float().to(torch.bfloat16 if self.dtype == 1 else torch.float16))
+        return pc
 
     def _bn(self, key):
         if key is None:
@@ -604,6 +613,9 @@ class Program:
         consumer is an fp32 kernel: encoder, max-pool, head, ...)"""
         assert x.cs >= pc.cin_pad and x.c == pc.cin, "conv input channels %d/%d vs weight %d" % (x.c, x.cs, pc.cin)
         assert x.dt in (0, pc.dtype), "16-bit stored input needs the matching 16-bit conv (input %d, conv %d)" % (x.dt, pc.dtype)
+        if (LP1X1 and pc.w_lp1 is not None and group is None and in2 is None and res2 is None and up == 1 and out_step == 1 and tuple(out_off) == (0, 0)
+                and out_hw is None and x.n * x.h * x.w <= LP1X1_MAX_PIX and (out is None or (out.n, out.h, out.w) == (x.n, x.h, x.w))):
+            return self.conv1x1_lp(x, pc, relu=relu, res1=res1, res_post=res_post, out=out, lane=lane, act=act, out_dt=out_dt)
         k = pc.ksize
         if pc.stride == 1:
             conv_h, conv_w = x.h, x.w  # 'same' geometry for 1x1 / 3x3 pad 1 / deconv parity 2x2
@@ -913,6 +925,19 @@ class Program:
         assert low.h * scale == out.h and low.w * scale == out.w and low.cs == out.cs == res.cs
         a = cabi.UpArgs(low.ptr, res.ptr, out.ptr, low.n, low.h, low.w, scale, low.c, low.cs, act)
         self.ops.append((cabi.OP_UPSAMPLE, lane, a))
+        return out
+
+    def conv1x1_lp(self, x, pc, relu=False, res1=None, res_post=None, out=None, lane=0, act=None, out_dt=None):
+        """single 1x1 conv over few pixels in the 16-bit modes (i2r_conv1x1_lp: operands straight from global memory, K split over the
+        workgroup's waves); same semantics as conv(): out = act(W x + b + res1) + res_post"""
+        if out is None:
+            out = self.alloc(x.n, x.h, x.w, pc.cout, x.dt if out_dt is None else out_dt)
+        assert out.cs >= pc.cout_pad and out.dt in (0, pc.dtype) and all(r is None or (r.dt == out.dt and r.cs == out.cs) for r in (res1, res_post))
+        self.keep.append(pc)
+        a = cabi.Conv1x1LpArgs(x.ptr, pc.w_lp1.data_ptr(), pc.bias.data_ptr(), res1.ptr if res1 is not None else None,
+                               res_post.ptr if res_post is not None else None, out.ptr, x.n * x.h * x.w, pc.cin_pad, pc.cout_pad, x.cs, out.cs,
+                               (int(relu) if act is None else act), pc.dtype, int(x.dt != 0), int(out.dt != 0), _LP1X1_MT)
+        self.ops.append((cabi.OP_CONV1X1_LP, lane, a))
         return out
 
     def conv1x1_pair(self, x, pa, res, pb, lane=0):

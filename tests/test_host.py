@@ -121,7 +121,7 @@ def test_struct_layouts_match_header():
     src = r'''
 #include <stdio.h>
 #include "i2r_hip.h"
-int main(void){ printf("%zu %zu %zu %zu %zu %zu %zu %zu %zu %zu %zu %zu %zu %zu %zu %zu\n", sizeof(i2r_conv1x1_pair_args), sizeof(i2r_fuse_up_args), sizeof(i2r_hrt_mlp_args), sizeof(i2r_hrt_attn_args), sizeof(i2r_pe_res_args), sizeof(i2r_conv_desc), sizeof(i2r_encoder_desc), sizeof(i2r_stem_args),
+int main(void){ printf("%zu %zu %zu %zu %zu %zu %zu %zu %zu %zu %zu %zu %zu %zu %zu %zu %zu\n", sizeof(i2r_conv1x1_lp_args), sizeof(i2r_conv1x1_pair_args), sizeof(i2r_fuse_up_args), sizeof(i2r_hrt_mlp_args), sizeof(i2r_hrt_attn_args), sizeof(i2r_pe_res_args), sizeof(i2r_conv_desc), sizeof(i2r_encoder_desc), sizeof(i2r_stem_args),
  sizeof(i2r_pool_args), sizeof(i2r_head_args), sizeof(i2r_op), sizeof(i2r_conv_group_args), sizeof(i2r_ln_args), sizeof(i2r_winattn_args), sizeof(i2r_dw_args), sizeof(i2r_up_args)); return 0; }
 '''
     import tempfile
@@ -131,7 +131,7 @@ int main(void){ printf("%zu %zu %zu %zu %zu %zu %zu %zu %zu %zu %zu %zu %zu %zu 
         exe = os.path.join(td, "s")
         subprocess.check_call(["gcc", "-I", os.path.join(ROOT, "include"), c, "-o", exe])
         sizes = [int(v) for v in subprocess.check_output([exe]).split()]
-    mine = [ctypes.sizeof(t) for t in (cabi.Conv1x1PairArgs, cabi.FuseUpArgs, cabi.HrtMlpArgs, cabi.HrtAttnArgs, cabi.PeResArgs, cabi.ConvDesc, cabi.EncoderDesc, cabi.StemArgs, cabi.PoolArgs, cabi.HeadArgs, cabi.Op, cabi.ConvGroupArgs, cabi.LnArgs,
+    mine = [ctypes.sizeof(t) for t in (cabi.Conv1x1LpArgs, cabi.Conv1x1PairArgs, cabi.FuseUpArgs, cabi.HrtMlpArgs, cabi.HrtAttnArgs, cabi.PeResArgs, cabi.ConvDesc, cabi.EncoderDesc, cabi.StemArgs, cabi.PoolArgs, cabi.HeadArgs, cabi.Op, cabi.ConvGroupArgs, cabi.LnArgs,
                                        cabi.WinAttnArgs, cabi.DwArgs, cabi.UpArgs)]
     assert sizes == mine
 

@@ -241,6 +241,60 @@ def test_conv1x1_pair_through_the_c_abi(k_a, cb, res, relu_a, relu_b, n_pix, mt)
     assert cabi.lib().i2r_conv1x1_pair(C.byref(bad), None) != 0 and b"k_a" in cabi.lib().i2r_last_error()
 
 
+@pytest.mark.parametrize("precision,cin,cout,n,h,w,in_dt,out_dt,act,nres1,npost", [
+    ("bf16", 312, 960, 3, 16, 12, 1, 0, 0, 0, 0),    # q|k|v projection of an unfused block (head-padded): 16-bit LN output in, fp32 out (60 fragments: NF 5)
+    ("bf16", 312, 312, 3, 16, 12, 0, 0, 0, 1, 0),    # out projection: fp32 input packed on load, + residual stream (fp32)
+    ("fp16", 312, 1248, 2, 16, 12, 2, 2, 2, 0, 0),   # fc1 + GELU, 16-bit in and out (78 fragments: NF 6)
+    ("fp16", 1248, 312, 2, 16, 12, 2, 0, 2, 0, 1),   # fc2 + GELU + post-activation residual, K = 78 steps
+    ("bf16", 624, 78, 5, 8, 6, 1, 1, 1, 1, 0),       # fuse 1x1 from the lowest branch, ReLU, 240 pixels (tile tail), cout 78 -> 5 fragments
+    ("bf16", 160, 156, 2, 5, 7, 1, 1, 0, 0, 0),      # 70 pixels: partial last tile; cin 156 padded to 160 (10 steps over 4 waves)
+])
+def test_conv1x1_lp_matches_torch_and_the_igemm_path(precision, cin, cout, n, h, w, in_dt, out_dt, act, nres1, npost):
+    """Program.conv routes single 1x1 convs over few pixels of the 16-bit modes to i2r_conv1x1_lp: against torch (float64 on the
+    16-bit-rounded operands) and against the implicit-GEMM 16-bit kernel on the same packed conv"""
+    tag = "lp1_%d_%d_%d" % (cin, cout, h)
+    sd = {"c.weight": _rand((cout, cin, 1, 1), "w" + tag, (3.0 / cin) ** 0.5), "c.bias": _rand((cout,), "cb" + tag, 0.3)}
+    tdt = {"bf16": torch.bfloat16, "fp16": torch.float16}[precision]
+    q = lambda t: t.to(tdt).double()
+    x = _rand((n, cin, h, w), "x" + tag)
+    xs = q(x) if in_dt else q(x)  # (an fp32 input is rounded to the operand type on load)
+    ref = F.conv2d(xs, q(sd["c.weight"]), sd["c.bias"].double())
+    r1 = _rand(tuple(ref.shape), "r1" + tag) if nres1 else None
+    rp = _rand(tuple(ref.shape), "rp" + tag) if npost else None
+    rq = (lambda t: q(t)) if out_dt else (lambda t: t.double())
+    if r1 is not None:
+        ref = ref + rq(r1)
+    if act == 1:
+        ref = F.relu(ref)
+    elif act == 2:
+        ref = F.gelu(ref)
+    if rp is not None:
+        ref = ref + rq(rp)
+    outs = {}
+    for lp in (True, False):
+        saved = engine.LP1X1
+        engine.LP1X1 = lp
+        try:
+            P = engine.Program(torch.device(DEV))
+            pc = engine.Packer(sd, torch.device(DEV), precision).conv("c")
+            assert pc.w_lp1 is not None
+            xa = to_act(P, x, in_dt)
+            out = P.conv(xa, pc, act=act, res1=to_act(P, r1, out_dt) if r1 is not None else None,
+                         res_post=to_act(P, rp, out_dt) if rp is not None else None, out_dt=out_dt)
+            kinds = [k for k, _, _ in P.ops]
+            run(P)
+        finally:
+            engine.LP1X1 = saved
+        assert kinds == [engine.cabi.OP_CONV1X1_LP if lp else engine.cabi.OP_CONV]
+        assert out.dt == out_dt and torch.isfinite(out.view().float()).all()
+        if out.cs > cout:
+            assert out.view()[..., cout:].float().abs().max().item() == 0.0, "padding channels must stay zero"
+        outs[lp] = from_act(out).double()
+        tol = ({"bf16": 1e-2, "fp16": 1.5e-3}[precision] if out_dt else 2e-4) * max(1.0, ref.abs().max().item())
+        assert (outs[lp] - ref).abs().max().item() < tol, "%s lp=%s: max-abs %.3e (tol %.3e)" % (tag, lp, (outs[lp] - ref).abs().max().item(), tol)
+    assert (outs[True] - outs[False]).abs().max().item() < ({"bf16": 1e-2, "fp16": 1.5e-3}[precision] if out_dt else 1e-4) * max(1.0, ref.abs().max().item())
+
+
 def test_deconv_matches_conv_transpose():
     sd = {"d.weight": _rand((96, 96, 4, 4), "dw", 0.08), "b.weight": _rand((96,), "dg", 0.5) + 1.0,
           "b.bias": _rand((96,), "db", 0.3), "b.running_mean": _rand((96,), "dm", 0.3),

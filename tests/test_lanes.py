@@ -45,6 +45,8 @@ def _accesses(kind, st):
         return [p for p in (g("base"), g("t1"), g("t2")) if p], [g("out")]
     if kind == cabi.OP_MAXPOOL:
         return [g("in_")], [g("out")]
+    if kind == cabi.OP_CONV1X1_LP:
+        return [p for p in (g("x"), g("res1"), g("res_post")) if p], [g("out")]
     if kind == cabi.OP_CONV1X1_PAIR:
         return [p for p in (g("x"), g("res")) if p], [p for p in (g("y"), g("z")) if p]
     raise AssertionError("op kind %d not modelled" % kind)
