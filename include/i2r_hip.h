@@ -295,7 +295,8 @@ int i2r_conv1x1_pair(const i2r_conv1x1_pair_args* a, void* stream);
  *     out = act(W x + bias [+ res1]) [+ res_post]          act: 0 none, 1 ReLU, 2 exact-erf GELU
  * Replaces the single 1x1 convs of the unfused HRFormer-B transformer blocks -- q|k|v and out projections (hrformer.py:1164-1180),
  * MlpDWBN fc1 / fc2 (:1094-1119) -- and of the fuse layers (:1629-1704) where the pixel count is a few thousand and i2r_conv is bound
- * by its per-chunk staging latency.  w: fragment-packed 16-bit [cout_pad / 16][cin_pad / 16][64 lanes][4] (engine.pack_frag); bias
+ * by its per-chunk staging latency.  w: fragment-packed 16-bit [cout_pad / 16][ceil(cin_pad / 32)][64 lanes][8] (engine.pack_frag32:
+ * lane (li, g) of fragment (f, c) holds W[16 f + li][32 c + 8 g .. + 8), columns beyond cin_pad zero); bias
  * fp32 [cout_pad]; x fp32 (in_16 = 0, packed on load) or stored in the operand type; out, res1, res_post fp32 or 16 bit (out_16).
  * cout_pad / 16 must be a multiple of 3, 4, 5 or 6; cin_pad >= 64.  res1 / res_post may alias out (in-place accumulation of a fuse sum).  mt: 16-pixel tiles per workgroup (1, 2; 0 = chosen from the grid size). */
 typedef struct i2r_conv1x1_lp_args {

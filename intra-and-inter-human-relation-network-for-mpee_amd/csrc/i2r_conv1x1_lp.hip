@@ -8,73 +8,68 @@
 // convolutions of the fuse layers (:1629-1704).  On the implicit-GEMM kernel such a conv is a few hundred workgroups that stage the
 // pixels' channels through LDS in 64-channel chunks, one barrier pair per chunk, for 8 MFMAs each: 15-36 us for 0.3-2.4 GFLOP, all of
 // it latency.  Here the GEMM is computed TRANSPOSED (Y^T = W X^T, as in the encoder kernels): the weight fragment is the MFMA A
-// operand (fragment-packed by the host: one 64-lane 8-byte load = 512 contiguous bytes), a pixel's 4 consecutive channels the B operand
-// (one 8-byte load from its row, or 16 bytes of fp32 packed on the fly) -- no LDS in the K loop, no barrier.  A workgroup owns MT
-// 16-pixel tiles x NF 16-channel output fragments and its four waves SPLIT K (cin / 16 steps, two steps fetched ahead): that is what
+// operand (v_mfma_f32_16x16x32; fragment-packed by the host: one 64-lane 16-byte load = 1 KB contiguous), a pixel's 8 consecutive
+// channels the B operand (one 16-byte load from its row, or 32 bytes of fp32 packed on the fly) -- no LDS in the K loop, no barrier.
+// (The loop is bound by the texture addresser -- NF + MT load instructions per NF x MT MFMAs -- which is why the 32-deep MFMA with its
+// 16-byte operands is used: the 16-deep one needs twice the load instructions per FLOP and measured 1.5x slower.)  A workgroup owns MT
+// 16-pixel tiles x NF 16-channel output fragments and its four waves SPLIT K (cin / 32 steps): that is what
 // puts enough waves on the chip for these shapes; the four partial sums meet once through LDS in a fixed order (wave 0 .. 3), and
 // the wave that finishes a fragment applies bias / residual / activation and stores 8- or 16-byte pieces of the pixels' rows.
-#include <type_traits>
-
 #include "i2r_common.h"
 #include "i2r_conv.h"
 
 namespace {
 
-typedef short s16x4 __attribute__((ext_vector_type(4)));
-typedef _Float16 h16x4 __attribute__((ext_vector_type(4)));
-typedef __bf16 b16x4 __attribute__((ext_vector_type(4)));
-typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
-
 template <int DT>
-__device__ __forceinline__ f32x4 mfma16_lp(u32x2 a, u32x2 b, f32x4 c) {
-    if constexpr (DT == 1)
-        return __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(__builtin_bit_cast(s16x4, a), __builtin_bit_cast(s16x4, b), c, 0, 0, 0);
-    else
-        return __builtin_amdgcn_mfma_f32_16x16x16f16(__builtin_bit_cast(h16x4, a), __builtin_bit_cast(h16x4, b), c, 0, 0, 0);
-}
-template <int DT>
-__device__ __forceinline__ u32x2 pack4_lp(f32x4 v) {
+__device__ __forceinline__ f32x4 pack8_lp(f32x4 lo, f32x4 hi) {  // 8 fp32 -> 8 16-bit values in order
     if constexpr (DT == 1) {
-        const b16x4 b = {(__bf16)v[0], (__bf16)v[1], (__bf16)v[2], (__bf16)v[3]};
-        return __builtin_bit_cast(u32x2, b);
+        const bf16x8 v = {(__bf16)lo[0], (__bf16)lo[1], (__bf16)lo[2], (__bf16)lo[3], (__bf16)hi[0], (__bf16)hi[1], (__bf16)hi[2], (__bf16)hi[3]};
+        return __builtin_bit_cast(f32x4, v);
     } else {
-        const h16x4 h = {(_Float16)v[0], (_Float16)v[1], (_Float16)v[2], (_Float16)v[3]};
-        return __builtin_bit_cast(u32x2, h);
+        const f16x8 v = {(_Float16)lo[0], (_Float16)lo[1], (_Float16)lo[2], (_Float16)lo[3], (_Float16)hi[0], (_Float16)hi[1], (_Float16)hi[2], (_Float16)hi[3]};
+        return __builtin_bit_cast(f32x4, v);
     }
 }
 
 struct Lp1K {
     const void* x; const void* w; const float* bias; const void* res1; const void* res_post; void* out;
-    int n_pix, n_tiles, kc, x_cs, out_cs, n_groups, act, out16;
+    int n_pix, n_tiles, kc, k_tail, x_cs, out_cs, n_groups, act, out16;  // kc: 32-channel steps (the last one half-filled when k_tail)
 };
 
 // IN16: x is stored in the operand type (else fp32, packed on load)
 template <int DT, int NF, int MT, bool IN16>
 __global__ __launch_bounds__(256) void conv1x1_lp_k(const Lp1K p) {
-    __shared__ f32x4 part[4][MT * NF][64];  // partial sums handed to the finishing wave (a wave's own slots stay unused)
+    __shared__ f32x4 part[MT * NF][3][64];  // partial sums handed to the finishing wave: slot (wave - owner - 1) mod 4 of the fragment
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, li = lane & 15, g = lane >> 4;
     const int grp = blockIdx.x % p.n_groups, tg = blockIdx.x / p.n_groups;  // output-fragment group, pixel-tile group
     const int tile0 = tg * MT, f0 = grp * NF;
     const unsigned xe = IN16 ? 2u : 4u;
     const __amdgpu_buffer_rsrc_t rs_x = make_rsrc(p.x, (unsigned)p.n_pix * p.x_cs * xe);
-    const __amdgpu_buffer_rsrc_t rs_w = make_rsrc(p.w, (unsigned)p.n_groups * NF * p.kc * 512);
-    unsigned xo[MT];
+    const __amdgpu_buffer_rsrc_t rs_w = make_rsrc(p.w, (unsigned)p.n_groups * NF * p.kc * 1024);
+    // byte offset of this lane's 8 channels (8 g ..) of a 32-channel step in its pixels' rows.  When the channel count is an odd multiple
+    // of 16 the last step is half a step: the lanes of its upper half (g >= 2) read nothing (zeros; the weights are zero-padded too)
+    unsigned xo[MT], xo_last[MT];
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt) {
         const int q = (tile0 + mt) * 16 + li;
-        xo[mt] = q < p.n_pix ? (unsigned)(q * p.x_cs + 4 * g) * xe : kOOB;
+        xo[mt] = q < p.n_pix ? (unsigned)(q * p.x_cs + 8 * g) * xe : kOOB;
+        xo_last[mt] = (p.k_tail && g >= 2) ? kOOB : xo[mt];
     }
     // this wave's share of the K steps
     const int c_lo = (p.kc * wave) >> 2, c_hi = (p.kc * (wave + 1)) >> 2;
-    typedef typename std::conditional<IN16, u32x2, f32x4>::type xraw;
-    struct Set { xraw x[MT]; u32x2 w[NF]; };
+    struct Set { f32x4 x[MT][IN16 ? 1 : 2]; f32x4 w[NF]; };
     auto fetch = [&](int c, Set& s) {
 #pragma unroll
-        for (int nf = 0; nf < NF; ++nf) s.w[nf] = __builtin_amdgcn_raw_buffer_load_b64(rs_w, lane * 8, ((f0 + nf) * p.kc + c) * 512, 0);
+        for (int nf = 0; nf < NF; ++nf) s.w[nf] = buf_ld16(rs_w, lane * 16, ((f0 + nf) * p.kc + c) * 1024);
+        const bool tail = c == p.kc - 1;  // (wave-uniform)
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt) {
-            if constexpr (IN16) s.x[mt] = __builtin_amdgcn_raw_buffer_load_b64(rs_x, xo[mt], c * 32, 0);
-            else s.x[mt] = buf_ld16(rs_x, xo[mt], c * 64);
+            const unsigned o = tail ? xo_last[mt] : xo[mt];
+            if constexpr (IN16) s.x[mt][0] = buf_ld16(rs_x, o, c * 64);
+            else {
+                s.x[mt][0] = buf_ld16(rs_x, o, c * 128);
+                s.x[mt][1] = buf_ld16(rs_x, o, c * 128 + 16);
+            }
         }
     };
     f32x4 acc[MT][NF];
@@ -85,34 +80,20 @@ __global__ __launch_bounds__(256) void conv1x1_lp_k(const Lp1K p) {
     auto step = [&](const Set& s) {
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt) {
-            u32x2 xb;
-            if constexpr (IN16) xb = s.x[mt];
-            else xb = pack4_lp<DT>(s.x[mt]);
+            f32x4 xb;
+            if constexpr (IN16) xb = s.x[mt][0];
+            else xb = pack8_lp<DT>(s.x[mt][0], s.x[mt][1]);
 #pragma unroll
-            for (int nf = 0; nf < NF; ++nf) acc[mt][nf] = mfma16_lp<DT>(s.w[nf], xb, acc[mt][nf]);
+            for (int nf = 0; nf < NF; ++nf) acc[mt][nf] = mfma32_lp<DT>(s.w[nf], xb, acc[mt][nf]);
         }
     };
-    {
-        Set s0, s1, s2;  // step c uses set (c - c_lo) % 3; two steps are in flight ahead of it (look-aheads past c_hi re-read the last step)
-        const int last = c_hi - 1;
-        fetch(min(c_lo, last), s0);
-        fetch(min(c_lo + 1, last), s1);
-        int c = c_lo;
-        for (; c + 3 <= c_hi; c += 3) {
-            fetch(min(c + 2, last), s2);
-            __builtin_amdgcn_sched_barrier(0);
-            step(s0);
-            fetch(min(c + 3, last), s0);
-            __builtin_amdgcn_sched_barrier(0);
-            step(s1);
-            fetch(min(c + 4, last), s1);
-            __builtin_amdgcn_sched_barrier(0);
-            step(s2);
-        }
-        if (c < c_hi) {
-            step(s0);
-            if (c + 1 < c_hi) step(s1);
-        }
+    // No software look-ahead: rings of 2, 3 and 6 operand sets were measured (configs 4 / 5, same box: 3.64 / 3.86 / 4.24 ms per forward
+    // against 3.54 ms like this) -- these launches share the chip with the other stream lanes' kernels, and what counts is how many
+    // waves fit next to them (registers), the latency of a step is covered by the neighbours.
+    for (int c = c_lo; c < c_hi; ++c) {
+        Set s;
+        fetch(c, s);
+        step(s);
     }
     // ---- the four partial sums meet: fragment (mt, nf) is finished by wave (mt * NF + nf) % 4, the other three hand theirs over ----
     const int slot = lane;
@@ -121,7 +102,7 @@ __global__ __launch_bounds__(256) void conv1x1_lp_k(const Lp1K p) {
 #pragma unroll
         for (int nf = 0; nf < NF; ++nf) {
             const int idx = mt * NF + nf;
-            if ((idx & 3) != wave) part[wave][idx][slot] = acc[mt][nf];  // (wave-uniform)
+            if ((idx & 3) != wave) part[idx][(wave - (idx & 3) + 3) & 3][slot] = acc[mt][nf];  // (wave-uniform)
         }
     __syncthreads();
     const bool o16 = p.out16 != 0;
@@ -138,7 +119,7 @@ __global__ __launch_bounds__(256) void conv1x1_lp_k(const Lp1K p) {
             if ((idx & 3) != wave) continue;  // (wave-uniform)
             f32x4 v = *reinterpret_cast<const f32x4*>(p.bias + 16 * (f0 + nf) + 4 * g);
 #pragma unroll
-            for (int w = 0; w < 4; ++w) v += (w == wave) ? acc[mt][nf] : part[w][idx][slot];  // fixed order: bit-identical replays
+            for (int w = 0; w < 4; ++w) v += (w == wave) ? acc[mt][nf] : part[idx][w == wave ? 0 : (w - wave + 3) & 3][slot];  // fixed order 0 .. 3: bit-identical replays
             const int soff = 16 * (f0 + nf) * (int)oe;
             if (p.res1) v += buf_ld_act4<DT>(rs_r1, orow + soff, o16);
             if (p.act == 1) {
@@ -158,6 +139,7 @@ template <int DT, int NF, bool IN16>
 lp1_fn pick_mt(int mt) {
     if (mt == 1) return conv1x1_lp_k<DT, NF, 1, IN16>;
     if (mt == 2) return conv1x1_lp_k<DT, NF, 2, IN16>;
+    if (mt == 4) return conv1x1_lp_k<DT, NF, 4, IN16>;
     return nullptr;
 }
 template <int DT>
@@ -185,13 +167,13 @@ extern "C" int i2r_conv1x1_lp(const i2r_conv1x1_lp_args* a, void* stream) {
     I2R_CHECK_ARG(nf != 0, "i2r_conv1x1_lp: cout_pad / 16 = %d is no multiple of 3, 4, 5 or 6 (use i2r_conv)", n_frag);
     Lp1K k;
     k.x = a->x; k.w = a->w; k.bias = a->bias; k.res1 = a->res1; k.res_post = a->res_post; k.out = a->out;
-    k.n_pix = a->n_pix; k.n_tiles = (a->n_pix + 15) / 16; k.kc = a->cin_pad / 16; k.x_cs = a->x_cs; k.out_cs = a->out_cs;
+    k.n_pix = a->n_pix; k.n_tiles = (a->n_pix + 15) / 16; k.kc = (a->cin_pad + 31) / 32; k.k_tail = (a->cin_pad & 16) != 0; k.x_cs = a->x_cs; k.out_cs = a->out_cs;
     k.n_groups = n_frag / nf; k.act = a->act; k.out16 = a->out_16;
     // two pixel tiles per workgroup (each weight fragment feeds two MFMAs) when that still leaves a workgroup per CU
     int mt = a->mt;
     if (mt == 0) mt = ((k.n_tiles + 1) / 2) * k.n_groups >= 256 ? 2 : 1;
     lp1_fn fn = a->dtype == 1 ? pick<1>(nf, mt, a->in_16 != 0) : pick<2>(nf, mt, a->in_16 != 0);
-    I2R_CHECK_ARG(fn != nullptr, "i2r_conv1x1_lp: mt=%d (1, 2)", mt);
+    I2R_CHECK_ARG(fn != nullptr, "i2r_conv1x1_lp: mt=%d (1, 2, 4)", mt);
     const long long nblk = (long long)((k.n_tiles + mt - 1) / mt) * k.n_groups;
     I2R_CHECK_ARG(nblk < (1ll << 31), "i2r_conv1x1_lp: grid");
     hipLaunchKernelGGL(fn, dim3((unsigned)nblk), dim3(256), 0, (hipStream_t)stream, k);

@@ -63,6 +63,15 @@ def pack_frag(m):
     return v.permute(0, 2, 3, 1, 4).contiguous().reshape(rows, cols)  # [rb, c, g, li, r]
 
 
+def pack_frag32(m):
+    """[rows, cols] (rows a multiple of 16, cols of 32) -> A-operand images of the 32-deep 16-bit MFMA in lane order (csrc/i2r_conv1x1_lp.hip):
+    packed[((rb*KC + c)*64 + l)*8 + r] = m[16 rb + (l & 15)][32 c + 8 (l >> 4) + r]; one 64-lane 16-byte load = 1 KB contiguous."""
+    rows, cols = m.shape
+    assert rows % 16 == 0 and cols % 32 == 0
+    v = m.reshape(rows // 16, 16, cols // 32, 4, 8)              # [rb, li, c, g, r]
+    return v.permute(0, 2, 3, 1, 4).contiguous().reshape(rows, cols)  # [rb, c, g, li, r]
+
+
 def pack_k8(w_taps, cin_pad, cout_pad, tdtype):
     """w_taps [ntaps, cin, cout] -> 16-bit [ntaps, g8_pad, cout_pad, 8] (cin zero-padded to whole 32-channel MFMA steps)."""
     nt, cin, cout = w_taps.shape
@@ -94,7 +103,7 @@ def wino_fragment(conv_h, conv_w):
 _WINO_TABLE = os.environ.get("I2R_WINO_TABLE", "0") == "1"  # tools/ A/B switch: LPT dispatch table for Winograd launches (default: members heaviest first)
 _WINO_MT = int(os.environ.get("I2R_WINO_MT", "0"))  # tools/ A/B switch: fragments per Winograd workgroup
 LP1X1 = os.environ.get("I2R_LP1X1", "1") != "0"  # 16-bit modes: single 1x1 convs over few pixels on i2r_conv1x1_lp (A/B switch for tools/)
-LP1X1_MAX_PIX = int(os.environ.get("I2R_LP1X1_MAX_PIX", "16384"))  # beyond that the implicit-GEMM kernel has enough workgroups to hide its staging
+LP1X1_MAX_PIX = int(os.environ.get("I2R_LP1X1_MAX_PIX", "65536"))  # beyond that the implicit-GEMM kernel has enough workgroups to hide its staging
 _LP1X1_MT = int(os.environ.get("I2R_LP1X1_MT", "0"))
 PAIR1X1 = os.environ.get("I2R_PAIR1X1", "1") != "0"  # layer1's conv3 + next conv1 as one i2r_conv1x1_pair launch (fp32; A/B switch for tools/)
 _PAIR_MT = int(os.environ.get("I2R_PAIR_MT", "0"))  # tools/ A/B switch: 16-pixel tiles per wave of that kernel
@@ -130,9 +139,9 @@ class Packer:
             w = pack_k8(w_taps, cin_pad, cout_pad, torch.bfloat16 if self.dtype == 1 else torch.float16)
         pc = PackedConv(self._dev(w), bias, cin, cout, taps, iy0, ix0, stride, ksize, cin_pad=cin_pad, dtype=self.dtype)
         if self.dtype != 0 and ksize == 1 and stride == 1 and w_taps.shape[0] == 1 and cin_pad >= 64 and any((cout_pad // 16) % k == 0 for k in (3, 4, 5, 6)):
-            full = torch.zeros(cout_pad, cin_pad, dtype=torch.float64)
+            full = torch.zeros(cout_pad, (cin_pad + 31) // 32 * 32, dtype=torch.float64)
             full[:cout, :cin] = w_taps[0].t()
-            pc.w_lp1 = self._dev(pack_frag(full).float().to(torch.bfloat16 if self.dtype == 1 else torch.float16))
+            pc.w_lp1 = self._dev(pack_frag32(full).float().to(torch.bfloat16 if self.dtype == 1 else torch.float16))
         return pc
 
     def _bn(self, key):
