@@ -7,8 +7,7 @@ cd $R
 timeout 900 python -m pytest tests/test_kernels_gpu.py -x -q -m gpu -k "conv1x1_lp" > $O/full.log 2>&1; grep -E "passed|failed|rror|assert" $O/full.log | tail -n 12 > $O/ab.log
 for w in hrt_192_p4_b4 coco_hrt_288_p2_b4; do
 for i in 1 2; do
-for v in "0 16384" "1 16384" "2 16384" "4 16384" "0 65536"; do
-set -- $v
-I2R_LP1X1_MT=$1 I2R_LP1X1_MAX_PIX=$2 timeout 300 python tools/host_rate.py $w 2>&1 | tail -n 2 | tr '\n' ' ' | sed "s/host issue.*GPU/GPU/; s/, host incl.*//; s/^/mt=$1 maxpix=$2 /" >> $O/ab.log; echo >> $O/ab.log
+for v in 1 0; do
+I2R_LN_FUSE=$v timeout 300 python tools/host_rate.py $w 2>&1 | tail -n 2 | tr '\n' ' ' | sed "s/host issue.*GPU/GPU/; s/, host incl.*//; s/^/ln_fuse=$v /" >> $O/ab.log; echo >> $O/ab.log
 done; done; done
 cat $O/ab.log
