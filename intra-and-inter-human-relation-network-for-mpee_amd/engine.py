@@ -105,6 +105,9 @@ _WINO_MT = int(os.environ.get("I2R_WINO_MT", "0"))  # tools/ A/B switch: fragmen
 LP1X1 = os.environ.get("I2R_LP1X1", "1") != "0"  # 16-bit modes: single 1x1 convs over few pixels on i2r_conv1x1_lp (A/B switch for tools/)
 LP1X1_MAX_PIX = int(os.environ.get("I2R_LP1X1_MAX_PIX", "65536"))  # beyond that the implicit-GEMM kernel has enough workgroups to hide its staging
 _LP1X1_MT = int(os.environ.get("I2R_LP1X1_MT", "0"))
+# tools/ A/B switches: branch widths whose transformer-block halves run as the fused 16-bit kernels (i2r_hrt_attn_block / i2r_hrt_mlp_block)
+_HRT_FUSED_ATTN = tuple(int(v) for v in os.environ.get("I2R_HRT_FUSED_ATTN", "78,156").split(",") if v)
+_HRT_FUSED_MLP = tuple(int(v) for v in os.environ.get("I2R_HRT_FUSED_MLP", "78,156").split(",") if v)
 PAIR1X1 = os.environ.get("I2R_PAIR1X1", "1") != "0"  # layer1's conv3 + next conv1 as one i2r_conv1x1_pair launch (fp32; A/B switch for tools/)
 _PAIR_MT = int(os.environ.get("I2R_PAIR_MT", "0"))  # tools/ A/B switch: 16-pixel tiles per wave of that kernel
 WINOGRAD = os.environ.get("I2R_WINOGRAD", "1") != "0"  # fp32 3x3 stride-1 convs on the Winograd F(2x2, 3x3) kernels (A/B switch for tools/)
@@ -1314,8 +1317,8 @@ class HRFormerB:
             blks = []
             for k in range(st["num_blocks"][i]):
                 r = "%s.branches.%d.%d" % (q, i, k)
-                fused = pk.attn_block_lp(r, ch[i], st["num_heads"][i]) if (pk.dtype != 0 and ch[i] in (78, 156)) else None
-                fused_mlp = pk.mlp_block_lp(r, ch[i]) if (pk.dtype != 0 and ch[i] in (78, 156)) else None
+                fused = pk.attn_block_lp(r, ch[i], st["num_heads"][i]) if (pk.dtype != 0 and ch[i] in _HRT_FUSED_ATTN) else None
+                fused_mlp = pk.mlp_block_lp(r, ch[i]) if (pk.dtype != 0 and ch[i] in _HRT_FUSED_MLP) else None
                 blks.append(dict(c=ch[i], heads=st["num_heads"][i], ln1=pk.ln(r + ".norm1", ch[i]), ln2=pk.ln(r + ".norm2", ch[i]), attn_lp=fused, mlp_lp=fused_mlp,
                                  qkv=pk.qkv(r + ".attn.attn", ch[i], st["num_heads"][i]),
                                  out=pk.attn_out(r + ".attn.attn", ch[i], st["num_heads"][i]),

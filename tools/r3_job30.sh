@@ -1,10 +1,12 @@
 #!/bin/bash
 cd /tmp && export TMPDIR=/tmp
 R=${GRAFT_REPO_ROOT:-/root/repo}
-O=$R/gpurun_out
+O=$R/gpurun_out/j30
+rm -rf $O; mkdir -p $O
 cd $R
-for c in hrt_192_p4_b4 coco_hrt_288_p2_b4; do
-  python bench.py --config $c > $O/bench_$c.json 2> $O/bench_$c.err
-  rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_stats_$c -- python bench.py --config $c --no-cpu-baseline --no-parity --no-roofline > $O/bench_under_rocprof_$c.json 2> $O/rocprof_stats_$c.err
-  cut -c1-200 $O/bench_$c.json
-done
+for w in hrt_192_p4_b4 coco_hrt_288_p2_b4; do
+for v in "78,156 78,156" "78,156 78" "78,156 156" "78,156 0" "78 78,156" "156 78,156" "0 78,156" "0 0"; do
+set -- $v
+I2R_HRT_FUSED_ATTN=$1 I2R_HRT_FUSED_MLP=$2 I2R_LP1X1_MAX_PIX=200000 timeout 300 python tools/host_rate.py $w 2>&1 | tail -n 2 | tr '\n' ' ' | sed "s/host issue.*GPU/GPU/; s/, host incl.*//; s/^/attn=$1 mlp=$2 /" >> $O/ab.log; echo >> $O/ab.log
+done; done
+cat $O/ab.log
