@@ -173,7 +173,8 @@ def op_model(kind, st, precision, enc_lens=None):
         return ("dwconv3x3_k", 18.0 * st.n_img * oh * ow * st.c, float(st.n_img * (st.in_h * st.in_w + oh * ow) * st.cs * _esz(st.dt) + 10 * st.cs * 4), None)
     if kind == cabi.OP_UPSAMPLE:
         n_out = st.n_img * st.low_h * st.low_w * st.scale * st.scale
-        return "upsample_add_k", 8.0 * n_out * st.c, float((st.n_img * st.low_h * st.low_w + 2 * n_out) * st.cs * 4), None
+        scales = [st.scale] + ([st.scale2] if st.low2 else []) + ([st.scale3] if st.low2 and st.low3 else [])
+        return ("upsample_add_k", 8.0 * n_out * st.c * len(scales), float((sum(n_out // (s_ * s_) for s_ in scales) + 2 * n_out) * st.cs * 4), None)
     if kind == cabi.OP_FUSE_UP:
         n_out = st.n_img * st.h * st.w
         low = n_out // (st.s1 * st.s1) + (n_out // (st.s2 * st.s2) if st.t2 else 0)

@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define I2R_ABI_VERSION 6
+#define I2R_ABI_VERSION 7
 
 #define I2R_OK 0
 #define I2R_E_ARG (-1)      /* bad argument (shape / alignment / unsupported combination) */
@@ -266,6 +266,12 @@ int i2r_dwconv3x3(const float* in, const float* w, const float* bias, float* out
  * 1718-1730). res may alias out. */
 int i2r_upsample_bilinear_add(const float* low, const float* res, float* out, int32_t n_img, int32_t low_h, int32_t low_w,
                               int32_t scale, int32_t c, int32_t cs, int32_t act, void* stream);
+/* the same with up to three up-sampled terms added in ONE pass, in the order given (a->low2 / a->low3 may be null): the sum of
+ * HighResolutionTransformerModule.forward over the lower-resolution branches j > i (hrformer.py:1718-1730) without handing the partial
+ * sums through memory; bit-identical to successive i2r_upsample_bilinear_add calls.  All terms share n_img, c, cs; the output is
+ * low_h * scale x low_w * scale and every scale divides it.  (i2r_up_args: below, with the program runner's structs.) */
+struct i2r_up_args;
+int i2r_upsample_bilinear_add_multi(const struct i2r_up_args* a, void* stream);
 
 /* i2r_fuse_up_add -- out = act(base + up(t1, s1) [+ up(t2, s2)]), up = nearest-neighbour up-sampling by s (a power of two; t_k is
  * [n, h/s_k, w/s_k, cs]).  The closing step of the HRNet fuse sum for the outputs that receive lower-resolution terms
@@ -442,6 +448,9 @@ typedef struct i2r_dw_args {
 typedef struct i2r_up_args {
     const float* low; const float* res; float* out;
     int32_t n_img, low_h, low_w, scale, c, cs, act;
+    /* optional further terms (i2r_upsample_bilinear_add_multi): out = act(((res + up(low, scale)) + up(low2, scale2)) + up(low3, scale3)) */
+    const float* low2; const float* low3;
+    int32_t scale2, scale3;
 } i2r_up_args;
 
 typedef struct i2r_fuse_up_args {

@@ -14,7 +14,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libi2r_hip.so")
 
 MAX_TAPS = 9
-ABI_VERSION = 6  # I2R_ABI_VERSION of include/i2r_hip.h
+ABI_VERSION = 7  # I2R_ABI_VERSION of include/i2r_hip.h
 OP_CONV, OP_STEM, OP_MAXPOOL, OP_HEAD, OP_ENC_KV, OP_ENC_LAYER, OP_FORK, OP_JOIN, OP_CONV_GROUP = 1, 2, 3, 4, 5, 6, 7, 8, 9
 MAX_GROUP = 4
 OP_LAYERNORM, OP_WINATTN, OP_DWCONV, OP_UPSAMPLE = 10, 11, 12, 13
@@ -107,7 +107,8 @@ class DwArgs(C.Structure):
 
 class UpArgs(C.Structure):
     _fields_ = [("low", _fp), ("res", _fp), ("out", _fp),
-                ("n_img", _i32), ("low_h", _i32), ("low_w", _i32), ("scale", _i32), ("c", _i32), ("cs", _i32), ("act", _i32)]
+                ("n_img", _i32), ("low_h", _i32), ("low_w", _i32), ("scale", _i32), ("c", _i32), ("cs", _i32), ("act", _i32),
+                ("low2", _fp), ("low3", _fp), ("scale2", _i32), ("scale3", _i32)]
 
 
 class FuseUpArgs(C.Structure):
@@ -144,7 +145,7 @@ class Op(C.Structure):
 
 # every symbol include/i2r_hip.h declares (tests/test_host.py::test_cabi_library_exports_every_declared_symbol checks the built library exports them all)
 EXPORTS = ("i2r_conv", "i2r_conv_grouped", "i2r_conv_kernel_name", "i2r_stem_conv", "i2r_pe_res_stem", "i2r_maxpool3x3s2", "i2r_head", "i2r_layernorm", "i2r_window_attn", "i2r_hrt_attn_block", "i2r_hrt_mlp_block", "i2r_dwconv3x3",
-           "i2r_upsample_bilinear_add", "i2r_fuse_up_add", "i2r_conv1x1_pair", "i2r_conv1x1_lp", "i2r_flip_merge", "i2r_decode", "i2r_crop_affine", "i2r_box_mask", "i2r_crop_affine_cv2", "i2r_box_mask_cv2", "i2r_conv_chain_pack", "i2r_conv_chain", "i2r_encoder_kv", "i2r_encoder_layer",
+           "i2r_upsample_bilinear_add", "i2r_upsample_bilinear_add_multi", "i2r_fuse_up_add", "i2r_conv1x1_pair", "i2r_conv1x1_lp", "i2r_flip_merge", "i2r_decode", "i2r_crop_affine", "i2r_box_mask", "i2r_crop_affine_cv2", "i2r_box_mask_cv2", "i2r_conv_chain_pack", "i2r_conv_chain", "i2r_encoder_kv", "i2r_encoder_layer",
            "i2r_run_program", "i2r_abi_version", "i2r_last_error", "i2r_device_check")
 
 _LIB = None
@@ -184,6 +185,7 @@ def load_library(path=LIB_PATH):
     L.i2r_hrt_attn_block.argtypes = [_fp, _fp, _fp, _fp, _fp, _fp, _fp, _fp, _i32, _i32, _i32, _i32, _i32, _i32, C.c_float, _i32, C.c_void_p]
     L.i2r_hrt_mlp_block.argtypes = [_fp] * 10 + [_i32] * 6 + [C.c_float, _i32, C.c_void_p]
     L.i2r_dwconv3x3.argtypes = [_fp, _fp, _fp, _fp, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, C.c_void_p]
+    L.i2r_upsample_bilinear_add_multi.argtypes = [C.POINTER(UpArgs), C.c_void_p]
     L.i2r_upsample_bilinear_add.argtypes = [_fp, _fp, _fp, _i32, _i32, _i32, _i32, _i32, _i32, _i32, C.c_void_p]
     L.i2r_encoder_kv.argtypes = [C.POINTER(EncoderDesc), C.c_void_p]
     L.i2r_encoder_layer.argtypes = [C.POINTER(EncoderDesc), C.c_void_p]

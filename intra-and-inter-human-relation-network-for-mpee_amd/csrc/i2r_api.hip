@@ -144,11 +144,7 @@ extern "C" int i2r_run_program(const i2r_op* ops, int32_t n_ops, void* const* st
                 rc = i2r_dwconv3x3(a->in, a->w, a->bias, a->out, a->n_img, a->in_h, a->in_w, a->c, a->cs, a->stride, a->act, a->dt, st);
                 break;
             }
-            case I2R_OP_UPSAMPLE: {
-                const i2r_up_args* a = (const i2r_up_args*)op.args;
-                rc = i2r_upsample_bilinear_add(a->low, a->res, a->out, a->n_img, a->low_h, a->low_w, a->scale, a->c, a->cs, a->act, st);
-                break;
-            }
+            case I2R_OP_UPSAMPLE: rc = i2r_upsample_bilinear_add_multi((const i2r_up_args*)op.args, st); break;
             case I2R_OP_FUSE_UP: {
                 const i2r_fuse_up_args* a = (const i2r_fuse_up_args*)op.args;
                 rc = i2r_fuse_up_add(a->base, a->t1, a->s1, a->t2, a->s2, a->out, a->n_img, a->h, a->w, a->cs, a->act, a->dt, st);

@@ -245,33 +245,46 @@ __global__ __launch_bounds__(256) void dwconv3x3_s1_k(const float* __restrict__ 
         if (oy0 + o < h) st_act4<DT>(out, ((size_t)(img * h + oy0 + o) * wd + ox) * cs + cg * 4, act4(acc[o], act), DT != 0);
 }
 
-// ---- out = act(res + bilinear_upsample(low)), align_corners = False, integer scale ----
-__global__ __launch_bounds__(256) void upsample_add_k(const float* __restrict__ low, const float* __restrict__ res,
-                                                      float* __restrict__ out, int n_img, int lh, int lw, int scale, int c4, int cs,
-                                                      int act) {
-    const int H = lh * scale, W = lw * scale;
+// ---- out = act(((res + up(low_0)) + up(low_1)) + up(low_2)), up = bilinear up-sampling (align_corners = False) by an integer scale;
+//      NT terms in ONE pass, summed in that order: bit-identical to NT passes that hand the fp32 sum through memory ----
+struct UpK {
+    const float* low[3]; const float* res; float* out;
+    int n_img, H, W, scale[3], c4, cs, act;
+};
+template <int NT>
+__global__ __launch_bounds__(256) void upsample_add_k(const UpK p) {
     const long long gid = (long long)blockIdx.x * 256 + threadIdx.x;
-    const int cg = (int)(gid % c4);
-    const long long pix = gid / c4;
-    if (pix >= (long long)n_img * H * W) return;
-    const int ox = (int)(pix % W);
-    const int oy = (int)((pix / W) % H);
-    const int img = (int)(pix / ((long long)W * H));
-    // PyTorch upsample_bilinear2d, align_corners=False: src = max((dst + 0.5) / scale - 0.5, 0)
-    const float rs = 1.f / (float)scale;
-    const float sy = fmaxf(((float)oy + 0.5f) * rs - 0.5f, 0.f), sx = fmaxf(((float)ox + 0.5f) * rs - 0.5f, 0.f);
-    const int y0 = (int)sy, x0 = (int)sx;
-    const int y1 = y0 + (y0 < lh - 1 ? 1 : 0), x1 = x0 + (x0 < lw - 1 ? 1 : 0);
-    const float ly = sy - (float)y0, lx = sx - (float)x0, hy = 1.f - ly, hx = 1.f - lx;
-    const float* base = low + (size_t)img * lh * lw * cs + cg * 4;
-    const f32x4 v00 = *reinterpret_cast<const f32x4*>(base + ((size_t)y0 * lw + x0) * cs);
-    const f32x4 v01 = *reinterpret_cast<const f32x4*>(base + ((size_t)y0 * lw + x1) * cs);
-    const f32x4 v10 = *reinterpret_cast<const f32x4*>(base + ((size_t)y1 * lw + x0) * cs);
-    const f32x4 v11 = *reinterpret_cast<const f32x4*>(base + ((size_t)y1 * lw + x1) * cs);
-    f32x4 r = *reinterpret_cast<const f32x4*>(res + (size_t)pix * cs + cg * 4);
+    const int cg = (int)(gid % p.c4);
+    const long long pix = gid / p.c4;
+    if (pix >= (long long)p.n_img * p.H * p.W) return;
+    const int ox = (int)(pix % p.W);
+    const int oy = (int)((pix / p.W) % p.H);
+    const int img = (int)(pix / ((long long)p.W * p.H));
+    f32x4 r = *reinterpret_cast<const f32x4*>(p.res + (size_t)pix * p.cs + cg * 4);
 #pragma unroll
-    for (int e = 0; e < 4; ++e) r[e] += hy * (hx * v00[e] + lx * v01[e]) + ly * (hx * v10[e] + lx * v11[e]);
-    *reinterpret_cast<f32x4*>(out + (size_t)pix * cs + cg * 4) = act4(r, act);
+    for (int t = 0; t < NT; ++t) {
+        const int scale = p.scale[t], lh = p.H / scale, lw = p.W / scale;
+        // PyTorch upsample_bilinear2d, align_corners=False: src = max((dst + 0.5) / scale - 0.5, 0)
+        const float rs = 1.f / (float)scale;
+        const float sy = fmaxf(((float)oy + 0.5f) * rs - 0.5f, 0.f), sx = fmaxf(((float)ox + 0.5f) * rs - 0.5f, 0.f);
+        const int y0 = (int)sy, x0 = (int)sx;
+        const int y1 = y0 + (y0 < lh - 1 ? 1 : 0), x1 = x0 + (x0 < lw - 1 ? 1 : 0);
+        const float ly = sy - (float)y0, lx = sx - (float)x0, hy = 1.f - ly, hx = 1.f - lx;
+        const float* base = p.low[t] + (size_t)img * lh * lw * p.cs + cg * 4;
+        const f32x4 v00 = *reinterpret_cast<const f32x4*>(base + ((size_t)y0 * lw + x0) * p.cs);
+        const f32x4 v01 = *reinterpret_cast<const f32x4*>(base + ((size_t)y0 * lw + x1) * p.cs);
+        const f32x4 v10 = *reinterpret_cast<const f32x4*>(base + ((size_t)y1 * lw + x0) * p.cs);
+        const f32x4 v11 = *reinterpret_cast<const f32x4*>(base + ((size_t)y1 * lw + x1) * p.cs);
+        {
+#pragma clang fp contract(off)  // (the same roundings whatever NT: a term is formed on its own, then added)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const float term = hy * (hx * v00[e] + lx * v01[e]) + ly * (hx * v10[e] + lx * v11[e]);
+                r[e] = r[e] + term;
+            }
+        }
+    }
+    *reinterpret_cast<f32x4*>(p.out + (size_t)pix * p.cs + cg * 4) = act4(r, p.act);
 }
 
 }  // namespace
@@ -326,13 +339,28 @@ extern "C" int i2r_dwconv3x3(const float* in, const float* w, const float* bias,
     return I2R_OK;
 }
 
-extern "C" int i2r_upsample_bilinear_add(const float* low, const float* res, float* out, int32_t n_img, int32_t low_h,
-                                         int32_t low_w, int32_t scale, int32_t c, int32_t cs, int32_t act, void* stream) {
-    I2R_CHECK_ARG(low && res && out, "i2r_upsample_bilinear_add: null pointer");
-    I2R_CHECK_ARG(scale >= 1 && c <= cs && cs % 4 == 0 && act >= 0 && act <= 2, "i2r_upsample_bilinear_add: args");
-    const long long nthr = (long long)n_img * low_h * scale * low_w * scale * (cs / 4);
-    hipLaunchKernelGGL(upsample_add_k, dim3((unsigned)((nthr + 255) / 256)), dim3(256), 0, (hipStream_t)stream, low, res, out, n_img,
-                       low_h, low_w, scale, cs / 4, cs, act);
+extern "C" int i2r_upsample_bilinear_add_multi(const i2r_up_args* a, void* stream) {
+    I2R_CHECK_ARG(a && a->low && a->res && a->out, "i2r_upsample_bilinear_add: null pointer");
+    const int nt = 1 + (a->low2 != nullptr) + (a->low2 && a->low3);
+    I2R_CHECK_ARG(a->scale >= 1 && a->c <= a->cs && a->cs % 4 == 0 && a->act >= 0 && a->act <= 2 && (a->low2 || !a->low3), "i2r_upsample_bilinear_add: args");
+    UpK k;
+    k.low[0] = a->low; k.low[1] = a->low2; k.low[2] = a->low3; k.res = a->res; k.out = a->out;
+    k.n_img = a->n_img; k.H = a->low_h * a->scale; k.W = a->low_w * a->scale; k.scale[0] = a->scale; k.scale[1] = a->scale2; k.scale[2] = a->scale3;
+    k.c4 = a->cs / 4; k.cs = a->cs; k.act = a->act;
+    for (int t = 1; t < nt; ++t)
+        I2R_CHECK_ARG(k.scale[t] >= 1 && k.H % k.scale[t] == 0 && k.W % k.scale[t] == 0, "i2r_upsample_bilinear_add: term %d: scale %d does not divide %dx%d", t, k.scale[t], k.H, k.W);
+    const long long nthr = (long long)k.n_img * k.H * k.W * k.c4;
+    const dim3 grid((unsigned)((nthr + 255) / 256));
+    if (nt == 1) hipLaunchKernelGGL(upsample_add_k<1>, grid, dim3(256), 0, (hipStream_t)stream, k);
+    else if (nt == 2) hipLaunchKernelGGL(upsample_add_k<2>, grid, dim3(256), 0, (hipStream_t)stream, k);
+    else hipLaunchKernelGGL(upsample_add_k<3>, grid, dim3(256), 0, (hipStream_t)stream, k);
     I2R_CHECK_LAUNCH("i2r_upsample_bilinear_add");
     return I2R_OK;
+}
+
+extern "C" int i2r_upsample_bilinear_add(const float* low, const float* res, float* out, int32_t n_img, int32_t low_h,
+                                         int32_t low_w, int32_t scale, int32_t c, int32_t cs, int32_t act, void* stream) {
+    i2r_up_args a = {};
+    a.low = low; a.res = res; a.out = out; a.n_img = n_img; a.low_h = low_h; a.low_w = low_w; a.scale = scale; a.c = c; a.cs = cs; a.act = act;
+    return i2r_upsample_bilinear_add_multi(&a, stream);
 }

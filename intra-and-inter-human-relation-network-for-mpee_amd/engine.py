@@ -933,9 +933,15 @@ class Program:
         return out
 
     def upsample_add(self, low, res, out, act=0, lane=0):
-        scale = out.h // low.h
-        assert low.h * scale == out.h and low.w * scale == out.w and low.cs == out.cs == res.cs
-        a = cabi.UpArgs(low.ptr, res.ptr, out.ptr, low.n, low.h, low.w, scale, low.c, low.cs, act)
+        """out = act(((res + up(low_0)) + up(low_1)) + up(low_2)): bilinear up-sampling of 1..3 lower-resolution maps (an Act or a list
+        of Acts, added in that order) in one pass (i2r_upsample_bilinear_add_multi)"""
+        lows = list(low) if isinstance(low, (list, tuple)) else [low]
+        assert 1 <= len(lows) <= 3
+        sc = [out.h // t.h for t in lows]
+        assert all(t.h * s == out.h and t.w * s == out.w and t.cs == out.cs == res.cs and t.n == out.n for t, s in zip(lows, sc))
+        a = cabi.UpArgs(lows[0].ptr, res.ptr, out.ptr, lows[0].n, lows[0].h, lows[0].w, sc[0], lows[0].c, lows[0].cs, act,
+                        lows[1].ptr if len(lows) > 1 else None, lows[2].ptr if len(lows) > 2 else None,
+                        sc[1] if len(lows) > 1 else 1, sc[2] if len(lows) > 2 else 1)
         self.ops.append((cabi.OP_UPSAMPLE, lane, a))
         return out
 
@@ -1396,11 +1402,13 @@ class HRFormerB:
                     continue
                 if y is None:
                     y = P.alloc(xs[i].n, xs[i].h, xs[i].w, xs[i].c)
-                if j > i:  # 1x1 conv + BN at low resolution, then bilinear up-sample and accumulate
-                    t = P.conv(xs[j], mod["fuse"][(i, j)], lane=ln)
-                    P.upsample_add(t, acc, y, act=1 if j + 1 >= nb else 0, lane=ln)
-                    P.release(t)
-                    jn = j + 1
+                if j > i:  # 1x1 conv + BN at low resolution of EVERY lower branch (they are the trailing terms of the sum), then
+                    # ONE pass that up-samples and adds them in order, + ReLU (bit-identical to a pass per term)
+                    ts = [P.conv(xs[jj], mod["fuse"][(i, jj)], lane=ln) for jj in range(j, nb)]
+                    for k0 in range(0, len(ts), 3):
+                        P.upsample_add(ts[k0:k0 + 3], acc if k0 == 0 else y, y, act=1 if k0 + 3 >= len(ts) else 0, lane=ln)
+                    P.release(*ts)
+                    jn = nb
                 else:
                     cur = xs[j]
                     hops = mod["fuse"][(i, j)]

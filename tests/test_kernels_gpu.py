@@ -873,6 +873,29 @@ def test_upsample_bilinear_add(scale):
     assert (from_act(out) - ref).abs().max().item() < 1e-5
 
 
+@pytest.mark.parametrize("scales", [(2, 4), (2, 4, 8), (4, 2)])
+def test_upsample_bilinear_add_several_terms_in_one_pass(scales):
+    """i2r_upsample_bilinear_add_multi: ((res + up(t0)) + up(t1)) + up(t2) in one pass -- against torch, and bit-identical to one pass
+    per term (the fuse sums of HighResolutionTransformerModule.forward, hrformer.py:1718-1730)"""
+    H, W, c = 16, 24, 78
+    res = _rand((2, c, H, W), "mur")
+    lows = [_rand((2, c, H // s_, W // s_), "mul%d_%d" % (i, s_)) for i, s_ in enumerate(scales)]
+    ref = res
+    for t, s_ in zip(lows, scales):
+        ref = ref + F.interpolate(t, scale_factor=s_, mode="bilinear", align_corners=False)
+    ref = F.relu(ref)
+    P = engine.Program(torch.device(DEV))
+    ra, la = to_act(P, res), [to_act(P, t) for t in lows]
+    one = P.alloc(2, H, W, c)
+    P.upsample_add(la, ra, one, act=1)
+    seq = P.alloc(2, H, W, c)
+    for i, t in enumerate(la):
+        P.upsample_add(t, ra if i == 0 else seq, seq, act=1 if i + 1 == len(la) else 0)
+    run(P)
+    assert (from_act(one) - ref).abs().max().item() < 2e-5
+    assert torch.equal(one.view(), seq.view())
+
+
 def test_conv_gelu_and_post_residual():
     sd = {"c.weight": _rand((78, 312, 1, 1), "gw", 0.08), "c.bias": _rand((78,), "gb", 0.2),
           "b.weight": _rand((78,), "gg", 0.5) + 1.0, "b.bias": _rand((78,), "gbb", 0.3),

@@ -40,7 +40,7 @@ def _accesses(kind, st):
     if kind == cabi.OP_DWCONV:
         return [g("in_")], [g("out")]
     if kind == cabi.OP_UPSAMPLE:
-        return [g("low"), g("res")], [g("out")]
+        return [p for p in (g("low"), g("low2"), g("low3"), g("res")) if p], [g("out")]
     if kind == cabi.OP_FUSE_UP:
         return [p for p in (g("base"), g("t1"), g("t2")) if p], [g("out")]
     if kind == cabi.OP_MAXPOOL:
