@@ -1,7 +1,7 @@
 #!/usr/bin/env python
 """bench.py -- throughput of the I2R-Net inference hot path on MI355X (BASELINE.json metric).
 
-  python bench.py [--gpus N] [--steps K] [--warmup W] [--config NAME] [--precision P] [--pipeline] [--ragged-stream]
+  python bench.py [--gpus N] [--steps K] [--warmup W] [--config NAME] [--precision P] [--pipeline] [--ragged-stream] [--scaling strong]
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
          bench.py --gpus N --steps K --warmup W
 
@@ -18,12 +18,20 @@ all-gathered over RCCL each step: the predicted HEAT MAPS (the collective BASELI
 gathers the decoded [S, J, 3] key points instead).  The line's `value` is timed with the --gather payload; `gather_alt` is the
 same K steps re-timed with the other payload.
 
+--scaling strong (default weak): the total job is FIXED -- 64 images with 1-6 persons -- and cut into contiguous image shards balanced by
+crop count (dist.shard_bounds); the ranks' crop counts differ, the line carries them and the imbalance (`shards`).
+
 One JSON line is printed by rank 0:
   value        crops/s of the whole job (all ranks), from the max-over-ranks wall time of exactly K steps
-  roofline     the kernel with the LARGEST share of the step (over all kernels): algorithmic FLOPs / HBM bytes per launch (op_model)
-               over its average launch duration, both from a per-launch HIP-event timing pass inside this script, against the roof
-               its arithmetic intensity selects (MI355X_MICROARCH.md: fp32 MFMA 157.3 TFLOP/s, bf16/fp16 2500 TFLOP/s, HBM 8 TB/s);
+  roofline     the kernel with the LARGEST share of the step (over all kernels): EXECUTED FLOPs / algorithmic HBM bytes per launch
+               (op_model; for the Winograd kernel the executed multiply-adds = the direct convolution's / 2.25, so frac <= 1 -- the
+               direct-convolution FLOPs it delivers are filed under direct_equivalent) over its average launch duration, both from a
+               per-launch HIP-event timing pass inside this script, against the roof its arithmetic intensity selects
+               (MI355X_MICROARCH.md: fp32 MFMA 157.3 TFLOP/s, bf16/fp16 2500 TFLOP/s, HBM 8 TB/s);
                `kernels` = the same figures for the five largest kernels; attention_blocks = the encoder kernels
+  other_workloads  (default single-GPU line only) BASELINE configs[2..4] at their own batch shapes and dtypes, the ragged stream and the
+               pipeline, ~10 steps each, measured in this process after the headline's timed region: value, ms_per_step, dominant kernel
+               with its roofline fraction, parity against the CPU oracle
   parity       max-abs difference of the first image of the timed batch against the CPU oracle (fp32: the 1e-3 bar of BASELINE.json)
   cpu_baseline the CPU oracle (oracle/i2r_cpu.py, a port of the reference forward) timed on this host, rank 0, N = 1 only
 --pipeline times the validate() step around the forward as one unit: uint8 image -> affine crops + bbox masks -> flip-test forward
@@ -55,6 +63,7 @@ from i2r_amd import dist as i2r_dist  # noqa: E402
 
 MFMA_PEAK_TFLOPS = {"fp32": 157.3, "bf16": 2500.0, "fp16": 2500.0}  # MI355X_MICROARCH.md (dense)
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E ~8 TB/s
+WINO_CUT = 2.25  # Winograd F(2x2, 3x3): 36 / 16 multiply-adds of the direct convolution per executed one
 DTYPE_NAME = {"fp32": "f32", "bf16": "bf16", "fp16": "f16"}
 
 
@@ -74,6 +83,10 @@ WORKLOADS = {
     "coco_hrt_288_p2_b4": dict(length=[12], precision="fp16", gflop=lambda n: 61.439 + 0.1165 * n,
                                label="I2R-Net HRFormer-B 384x288, one image of 12 persons (BASELINE configs[4])"),
 }
+
+
+# --scaling strong: the fixed job -- 64 images, persons per image = rng(seed 0).integers(1, 7) (the config-3 distribution, 4 x 16 images)
+STRONG_LENGTH = [int(v) for v in np.random.default_rng(0).integers(1, 7, size=64)]
 
 
 def refuse_tuning_env():
@@ -287,7 +300,7 @@ def hbm_traffic(cname):
     """HBM bytes per launch of the dominant kernel from the committed PMC passes (separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE
     runs, FETCH_SIZE doubled per MI355X_MICROARCH.md).  bench.py itself cannot collect PMC counters: this is a constant read from
     profiles/ (named in traffic_source), together with the kernel it was measured on; null when no profile exists for the workload."""
-    for rnd in ("round3", "round2", "round1"):
+    for rnd in ("round4", "round3", "round2", "round1"):
         path = os.path.join(ROOT, "profiles", "%s_hbm_traffic%s.json" % (rnd, "" if cname == "w48_pure_en6" else "_" + cname))
         try:
             with open(path) as f:
@@ -299,31 +312,36 @@ def hbm_traffic(cname):
 
 
 def _kernel_view(name, s, reps, total_ms, precision):
-    """roofline figures of one kernel from its per_launch_timing entry"""
+    """roofline figures of one kernel from its per_launch_timing entry.  `achieved` / `frac` are what the kernel EXECUTES on the roof
+    that bounds it, so frac <= 1 always.  For the Winograd kernel (csrc/i2r_conv_wino.hip) that is 16 multiply-adds per 2x2 output
+    tile and (cin, cout) pair where the direct convolution of SURVEY 8d (2 pixels cout cin 9) needs 36: its executed FLOPs are the
+    algorithmic ones / 2.25 (checked against PMC SQ_INSTS_MFMA x 2048 FLOP in profiles/round3_pmc_sq_grouped_conv.json); the
+    direct-convolution FLOPs it DELIVERS per second are reported separately as `direct_equivalent` and are not a pipe fraction."""
     cnt, ms, flop, nbytes, pipe = s
-    tf = flop / (ms * 1e-3) / 1e12
+    wino = name.startswith("conv_wino")
+    flop_exec = flop / WINO_CUT if wino else flop
+    tf = flop_exec / (ms * 1e-3) / 1e12
     gbs = nbytes / (ms * 1e-3) / 1e9
     out = {"kernel": name + ("/" + precision if pipe not in (None, "fp32") and name.startswith("conv_") else ""),
            "launches_per_step": cnt // reps, "avg_launch_us": round(ms / cnt * 1e3, 2), "ms_per_step": round(ms / reps, 3),
-           "share_of_step_kernel_time": round(ms / total_ms, 3), "gflop_per_launch": round(flop / cnt / 1e9, 4),
+           "share_of_step_kernel_time": round(ms / total_ms, 3), "gflop_per_launch": round(flop_exec / cnt / 1e9, 4),
            "gbytes_per_launch": round(nbytes / cnt / 1e9, 4)}
     peak = MFMA_PEAK_TFLOPS[pipe] if pipe else None
-    ai = flop / nbytes if nbytes else 0.0
+    ai = flop_exec / nbytes if nbytes else 0.0
     balance = peak * 1e12 / (HBM_PEAK_GBS * 1e9) if peak else float("inf")
     mfma = {"achieved": round(tf, 2), "peak": peak, "unit": "TFLOP/s", "frac": round(tf / peak, 4)} if peak else None
     hbm = {"achieved": round(gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(gbs / HBM_PEAK_GBS, 4)}
     out["intensity_flop_per_byte"] = round(ai, 1)
     if peak:
         out["machine_balance_flop_per_byte"] = round(balance, 1)
-    # which roof bounds the kernel: its arithmetic intensity (algorithmic FLOP / algorithmic HBM byte) against the machine balance
+    if wino:
+        out["algorithm"] = ("winograd F(2x2,3x3): gflop_per_launch / achieved / frac count the multiply-adds the matrix pipe executes "
+                            "(= direct-convolution FLOPs / 2.25)")
+        out["direct_equivalent"] = {"gflop_per_launch": round(flop / cnt / 1e9, 4), "tflops_delivered": round(tf * WINO_CUT, 2),
+                                    "note": "SURVEY 8d direct-convolution FLOPs per second; a speed-up over a direct kernel, not a fraction of the pipe"}
+    # which roof bounds the kernel: its arithmetic intensity (executed FLOP / algorithmic HBM byte) against the machine balance
     # peak FLOP/s : 8 TB/s of the pipe it computes on.  fp32 convs sit far above it (MFMA-bound); with 16-bit operands the matrix
     # peak is 16x higher and the same launches can fall BELOW it: their roof is HBM.  Kernels without matrix work: HBM.
-    if name.startswith("conv_wino"):
-        # Winograd F(2x2, 3x3) (csrc/i2r_conv_wino.hip): `achieved` keeps counting the ALGORITHMIC FLOPs of the direct convolution
-        # (SURVEY 8d: 2 pixels cout cin 9), but the kernel issues 16 multiply-adds per 2x2 output tile and (cin, cout) pair instead of
-        # 36 -- so `frac` is work delivered per peak pipe-second and may exceed 1; `executed` is what the matrix pipe really ran
-        out["algorithm"] = "winograd F(2x2,3x3): 2.25x fewer matrix-pipe operations than the algorithmic (direct-convolution) FLOPs counted in achieved"
-        out["executed"] = {"achieved": round(tf / 2.25, 2), "peak": peak, "unit": "TFLOP/s", "frac": round(tf / 2.25 / peak, 4)}
     if peak and ai >= balance:
         out.update(bound="mfma", **mfma)
         out["hbm_view"] = hbm
@@ -346,12 +364,17 @@ def roofline_report(prog, precision, cname):
     r["traffic"], r["traffic_source"] = traffic, traffic_src
     conv = [k for k in stats if k.startswith("conv_")]
     if conv:
-        r["all_conv_tflops"] = round(sum(stats[k][2] for k in conv) / (sum(stats[k][1] for k in conv) * 1e-3) / 1e12, 2)
+        t_conv = sum(stats[k][1] for k in conv) * 1e-3
+        # all convolution launches together, in EXECUTED matrix-pipe FLOPs (Winograd launches counted / 2.25) over the fp32 / 16-bit peak
+        ex = sum(stats[k][2] / (WINO_CUT if k.startswith("conv_wino") else 1.0) for k in conv)
+        r["all_conv"] = {"tflops_executed": round(ex / t_conv / 1e12, 2), "frac_of_mfma_peak": round(ex / t_conv / 1e12 / MFMA_PEAK_TFLOPS[precision], 4),
+                         "tflops_direct_equivalent": round(sum(stats[k][2] for k in conv) / t_conv / 1e12, 2), "ms_per_step": round(t_conv / reps * 1e3, 3)}
     r["kernels"] = [_kernel_view(k, stats[k], reps, total_ms, precision) for k in order[:5]]
     for kv in r["kernels"]:
         for drop in ("hbm_view", "mfma_view", "machine_balance_flop_per_byte", "gbytes_per_launch"):
             kv.pop(drop, None)
     r["per_kernel_ms_per_step"] = {k: round(stats[k][1] / reps, 3) for k in order}
+    r["_executed_gflop_per_step"] = sum(stats[k][2] / (WINO_CUT if k.startswith("conv_wino") else 1.0) for k in stats) / reps / 1e9
     att_k = sorted(k for k in stats if k.startswith("enc_"))
     att_flop = sum(stats[k][2] for k in att_k) / reps
     att_ms = stack_timing(prog, precision)  # (each encoder stack timed as one unit; the per-kernel split stays in per_kernel_ms_per_step)
@@ -434,8 +457,7 @@ def make_pipeline(net, cfg, length, H, W, dev, seed):
         images.append(torch.from_numpy(rng.integers(0, 256, size=(ih, iw, 3), dtype=np.uint8)).to(dev))
         b = np.stack([rng.uniform(20, iw * 0.5, n), rng.uniform(20, ih * 0.5, n), rng.uniform(60, iw * 0.45, n), rng.uniform(90, ih * 0.45, n)], 1)
         boxes.append(b)
-    ds = cfg.DATASET.DATASET.lower() if cfg.DATASET.DATASET.lower() in caller.FLIP_PAIRS else ("crowdpose" if cfg.MODEL.NUM_JOINTS == 14 else "coco")
-    pairs = caller.FLIP_PAIRS[ds]
+    pairs = caller.FLIP_PAIRS[_dataset_name(cfg)]
     cs = [[i2r_input.box_to_center_scale(b, (W, H)) for b in bs] for bs in boxes]
     centers = np.concatenate([np.stack([c for c, _ in one]) for one in cs])
     scales = np.concatenate([np.stack([s for _, s in one]) for one in cs])
@@ -505,6 +527,111 @@ def ragged_stream(net, cfg, dev, H, W, n_batches, flip_pairs=None, seed=0):
             "warm_vs_fixed": round((crops / warm_s) / (mean_s * n_batches / fixed_s), 4)}
 
 
+def _dataset_name(cfg):
+    from i2r_amd import caller
+    ds = cfg.DATASET.DATASET.lower()
+    return ds if ds in caller.FLIP_PAIRS else ("crowdpose" if cfg.MODEL.NUM_JOINTS == 14 else "coco")
+
+
+def build_net(cname, precision, dev):
+    cfg = config.load_config(cname)
+    sd = synth.make_state_dict(arch.param_spec(cfg))
+    net = eval("models." + cfg.MODEL.NAME + ".get_pose_net")(cfg, is_train=False)
+    net.load_state_dict(sd, strict=True)
+    return cfg, sd, net.to(dev).set_precision(precision)
+
+
+def _time_steps(fn, steps, warmup):
+    for _ in range(warmup):
+        fn()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        y = fn()
+    torch.cuda.synchronize()
+    return time.perf_counter() - t0, y
+
+
+def _brief(kv):
+    """the figures of a _kernel_view that identify the kernel and its roofline fraction"""
+    keep = ("kernel", "launches_per_step", "avg_launch_us", "share_of_step_kernel_time", "bound", "achieved", "peak", "unit", "frac")
+    out = {k: kv[k] for k in keep if k in kv}
+    for view in ("mfma_view", "hbm_view"):
+        if view in kv:
+            out[view + "_frac"] = kv[view]["frac"]
+    return out
+
+
+def quick_workload(cname, dev, steps=10, warmup=3):
+    """One of the other BASELINE workloads at its own batch shape and dtype, measured like the headline but short: `steps` timed forwards
+    (inputs resident), the per-launch roofline pass (dominant kernel + the next two, attention blocks), parity of image 0 against the
+    CPU oracle.  Everything it allocates is released on return."""
+    wl = WORKLOADS[cname]
+    precision = wl["precision"]
+    cfg, sd, net = build_net(cname, precision, dev)
+    W_, H_ = cfg.MODEL.IMAGE_SIZE
+    length = list(wl["length"])
+    x, m, _ = synth.make_inputs(length, H_, W_, seed=0)
+    x, m = x.to(dev), m.to(dev)
+
+    def fwd():
+        y = net(x, m, length)
+        return y["multi"] if isinstance(y, dict) else y
+    dt, y = _time_steps(fwd, steps, warmup)
+    assert torch.isfinite(y).all()
+    eng = net.engine()
+    key = next(k for k in eng.programs if k[3] is False and k[0] == eng.capacity(sum(length)))
+    r = roofline_report(eng.programs[key][0], precision, cname)
+    gflop = sum(n * wl["gflop"](n) for n in length)
+    out = {"workload": wl["label"], "dtype": DTYPE_NAME[precision], "crops_per_step": sum(length), "steps": steps, "warmup": warmup,
+           "value": round(sum(length) * steps / dt, 1), "unit": "images/sec", "ms_per_step": round(dt / steps * 1e3, 3),
+           "model_tflops_algorithmic": round(gflop * steps / dt / 1e3, 2),
+           "dominant_kernel": _brief(r), "next_kernels": [_brief(k) for k in r["kernels"][1:3]],
+           "traffic": r.get("traffic"), "traffic_source": r.get("traffic_source")}
+    if "attention_blocks" in r:
+        out["attention_blocks"] = {k: r["attention_blocks"][k] for k in ("kernels", "ms_per_step", "achieved", "peak", "frac")}
+    out["parity"] = oracle_parity(cfg, sd, x, m, length, fwd(), precision)
+    return out
+
+
+def other_workloads(net, cfg, dev):
+    """BASELINE configs[2..4] + the two caller-side modes, each measured briefly in this process (the driver runs `bench.py --gpus 1` only):
+    {name: {value, ms_per_step, dtype, dominant kernel + frac, parity}}.  `net` / `cfg` = the headline model (re-used for the ragged
+    stream and the pipeline, which BASELINE quotes on the vanilla W48 model)."""
+    from i2r_amd import caller
+    out = {}
+    for cname in ("tph_192_p6_b4", "hrt_192_p4_b4", "coco_hrt_288_p2_b4"):
+        out[cname] = quick_workload(cname, dev)
+        torch.cuda.empty_cache()
+    W_, H_ = cfg.MODEL.IMAGE_SIZE
+    rs = ragged_stream(net, cfg, dev, H_, W_, 16)
+    out["ragged_stream"] = {"what": "16 batches of 16 images with 1-6 persons each (S changes per batch, lib/core/function.py:124-140), w48 fp32",
+                            "value": rs["warm"]["crops_per_s"], "unit": "images/sec", "ms_per_batch": rs["warm"]["ms_per_batch"],
+                            "cold_value": rs["cold"]["crops_per_s"], "program_builds_cold": rs["cold"]["program_builds"],
+                            "padded_crop_fraction": rs["padded_crop_fraction"], "fixed_s_value": rs["fixed_s"]["crops_per_s"],
+                            "warm_vs_fixed": rs["warm_vs_fixed"]}
+    length = list(WORKLOADS["w48_pure_en6"]["length"])
+    pipe = make_pipeline(net, cfg, length, H_, W_, dev, seed=0)
+    dt, (preds, maxv) = _time_steps(pipe, 10, 3)
+    assert torch.isfinite(preds).all() and torch.isfinite(maxv).all()
+    fwd_ms = _pipeline_forward_ms(net, cfg, length, H_, W_, dev)
+    out["pipeline"] = {"what": "uint8 image -> affine crops + bbox masks -> flip-test forward (2 x 32 crops) -> key-point decode, w48 fp32 "
+                               "(lib/core/function.py:124-200)", "value": round(sum(length) * 10 / dt, 1), "unit": "images/sec",
+                       "ms_per_step": round(dt / 10 * 1e3, 3), "forward_flip_only_ms": round(fwd_ms, 3),
+                       "share_outside_forward": round(1.0 - fwd_ms / (dt / 10 * 1e3), 4)}
+    return out
+
+
+def _pipeline_forward_ms(net, cfg, length, H_, W_, dev):
+    """ms of the flip-test forward alone (inputs resident): what the pipeline step costs without crops / masks / decode"""
+    from i2r_amd import caller
+    x, m, _ = synth.make_inputs(length, H_, W_, seed=0)
+    x, m = x.to(dev), m.to(dev)
+    pairs = caller.FLIP_PAIRS[_dataset_name(cfg)]
+    dt, _ = _time_steps(lambda: net.forward_flip(x, m, length, pairs), 10, 3)
+    return dt / 10 * 1e3
+
+
 # ------------------------------------------------------------------------------------------------------------------------------
 def self_launch(argv, n):
     """`python bench.py --gpus N` without a launcher: start the N ranks (one process per GPU) under torch.distributed.run on the
@@ -536,6 +663,13 @@ def parse_args(argv=None):
     ap.add_argument("--gather", default="heatmaps", choices=["keypoints", "heatmaps"],
                     help="N > 1: payload of the per-step all-gather whose timing is `value` (heat maps [S,J,h,w] as north_star names, or the "
                          "decoded key points [S,J,3]); the other payload is re-timed and reported as gather_alt")
+    ap.add_argument("--scaling", default="weak", choices=["weak", "strong"],
+                    help="weak (default): every rank runs a batch of the workload's shape.  strong: a FIXED ragged list of 64 images with 1-6 persons "
+                         "each (rng seed 0) is cut into contiguous shards balanced by crop count (dist.shard_bounds); a step = one pass over the whole "
+                         "list, each rank running its images in batches of <= 16 (TEST.BATCH_SIZE_PER_GPU) and one padded all-gather of its uneven crop count")
+    ap.add_argument("--no-other-workloads", action="store_true",
+                    help="default single-GPU run only: skip the short runs of BASELINE configs[2..4], the ragged stream and the pipeline that are "
+                         "embedded in the line as other_workloads")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--no-parity", action="store_true")
@@ -550,6 +684,8 @@ def main(argv=None):
     args = parse_args(argv)
     refuse_tuning_env()
 
+    if args.scaling == "strong" and (args.pipeline or args.ragged_stream):
+        raise SystemExit("--scaling strong times the bare forward over the fixed image list (no --pipeline / --ragged-stream)")
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         raise SystemExit(self_launch(argv, args.gpus))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -578,24 +714,37 @@ def main(argv=None):
     J = cfg.MODEL.NUM_JOINTS
     sd = net = None
     if not stub:
-        sd = synth.make_state_dict(arch.param_spec(cfg))
-        net = eval("models." + cfg.MODEL.NAME + ".get_pose_net")(cfg, is_train=False)
-        net.load_state_dict(sd, strict=True)
-        net = net.to(dev).set_precision(precision)
+        cfg, sd, net = build_net(args.config, precision, dev)
 
-    # global workload: every rank's batch has the workload's shape (weak scaling); this rank's contiguous shard of the image list
-    per_gpu = list(wl["length"])
-    length_all = per_gpu * world
-    bounds = i2r_dist.shard_bounds(length_all, world) if world > 1 else [0, len(length_all)]
-    if world > 1:  # identical shapes -> the balanced cuts are the per-GPU batches
-        assert [bounds[r + 1] - bounds[r] for r in range(world)] == [len(per_gpu)] * world, bounds
+    strong = args.scaling == "strong"
+    if strong:
+        # strong scaling: the total work is fixed -- 64 images of 1-6 persons (the crop counts validate() sees on CrowdPose, MAX_PATCH 6) --
+        # and is cut into contiguous image shards balanced by crop count; the shards are UNEVEN in crops, so the padded all-gather and
+        # the max-over-ranks timing carry the imbalance that dist.shard_bounds leaves
+        length_all = STRONG_LENGTH
+        bounds = i2r_dist.shard_bounds(length_all, world)
+    else:
+        # weak scaling: every rank's batch has the workload's shape; this rank's contiguous shard of the image list
+        per_gpu = list(wl["length"])
+        length_all = per_gpu * world
+        bounds = i2r_dist.shard_bounds(length_all, world) if world > 1 else [0, len(length_all)]
+        if world > 1:  # identical shapes -> the balanced cuts are the per-GPU batches
+            assert [bounds[r + 1] - bounds[r] for r in range(world)] == [len(per_gpu)] * world, bounds
     length = length_all[bounds[rank]:bounds[rank + 1]]
     counts = [sum(length_all[bounds[r]:bounds[r + 1]]) for r in range(world)]
     gflop_per_step = sum(n * wl["gflop"](n) for n in length_all)
+    # this rank's forwards of one step: the whole shard (weak), or batches of <= 16 images (strong; TEST.BATCH_SIZE_PER_GPU of the yamls)
+    chunks = [length[i:i + 16] for i in range(0, len(length), 16)] if strong else [length]
+    batches = []
     x = m = None
     if not stub:
-        x, m, _ = synth.make_inputs(length, H_, W_, seed=rank)
-        x, m = x.to(dev), m.to(dev)
+        for ci, ln in enumerate(chunks):
+            if not ln:
+                continue
+            xb, mb, _ = synth.make_inputs(ln, H_, W_, seed=rank * 16 + ci)
+            batches.append((xb.to(dev), mb.to(dev), ln))
+        if batches:
+            x, m = batches[0][0], batches[0][1]
 
     from i2r_amd import caller
     pending = [None]
@@ -617,9 +766,12 @@ def main(argv=None):
                 if world > 1:
                     h = i2r_dist.gather_heatmaps_async(y, counts)
             else:
-                y = net(x, m, length)
-                if isinstance(y, dict):
-                    y = y["multi"]
+                ys = []
+                for xb, mb, ln in batches:
+                    yb = net(xb, mb, ln)
+                    ys.append(yb["multi"] if isinstance(yb, dict) else yb)
+                # (strong scaling: a rank's forwards of one step are gathered together -- ranks run different numbers of forwards)
+                y = ys[0] if len(ys) == 1 else (torch.cat(ys, 0) if ys else torch.zeros(0, J, H_ // 4, W_ // 4, device=dev))
                 if world > 1:
                     if gather == "keypoints":  # decode on the device, gather [S, J, 3] (168 B/crop) instead of 172 KB/crop
                         preds, maxv = caller.decode(y, None, None, cfg.TEST.BLUR_KERNEL, transform_back=False)
@@ -677,44 +829,64 @@ def main(argv=None):
     crops_per_step = sum(length_all)
     value = crops_per_step * args.steps / dt
     payload = "key points" if (args.pipeline or args.gather == "keypoints") else "heat maps"
+    first = batches[0][2] if batches else length  # the batch the roofline / parity legs look at
     out = {
         "metric": "images/sec (%dx%d crops) I2R-Net inference" % (H_, W_) if args.config != "w48_pure_en6"
                   else "images/sec (256x192 crops) I2R-Net HRNet-W48 inference",
         "value": round(value, 2), "unit": "images/sec",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 4),
-        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": DTYPE_NAME[precision], "data": "synthetic",
+        "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None, "dtype": DTYPE_NAME[precision], "data": "synthetic",
         "config": {"workload": wl["label"] + ("" if precision == wl["precision"] else " -- run with %s MFMA operands" % precision)
-                               + (" -- PIPELINE: uint8 image -> crops + masks -> flip-test forward -> key points" if args.pipeline else ""),
-                   "images_per_gpu": len(length), "persons_per_image": length if len(set(length)) > 1 else length[0],
+                               + (" -- PIPELINE: uint8 image -> crops + masks -> flip-test forward -> key points" if args.pipeline else "")
+                               + (" -- STRONG SCALING: the batch shape is replaced by a fixed list of 64 images with 1-6 persons (%d crops), "
+                                  "run in batches of <= 16 images" % sum(STRONG_LENGTH) if strong else ""),
+                   "images_per_gpu": len(length), "persons_per_image": length if len(set(length)) > 1 else (length[0] if length else 0),
                    "crops_per_gpu_step": sum(length),
                    "parallelism": "dp%d (images sharded, one RCCL all-gather of the %s per step, waited for one step later)" % (world, payload)
                                   if world > 1 else "single GPU",
                    "gflop_per_step_per_gpu": round(gflop_per_step / world, 2)},
-        "model_tflops": round(gflop_per_step * (2 if args.pipeline else 1) * args.steps / dt / 1e3, 2),
+        # SURVEY 8d algorithmic FLOPs of the reference forward (direct convolutions) per second of wall time: a delivered-work figure,
+        # NOT a fraction of any pipe (the Winograd launches execute 2.25x fewer multiply-adds); roofline.model_tflops_executed is
+        "model_tflops_algorithmic": round(gflop_per_step * (2 if args.pipeline else 1) * args.steps / dt / 1e3, 2),
     }
+    if strong:
+        out["shards"] = {"images_total": len(length_all), "crops_total": sum(length_all), "image_bounds": bounds, "crops_per_rank": counts,
+                         "forwards_per_rank_step": [-(-(bounds[r + 1] - bounds[r]) // 16) for r in range(world)],
+                         "imbalance_max_over_mean": round(max(counts) * world / float(sum(counts)), 4),
+                         "gather_rows_padded_to": max(counts)}
     if alt is not None:
         out["gather_alt"] = alt
     if stub:
         out["data"] = "SELFTEST STUB: no model ran (launcher / sharding / all-gather / timing path only)"
-        out["value"], out["model_tflops"] = 0.0, 0.0
+        out["value"], out["model_tflops_algorithmic"] = 0.0, 0.0
         out["gathered_ok"] = True
     if rank == 0 and not stub:
         eng = net.engine()
         if not args.no_roofline:
-            key = next(k for k in eng.programs if k[3] == bool(args.pipeline) and k[0] == eng.capacity(sum(length)))
+            key = next(k for k in eng.programs if k[3] == bool(args.pipeline) and k[0] == eng.capacity(sum(first)))
             out["roofline"] = roofline_report(eng.programs[key][0], precision, args.config)
+            if not strong and not args.pipeline:  # executed matrix-pipe + element-wise FLOPs of one forward over the step's wall time
+                out["roofline"]["model_tflops_executed"] = round(out["roofline"].pop("_executed_gflop_per_step") * args.steps / dt / 1e3, 2)
+            out["roofline"].pop("_executed_gflop_per_step", None)
         if not args.no_parity and not args.pipeline:
-            y1 = net(x, m, length)
+            y1 = net(x, m, first)
             y1 = y1["multi"] if isinstance(y1, dict) else y1
-            out["parity"] = oracle_parity(cfg, sd, x, m, length, y1, precision)
+            out["parity"] = oracle_parity(cfg, sd, x, m, first, y1, precision)
         if args.ragged_stream:
             pairs = None
             if args.pipeline:
-                ds = cfg.DATASET.DATASET.lower() if cfg.DATASET.DATASET.lower() in caller.FLIP_PAIRS else ("crowdpose" if J == 14 else "coco")
-                pairs = caller.FLIP_PAIRS[ds]
+                pairs = caller.FLIP_PAIRS[_dataset_name(cfg)]
             out["ragged_stream"] = ragged_stream(net, cfg, dev, H_, W_, 64, flip_pairs=pairs)
+        default_line = (world == 1 and args.config == "w48_pure_en6" and not args.pipeline and not args.ragged_stream and not strong
+                        and args.precision in (None, "fp32"))
+        if default_line and not args.no_other_workloads:
+            # the driver only runs `bench.py --gpus 1`: BASELINE configs[2..4] at their own batch shapes / dtypes, the ragged stream and
+            # the pipeline are measured in the same process right after the headline's timed region, ~10 steps each
+            t_other = time.perf_counter()
+            out["other_workloads"] = other_workloads(net, cfg, dev)
+            out["other_workloads"]["wall_s"] = round(time.perf_counter() - t_other, 1)
         if not args.no_cpu_baseline and world == 1:
-            out["cpu_baseline"] = cpu_baseline(cfg, sd, H_, W_, length)
+            out["cpu_baseline"] = cpu_baseline(cfg, sd, H_, W_, first)
     if rank == 0:
         print(json.dumps(out), flush=True)
     if world > 1:

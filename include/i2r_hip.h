@@ -87,7 +87,7 @@ typedef struct i2r_conv_desc {
                                       rep = out_step = 1, no in2; `w` then holds the TRANSFORMED weights U = G g G^T in the k4 layout with the 16
                                       Winograd positions (row-major 4x4) in place of the taps: float w[16][cin/4][cout_pad][4].  tile_w selects the
                                       fragment shape (16 Winograd tiles = 64 output pixels): 16, 8 or 4 pixels wide (0 = choose); mt = fragments per
-                                      workgroup (1 or 2, 0 = 2).  2.25x fewer matrix-pipe operations than algo 0 for the same sum. */
+                                      workgroup (1 or 2, 0 = 1; 2 only for cout_pad / 16 a multiple of 3).  2.25x fewer matrix-pipe operations than algo 0 for the same sum. */
 } i2r_conv_desc;
 
 int i2r_conv(const i2r_conv_desc* d, void* stream);
@@ -374,9 +374,12 @@ typedef struct i2r_encoder_desc {
     const float* vec_lp;
     /* fp32 mode, optional: scratch of the "partial key split".  A launch with between one and two 16-query tiles per CU (256 < n_qtiles16
      * < 512) handles just enough tiles with TWO workgroups (each over half of the group's keys) that every CU carries two workgroups
-     * (csrc/i2r_encoder.hip).  split_ws: 256 * 2 * 1792 floats; split_cnt: 256 int32, zero before the first launch (the kernel leaves
-     * them zero; a launch that faults half-way may not -- re-zero them before the next one).  Launches that share a scratch pair must be
-     * stream-ordered, never concurrent.  Both null = one workgroup per tile. */
+     * (csrc/i2r_encoder.hip).  split_ws: 256 * 2 * 1792 floats; split_cnt: 256 int32 hand-off counters: i2r_encoder_kv (the first launch
+     * of every stack) zeroes them and every layer launch leaves them zero, so a forward that follows a faulted one starts clean.  The
+     * hand-off itself is write-through (sc1 payload stores, drained, then an agent-scope atomic; sc1 loads on the other side).
+     * SINGLE-STREAM CONTRACT: launches that share a scratch pair -- i.e. all launches of one i2r_run_program list / one Program --
+     * must be stream-ordered; replaying the same list concurrently on two streams pairs partials of different forwards.
+     * Both null = one workgroup per tile. */
     float* split_ws; int32_t* split_cnt;
 } i2r_encoder_desc;
 

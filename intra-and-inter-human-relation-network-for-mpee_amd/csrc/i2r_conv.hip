@@ -416,7 +416,7 @@ static int prepare_wino(const i2r_conv_desc* d, int force_mt, ConvK& k, int* nt_
     const int nfrag = d->cout_pad / 16;
     const int nt = nfrag % 3 == 0 ? 3 : (nfrag % 4 == 0 ? 4 : 0);
     I2R_CHECK_ARG(nt != 0, "i2r_conv: algo 1 needs cout_pad=%d to be a multiple of 48 or 64", d->cout_pad);
-    const int mt = force_mt ? force_mt : (d->mt ? d->mt : 2);
+    const int mt = force_mt ? force_mt : (d->mt ? d->mt : 1);  // (one fragment per item = 4 waves per SIMD: the measured optimum, and the only form NT = 4 is built for)
     I2R_CHECK_ARG(mt == 1 || mt == 2, "i2r_conv: algo 1 takes mt 1 or 2 (got %d)", mt);
     int fw = 0;  // Winograd tiles across a fragment of 16 (64 output pixels): the shape that covers the map with the fewest fragments
     if (d->tile_w) {

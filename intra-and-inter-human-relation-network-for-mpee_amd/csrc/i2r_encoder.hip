@@ -151,6 +151,10 @@ template <int DC>
 __global__ __launch_bounds__(256) void enc_kv_k(const EncK p) {
     constexpr int cs = DC * 16, SK = (2 * DC + 3) / 4;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, li = lane & 15, g = lane >> 4;
+    // Re-arm the hand-off counters of the partial key split for the layers that follow in this stream (a kernel boundary orders this
+    // store before them): enc_layer4_k leaves them zero itself, but a launch that faulted or was aborted half-way may not -- the
+    // first kernel of every encoder stack therefore makes the invariant true again instead of trusting the previous forward.
+    if (blockIdx.x == 0 && p.split_cnt) p.split_cnt[tid] = 0;
     int s0, e0;
     load_groups(p, lane, s0, e0);
     f32x4 wk[SK][DC], bk[SK];
@@ -504,6 +508,12 @@ __global__ __launch_bounds__(256, 2) void enc_layer4_k(const EncK p) {
         if (split) {  // (workgroup-uniform) ---- hand-off between the two halves of the tile ----
             float* const mine = p.split_ws + ((size_t)slot * 2 + half) * kSplitSlot + lane * 4;
             const float* const other = p.split_ws + ((size_t)slot * 2 + (half ^ 1)) * kSplitSlot + lane * 4;
+            // Publish / consume in the write-through form of MI355X_MICROARCH.md (section "inter-workgroup visibility", valid forms):
+            // 16-byte `sc1` payload stores (they leave the XCD's L2 for the coherence point) -> asm `s_waitcnt vmcnt(0)` (inline asm: the
+            // compiler cannot drop it) -> agent-scope atomic on the counter; the consumer reads the payload with `sc1` loads, which
+            // bypass its CU's L1.  No L2 write-back / L1 invalidate fence is needed on either side (a release / acquire pair would cost
+            // ~3.5 us per tile, a quarter of the layer), and the second arriver never spins: whoever sees the counter at 1 finishes.
+            // One Program = one stream: launches sharing a (split_ws, split_cnt) pair must be stream-ordered (include/i2r_hip.h).
             if (wave == 0) {
 #pragma unroll
                 for (int nt = 0; nt < DC; ++nt) st_agent(mine + nt * 256, oc[0][nt]);

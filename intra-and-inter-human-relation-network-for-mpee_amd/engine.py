@@ -100,17 +100,25 @@ def wino_fragment(conv_h, conv_w):
     return best[1], best[2]
 
 
-_WINO_TABLE = os.environ.get("I2R_WINO_TABLE", "0") == "1"  # tools/ A/B switch: LPT dispatch table for Winograd launches (default: members heaviest first)
-_WINO_MT = int(os.environ.get("I2R_WINO_MT", "0"))  # tools/ A/B switch: fragments per Winograd workgroup
-LP1X1 = os.environ.get("I2R_LP1X1", "1") != "0"  # 16-bit modes: single 1x1 convs over few pixels on i2r_conv1x1_lp (A/B switch for tools/)
-LP1X1_MAX_PIX = int(os.environ.get("I2R_LP1X1_MAX_PIX", "65536"))  # beyond that the implicit-GEMM kernel has enough workgroups to hide its staging
-_LP1X1_MT = int(os.environ.get("I2R_LP1X1_MT", "0"))
-# tools/ A/B switches: branch widths whose transformer-block halves run as the fused 16-bit kernels (i2r_hrt_attn_block / i2r_hrt_mlp_block)
-_HRT_FUSED_ATTN = tuple(int(v) for v in os.environ.get("I2R_HRT_FUSED_ATTN", "78,156").split(",") if v)
-_HRT_FUSED_MLP = tuple(int(v) for v in os.environ.get("I2R_HRT_FUSED_MLP", "78,156").split(",") if v)
-PAIR1X1 = os.environ.get("I2R_PAIR1X1", "1") != "0"  # layer1's conv3 + next conv1 as one i2r_conv1x1_pair launch (fp32; A/B switch for tools/)
-_PAIR_MT = int(os.environ.get("I2R_PAIR_MT", "0"))  # tools/ A/B switch: 16-pixel tiles per wave of that kernel
-WINOGRAD = os.environ.get("I2R_WINOGRAD", "1") != "0"  # fp32 3x3 stride-1 convs on the Winograd F(2x2, 3x3) kernels (A/B switch for tools/)
+def _tune(name, default):
+    """A/B switches of tools/ (kernel variants, fusion on/off): read from the environment ONLY when I2R_TUNING=1 is set, so a product
+    run (bench.py refuses any I2R_* variable, tests never set them) cannot pick up a stray one.  16-bit note: LP1X1_MAX_PIX selects
+    the 1x1 kernel by the batch's pixel count, so a crop's 16-bit heat map is tolerance-stable, not bit-stable, across batch sizes
+    (fp32 results do not depend on the batch)."""
+    return os.environ.get(name, default) if os.environ.get("I2R_TUNING") == "1" else default
+
+
+_WINO_TABLE = _tune("I2R_WINO_TABLE", "0") == "1"  # LPT dispatch table for Winograd launches (default: members heaviest first)
+_WINO_MT = int(_tune("I2R_WINO_MT", "0"))  # fragments per Winograd workgroup
+LP1X1 = _tune("I2R_LP1X1", "1") != "0"  # 16-bit modes: single 1x1 convs over few pixels on i2r_conv1x1_lp
+LP1X1_MAX_PIX = int(_tune("I2R_LP1X1_MAX_PIX", "65536"))  # beyond that the implicit-GEMM kernel has enough workgroups to hide its staging
+_LP1X1_MT = int(_tune("I2R_LP1X1_MT", "0"))
+# branch widths whose transformer-block halves run as the fused 16-bit kernels (i2r_hrt_attn_block / i2r_hrt_mlp_block)
+_HRT_FUSED_ATTN = tuple(int(v) for v in _tune("I2R_HRT_FUSED_ATTN", "78,156").split(",") if v)
+_HRT_FUSED_MLP = tuple(int(v) for v in _tune("I2R_HRT_FUSED_MLP", "78,156").split(",") if v)
+PAIR1X1 = _tune("I2R_PAIR1X1", "1") != "0"  # layer1's conv3 + next conv1 as one i2r_conv1x1_pair launch (fp32)
+_PAIR_MT = int(_tune("I2R_PAIR_MT", "0"))  # 16-pixel tiles per wave of that kernel
+WINOGRAD = _tune("I2R_WINOGRAD", "1") != "0"  # fp32 3x3 stride-1 convs on the Winograd F(2x2, 3x3) kernels
 
 
 class PackedConv:
@@ -626,7 +634,10 @@ class Program:
         assert x.cs >= pc.cin_pad and x.c == pc.cin, "conv input channels %d/%d vs weight %d" % (x.c, x.cs, pc.cin)
         assert x.dt in (0, pc.dtype), "16-bit stored input needs the matching 16-bit conv (input %d, conv %d)" % (x.dt, pc.dtype)
         if (LP1X1 and pc.w_lp1 is not None and group is None and in2 is None and res2 is None and up == 1 and out_step == 1 and tuple(out_off) == (0, 0)
-                and out_hw is None and x.n * x.h * x.w <= LP1X1_MAX_PIX and (out is None or (out.n, out.h, out.w) == (x.n, x.h, x.w))):
+                and out_hw is None and x.n * x.h * x.w <= LP1X1_MAX_PIX and (out is None or (out.n, out.h, out.w) == (x.n, x.h, x.w))
+                # (the kernel's own limits, i2r_conv1x1_lp: whole output rows of cout_pad channels, residual rows laid out like the output)
+                and (out is None or out.cs >= pc.cout_pad) and all(r is None or out is None or r.cs == out.cs for r in (res1, res_post))
+                and all(r is None or r.cs >= pc.cout_pad for r in (res1, res_post))):
             return self.conv1x1_lp(x, pc, relu=relu, res1=res1, res_post=res_post, out=out, lane=lane, act=act, out_dt=out_dt)
         k = pc.ksize
         if pc.stride == 1:
@@ -720,7 +731,7 @@ class Program:
         G = len(layers[0])
         ok = (G <= cabi.MAX_GROUP and all(len(g) == G for g in layers) and len({m[2] for g in layers for m in g}) == 1
               and not any(m[0].algo for g in layers for m in g))
-        if not ok or os.environ.get("I2R_CONV_CHAIN", "0") != "1":
+        if not ok or _tune("I2R_CONV_CHAIN", "0") != "1":
             for g in layers:
                 self.flush_group(g, lane)
             return False
@@ -738,7 +749,7 @@ class Program:
         a.descs, a.n_layers, a.n_members = ptrs, L, G
         lib = cabi.lib()
         if lib.i2r_conv_chain_pack(C.byref(a), None, 0) != 0 or a.capacity < 8:
-            if os.environ.get("I2R_CONV_CHAIN_VERBOSE"):
+            if _tune("I2R_CONV_CHAIN_VERBOSE", ""):
                 print("conv_chain fallback:", lib.i2r_last_error(), "capacity", a.capacity)
             for g in layers:  # (no chain kernel for this blocking)
                 self.flush_group(g, lane)
@@ -841,7 +852,13 @@ class Program:
         self.release(a)
         t1 = self.conv(x, first["c1"], relu=True)
         self.conv(t1, first["c2"], relu=True, out=t2)
-        if PAIR1X1 and a.dt == 0 and first["c3ds"].w_frag is not None and all(b["c1"].w_frag is not None and b["c3"].w_frag is not None for b in blocks[1:]):
+        def pair_ok(pa, pb):
+            """shape limits of i2r_conv1x1_pair (csrc/i2r_conv1x1.hip): K of the first conv 64 | 128, its outputs in whole 32-channel steps,
+            the second conv 64 wide; anything else takes the generic conv path below"""
+            return (pa.w_frag is not None and pa.cin in (64, 128) and pa.cout % 32 == 0 and pa.cout == pa.cout_pad
+                    and (pb is None or (pb.w_frag is not None and pb.cout == 64 and pb.cin == pa.cout)))
+        nxt = [b["c1"] for b in blocks[1:]] + [None]
+        if PAIR1X1 and a.dt == 0 and pair_ok(first["c3ds"], nxt[0]) and all(pair_ok(b["c3"], nxt[i]) for i, b in enumerate(blocks[1:], 1)):
             # conv3 (+ residual + ReLU) of a block and conv1 (+ ReLU) of the next one in ONE launch: the 256-channel map is written once
             # (it is the next residual) and not read back by conv1
             self.release(t1)
@@ -1451,7 +1468,7 @@ class HRFormerB:
                     P.release(ys[i])
             # one fork region per stage: lanes 1..nb-1 start behind the transition convs (lane 0) and are joined after the last module
             nb = st["mods"][0]["nb"]
-            lanes = 1 < nb <= 4 and os.environ.get("I2R_BRANCH_LANES", "1") != "0"
+            lanes = 1 < nb <= 4 and _tune("I2R_BRANCH_LANES", "1") != "0"
             mask = ((1 << nb) - 1) & ~1
             if lanes:
                 P.fork(mask)

@@ -107,9 +107,19 @@ class I2RModule(nn.Module):
                     out[pre + k] = v
         return out
 
+    def _device(self):
+        """device of the first parameter (O(1) per forward; DataParallel replicas keep theirs in `_former_parameters`)"""
+        for m in self.modules():
+            for v in m._parameters.values():
+                if v is not None:
+                    return v.device
+            for v in (getattr(m, "_former_parameters", None) or {}).values():
+                if v is not None:
+                    return v.device
+        raise RuntimeError("module has no parameters")
+
     def engine(self):
-        tensors = self._tensors()
-        dev = next(iter(tensors.values())).device
+        dev = self._device()
         if dev.type != "cuda":
             raise RuntimeError(
                 "i2r_amd models run on an MI355X through the HIP extension only; move the module to the GPU "
@@ -117,9 +127,9 @@ class I2RModule(nn.Module):
         if dev.index is None:
             dev = torch.device("cuda", torch.cuda.current_device())
         eng = self._engines.get(dev)
-        if eng is None:
+        if eng is None:  # (cache miss only: walk the module tree for the full name -> tensor map the engine is packed from)
             from ..engine import Engine
-            eng = self._engines[dev] = Engine(self.cfg, tensors, dev, self.precision, name=self._engine_name())
+            eng = self._engines[dev] = Engine(self.cfg, self._tensors(), dev, self.precision, name=self._engine_name())
         return eng
 
     def _engine_name(self):

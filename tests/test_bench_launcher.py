@@ -62,3 +62,30 @@ def test_op_model_covers_every_launch_kind():
     st = cabi.HrtMlpArgs(*([0] * 10), 16, 64, 48, 78, 80, 320, 1e-6, 1)
     name, flop, nbytes, pipe = bench.op_model(cabi.OP_HRT_MLP, st, "bf16")
     assert name == "hrt_mlp_block_k" and pipe == "bf16" and abs(flop - 16 * 64 * 48 * (16 * 78 * 78 + 72 * 78)) < 1
+
+
+def test_gpus2_strong_scaling_gloo_stub():
+    """--scaling strong: a fixed ragged list of 64 images cut by dist.shard_bounds -> uneven crop counts per rank go through the padded
+    all-gather on the timed path; the line reports the shards and their imbalance"""
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--backend", "gloo",
+                        "--selftest-stub", "--scaling", "strong"], cwd=ROOT, env=_env(), capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-4000:]
+    lines = [l for l in p.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, p.stdout
+    out = json.loads(lines[0])
+    sys.path.insert(0, ROOT)
+    import bench
+    from i2r_amd import dist as i2r_dist
+    total = sum(bench.STRONG_LENGTH)
+    assert len(bench.STRONG_LENGTH) == 64 and all(1 <= n <= 6 for n in bench.STRONG_LENGTH)
+    sh = out["shards"]
+    assert out["scaling"] == "strong" and out["n_gpus"] == 2
+    assert sh["images_total"] == 64 and sh["crops_total"] == total and sum(sh["crops_per_rank"]) == total
+    assert sh["image_bounds"] == i2r_dist.shard_bounds(bench.STRONG_LENGTH, 2)
+    assert sh["crops_per_rank"][0] != sh["crops_per_rank"][1] or total % 2 == 0  # (uneven unless the list happens to split exactly)
+    assert 1.0 <= sh["imbalance_max_over_mean"] < 1.1  # at most one image (<= 6 crops) off an equal share of ~110 crops
+    assert sh["gather_rows_padded_to"] == max(sh["crops_per_rank"])
+    b = sh["image_bounds"]
+    assert sh["forwards_per_rank_step"] == [-(-(b[r + 1] - b[r]) // 16) for r in range(2)]  # batches of <= 16 images (31 / 33 images: 2 / 3)
+    assert out["config"]["crops_per_gpu_step"] == sh["crops_per_rank"][0]
+    assert "STUB" in out["data"] and out["value"] == 0.0

@@ -243,7 +243,7 @@ def test_module_tensors_survive_dataparallel_replication():
     net = models.interformer_pureMulti.get_pose_net(cfg, is_train=False)
     sd = net.state_dict()
     mine = net._tensors()
-    assert list(mine.keys()).sort() == list(sd.keys()).sort() and set(mine) == set(sd)
+    assert sorted(mine) == sorted(sd)
     assert all(mine[k].data_ptr() == sd[k].data_ptr() for k in sd)
     # replicate the tree (one replica, same device: the copies are clones)
     mods = list(net.modules())

@@ -121,6 +121,30 @@ def test_conv_winograd_matches_torch_and_direct(cin, cout, n, h, w, relu, nres):
     assert (outs[True] - outs[False]).abs().max().item() < 2e-5 * max(1.0, ref.abs().max().item())
 
 
+def test_conv_winograd_default_mt_through_raw_cabi():
+    """i2r_conv called directly (no Program) with algo = 1 and mt = 0 on a cout_pad = 64 conv (NT = 4): the documented default (one
+    fragment per workgroup) must resolve to a kernel that exists (the default used to be 2, which NT = 4 is not built for)"""
+    import ctypes as C
+    from i2r_amd import cabi
+    cin, cout, n, h, w = 64, 64, 2, 16, 12
+    sd = {"c.weight": _rand((cout, cin, 3, 3), "wdm", (6.0 / (cin * 9)) ** 0.5)}
+    x = _rand((n, cin, h, w), "xdm")
+    ref = F.conv2d(x.double(), sd["c.weight"].double(), None, padding=1)
+    P = engine.Program(torch.device(DEV))
+    pc = engine.Packer(sd, torch.device(DEV)).conv("c")
+    assert pc.w_wino is not None and pc.cout_pad == 64
+    out = P.conv(to_act(P, x), pc)
+    (d,) = [st.d[0].contents for k, _, st in P.ops if k == cabi.OP_CONV_GROUP]
+    assert d.algo == 1
+    d.mt, d.tile_h, d.tile_w = 0, 0, 0  # everything left to the library's defaults
+    st = torch.cuda.current_stream(torch.device(DEV)).cuda_stream
+    rc = cabi.lib().i2r_conv(C.byref(d), st)
+    assert rc == 0, cabi.lib().i2r_last_error()
+    torch.cuda.synchronize()
+    err = (from_act(out).double() - ref).abs().max().item()
+    assert err < 2e-5 * max(1.0, ref.abs().max().item()), err
+
+
 def test_conv_without_bn_and_channel_padding():
     _conv_case(192, 96, 1, 1, 2, 16, 12, False, 0, bn=False, tag="nobn")
     # cin 78 (padded to 80 in the activation), cout 78
@@ -514,7 +538,7 @@ def test_hrnet_fuse_module_matches_torch(nb):
 
 def _chain_case(use_chain, n_img=9):
     """two BasicBlocks (4 dependent 3x3 convs, residuals) on two branches, the way HRNetW48._emit_module emits them"""
-    os.environ["I2R_CONV_CHAIN"] = "1" if use_chain else "0"
+    os.environ["I2R_TUNING"], os.environ["I2R_CONV_CHAIN"] = "1", ("1" if use_chain else "0")  # (engine._tune: switches need I2R_TUNING=1)
     saved_wino, engine.WINOGRAD = engine.WINOGRAD, False  # (the experimental chain launch drives the direct kernel)
     try:
         P = engine.Program(torch.device(DEV))
@@ -546,6 +570,7 @@ def _chain_case(use_chain, n_img=9):
         return used, [from_act(t) for t in cur], errs
     finally:
         os.environ.pop("I2R_CONV_CHAIN", None)
+        os.environ.pop("I2R_TUNING", None)
         engine.WINOGRAD = saved_wino
 
 

@@ -8,6 +8,7 @@ from i2r_amd import config, synth, arch, engine
 DEV = torch.device("cuda:0")
 cfg = config.load_config("w48_pure_en6")
 sd = synth.make_state_dict(arch.param_spec(cfg))
+os.environ["I2R_TUNING"] = "1"  # engine._tune reads the A/B switches only with it
 os.environ["I2R_CONV_CHAIN"] = "0"
 ref_eng = engine.Engine(cfg, sd, DEV)
 os.environ["I2R_CONV_CHAIN"] = "1"
