@@ -322,7 +322,7 @@ def _kernel_view(name, s, reps, total_ms, precision):
     flop_exec = flop / WINO_CUT if wino else flop
     tf = flop_exec / (ms * 1e-3) / 1e12
     gbs = nbytes / (ms * 1e-3) / 1e9
-    out = {"kernel": name + ("/" + precision if pipe not in (None, "fp32") and name.startswith("conv_") else ""),
+    out = {"kernel": name,  # (16-bit conv instantiations carry their operand type in the name: conv_igemm_lp<..>/bf16)
            "launches_per_step": cnt // reps, "avg_launch_us": round(ms / cnt * 1e3, 2), "ms_per_step": round(ms / reps, 3),
            "share_of_step_kernel_time": round(ms / total_ms, 3), "gflop_per_launch": round(flop_exec / cnt / 1e9, 4),
            "gbytes_per_launch": round(nbytes / cnt / 1e9, 4)}

@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define I2R_ABI_VERSION 7
+#define I2R_ABI_VERSION 8
 
 #define I2R_OK 0
 #define I2R_E_ARG (-1)      /* bad argument (shape / alignment / unsupported combination) */
@@ -231,13 +231,17 @@ int i2r_window_attn(const float* qkv, const float* bias_qkv, float* out, int32_t
 /* i2r_hrt_attn_block -- 16-bit modes only: the attention half of a GeneralTransformerBlock in ONE launch,
  *     out = x + out_proj(window_attention(q|k|v_proj(LayerNorm(x))))      (hrformer.py:1230-1236; same semantics as
  * i2r_layernorm + i2r_conv(q|k|v) + i2r_window_attn + i2r_conv(out_proj, res1 = x)), one workgroup per 7x7 window, on
- * v_mfma_f32_16x16x16_{bf16,f16} with fp32 LayerNorm / softmax / accumulation; x and out are fp32 NHWC [n, h, w, cs] (may not alias).
+ * v_mfma_f32_16x16x32_{bf16,f16} with fp32 LayerNorm / softmax / accumulation; x and out are fp32 NHWC [n, h, w, cs] (may not alias).
  * Built for the two high-resolution HRFormer-B branches: (c, heads, cs) = (78, 2, 80) or (156, 4, 160); head_dim 39 padded to 48.
- * Operand images (16-bit, fragment-packed: element r of lane l of a fragment = M[16*rowblk + (l & 15)][16*colblk + 4*(l >> 4) + r]):
- *   wqkv  [head][q, k, v][3 dim blocks][cs/16 input blocks][64 lanes][4]: rows = the head's 39 output dims (+ 9 zero rows) of
- *         q_proj / k_proj / v_proj, columns = input channels; q rows (and bias) pre-multiplied by head_dim^-0.5 * log2(e);
- *   bqkv  float [head][3][48];   wo [cs/16 output blocks][head][3 dim blocks][64 lanes][4]: rows = out_proj outputs, columns = the
- *         head's dims (zero beyond 39);   bo float [cs];   ln_w, ln_b float [cs] zero-padded. */
+ * Operand images (16-bit, fragment-packed for the 32-deep MFMA: element e of lane l of a fragment = M[16*rowblk + (l & 15)][32*kstep +
+ * 8*(l >> 4) + e], 16 bytes per lane, 1 KB per fragment):
+ *   wqkv  [head][q, k, v][cs/32 rounded up k-steps][3 dim blocks][64 lanes][8]: rows = the head's 39 output dims (+ 9 zero rows) of
+ *         q_proj / k_proj / v_proj, columns = input channels (zero beyond cs); q rows (and bias) pre-multiplied by head_dim^-0.5 * log2(e);
+ *   bqkv  float [head][3][48];
+ *   wo    [cs/16 output blocks][heads*48/32 k-steps][64 lanes][8]: rows = out_proj outputs, columns = (head, dim) with zeros beyond 39,
+ *         re-ordered inside every 32-column k-step to the kernel's slot order: slot 8g + 4h + r <- column 16 (2 kstep + h) + 4g + r
+ *         (g < 4, h < 2, r < 4): the B operand of that GEMM is two 16-dim accumulator fragments packed side by side;
+ *   bo float [cs];   ln_w, ln_b float [cs] zero-padded. */
 int i2r_hrt_attn_block(const float* x, float* out, const float* ln_w, const float* ln_b, const void* wqkv, const float* bqkv,
                        const void* wo, const float* bo, int32_t n_img, int32_t h, int32_t w, int32_t c, int32_t cs, int32_t heads,
                        float eps, int32_t dtype, void* stream);

@@ -418,12 +418,20 @@ class Packer:
             for hh in range(heads):
                 wq[hh, i, :hd, :c] = W[hh * hd:(hh + 1) * hd]
                 bq[hh, i, :hd] = b[hh * hd:(hh + 1) * hd]
-        wqkv = self._frag16(wq.reshape(heads * 3 * 48, cs).float(), tdt)            # [(h, part, db)][cb][64][4]
+        # 32-deep MFMA fragments (pack_frag32): input channels padded to whole 32-channel k-steps
+        csp = (cs + 31) // 32 * 32
+        wq_p = torch.zeros(heads * 3 * 48, csp, dtype=torch.float64)
+        wq_p[:, :cs] = wq.reshape(heads * 3 * 48, cs)
+        ks = csp // 32
+        wqkv = pack_frag32(wq_p.float()).view(heads * 3, 3, ks, 512).permute(0, 2, 1, 3).contiguous().to(tdt)  # [(h, part)][k-step][db][64 lanes x 8]
         Wo = self.sd[a + ".out_proj.weight"].double()
         wo = torch.zeros(cs, heads, 48, dtype=torch.float64)
         for hh in range(heads):
             wo[:c, hh, :hd] = Wo[:, hh * hd:(hh + 1) * hd]
-        wo = self._frag16(wo.reshape(cs, heads * 48).float(), tdt)                   # [ob][(h, db)][64][4]
+        # columns (head, dim) in the kernel's k-slot order: slot 8g + 4h + r of k-step s <- column 16 (2s + h) + 4g + r (two 16-dim
+        # D fragments packed into one 32-deep B operand, csrc/i2r_hrformer_lp.hip)
+        wo = wo.reshape(cs, heads * 48 // 32, 2, 4, 4).permute(0, 1, 3, 2, 4).reshape(cs, heads * 48)
+        wo = pack_frag32(wo.float()).to(tdt)                                         # [ob][k-step][64 lanes][8]
         bo = torch.zeros(cs)
         bo[:c] = self.sd[a + ".out_proj.bias"]
         ln = self.ln(p + ".norm1", c)

@@ -4,7 +4,9 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import torch
 import i2r_amd  # noqa
-from i2r_amd import engine, synth
+from i2r_amd import cabi, engine, synth
+if os.environ.get("I2R_TOOL_LIB"):  # an A/B library variant (tools/ab/build_variant.sh)
+    cabi._LIB = cabi.load_library(os.path.join(ROOT, os.environ["I2R_TOOL_LIB"]))
 DEV = torch.device("cuda:0")
 prec = sys.argv[1] if len(sys.argv) > 1 else "bf16"
 n = int(sys.argv[2]) if len(sys.argv) > 2 else 16
