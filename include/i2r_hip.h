@@ -248,12 +248,14 @@ int i2r_hrt_attn_block(const float* x, float* out, const float* ln_w, const floa
 
 /* i2r_hrt_mlp_block -- 16-bit modes only: the MLP half of a GeneralTransformerBlock in ONE launch,
  *     out = x + GELU(BN3(fc2( GELU(BN2(dw3x3( GELU(BN1(fc1( LayerNorm(x) ))) ))) )))      (hrformer.py:1237, MlpDWBN :1094-1119; same
- * semantics as i2r_layernorm + i2r_conv(fc1, GELU) + i2r_dwconv3x3(GELU) + i2r_conv(fc2, GELU, res_post = x)), one workgroup per 8x8
- * pixel tile (+ halo of 1, recomputed); the 4C-wide hidden tensor only exists in LDS, chunk by chunk.  x and out: fp32 NHWC [n, h, w, cs], distinct buffers.
- * (c, cs) = (78, 80) or (156, 160); hidden_pad = 4c rounded up to a multiple of 64 (zero weights / biases beyond 4c).
- * w1: 16-bit fragments [hidden_pad/16][cs/16][64 lanes][4] of the BN-folded fc1 matrix [hidden, c] (fragment layout as in
- * i2r_hrt_attn_block), b1 float [hidden_pad]; wdw float [9][hidden_pad] tap-major BN-folded depth-wise weights, bdw [hidden_pad];
- * w2: fragments [cs/16][hidden_pad/16][64][4] of the BN-folded fc2 matrix [c, hidden], b2 float [cs]. */
+ * semantics as i2r_layernorm + i2r_conv(fc1, GELU) + i2r_dwconv3x3(GELU) + i2r_conv(fc2, GELU, res_post = x)), one workgroup per 8x6
+ * pixel tile (+ halo of 1, recomputed) on v_mfma_f32_16x16x32_{bf16,f16}; the 4C-wide hidden tensor only exists in LDS, 16 channels per
+ * wave at a time.  x and out: fp32 NHWC [n, h, w, cs], distinct buffers; pad channels of x must be zero (they are everywhere in this library).
+ * (c, cs) = (78, 80) or (156, 160); hidden_pad = 4 cs (zero weights / biases beyond 4c).
+ * w1: 16-bit 32-deep fragments [hidden_pad/16][cs/32 rounded up][64 lanes][8] of the BN-folded fc1 matrix [hidden, c] (fragment layout as
+ * in i2r_hrt_attn_block; columns zero beyond cs), b1 float [hidden_pad]; wdw float [9][hidden_pad] tap-major BN-folded depth-wise
+ * weights, bdw [hidden_pad]; w2: fragments [cs/16][hidden_pad/32][64][8] of the BN-folded fc2 matrix [c, hidden] with the hidden columns
+ * of every 32-column k-step in slot order (slot 8g + 4h + r <- column 16 (2 kstep + h) + 4g + r), b2 float [cs]. */
 int i2r_hrt_mlp_block(const float* x, float* out, const float* ln_w, const float* ln_b, const void* w1, const float* b1,
                       const float* wdw, const float* bdw, const void* w2, const float* b2, int32_t n_img, int32_t h, int32_t w,
                       int32_t c, int32_t cs, int32_t hidden_pad, float eps, int32_t dtype, void* stream);

@@ -20,31 +20,31 @@
 //     ob % NBG: + bias, GELU, + x1 (fp32 residual), fp32 store.
 // LDS layout of H (floats): quad g at g*448, halo row hy at hy*40, halo column hx at hx*4: the 16-lane groups of ds_read_b128 /
 // the 8-lane groups of ds_write_b128 then hit 64 distinct banks for every tap (checked exhaustively, tools/lds_layout.py).
-// x / out are the fp32 residual stream [n, h, w, cs]; operands bf16 / f16 (v_mfma_f32_16x16x16), accumulation fp32.
+// x / out are the fp32 residual stream [n, h, w, cs]; operands bf16 / f16, accumulation fp32.
+// Round 4: both GEMMs on v_mfma_f32_16x16x32 -- fc1 over 32-channel k-steps of the LayerNorm-ed pixel columns, fc2 over PAIRS of hidden
+// blocks (the depth-wise results of blocks 2p and 2p + 1 packed side by side are one 32-deep B operand; the host stores W2's columns in
+// that slot order, as for the attention kernel's out-proj) -- and the per-element masks of the prologue / epilogue are gone: pad
+// channels are exact zeros on both sides (zero weights and biases, GELU(0) = 0), the LayerNorm variance subtracts their (cs - c)
+// mean^2 instead of masking them.
 #include "i2r_common.h"
 
 namespace {
 
-typedef short s16x4 __attribute__((ext_vector_type(4)));
-typedef _Float16 h16x4 __attribute__((ext_vector_type(4)));
-typedef __bf16 b16x4 __attribute__((ext_vector_type(4)));
-
-template <int DT>
-__device__ __forceinline__ f32x4 mfma16(uint2 a, uint2 b, f32x4 c) {  // D = A(16x16) B(16x16) + C
-    if constexpr (DT == 1)
-        return __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(__builtin_bit_cast(s16x4, a), __builtin_bit_cast(s16x4, b), c, 0, 0, 0);
-    else
-        return __builtin_amdgcn_mfma_f32_16x16x16f16(__builtin_bit_cast(h16x4, a), __builtin_bit_cast(h16x4, b), c, 0, 0, 0);
-}
 template <int DT>
 __device__ __forceinline__ uint2 pack4(f32x4 v) {
     if constexpr (DT == 1) {
+        typedef __bf16 b16x4 __attribute__((ext_vector_type(4)));
         const b16x4 b = {(__bf16)v[0], (__bf16)v[1], (__bf16)v[2], (__bf16)v[3]};
         return __builtin_bit_cast(uint2, b);
     } else {
+        typedef _Float16 h16x4 __attribute__((ext_vector_type(4)));
         const h16x4 h = {(_Float16)v[0], (_Float16)v[1], (_Float16)v[2], (_Float16)v[3]};
         return __builtin_bit_cast(uint2, h);
     }
+}
+__device__ __forceinline__ f32x4 join8(uint2 lo, uint2 hi) {  // two packed 4-element halves -> one 8-element MFMA operand
+    const uint4 v = {lo.x, lo.y, hi.x, hi.y};
+    return __builtin_bit_cast(f32x4, v);
 }
 __device__ __forceinline__ float xsum4(float v) {  // over the 4 lanes that share l & 15
     v += __shfl_xor(v, 16);
@@ -55,9 +55,9 @@ __device__ __forceinline__ float xsum4(float v) {  // over the 4 lanes that shar
 struct MlpK {
     const float* x; float* out;
     const float* ln_w; const float* ln_b;
-    const uint2* w1; const float* b1;     // fc1 (+BN1): fragments [hidden block][CB][64 lanes]; bias [hidden_pad]
+    const f32x4* w1; const float* b1;     // fc1 (+BN1): 32-deep fragments [hidden block][KS k-steps][64 lanes]; bias [hidden_pad]
     const float* wdw; const float* bdw;   // depth-wise 3x3 (+BN2): [9][hidden_pad] tap-major; bias [hidden_pad]
-    const uint2* w2; const float* b2;     // fc2 (+BN3): fragments [CB out blocks][hidden blocks][64 lanes]; bias [cs]
+    const f32x4* w2; const float* b2;     // fc2 (+BN3): 32-deep fragments [CB out blocks][hidden block pairs][64 lanes] (slot order); bias [cs]
     int n_img, h, w, c, tiles_y, tiles_x;
     float eps;
 };
@@ -105,6 +105,9 @@ __device__ __forceinline__ f32x4 gelu4(f32x4 v, const GeluC& k) {
     return (f32x4){lo[0], lo[1], hi[0], hi[1]};
 }
 
+#ifndef I2R_MLP_FC1_LATE
+#define I2R_MLP_FC1_LATE 1   // A/B knob (0 spills 77 registers at C = 78): 1 = fc1 of the next block is issued AFTER the depth-wise phase (its five accumulators are not live across it)
+#endif
 constexpr int TY = 8, TX = 6;                    // output sub-tile (rows x columns)
 constexpr int HY = TY + 2, HX = TX + 2;          // halo grid 10 x 8 = 80 pixels = 5 fragments (two halo rows each)
 constexpr int NF = HY * HX / 16, NPF = TY * TX / 16;
@@ -113,11 +116,11 @@ static_assert(NF == 5 && NPF == 3, "sub-tile geometry");
 
 template <int DT, int CB, int NBG>
 __global__ __launch_bounds__(NBG * 64, NBG == 2 ? 2 : 1) void hrt_mlp_block_k(const MlpK p) {
-    constexpr int cs = CB * 16, HBT = 4 * CB, HID = HBT * 16, NB = HBT / NBG;  // NB hidden blocks per wave
-    static_assert(HBT % NBG == 0, "even split of the hidden blocks");
+    constexpr int cs = CB * 16, KS = (cs + 31) / 32, HBT = 4 * CB, HID = HBT * 16, NB = HBT / NBG, NP = NB / 2;  // NB hidden blocks = NP pairs per wave
+    static_assert(HBT % (2 * NBG) == 0, "whole pairs of hidden blocks per wave");
     constexpr int WD_WAVE = NB * 160;                           // floats: per block [10 = 9 taps + bias][16 channels]
     constexpr int H_WAVE = 4 * H_QUAD;                          // floats
-    constexpr int X_FLOATS = NF * CB * 64 * 2;                  // packed pixel columns, uint2 per lane
+    constexpr int X_FLOATS = NF * KS * 64 * 4;                  // packed pixel columns, 16 bytes per lane and (fragment, k-step)
     constexpr int R1 = X_FLOATS > NBG * H_WAVE ? X_FLOATS : NBG * H_WAVE;
     constexpr int RED_FLOATS = (NBG == 2 ? CB : (CB + 1) / 2) * (NBG - 1) * NPF * 64 * 4;  // partial fc2 sums handed to the finishing wave
     constexpr int SMEM = NBG * WD_WAVE + R1 > RED_FLOATS ? NBG * WD_WAVE + R1 : RED_FLOATS;
@@ -125,64 +128,76 @@ __global__ __launch_bounds__(NBG * 64, NBG == 2 ? 2 : 1) void hrt_mlp_block_k(co
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, li = lane & 15, g = lane >> 4;
     float* const Wd = smem + wave * WD_WAVE;                    // this wave's depth-wise weights
     float* const Hs = smem + NBG * WD_WAVE + wave * H_WAVE;     // this wave's hidden tile
-    uint2* const Xs = reinterpret_cast<uint2*>(smem + NBG * WD_WAVE);  // (prologue only; aliases the H tiles)
+    f32x4* const Xs = reinterpret_cast<f32x4*>(smem + NBG * WD_WAVE);  // (prologue only; aliases the H tiles)
     int bid = blockIdx.x;
     const int sx = bid % p.tiles_x; bid /= p.tiles_x;
     const int sy = bid % p.tiles_y;
     const int img = bid / p.tiles_y;
     const int y0 = sy * TY - 1, x0 = sx * TX - 1;               // image coordinate of halo pixel (0, 0)
+    // hidden block b (0 .. NB-1) of this wave: pair wave + NBG (b >> 1), half b & 1
+    auto hblock = [&](int b) { return 2 * (wave + NBG * (b >> 1)) + (b & 1); };
 
-    // ---- depth-wise weights + bias of this wave's blocks -> its LDS region: [block i][tap][16] ----
-    for (int i = lane; i < NB * 40; i += 64) {
-        const int blk = i / 40, r = i - blk * 40, tap = r >> 2, q = r & 3;
-        const int hb = wave + NBG * blk;
-        const f32x4 v = tap < 9 ? *reinterpret_cast<const f32x4*>(p.wdw + tap * HID + hb * 16 + 4 * q)
-                                : *reinterpret_cast<const f32x4*>(p.bdw + hb * 16 + 4 * q);
-        *reinterpret_cast<f32x4*>(Wd + blk * 160 + tap * 16 + 4 * q) = v;
+    // ---- depth-wise weights + bias of this wave's blocks -> its LDS region: [block][tap | bias][16] ----
+#pragma unroll
+    for (int i0 = 0; i0 < NB * 40; i0 += 64) {
+        const int i = i0 + lane;
+        if (i < NB * 40) {
+            const int blk = i / 40, r = i - blk * 40, tap = r >> 2, q = r & 3;
+            const int hb = hblock(blk);
+            const f32x4 v = tap < 9 ? *reinterpret_cast<const f32x4*>(p.wdw + tap * HID + hb * 16 + 4 * q)
+                                    : *reinterpret_cast<const f32x4*>(p.bdw + hb * 16 + 4 * q);
+            *reinterpret_cast<f32x4*>(Wd + blk * 160 + tap * 16 + 4 * q) = v;
+        }
     }
-    // ---- LayerNorm 2 of halo fragments wave, wave + NBG, ...: packed B operands -> Xs[fragment][c][lane] ----
+    // ---- LayerNorm 2 of halo fragments wave, wave + NBG, ...: packed B operands -> Xs[fragment][k-step][lane] ----
     float hinf[NF];  // 1 = halo pixel (16 f + li) lies inside the image
 #pragma unroll
     for (int f = 0; f < NF; ++f) {
         const int y = y0 + 2 * f + (li >> 3), x = x0 + (li & 7);
         hinf[f] = (y >= 0 && y < p.h && x >= 0 && x < p.w) ? 1.f : 0.f;
     }
+    const float npad = (float)(cs - p.c);  // zero pad channels inside the loaded rows: each adds mean^2 to the sum of squares
 #pragma unroll
     for (int f = 0; f < NF; ++f) {
         if (f % NBG != wave) continue;  // (wave-uniform)
         const int y = y0 + 2 * f + (li >> 3), x = x0 + (li & 7);
         const bool in = hinf[f] != 0.f;
         const float* row = p.x + (((size_t)img * p.h + (in ? y : 0)) * p.w + (in ? x : 0)) * cs;
-        f32x4 xr[CB];
-        float s = 0.f;
+        f32x4 xa[KS], xb[KS];  // features 32 s + 8 g .. + 3 / + 4 .. + 7
+        float s1 = 0.f;
 #pragma unroll
-        for (int c = 0; c < CB; ++c) {
-            xr[c] = *reinterpret_cast<const f32x4*>(row + 16 * c + 4 * g);
-            s += (xr[c][0] + xr[c][1]) + (xr[c][2] + xr[c][3]);
+        for (int s = 0; s < KS; ++s) {
+            const bool ok = 32 * s + 8 * g < cs;  // (cs = 80: the last k-step holds 16 channels, lanes g >= 2 supply zeros)
+            xa[s] = ok ? *reinterpret_cast<const f32x4*>(row + 32 * s + 8 * g) : (f32x4){0.f, 0.f, 0.f, 0.f};
+            xb[s] = ok ? *reinterpret_cast<const f32x4*>(row + 32 * s + 8 * g + 4) : (f32x4){0.f, 0.f, 0.f, 0.f};
+            s1 += ((xa[s][0] + xa[s][1]) + (xa[s][2] + xa[s][3])) + ((xb[s][0] + xb[s][1]) + (xb[s][2] + xb[s][3]));
         }
-        const float mean = xsum4(s) / (float)p.c;
+        const float mean = xsum4(s1) / (float)p.c;
         float q2 = 0.f;
 #pragma unroll
-        for (int c = 0; c < CB; ++c)
+        for (int s = 0; s < KS; ++s) {
+            const float keep = 32 * s + 8 * g < cs ? 1.f : 0.f;  // (compile-time 1 except in a partial last k-step)
+            const f32x4 da = (xa[s] - mean) * keep, db = (xb[s] - mean) * keep;
+            q2 += ((da[0] * da[0] + da[1] * da[1]) + (da[2] * da[2] + da[3] * da[3])) + ((db[0] * db[0] + db[1] * db[1]) + (db[2] * db[2] + db[3] * db[3]));
+        }
+        const float var = (xsum4(q2) - npad * mean * mean) / (float)p.c;
+        const float rstd = in ? rsqrtf(fmaxf(var, 0.f) + p.eps) : 0.f;  // outside the image: zero columns
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const float d = (16 * c + 4 * g + r < p.c) ? xr[c][r] - mean : 0.f;
-                q2 += d * d;
-            }
-        const float rstd = in ? rsqrtf(xsum4(q2) / (float)p.c + p.eps) : 0.f;  // outside the image: zero columns
-#pragma unroll
-        for (int c = 0; c < CB; ++c) {
-            const f32x4 wv = *reinterpret_cast<const f32x4*>(p.ln_w + 16 * c + 4 * g), bv = *reinterpret_cast<const f32x4*>(p.ln_b + 16 * c + 4 * g);
-            const f32x4 v = (xr[c] - mean) * rstd * wv + bv * hinf[f];
-            Xs[(f * CB + c) * 64 + lane] = pack4<DT>(v);
+        for (int s = 0; s < KS; ++s) {
+            const int f0 = 32 * s + 8 * g < cs ? 32 * s + 8 * g : 0;
+            const f32x4 wa = *reinterpret_cast<const f32x4*>(p.ln_w + f0), wb = *reinterpret_cast<const f32x4*>(p.ln_w + f0 + 4);
+            const f32x4 ba = *reinterpret_cast<const f32x4*>(p.ln_b + f0), bb = *reinterpret_cast<const f32x4*>(p.ln_b + f0 + 4);
+            const float keep = 32 * s + 8 * g < cs ? hinf[f] : 0.f;
+            // (pad channels: ln_w = ln_b = 0 -> exact zeros)
+            Xs[(f * KS + s) * 64 + lane] = pack8<DT>((xa[s] - mean) * rstd * wa + ba * keep, (xb[s] - mean) * rstd * wb + bb * keep);
         }
     }
     __syncthreads();
-    uint2 xn[NF][CB];
+    f32x4 xn[NF][KS];
 #pragma unroll
     for (int f = 0; f < NF; ++f)
 #pragma unroll
-        for (int c = 0; c < CB; ++c) xn[f][c] = Xs[(f * CB + c) * 64 + lane];
+        for (int s = 0; s < KS; ++s) xn[f][s] = Xs[(f * KS + s) * 64 + lane];
     __syncthreads();  // everyone holds the pixel columns in registers: the region becomes the H tiles
 
     // this lane's three output pixels: row oy, columns 3 xb .. 3 xb + 2 of the sub-tile
@@ -197,34 +212,36 @@ __global__ __launch_bounds__(NBG * 64, NBG == 2 ? 2 : 1) void hrt_mlp_block_k(co
     for (int pf = 0; pf < NPF; ++pf)
 #pragma unroll
         for (int ob = 0; ob < CB; ++ob) acc[pf][ob] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    uint2 w1f[CB], w2f[CB];
+    f32x4 w1f[KS], w2f[CB];
     f32x4 b1v;
-    auto fetch1 = [&](int hb) {
+    auto fetch1 = [&](int b) {
+        const int hb = hblock(b);
 #pragma unroll
-        for (int c = 0; c < CB; ++c) w1f[c] = p.w1[(hb * CB + c) * 64 + lane];
+        for (int s = 0; s < KS; ++s) w1f[s] = p.w1[(hb * KS + s) * 64 + lane];
         b1v = *reinterpret_cast<const f32x4*>(p.b1 + hb * 16 + 4 * g);
     };
-    auto fetch2 = [&](int hb) {
+    auto fetch2 = [&](int pr) {  // pair pr of this wave
+        const int gp = wave + NBG * pr;
 #pragma unroll
-        for (int ob = 0; ob < CB; ++ob) w2f[ob] = p.w2[(ob * HBT + hb) * 64 + lane];
+        for (int ob = 0; ob < CB; ++ob) w2f[ob] = p.w2[(ob * (HBT / 2) + gp) * 64 + lane];
     };
     f32x4 a[NF];
-    auto fc1 = [&]() {  // hidden block in w1f / b1v, all five halo fragments (interleaved dependency chains)
+    auto fc1 = [&]() {  // hidden block in w1f / b1v, all five halo fragments (k-step-major: five independent accumulators)
 #pragma unroll
         for (int f = 0; f < NF; ++f) a[f] = b1v * hinf[f];
 #pragma unroll
-        for (int c = 0; c < CB; ++c)
+        for (int s = 0; s < KS; ++s)
 #pragma unroll
-            for (int f = 0; f < NF; ++f) a[f] = mfma16<DT>(w1f[c], xn[f][c], a[f]);
+            for (int f = 0; f < NF; ++f) a[f] = mfma32_lp<DT>(w1f[s], xn[f][s], a[f]);
     };
     auto store_h = [&]() {
 #pragma unroll
         for (int f = 0; f < NF; ++f) *reinterpret_cast<f32x4*>(hwr + 2 * f * H_ROW) = gelu4<4>(a[f], gk);
     };
 
-    // depth-wise 3x3 + bias + GELU of block i (three output pixels x 4 channels per lane), then its fc2 partial products
-    auto dw_fc2 = [&](int i) {
-        const float* const wch = wrd + i * 160;
+    // depth-wise 3x3 + bias + GELU of block b (three output pixels x 4 channels per lane) -> packed 16-bit halves of the fc2 B operand
+    auto dwconv = [&](int b, uint2 (&dp)[NPF]) {
+        const float* const wch = wrd + b * 160;
         f32x4 d[NPF];
         {
             const f32x4 bias = *reinterpret_cast<const f32x4*>(wch + 9 * 16);
@@ -243,31 +260,40 @@ __global__ __launch_bounds__(NBG * 64, NBG == 2 ? 2 : 1) void hrt_mlp_block_k(co
 #pragma unroll
                 for (int kx = 0; kx < 3; ++kx) d[pf] = t[pf + kx] * wv[kx] + d[pf];
         }
-        uint2 dB[NPF];
 #pragma unroll
-        for (int pf = 0; pf < NPF; ++pf) dB[pf] = pack4<DT>(gelu4<4>(d[pf], gk));
+        for (int pf = 0; pf < NPF; ++pf) dp[pf] = pack4<DT>(gelu4<4>(d[pf], gk));
+    };
+
+    // software pipeline over the wave's blocks: fc1 of block b + 1 goes to the matrix pipe before the depth-wise phase of block b; a
+    // PAIR of blocks feeds one 32-deep fc2 step (slot 8g + 4h + r <- hidden channel 16 (2 pair + h) + 4g + r)
+    fetch1(0);
+    fetch2(0);
+    fc1();
+    fetch1(1);
+    store_h();
+#pragma unroll 1
+    for (int pr = 0; pr < NP; ++pr) {
+        uint2 d0[NPF], d1[NPF];
+        __builtin_amdgcn_wave_barrier();  // (H of block 2 pr is complete in program order; LDS executes a wave's accesses in order)
+        if constexpr (!I2R_MLP_FC1_LATE) fc1();  // block 2 pr + 1 goes to the matrix pipe first
+        dwconv(2 * pr, d0);
+        if constexpr (I2R_MLP_FC1_LATE) fc1();
+        fetch1(2 * pr + 2 < NB ? 2 * pr + 2 : 2 * pr + 1);  // (last round: a harmless re-fetch instead of a branch)
+        store_h();                        // block 2 pr + 1's hidden tile (block 2 pr's taps have all been read)
+        __builtin_amdgcn_wave_barrier();
+        if constexpr (!I2R_MLP_FC1_LATE) { if (pr + 1 < NP) fc1(); }  // block 2 pr + 2 (wave-uniform branch)
+        dwconv(2 * pr + 1, d1);
 #pragma unroll
         for (int ob = 0; ob < CB; ++ob)
 #pragma unroll
-            for (int pf = 0; pf < NPF; ++pf) acc[pf][ob] = mfma16<DT>(w2f[ob], dB[pf], acc[pf][ob]);
-    };
-
-    fetch1(wave);
-    fetch2(wave);
-    fc1();
-    fetch1(wave + NBG * (NB > 1 ? 1 : 0));
-    store_h();
-    for (int i = 0; i + 1 < NB; ++i) {
-        const int hb = wave + NBG * i;
-        __builtin_amdgcn_wave_barrier();  // (H of block i is complete in program order; LDS executes a wave's accesses in order)
-        fc1();  // block i + 1 goes to the matrix pipe first; its results are only needed after this block's depth-wise phase
-        fetch1(i + 2 < NB ? hb + 2 * NBG : hb);  // (last round: a harmless re-fetch instead of a branch)
-        dw_fc2(i);
-        fetch2(hb + NBG);
-        store_h();  // block i + 1's hidden tile (block i's taps have all been read: LDS keeps a wave's accesses in order)
+            for (int pf = 0; pf < NPF; ++pf) acc[pf][ob] = mfma32_lp<DT>(w2f[ob], join8(d0[pf], d1[pf]), acc[pf][ob]);
+        fetch2(pr + 1 < NP ? pr + 1 : pr);
+        if (pr + 1 < NP) {
+            if constexpr (I2R_MLP_FC1_LATE) fc1();
+            fetch1(2 * pr + 3);
+            store_h();
+        }
     }
-    __builtin_amdgcn_wave_barrier();
-    dw_fc2(NB - 1);
 
     // ---- the waves' partial sums meet: output block ob is finished by wave ob % NBG ----
     const int gy = sy * TY + oy;
@@ -308,10 +334,8 @@ __global__ __launch_bounds__(NBG * 64, NBG == 2 ? 2 : 1) void hrt_mlp_block_k(co
                     v += Red[(((ob - ob0) * (NBG - 1) + (s - 1)) * NPF + pf) * 64 + lane];
                 if (!oin[pf]) continue;
                 const f32x4 xres = *reinterpret_cast<const f32x4*>(p.x + prow[pf] + 16 * ob + 4 * g);
-                f32x4 o = gelu4<5>(v + b, gk) + xres;
-#pragma unroll
-                for (int r = 0; r < 4; ++r) o[r] = (16 * ob + 4 * g + r < p.c) ? o[r] : 0.f;
-                *reinterpret_cast<f32x4*>(p.out + prow[pf] + 16 * ob + 4 * g) = o;
+                // (pad channels: zero W2 rows and bias -> GELU(0) = 0 exactly, + the residual's zero: no mask)
+                *reinterpret_cast<f32x4*>(p.out + prow[pf] + 16 * ob + 4 * g) = gelu4<5>(v + b, gk) + xres;
             }
         }
     }
@@ -327,7 +351,7 @@ extern "C" int i2r_hrt_mlp_block(const float* x, float* out, const float* ln_w, 
     I2R_CHECK_ARG((cs == 80 || cs == 160) && c <= cs && c > cs - 16 && hidden_pad >= 4 * c && hidden_pad == 4 * cs,
                   "i2r_hrt_mlp_block: c=%d cs=%d hidden_pad=%d (built for the two high-resolution HRFormer-B branches; hidden padded to 4 cs)", c, cs, hidden_pad);
     MlpK k;
-    k.x = x; k.out = out; k.ln_w = ln_w; k.ln_b = ln_b; k.w1 = (const uint2*)w1; k.b1 = b1; k.wdw = wdw; k.bdw = bdw; k.w2 = (const uint2*)w2; k.b2 = b2;
+    k.x = x; k.out = out; k.ln_w = ln_w; k.ln_b = ln_b; k.w1 = (const f32x4*)w1; k.b1 = b1; k.wdw = wdw; k.bdw = bdw; k.w2 = (const f32x4*)w2; k.b2 = b2;
     k.n_img = n_img; k.h = h; k.w = w; k.c = c; k.eps = eps;
     k.tiles_y = (h + TY - 1) / TY; k.tiles_x = (w + TX - 1) / TX;
     const long long nblk = (long long)n_img * k.tiles_y * k.tiles_x;

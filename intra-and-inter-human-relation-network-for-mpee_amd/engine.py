@@ -460,8 +460,14 @@ class Packer:
             o = torch.zeros(n, dtype=torch.float64)
             o[:v.shape[0]] = v
             return o.float()
-        return dict(w1=self._dev(self._frag16(W1.float(), tdt)), b1=self._dev(padv(b1, hp)), wdw=self._dev(WD.float()), bdw=self._dev(padv(bd, hp)),
-                    w2=self._dev(self._frag16(W2.float(), tdt)), b2=self._dev(padv(b2, cs)), ln=self.ln(p + ".norm2", c), c=c, cs=cs, hidden_pad=hp,
+        # 32-deep MFMA fragments (pack_frag32): fc1's input channels padded to whole 32-channel k-steps; fc2's hidden columns in the
+        # kernel's slot order (slot 8g + 4h + r of a k-step <- hidden channel 16 (2 kstep + h) + 4g + r: a PAIR of 16-channel hidden blocks)
+        csp = (cs + 31) // 32 * 32
+        W1p = torch.zeros(hp, csp, dtype=torch.float64)
+        W1p[:, :cs] = W1
+        W2s = W2.reshape(cs, hp // 32, 2, 4, 4).permute(0, 1, 3, 2, 4).reshape(cs, hp)
+        return dict(w1=self._dev(pack_frag32(W1p.float()).to(tdt)), b1=self._dev(padv(b1, hp)), wdw=self._dev(WD.float()), bdw=self._dev(padv(bd, hp)),
+                    w2=self._dev(pack_frag32(W2s.float()).to(tdt)), b2=self._dev(padv(b2, cs)), ln=self.ln(p + ".norm2", c), c=c, cs=cs, hidden_pad=hp,
                     dtype=self.dtype)
 
     def table(self, key, rows, d):
