@@ -447,8 +447,10 @@ def cpu_baseline(cfg, sd, H, W, length, budget_s=20.0):
 
 def make_pipeline(net, cfg, length, H, W, dev, seed):
     """The validate() step around the forward as one device-side unit (lib/core/function.py:124-200, JointsDataset.py:296-333):
-    uint8 image + person boxes -> affine crops + bbox masks (i2r_crop_affine / i2r_box_mask) -> flip-test forward -> key points
-    (i2r_decode).  Synthetic 640x480 images, boxes from the seeded generator; returns step() -> (preds [S,J,2], maxvals [S,J,1])."""
+    uint8 images + person boxes -> ALL affine crops + bbox masks of the batch in one launch, written straight into the collated tensors
+    (input.person_inputs_batch: one pinned upload of the crop / image tables, i2r_person_inputs_cv2) -> flip-test forward -> key points
+    (i2r_decode).  Synthetic 640x480 images, boxes from the seeded generator; returns step() -> (preds [S,J,2], maxvals [S,J,1]).
+    The host's share per step: box -> centre / scale (the dataset's _box2cs), the batched 3-point affine solves, one table upload."""
     from i2r_amd import caller, input as i2r_input
     rng = np.random.default_rng(seed)
     ih, iw = 480, 640
@@ -458,20 +460,13 @@ def make_pipeline(net, cfg, length, H, W, dev, seed):
         b = np.stack([rng.uniform(20, iw * 0.5, n), rng.uniform(20, ih * 0.5, n), rng.uniform(60, iw * 0.45, n), rng.uniform(90, ih * 0.45, n)], 1)
         boxes.append(b)
     pairs = caller.FLIP_PAIRS[_dataset_name(cfg)]
-    cs = [[i2r_input.box_to_center_scale(b, (W, H)) for b in bs] for bs in boxes]
-    centers = np.concatenate([np.stack([c for c, _ in one]) for one in cs])
-    scales = np.concatenate([np.stack([s for _, s in one]) for one in cs])
 
     def step():
-        xs, ms = [], []
-        for img, bs, one in zip(images, boxes, cs):  # per image, as JointsDataset.__getitem__ does (host: 2x3 affine solve per person)
-            x, m = i2r_input.person_inputs(img, [c for c, _ in one], [s for _, s in one], bs, (W, H),
-                                           color_rgb=bool(cfg.DATASET.COLOR_RGB), device=dev)
-            xs.append(x)
-            ms.append(m)
-        x, m, lens = i2r_input.collate(list(zip(xs, ms)))
+        cs = [[i2r_input.box_to_center_scale(b, (W, H)) for b in bs] for bs in boxes]   # (per person, as JointsDataset.__getitem__ does)
+        x, m, lens, cen, scl = i2r_input.person_inputs_batch(images, [[c for c, _ in one] for one in cs], [[s for _, s in one] for one in cs],
+                                                            boxes, (W, H), color_rgb=bool(cfg.DATASET.COLOR_RGB), device=dev)
         hm = net.forward_flip(x, m, lens, pairs)
-        return caller.decode(hm, centers, scales, cfg.TEST.BLUR_KERNEL)
+        return caller.decode(hm, cen, scl, cfg.TEST.BLUR_KERNEL)
     return step
 
 

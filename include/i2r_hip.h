@@ -210,6 +210,25 @@ int i2r_crop_affine_cv2(const unsigned char* img, int32_t ih, int32_t iw, int32_
                         const float* mean, const float* inv_std, float* out, int32_t n, int32_t oh, int32_t ow, void* stream);
 int i2r_box_mask_cv2(const int32_t* boxes, int32_t ih, int32_t iw, float* out, int32_t n, int32_t oh, int32_t ow, void* stream);
 
+/* i2r_person_inputs_cv2 -- the input side of a whole validate() BATCH in one launch: for every person crop p of every image,
+ * i2r_crop_affine_cv2 and i2r_box_mask_cv2 (same arithmetic, bit-identical results) written straight into the collated tensors
+ * x_out [n_crops, 3, oh, ow] and mask_out [n_crops, 1, oh, ow] that collater.__call__ would build (lib/dataset/collater.py:14-26).
+ * images / crops: DEVICE tables (the caller uploads both in one pinned, stream-ordered copy); crops[p].image indexes `images`;
+ * the crops of an image must be consecutive for the model's `length` list to describe them, the kernel itself does not care.
+ * mean / inv_std: HOST float[3] (passed on as kernel arguments). */
+typedef struct {
+    const unsigned char* img;      /* device uint8 [ih, iw, 3], channel order as cv2.imread delivers it */
+    int32_t ih, iw, row_bytes, reserved;
+} i2r_image_ref;                   /* 24 bytes */
+typedef struct {
+    double inv_m[6];               /* the INVERSE of get_affine_transform(center, scale, 0, size) in double, as cv2.warpAffine derives it */
+    int32_t box[4];                /* (int(x), int(y), int(x + w), int(y + h)): the inclusive corners cv2.rectangle fills */
+    int32_t image;                 /* index into the image table */
+    int32_t reserved[3];
+} i2r_crop_ref;                    /* 80 bytes */
+int i2r_person_inputs_cv2(const i2r_image_ref* images, int32_t n_images, const i2r_crop_ref* crops, int32_t n_crops, int32_t swap_rb,
+                          const float* mean, const float* inv_std, float* x_out, float* mask_out, int32_t oh, int32_t ow, void* stream);
+
 /* ---- HRFormer-B glue (reference lib/models/hrformer.py) ---------------------------------------------------- */
 /* i2r_layernorm -- nn.LayerNorm(c, eps) over the channels of every pixel/token of an NHWC tensor
  * (GeneralTransformerBlock.norm1/norm2, hrformer.py:1198,1235-1237). w, b: [cs] zero-padded. */

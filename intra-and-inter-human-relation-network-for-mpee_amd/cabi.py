@@ -139,13 +139,21 @@ class ConvChainArgs(C.Structure):
                 ("lds_bytes", _i32), ("tiles", (_i32 * 4) * MAX_GROUP)]
 
 
+class ImageRef(C.Structure):   # i2r_image_ref (24 bytes)
+    _fields_ = [("img", C.c_void_p), ("ih", _i32), ("iw", _i32), ("row_bytes", _i32), ("reserved", _i32)]
+
+
+class CropRef(C.Structure):    # i2r_crop_ref (80 bytes)
+    _fields_ = [("inv_m", C.c_double * 6), ("box", _i32 * 4), ("image", _i32), ("reserved", _i32 * 3)]
+
+
 class Op(C.Structure):
     _fields_ = [("kind", _i32), ("lane", _i32), ("args", C.c_void_p)]
 
 
 # every symbol include/i2r_hip.h declares (tests/test_host.py::test_cabi_library_exports_every_declared_symbol checks the built library exports them all)
 EXPORTS = ("i2r_conv", "i2r_conv_grouped", "i2r_conv_kernel_name", "i2r_stem_conv", "i2r_pe_res_stem", "i2r_maxpool3x3s2", "i2r_head", "i2r_layernorm", "i2r_window_attn", "i2r_hrt_attn_block", "i2r_hrt_mlp_block", "i2r_dwconv3x3",
-           "i2r_upsample_bilinear_add", "i2r_upsample_bilinear_add_multi", "i2r_fuse_up_add", "i2r_conv1x1_pair", "i2r_conv1x1_lp", "i2r_flip_merge", "i2r_decode", "i2r_crop_affine", "i2r_box_mask", "i2r_crop_affine_cv2", "i2r_box_mask_cv2", "i2r_conv_chain_pack", "i2r_conv_chain", "i2r_encoder_kv", "i2r_encoder_layer",
+           "i2r_upsample_bilinear_add", "i2r_upsample_bilinear_add_multi", "i2r_fuse_up_add", "i2r_conv1x1_pair", "i2r_conv1x1_lp", "i2r_flip_merge", "i2r_decode", "i2r_crop_affine", "i2r_box_mask", "i2r_crop_affine_cv2", "i2r_box_mask_cv2", "i2r_person_inputs_cv2", "i2r_conv_chain_pack", "i2r_conv_chain", "i2r_encoder_kv", "i2r_encoder_layer",
            "i2r_run_program", "i2r_abi_version", "i2r_last_error", "i2r_device_check")
 
 _LIB = None
@@ -175,6 +183,7 @@ def load_library(path=LIB_PATH):
     L.i2r_box_mask.argtypes = [_fp, _i32, _i32, _fp, _i32, _i32, _i32, C.c_void_p]
     L.i2r_crop_affine_cv2.argtypes = [_fp, _i32, _i32, _i32, _i32, _fp, _fp, _fp, _fp, _i32, _i32, _i32, C.c_void_p]
     L.i2r_box_mask_cv2.argtypes = [_fp, _i32, _i32, _fp, _i32, _i32, _i32, C.c_void_p]
+    L.i2r_person_inputs_cv2.argtypes = [_fp, _i32, _fp, _i32, _i32, C.POINTER(C.c_float), C.POINTER(C.c_float), _fp, _fp, _i32, _i32, C.c_void_p]
     L.i2r_fuse_up_add.argtypes = [_fp, _fp, _i32, _fp, _i32, _fp, _i32, _i32, _i32, _i32, _i32, _i32, C.c_void_p]
     L.i2r_conv1x1_pair.argtypes = [C.POINTER(Conv1x1PairArgs), C.c_void_p]
     L.i2r_conv1x1_lp.argtypes = [C.POINTER(Conv1x1LpArgs), C.c_void_p]

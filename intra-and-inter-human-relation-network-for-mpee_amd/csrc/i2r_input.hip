@@ -72,15 +72,9 @@ __device__ __forceinline__ void cv2_tab(int fx, int fy, int (&w)[4]) {
 
 // cv2.warpAffine(img, trans, (ow, oh), INTER_LINEAR), BORDER_CONSTANT 0, then ToTensor + Normalize.  m: the INVERSE map in double, as
 // cv2 derives it from `trans`; coordinates on the 1/32 grid: X = (rint((m1 y + m2) 1024) + 16 + rint(m0 x 1024)) >> 5.
-__global__ __launch_bounds__(256) void crop_affine_cv2_k(const unsigned char* __restrict__ img, int ih, int iw, int row_bytes, int swap_rb,
-                                                         const double* __restrict__ inv_m, const float* __restrict__ mean,
-                                                         const float* __restrict__ inv_std, float* __restrict__ out, int n, int oh, int ow) {
-    const long long gid = (long long)blockIdx.x * 256 + threadIdx.x;
-    if (gid >= (long long)n * oh * ow) return;
-    const int x = (int)(gid % ow);
-    const int y = (int)((gid / ow) % oh);
-    const int p = (int)(gid / ((long long)ow * oh));
-    const double* m = inv_m + p * 6;
+struct Norm3 { float mean[3], inv_std[3]; };
+__device__ __forceinline__ void crop_pixel_cv2(const unsigned char* __restrict__ img, int ih, int iw, int row_bytes, int swap_rb,
+                                               const double* __restrict__ m, const Norm3& nm, float* __restrict__ out_p, int x, int y, int oh, int ow) {
     const long long X = (llrint((m[1] * y + m[2]) * 1024.0) + 16 + llrint(m[0] * x * 1024.0)) >> 5;
     const long long Y = (llrint((m[4] * y + m[5]) * 1024.0) + 16 + llrint(m[3] * x * 1024.0)) >> 5;
     const long long sxl = X >> 5, syl = Y >> 5;
@@ -98,21 +92,26 @@ __global__ __launch_bounds__(256) void crop_affine_cv2_k(const unsigned char* __
 #pragma unroll
     for (int c = 0; c < 3; ++c) {
         const int v = min(max(acc[c] >> 15, 0), 255);
-        out[(((size_t)p * 3 + c) * oh + y) * ow + x] = ((float)v * (1.f / 255.f) - mean[c]) * inv_std[c];
+        out_p[((size_t)c * oh + y) * ow + x] = ((float)v * (1.f / 255.f) - nm.mean[c]) * nm.inv_std[c];
     }
 }
-
-// get_position + rotate_bound(., 0) + cv2.resize(., (ow, oh)) + ToTensor, all in cv2's 8-bit arithmetic: the filled rectangle (255) is
-// first shifted by half a pixel along every odd image dimension (rotate_bound's nW / 2 - w // 2, a fixed-point warp), then resized
-// with 11-bit coefficients: ((b0 (H0 >> 4)) >> 16) + ((b1 (H1 >> 4)) >> 16) + 2 >> 2.
-__global__ __launch_bounds__(256) void box_mask_cv2_k(const int* __restrict__ boxes, int ih, int iw, float* __restrict__ out, int n, int oh,
-                                                      int ow) {
+__global__ __launch_bounds__(256) void crop_affine_cv2_k(const unsigned char* __restrict__ img, int ih, int iw, int row_bytes, int swap_rb,
+                                                         const double* __restrict__ inv_m, const float* __restrict__ mean,
+                                                         const float* __restrict__ inv_std, float* __restrict__ out, int n, int oh, int ow) {
     const long long gid = (long long)blockIdx.x * 256 + threadIdx.x;
     if (gid >= (long long)n * oh * ow) return;
     const int x = (int)(gid % ow);
     const int y = (int)((gid / ow) % oh);
     const int p = (int)(gid / ((long long)ow * oh));
-    const int bx0 = max(boxes[p * 4], 0), by0 = max(boxes[p * 4 + 1], 0), bx1 = min(boxes[p * 4 + 2], iw - 1), by1 = min(boxes[p * 4 + 3], ih - 1);
+    const Norm3 nm = {{mean[0], mean[1], mean[2]}, {inv_std[0], inv_std[1], inv_std[2]}};
+    crop_pixel_cv2(img, ih, iw, row_bytes, swap_rb, inv_m + p * 6, nm, out + (size_t)p * 3 * oh * ow, x, y, oh, ow);
+}
+
+// get_position + rotate_bound(., 0) + cv2.resize(., (ow, oh)) + ToTensor, all in cv2's 8-bit arithmetic: the filled rectangle (255) is
+// first shifted by half a pixel along every odd image dimension (rotate_bound's nW / 2 - w // 2, a fixed-point warp), then resized
+// with 11-bit coefficients: ((b0 (H0 >> 4)) >> 16) + ((b1 (H1 >> 4)) >> 16) + 2 >> 2.
+__device__ __forceinline__ float mask_pixel_cv2(const int* __restrict__ box, int ih, int iw, int x, int y, int oh, int ow) {
+    const int bx0 = max(box[0], 0), by0 = max(box[1], 0), bx1 = min(box[2], iw - 1), by1 = min(box[3], ih - 1);
     const int ox = iw & 1, oy = ih & 1;  // odd dimension: source coordinate = pixel - 1/2, i.e. taps (pixel - 1, pixel) at fraction 16/32
     int wt[4];
     cv2_tab(16 * ox, 16 * oy, wt);
@@ -141,10 +140,48 @@ __global__ __launch_bounds__(256) void box_mask_cv2_k(const int* __restrict__ bo
     const int h0 = shifted(x0, y0) * a0 + shifted(x1, y0) * a1;
     const int h1 = shifted(x0, y1) * a0 + shifted(x1, y1) * a1;
     const int v = (((b0 * (h0 >> 4)) >> 16) + ((b1 * (h1 >> 4)) >> 16) + 2) >> 2;
-    out[((size_t)p * oh + y) * ow + x] = (float)min(max(v, 0), 255) * (1.f / 255.f);
+    return (float)min(max(v, 0), 255) * (1.f / 255.f);
+}
+__global__ __launch_bounds__(256) void box_mask_cv2_k(const int* __restrict__ boxes, int ih, int iw, float* __restrict__ out, int n, int oh,
+                                                      int ow) {
+    const long long gid = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (gid >= (long long)n * oh * ow) return;
+    const int x = (int)(gid % ow);
+    const int y = (int)((gid / ow) % oh);
+    const int p = (int)(gid / ((long long)ow * oh));
+    out[((size_t)p * oh + y) * ow + x] = mask_pixel_cv2(boxes + p * 4, ih, iw, x, y, oh, ow);
+}
+
+// the whole batch of a validate() step in ONE launch: every person crop of every image + its box mask, written straight into the
+// collated [S, 3, oh, ow] / [S, 1, oh, ow] tensors (collater.py:14-26); images and crops are described by two device tables
+__global__ __launch_bounds__(256) void person_inputs_cv2_k(const i2r_image_ref* __restrict__ images, const i2r_crop_ref* __restrict__ crops,
+                                                           int swap_rb, Norm3 nm, float* __restrict__ x_out, float* __restrict__ m_out, int n,
+                                                           int oh, int ow) {
+    const long long gid = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (gid >= (long long)n * oh * ow) return;
+    const int x = (int)(gid % ow);
+    const int y = (int)((gid / ow) % oh);
+    const int p = (int)(gid / ((long long)ow * oh));
+    const i2r_crop_ref* cr = crops + p;
+    const i2r_image_ref im = images[cr->image];
+    crop_pixel_cv2(im.img, im.ih, im.iw, im.row_bytes, swap_rb, cr->inv_m, nm, x_out + (size_t)p * 3 * oh * ow, x, y, oh, ow);
+    m_out[((size_t)p * oh + y) * ow + x] = mask_pixel_cv2(cr->box, im.ih, im.iw, x, y, oh, ow);
 }
 
 }  // namespace
+
+extern "C" int i2r_person_inputs_cv2(const i2r_image_ref* images, int32_t n_images, const i2r_crop_ref* crops, int32_t n_crops, int32_t swap_rb,
+                                     const float* mean, const float* inv_std, float* x_out, float* mask_out, int32_t oh, int32_t ow, void* stream) {
+    I2R_CHECK_ARG(images && crops && mean && inv_std && x_out && mask_out, "i2r_person_inputs_cv2: null pointer");
+    I2R_CHECK_ARG(n_images > 0 && n_crops > 0 && oh > 0 && ow > 0, "i2r_person_inputs_cv2: sizes");
+    Norm3 nm;
+    for (int c = 0; c < 3; ++c) { nm.mean[c] = mean[c]; nm.inv_std[c] = inv_std[c]; }  // (HOST arrays: they travel as kernel arguments)
+    const long long nthr = (long long)n_crops * oh * ow;
+    hipLaunchKernelGGL(person_inputs_cv2_k, dim3((unsigned)((nthr + 255) / 256)), dim3(256), 0, (hipStream_t)stream, images, crops, swap_rb, nm,
+                       x_out, mask_out, n_crops, oh, ow);
+    I2R_CHECK_LAUNCH("i2r_person_inputs_cv2");
+    return I2R_OK;
+}
 
 extern "C" int i2r_crop_affine_cv2(const unsigned char* img, int32_t ih, int32_t iw, int32_t row_bytes, int32_t swap_rb, const double* inv_m,
                                    const float* mean, const float* inv_std, float* out, int32_t n, int32_t oh, int32_t ow, void* stream) {

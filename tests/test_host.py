@@ -121,7 +121,7 @@ def test_struct_layouts_match_header():
     src = r'''
 #include <stdio.h>
 #include "i2r_hip.h"
-int main(void){ printf("%zu %zu %zu %zu %zu %zu %zu %zu %zu %zu %zu %zu %zu %zu %zu %zu %zu\n", sizeof(i2r_conv1x1_lp_args), sizeof(i2r_conv1x1_pair_args), sizeof(i2r_fuse_up_args), sizeof(i2r_hrt_mlp_args), sizeof(i2r_hrt_attn_args), sizeof(i2r_pe_res_args), sizeof(i2r_conv_desc), sizeof(i2r_encoder_desc), sizeof(i2r_stem_args),
+int main(void){ printf("%zu %zu %zu %zu %zu %zu %zu %zu %zu %zu %zu %zu %zu %zu %zu %zu %zu %zu %zu\n", sizeof(i2r_image_ref), sizeof(i2r_crop_ref), sizeof(i2r_conv1x1_lp_args), sizeof(i2r_conv1x1_pair_args), sizeof(i2r_fuse_up_args), sizeof(i2r_hrt_mlp_args), sizeof(i2r_hrt_attn_args), sizeof(i2r_pe_res_args), sizeof(i2r_conv_desc), sizeof(i2r_encoder_desc), sizeof(i2r_stem_args),
  sizeof(i2r_pool_args), sizeof(i2r_head_args), sizeof(i2r_op), sizeof(i2r_conv_group_args), sizeof(i2r_ln_args), sizeof(i2r_winattn_args), sizeof(i2r_dw_args), sizeof(i2r_up_args)); return 0; }
 '''
     import tempfile
@@ -131,7 +131,7 @@ int main(void){ printf("%zu %zu %zu %zu %zu %zu %zu %zu %zu %zu %zu %zu %zu %zu 
         exe = os.path.join(td, "s")
         subprocess.check_call(["gcc", "-I", os.path.join(ROOT, "include"), c, "-o", exe])
         sizes = [int(v) for v in subprocess.check_output([exe]).split()]
-    mine = [ctypes.sizeof(t) for t in (cabi.Conv1x1LpArgs, cabi.Conv1x1PairArgs, cabi.FuseUpArgs, cabi.HrtMlpArgs, cabi.HrtAttnArgs, cabi.PeResArgs, cabi.ConvDesc, cabi.EncoderDesc, cabi.StemArgs, cabi.PoolArgs, cabi.HeadArgs, cabi.Op, cabi.ConvGroupArgs, cabi.LnArgs,
+    mine = [ctypes.sizeof(t) for t in (cabi.ImageRef, cabi.CropRef, cabi.Conv1x1LpArgs, cabi.Conv1x1PairArgs, cabi.FuseUpArgs, cabi.HrtMlpArgs, cabi.HrtAttnArgs, cabi.PeResArgs, cabi.ConvDesc, cabi.EncoderDesc, cabi.StemArgs, cabi.PoolArgs, cabi.HeadArgs, cabi.Op, cabi.ConvGroupArgs, cabi.LnArgs,
                                        cabi.WinAttnArgs, cabi.DwArgs, cabi.UpArgs)]
     assert sizes == mine
 
@@ -268,3 +268,18 @@ def test_module_tensors_survive_dataparallel_replication():
     assert set(got) == set(sd)
     assert all(torch.equal(got[k], sd[k]) and got[k].data_ptr() != sd[k].data_ptr() for k in sd)
     assert rep._engines is net._engines, "replicas share the per-device engine table"
+
+
+def test_batched_affine_transforms_equal_the_scalar_functions():
+    """input.affine_transforms / cv2_inverse_batch (one numpy call for all crops of a batch, bench.py --pipeline) reproduce
+    get_affine_transform(., ., 0, size) / cv2_inverse (lib/utils/transforms.py:61-96) bit for bit"""
+    import numpy as np
+    from i2r_amd import input as inp
+    rng = np.random.default_rng(3)
+    cen = rng.uniform(-20, 600, (40, 2)).astype(np.float32)
+    scl = rng.uniform(0.2, 4.0, (40, 2)).astype(np.float32)
+    for size in ((192, 256), (288, 384)):
+        a = inp.affine_transforms(cen, scl, size)
+        b = np.stack([inp.get_affine_transform(cen[i], scl[i], 0, size) for i in range(40)])
+        assert np.array_equal(a, b)
+        assert np.array_equal(inp.cv2_inverse_batch(a), np.stack([inp.cv2_inverse(t).reshape(6) for t in b]))

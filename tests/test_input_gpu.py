@@ -66,6 +66,22 @@ def test_crops_and_masks_cv2_fixed_point(ih, iw, n, rgb):
     assert (x - x32).abs().mean().item() < 0.02
 
 
+def test_person_inputs_batch_is_bit_identical_to_per_image_path():
+    """input.person_inputs_batch (ONE launch + ONE table upload for all persons of all images of a batch, images of different sizes)
+    writes exactly what person_inputs per image + collate produce, and hands centres / scales over as device tensors"""
+    scenes = [_scene(11, 240, 320, 3), _scene(12, 333, 517, 1), _scene(13, 121, 90, 2)]
+    per_image = [inp.person_inputs(*sc, (192, 256), color_rgb=True) for sc in scenes]
+    x_ref, m_ref, len_ref = inp.collate(per_image)
+    imgs = [torch.from_numpy(sc[0]).cuda() for sc in scenes]
+    x, m, length, cen, scl = inp.person_inputs_batch(imgs, [sc[1] for sc in scenes], [sc[2] for sc in scenes], [sc[3] for sc in scenes],
+                                                     (192, 256), color_rgb=True)
+    torch.cuda.synchronize()
+    assert length == len_ref == [3, 1, 2]
+    assert torch.equal(x, x_ref) and torch.equal(m, m_ref)
+    assert np.array_equal(cen.cpu().numpy(), np.concatenate([np.stack(sc[1]) for sc in scenes]).astype(np.float32))
+    assert np.array_equal(scl.cpu().numpy(), np.concatenate([np.stack(sc[2]) for sc in scenes]).astype(np.float32))
+
+
 def test_image_to_heatmaps_chain():
     """image bytes -> device crops / masks -> collate -> model: the crops of one image, collated with a second image's, give the same
     heat maps as running that image alone (and the forward accepts what the input side produces)."""
