@@ -58,6 +58,17 @@ __device__ __forceinline__ f32x4 quad_transpose(f32x4 v, int j) {
     return v;
 }
 
+// XCD-banded work-item order for kernels whose items are listed in (image, row, column) order: workgroup b runs on XCD b % 8 (observed
+// dispatch rule, MI355X_MICROARCH.md -- used for speed only), so XCD x is handed the CONTIGUOUS eighth [x total / 8, (x + 1) total / 8) of
+// the list.  Two consecutive kernels that walk the same map in this order (the attention and MLP halves of a transformer block, whose
+// 7x7 windows and 8x6 tiles do not coincide) then touch the same band of pixel rows from the same XCD: what one wrote with plain
+// stores is still in that XCD's 4 MB L2 when the next one reads it.  Launch 8 * ceil(total / 8) workgroups; -1 = nothing to do.
+__device__ __forceinline__ int xcd_band_item(int b, int total) {
+    const int x = b & 7, q = b >> 3;
+    const int lo = (int)(((long long)x * total) >> 3), hi = (int)(((long long)(x + 1) * total) >> 3);
+    return lo + q < hi ? lo + q : -1;
+}
+
 void i2r_set_error(const char* fmt, ...);
 
 #define I2R_CHECK_ARG(cond, ...)            \

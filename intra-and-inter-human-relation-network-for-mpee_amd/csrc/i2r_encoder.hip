@@ -325,11 +325,6 @@ __global__ __launch_bounds__(256, 2) void enc_layer4_k(const EncK p) {
         slot = xcd * (p.tiles_per_xcd - F) + (qh >> 1);
     }
     if (v >= p.n_qblk) return;
-#ifdef I2R_ENC_WHOLE_PRIO
-    // A/B knob: in a partial-split launch the whole tiles are the longest chains (start-up + ALL keys + tail, tools/stamp_enc.py):
-    // let them win the SIMD's issue arbitration against the half-tile workgroup they share it with
-    if constexpr (KS == 2) { if (!split) __builtin_amdgcn_s_setprio(I2R_ENC_WHOLE_PRIO); }
-#endif
     const Tile t = locate_tile<QT>(p, v, lane, gs0, ge0);
     if (tid * 4 < P_END) *reinterpret_cast<f32x4*>(Ps + tid * 4) = pstage;  // (visible after the barrier that follows the q projection)
     const int gs = t.gs, ge = t.ge;

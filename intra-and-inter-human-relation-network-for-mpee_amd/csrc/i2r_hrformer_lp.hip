@@ -64,7 +64,7 @@ struct AttnK {
     const float* ln_w; const float* ln_b;
     const f32x4* wqkv; const float* bqkv;   // [head][q,k,v][KS k-steps][3 dim blocks][64 lanes] 16-byte fragments; [head][3][48] biases
     const f32x4* wo; const float* bo;       // [CB out blocks][HEADS*3/2 k-steps][64 lanes] (columns in slot order); [cs]
-    int n_img, h, w, c, nwy, nwx, pad_top, pad_left;
+    int n_img, h, w, c, nwy, nwx, pad_top, pad_left, total;
     float eps;
 };
 
@@ -81,22 +81,9 @@ struct AttnK {
 #ifndef I2R_ATT_OCC156
 #define I2R_ATT_OCC156 4
 #endif
-#ifndef I2R_ABL
-#define I2R_ABL 0   // ablation bits for timing studies only (results become garbage): 1 weight stream from one address, 2 no LDS K/V traffic,
-#endif              // 4 no exp, 8 no barriers, 16 no x loads, 32 no stores, 64 no MFMAs
-constexpr int ABL = I2R_ABL;
-template <int DT>
-__device__ __forceinline__ f32x4 mm(f32x4 a, f32x4 b, f32x4 c) {
-    if constexpr (ABL & 64) return c + a * b[0];
-    else return mfma32_lp<DT>(a, b, c);
-}
-__device__ __forceinline__ void wg_barrier() {
-    if constexpr (!(ABL & 8)) __syncthreads();
-}
-__device__ __forceinline__ f32x4 lds16(const unsigned short* q, f32x4 alt) {  // one A operand from LDS (ablation 2: a register value instead)
-    if constexpr (ABL & 2) return alt;
-    else return *reinterpret_cast<const f32x4*>(q);
-}
+#ifndef I2R_XCD_BAND
+#define I2R_XCD_BAND 1   // A/B knob: 0 = windows in plain blockIdx order
+#endif
 constexpr int ROW = 64;  // 16-bit elements per LDS row (K: key x 64 dim slots; V^T: dim x 64 key slots) = 8 chunks of 16 bytes
 
 template <int DT, int CB, int HEADS, int HG, int RB>
@@ -110,7 +97,8 @@ __global__ __launch_bounds__(256 * HG, HG == 1 ? I2R_ATT_OCC78 : I2R_ATT_OCC156)
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, li = lane & 15, g = lane >> 4;
     const int tg = wave & 3, hg = wave >> 2;
     unsigned short* const kv = reinterpret_cast<unsigned short*>(smem) + hg * 2 * KV_EL;
-    int bid = blockIdx.x;
+    int bid = I2R_XCD_BAND ? xcd_band_item(blockIdx.x, p.total) : (int)blockIdx.x;  // (workgroup-uniform)
+    if (bid < 0 || bid >= p.total) return;
     const int wx = bid % p.nwx; bid /= p.nwx;
     const int wy = bid % p.nwy;
     const int img = bid / p.nwy;
@@ -118,8 +106,7 @@ __global__ __launch_bounds__(256 * HG, HG == 1 ? I2R_ATT_OCC78 : I2R_ATT_OCC156)
     const int t = tg * 16 + li;
     const int ty = t / 7, tx = t - ty * 7;
     const int y = wy * 7 + ty - p.pad_top, x = wx * 7 + tx - p.pad_left;
-    const bool inmap = (ABL & 16) ? false : (t < 49 && y >= 0 && y < p.h && x >= 0 && x < p.w);
-    const bool wr = (ABL & 32) ? (p.eps == 123.f) : ((ABL & 16) ? t < 49 : inmap);
+    const bool inmap = t < 49 && y >= 0 && y < p.h && x >= 0 && x < p.w;
     const size_t row = (((size_t)img * p.h + (inmap ? y : 0)) * p.w + (inmap ? x : 0)) * cs;
     const int sw = (li >> 1) & 7;  // swizzle of a row this lane READS as A operand (rows 16 b + li)
 
@@ -127,7 +114,7 @@ __global__ __launch_bounds__(256 * HG, HG == 1 ? I2R_ATT_OCC78 : I2R_ATT_OCC156)
     //      that consecutive MFMAs go to three different accumulators (a dependent 16x16x32 chain would stall the wave at every link) ----
     f32x4 wf[RB][3];
     auto fetch = [&](int slot, int u) {
-        const f32x4* src = p.wqkv + ((size_t)hg * NU + ((ABL & 1) ? 0 : u)) * 3 * 64 + lane;
+        const f32x4* src = p.wqkv + ((size_t)hg * NU + u) * 3 * 64 + lane;
 #pragma unroll
         for (int db = 0; db < 3; ++db) wf[slot][db] = src[db * 64];
     };
@@ -192,13 +179,11 @@ __global__ __launch_bounds__(256 * HG, HG == 1 ? I2R_ATT_OCC78 : I2R_ATT_OCC156)
                 const int u = (j * 3 + part) * KS + s;
                 if (u + RB - 1 < NU) fetch((u + RB - 1) % RB, u + RB - 1);
 #pragma unroll
-                for (int db = 0; db < 3; ++db) acc[db] = mm<DT>(wf[u % RB][db], xn[s], acc[db]);
+                for (int db = 0; db < 3; ++db) acc[db] = mfma32_lp<DT>(wf[u % RB][db], xn[s], acc[db]);
             }
             if (part == 0) {
 #pragma unroll
                 for (int db = 0; db < 3; ++db) q[db] = acc[db];
-            } else if ((ABL & 2) && part > 0) {
-                q[0] += acc[0] + acc[1] + acc[2];  // (ablation: keep the projections alive without LDS traffic)
             } else if (part == 1) {
                 // K[key t][dims 16 db + 4g ..]: slot chunk (db >> 1) * 4 + g, half db & 1; block 2 fills its (empty) partner half with zeros
                 const int c0 = (g ^ ((t >> 1) & 7)) * 8, c1 = ((4 + g) ^ ((t >> 1) & 7)) * 8;
@@ -217,15 +202,15 @@ __global__ __launch_bounds__(256 * HG, HG == 1 ? I2R_ATT_OCC78 : I2R_ATT_OCC156)
             }
         }
         const f32x4 qB0 = pack8<DT>(q[0], q[1]), qB1 = pack8<DT>(q[2], (f32x4){0.f, 0.f, 0.f, 0.f});
-        wg_barrier();
+        __syncthreads();
         // ---- S^T[key][query] for the 64 keys (k-step-major: four independent accumulators), softmax over the 49 real ones (base 2) ----
         f32x4 st[4];
 #pragma unroll
         for (int kf = 0; kf < 4; ++kf)
-            st[kf] = mm<DT>(lds16(kb + (16 * kf + li) * ROW + ((0 + g) ^ sw) * 8, qB1), qB0, (f32x4){0.f, 0.f, 0.f, 0.f});
+            st[kf] = mfma32_lp<DT>(*reinterpret_cast<const f32x4*>(kb + (16 * kf + li) * ROW + ((0 + g) ^ sw) * 8), qB0, (f32x4){0.f, 0.f, 0.f, 0.f});
 #pragma unroll
         for (int kf = 0; kf < 4; ++kf)
-            st[kf] = mm<DT>(lds16(kb + (16 * kf + li) * ROW + ((4 + g) ^ sw) * 8, qB0), qB1, st[kf]);
+            st[kf] = mfma32_lp<DT>(*reinterpret_cast<const f32x4*>(kb + (16 * kf + li) * ROW + ((4 + g) ^ sw) * 8), qB1, st[kf]);
         float mx = -__builtin_inff();
 #pragma unroll
         for (int kf = 0; kf < 4; ++kf)
@@ -240,7 +225,7 @@ __global__ __launch_bounds__(256 * HG, HG == 1 ? I2R_ATT_OCC78 : I2R_ATT_OCC156)
         for (int kf = 0; kf < 4; ++kf)
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                st[kf][r] = (ABL & 4) ? st[kf][r] - mx : __builtin_amdgcn_exp2f(st[kf][r] - mx);
+                st[kf][r] = __builtin_amdgcn_exp2f(st[kf][r] - mx);
                 sum += st[kf][r];
             }
         const f32x4 pB0 = pack8<DT>(st[0], st[1]), pB1 = pack8<DT>(st[2], st[3]);
@@ -249,10 +234,10 @@ __global__ __launch_bounds__(256 * HG, HG == 1 ? I2R_ATT_OCC78 : I2R_ATT_OCC156)
         f32x4 o[3];
 #pragma unroll
         for (int db = 0; db < 3; ++db)
-            o[db] = mm<DT>(lds16(vt + (16 * db + li) * ROW + ((0 + g) ^ sw) * 8, pB1), pB0, (f32x4){0.f, 0.f, 0.f, 0.f});
+            o[db] = mfma32_lp<DT>(*reinterpret_cast<const f32x4*>(vt + (16 * db + li) * ROW + ((0 + g) ^ sw) * 8), pB0, (f32x4){0.f, 0.f, 0.f, 0.f});
 #pragma unroll
         for (int db = 0; db < 3; ++db)
-            o[db] = mm<DT>(lds16(vt + (16 * db + li) * ROW + ((4 + g) ^ sw) * 8, pB0), pB1, o[db]);
+            o[db] = mfma32_lp<DT>(*reinterpret_cast<const f32x4*>(vt + (16 * db + li) * ROW + ((4 + g) ^ sw) * 8), pB1, o[db]);
 #pragma unroll
         for (int db = 0; db < 3; ++db) of[j * 3 + db] = o[db] * inv;
         // (no second barrier: the next head writes the other K / V^T buffer, and the one after that is separated by the next barrier)
@@ -274,14 +259,14 @@ __global__ __launch_bounds__(256 * HG, HG == 1 ? I2R_ATT_OCC78 : I2R_ATT_OCC156)
         f32x4 wv[2][NB];
         auto fetch_o = [&](int slot, int s) {
 #pragma unroll
-            for (int i = 0; i < NB; ++i) wv[slot][i] = p.wo[((ABL & 1) ? (size_t)i : ((size_t)(ob0 + i) * OSG + hg * OS + s)) * 64 + lane];
+            for (int i = 0; i < NB; ++i) wv[slot][i] = p.wo[((size_t)(ob0 + i) * OSG + hg * OS + s) * 64 + lane];
         };
         fetch_o(0, 0);
 #pragma unroll
         for (int s = 0; s < OS; ++s) {
             if (s + 1 < OS) fetch_o((s + 1) & 1, s + 1);
 #pragma unroll
-            for (int i = 0; i < NB; ++i) acc[i] = mm<DT>(wv[s & 1][i], oB[s], acc[i]);
+            for (int i = 0; i < NB; ++i) acc[i] = mfma32_lp<DT>(wv[s & 1][i], oB[s], acc[i]);
         }
     };
     if constexpr (HG == 1) {
@@ -291,7 +276,7 @@ __global__ __launch_bounds__(256 * HG, HG == 1 ? I2R_ATT_OCC78 : I2R_ATT_OCC156)
         outgroup(0, acc);
 #pragma unroll
         for (int ob = 0; ob < CB; ++ob)
-            if (wr) *reinterpret_cast<f32x4*>(p.out + row + 16 * ob + 4 * g) = acc[ob] + xres[ob];
+            if (inmap) *reinterpret_cast<f32x4*>(p.out + row + 16 * ob + 4 * g) = acc[ob] + xres[ob];
     } else {
         f32x4* const red = reinterpret_cast<f32x4*>(smem);  // [tg][hg of the OWNER][OWN blocks][64 lanes]
         const int other = hg ^ 1;
@@ -302,22 +287,22 @@ __global__ __launch_bounds__(256 * HG, HG == 1 ? I2R_ATT_OCC78 : I2R_ATT_OCC156)
             mine[i] = *reinterpret_cast<const f32x4*>(p.bo + 16 * (hg * OWN + i) + 4 * g);
         }
         outgroup(other * OWN, theirs);  // the partner's blocks first: it waits for them
-        wg_barrier();  // every wave has finished reading K / V^T of the last head: the area becomes the exchange buffer
+        __syncthreads();  // every wave has finished reading K / V^T of the last head: the area becomes the exchange buffer
 #pragma unroll
         for (int i = 0; i < OWN; ++i) red[((tg * HG + other) * OWN + i) * 64 + lane] = theirs[i];
         outgroup(hg * OWN, mine);
-        wg_barrier();
+        __syncthreads();
 #pragma unroll
         for (int i = 0; i < OWN; ++i) {
             const f32x4 o = (mine[i] + red[((tg * HG + hg) * OWN + i) * 64 + lane]) + xres[i];
-            if (wr) *reinterpret_cast<f32x4*>(p.out + row + 16 * (hg * OWN + i) + 4 * g) = o;
+            if (inmap) *reinterpret_cast<f32x4*>(p.out + row + 16 * (hg * OWN + i) + 4 * g) = o;
         }
     }
 }
 
 template <int DT>
 int launch(const AttnK& k, int heads, long long nblk, hipStream_t stream) {
-    const dim3 grid((unsigned)nblk);
+    const dim3 grid((unsigned)((nblk + 7) / 8 * 8));
     if (heads == 2) hipLaunchKernelGGL((hrt_attn_block_k<DT, 5, 2, 1, I2R_ATT_RB78>), grid, dim3(256), 0, stream, k);
     else hipLaunchKernelGGL((hrt_attn_block_k<DT, 10, 4, 2, I2R_ATT_RB156>), grid, dim3(512), 0, stream, k);
     return 0;
@@ -338,7 +323,8 @@ extern "C" int i2r_hrt_attn_block(const float* x, float* out, const float* ln_w,
     k.nwy = (h + 6) / 7; k.nwx = (w + 6) / 7;
     k.pad_top = (k.nwy * 7 - h) / 2; k.pad_left = (k.nwx * 7 - w) / 2;
     const long long nblk = (long long)n_img * k.nwy * k.nwx;
-    I2R_CHECK_ARG(nblk > 0 && nblk < (1ll << 31), "i2r_hrt_attn_block: grid");
+    I2R_CHECK_ARG(nblk > 0 && nblk < (1ll << 30), "i2r_hrt_attn_block: grid");
+    k.total = (int)nblk;
     if (dtype == 1) launch<1>(k, heads, nblk, (hipStream_t)stream);
     else launch<2>(k, heads, nblk, (hipStream_t)stream);
     I2R_CHECK_LAUNCH("i2r_hrt_attn_block");

@@ -30,16 +30,9 @@
 
 namespace {
 
-#ifndef I2R_ABL
-#define I2R_ABL 0   // ablation bits for timing studies only (results become garbage): 1 weight fragments from one address, 2 GELU -> identity,
-#endif              // 4 no depth-wise LDS reads, 8 no hidden-tile stores, 16 no MFMAs, 32 no x loads / stores, 64 no depth-wise FMAs
-constexpr int ABL = I2R_ABL;
-template <int DT>
-__device__ __forceinline__ f32x4 mm(f32x4 a, f32x4 b, f32x4 c) {
-    if constexpr (ABL & 16) return c + a * b[0];
-    else return mfma32_lp<DT>(a, b, c);
-}
-
+#ifndef I2R_XCD_BAND
+#define I2R_XCD_BAND 1   // A/B knob: 0 = tiles in plain blockIdx order
+#endif
 template <int DT>
 __device__ __forceinline__ uint2 pack4(f32x4 v) {
     if constexpr (DT == 1) {
@@ -68,7 +61,7 @@ struct MlpK {
     const f32x4* w1; const float* b1;     // fc1 (+BN1): 32-deep fragments [hidden block][KS k-steps][64 lanes]; bias [hidden_pad]
     const float* wdw; const float* bdw;   // depth-wise 3x3 (+BN2): [9][hidden_pad] tap-major; bias [hidden_pad]
     const f32x4* w2; const float* b2;     // fc2 (+BN3): 32-deep fragments [CB out blocks][hidden block pairs][64 lanes] (slot order); bias [cs]
-    int n_img, h, w, c, tiles_y, tiles_x;
+    int n_img, h, w, c, tiles_y, tiles_x, total;
     float eps;
 };
 
@@ -111,7 +104,6 @@ __device__ __forceinline__ f32x2 gelu2(f32x2 x, const GeluC& k) {
 }
 template <int DEG>
 __device__ __forceinline__ f32x4 gelu4(f32x4 v, const GeluC& k) {
-    if constexpr (ABL & 2) return v;
     const f32x2 lo = gelu2<DEG>(v.xy, k), hi = gelu2<DEG>(v.zw, k);
     return (f32x4){lo[0], lo[1], hi[0], hi[1]};
 }
@@ -140,7 +132,8 @@ __global__ __launch_bounds__(NBG * 64, NBG == 2 ? 2 : 1) void hrt_mlp_block_k(co
     float* const Wd = smem + wave * WD_WAVE;                    // this wave's depth-wise weights
     float* const Hs = smem + NBG * WD_WAVE + wave * H_WAVE;     // this wave's hidden tile
     f32x4* const Xs = reinterpret_cast<f32x4*>(smem + NBG * WD_WAVE);  // (prologue only; aliases the H tiles)
-    int bid = blockIdx.x;
+    int bid = I2R_XCD_BAND ? xcd_band_item(blockIdx.x, p.total) : (int)blockIdx.x;  // (workgroup-uniform)
+    if (bid < 0 || bid >= p.total) return;
     const int sx = bid % p.tiles_x; bid /= p.tiles_x;
     const int sy = bid % p.tiles_y;
     const int img = bid / p.tiles_y;
@@ -165,7 +158,7 @@ __global__ __launch_bounds__(NBG * 64, NBG == 2 ? 2 : 1) void hrt_mlp_block_k(co
 #pragma unroll
     for (int f = 0; f < NF; ++f) {
         const int y = y0 + 2 * f + (li >> 3), x = x0 + (li & 7);
-        hinf[f] = ((ABL & 32) ? (p.eps == 123.f) : (y >= 0 && y < p.h && x >= 0 && x < p.w)) ? 1.f : 0.f;
+        hinf[f] = (y >= 0 && y < p.h && x >= 0 && x < p.w) ? 1.f : 0.f;
     }
     const float npad = (float)(cs - p.c);  // zero pad channels inside the loaded rows: each adds mean^2 to the sum of squares
 #pragma unroll
@@ -226,13 +219,13 @@ __global__ __launch_bounds__(NBG * 64, NBG == 2 ? 2 : 1) void hrt_mlp_block_k(co
     f32x4 w1f[KS], w2f[CB];
     f32x4 b1v;
     auto fetch1 = [&](int b) {
-        const int hb = (ABL & 1) ? 0 : hblock(b);
+        const int hb = hblock(b);
 #pragma unroll
         for (int s = 0; s < KS; ++s) w1f[s] = p.w1[(hb * KS + s) * 64 + lane];
         b1v = *reinterpret_cast<const f32x4*>(p.b1 + hb * 16 + 4 * g);
     };
     auto fetch2 = [&](int pr) {  // pair pr of this wave
-        const int gp = (ABL & 1) ? 0 : wave + NBG * pr;
+        const int gp = wave + NBG * pr;
 #pragma unroll
         for (int ob = 0; ob < CB; ++ob) w2f[ob] = p.w2[(ob * (HBT / 2) + gp) * 64 + lane];
     };
@@ -243,14 +236,11 @@ __global__ __launch_bounds__(NBG * 64, NBG == 2 ? 2 : 1) void hrt_mlp_block_k(co
 #pragma unroll
         for (int s = 0; s < KS; ++s)
 #pragma unroll
-            for (int f = 0; f < NF; ++f) a[f] = mm<DT>(w1f[s], xn[f][s], a[f]);
+            for (int f = 0; f < NF; ++f) a[f] = mfma32_lp<DT>(w1f[s], xn[f][s], a[f]);
     };
     auto store_h = [&]() {
 #pragma unroll
-        for (int f = 0; f < NF; ++f) {
-            if constexpr (ABL & 8) a[f] = gelu4<4>(a[f], gk);
-            else *reinterpret_cast<f32x4*>(hwr + 2 * f * H_ROW) = gelu4<4>(a[f], gk);
-        }
+        for (int f = 0; f < NF; ++f) *reinterpret_cast<f32x4*>(hwr + 2 * f * H_ROW) = gelu4<4>(a[f], gk);
     };
 
     // depth-wise 3x3 + bias + GELU of block b (three output pixels x 4 channels per lane) -> packed 16-bit halves of the fc2 B operand
@@ -266,13 +256,13 @@ __global__ __launch_bounds__(NBG * 64, NBG == 2 ? 2 : 1) void hrt_mlp_block_k(co
         for (int ky = 0; ky < 3; ++ky) {
             f32x4 t[5], wv[3];
 #pragma unroll
-            for (int j = 0; j < 5; ++j) t[j] = (ABL & 4) ? a[j] : *reinterpret_cast<const f32x4*>(hrd + ky * H_ROW + j * 4);
+            for (int j = 0; j < 5; ++j) t[j] = *reinterpret_cast<const f32x4*>(hrd + ky * H_ROW + j * 4);
 #pragma unroll
-            for (int kx = 0; kx < 3; ++kx) wv[kx] = (ABL & 4) ? a[kx] : *reinterpret_cast<const f32x4*>(wch + (ky * 3 + kx) * 16);
+            for (int kx = 0; kx < 3; ++kx) wv[kx] = *reinterpret_cast<const f32x4*>(wch + (ky * 3 + kx) * 16);
 #pragma unroll
             for (int pf = 0; pf < NPF; ++pf)
 #pragma unroll
-                for (int kx = 0; kx < 3; ++kx) d[pf] = (ABL & 64) ? d[pf] + t[pf + kx][kx] : t[pf + kx] * wv[kx] + d[pf];
+                for (int kx = 0; kx < 3; ++kx) d[pf] = t[pf + kx] * wv[kx] + d[pf];
         }
 #pragma unroll
         for (int pf = 0; pf < NPF; ++pf) dp[pf] = pack4<DT>(gelu4<4>(d[pf], gk));
@@ -300,7 +290,7 @@ __global__ __launch_bounds__(NBG * 64, NBG == 2 ? 2 : 1) void hrt_mlp_block_k(co
 #pragma unroll
         for (int ob = 0; ob < CB; ++ob)
 #pragma unroll
-            for (int pf = 0; pf < NPF; ++pf) acc[pf][ob] = mm<DT>(w2f[ob], join8(d0[pf], d1[pf]), acc[pf][ob]);
+            for (int pf = 0; pf < NPF; ++pf) acc[pf][ob] = mfma32_lp<DT>(w2f[ob], join8(d0[pf], d1[pf]), acc[pf][ob]);
         fetch2(pr + 1 < NP ? pr + 1 : pr);
         if (pr + 1 < NP) {
             if constexpr (I2R_MLP_FC1_LATE) fc1();
@@ -317,7 +307,7 @@ __global__ __launch_bounds__(NBG * 64, NBG == 2 ? 2 : 1) void hrt_mlp_block_k(co
 #pragma unroll
     for (int pf = 0; pf < NPF; ++pf) {
         const int gx = sx * TX + 3 * xb + pf;
-        oin[pf] = (ABL & 32) ? (p.eps == 123.f) : (rowin && gx < p.w);
+        oin[pf] = rowin && gx < p.w;
         prow[pf] = (((size_t)img * p.h + (rowin ? gy : 0)) * p.w + (gx < p.w ? gx : 0)) * cs;
     }
     // (partials of OBC output blocks at a time, so the exchange area fits the loop's LDS footprint)
@@ -369,8 +359,9 @@ extern "C" int i2r_hrt_mlp_block(const float* x, float* out, const float* ln_w, 
     k.n_img = n_img; k.h = h; k.w = w; k.c = c; k.eps = eps;
     k.tiles_y = (h + TY - 1) / TY; k.tiles_x = (w + TX - 1) / TX;
     const long long nblk = (long long)n_img * k.tiles_y * k.tiles_x;
-    I2R_CHECK_ARG(nblk > 0 && nblk < (1ll << 31), "i2r_hrt_mlp_block: grid");
-    const dim3 grid((unsigned)nblk);
+    I2R_CHECK_ARG(nblk > 0 && nblk < (1ll << 30), "i2r_hrt_mlp_block: grid");
+    k.total = (int)nblk;
+    const dim3 grid((unsigned)((nblk + 7) / 8 * 8));
     if (dtype == 1) {
         if (cs == 80) hipLaunchKernelGGL((hrt_mlp_block_k<1, 5, 2>), grid, dim3(128), 0, (hipStream_t)stream, k);
         else hipLaunchKernelGGL((hrt_mlp_block_k<1, 10, 4>), grid, dim3(256), 0, (hipStream_t)stream, k);
