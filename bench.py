@@ -359,7 +359,7 @@ def roofline_report(prog, precision, cname):
     dom = order[0]  # the kernel with the largest share of the step's kernel time, whatever it is
     r = _kernel_view(dom, stats[dom], reps, total_ms, precision)
     traffic, traffic_src, traffic_kernel = hbm_traffic(cname)
-    if traffic_kernel is not None and not r["kernel"].startswith(traffic_kernel):
+    if traffic_kernel is not None and r["kernel"].split("<")[0].split("/")[0] != traffic_kernel.split("<")[0].split("/")[0]:
         traffic, traffic_src = None, None  # (the committed PMC pass was made on another kernel)
     r["traffic"], r["traffic_source"] = traffic, traffic_src
     conv = [k for k in stats if k.startswith("conv_")]
