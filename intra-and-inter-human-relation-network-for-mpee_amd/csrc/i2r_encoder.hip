@@ -145,6 +145,19 @@ __device__ __forceinline__ f32x4 frag_mm(const f32x4 (&wr)[KC], const f32x4 (&x)
         for (int s = 0; s < 4; ++s) acc = mfma16(wr[c][s], x[c][s], acc);
     return acc;
 }
+// fragment `idx` (wave-uniform, in an SGPR) of a register array: a scalar branch tree instead of DC selects per element
+template <int DC>
+__device__ __forceinline__ f32x4 pick_frag(const f32x4 (&v)[DC], int idx) {
+    static_assert(DC == 5 || DC == 6, "DC");
+    switch (idx) {
+        case 0: return v[0];
+        case 1: return v[1];
+        case 2: return v[2];
+        case 3: return v[3];
+        case 4: return v[4];
+        default: return v[DC - 1];
+    }
+}
 // ---- K / V projection of one 16-token tile per workgroup (first layer of a stack; later layers get theirs from the fused tail).
 //      4 waves: wave w computes the output fragments w, w+4, ... of [K | V] (2*DC fragments), weight rows fetched up front ----
 template <int DC>
@@ -188,27 +201,29 @@ __global__ __launch_bounds__(256) void enc_kv_k(const EncK p) {
     }
 }
 
-// LayerNorm over the real d features of each token column (features live in y[nt][r] x 4 lanes)
+// LayerNorm over the real d features of each token column (features live in y[nt][r] x 4 lanes).  The pad features of y are exact
+// zeros (zero weight rows, biases and residual), so the sum of squares over all cs features minus their (cs - d) mean^2 is the sum over
+// the real ones -- no per-element mask -- and the two divisions by d are one reciprocal.  In the fp32 kernels every vector instruction
+// competes with the MFMAs for the SIMD's fp32 ALUs (PMC: 1912 VALU next to 687 MFMAs per wave), so instructions saved here are pipe time.
 template <int DC>
 __device__ __forceinline__ void layer_norm(f32x4 (&y)[DC], const float* w, const float* b, int d, float eps, int g) {
+    const float inv_d = __builtin_amdgcn_rcpf((float)d);
     float s = 0.f;
 #pragma unroll
     for (int nt = 0; nt < DC; ++nt) s += (y[nt][0] + y[nt][1]) + (y[nt][2] + y[nt][3]);
-    const float mean = xsum(s) / (float)d;
+    const float mean = xsum(s) * inv_d;
     float v = 0.f;
 #pragma unroll
-    for (int nt = 0; nt < DC; ++nt)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const float t = (16 * nt + 4 * g + r < d) ? y[nt][r] - mean : 0.f;
-            v += t * t;
-        }
-    const float rstd = rsqrtf(xsum(v) / (float)d + eps);
+    for (int nt = 0; nt < DC; ++nt) {
+        y[nt] -= mean;
+        v += (y[nt][0] * y[nt][0] + y[nt][1] * y[nt][1]) + (y[nt][2] * y[nt][2] + y[nt][3] * y[nt][3]);
+    }
+    const float var = (xsum(v) - (float)(DC * 16 - d) * mean * mean) * inv_d;
+    const float rstd = rsqrtf(fmaxf(var, 0.f) + eps);
 #pragma unroll
     for (int nt = 0; nt < DC; ++nt) {
         const f32x4 wv = ld4(w + 16 * nt + 4 * g), bv = ld4(b + 16 * nt + 4 * g);
-#pragma unroll
-        for (int r = 0; r < 4; ++r) y[nt][r] = (y[nt][r] - mean) * rstd * wv[r] + bv[r];
+        y[nt] = y[nt] * (rstd * wv) + bv;  // (pad features: w = b = 0 -> exact zeros again)
     }
 }
 
@@ -263,7 +278,7 @@ __global__ __launch_bounds__(256, 2) void enc_layer4_k(const EncK p) {
                   P_LN2B = 5 * cs + dff, P_BKV = 6 * cs + dff, P_END = 8 * cs + dff;
     __shared__ __attribute__((aligned(16))) float Ps[P_END];
     __shared__ int s_arrived;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // (scalar: the slot tests below are scalar branches)
     const int li = lane & 15, g = lane >> 4;
 #ifdef I2R_TUNING
 #define STAMP(i) do { if (p.stamp && lane == 0) p.stamp[((size_t)blockIdx.x * 4 + wave) * 8 + (i)] = (long long)__builtin_amdgcn_s_memtime(); } while (0)
@@ -282,6 +297,7 @@ __global__ __launch_bounds__(256, 2) void enc_layer4_k(const EncK p) {
     f32x4 wq[SD][DC], bq[SD];
 #pragma unroll
     for (int s = 0; s < SD; ++s) {
+        // (a slot past the last fragment loads a clamped row -- no branch around the loads -- but is not COMPUTED: time follows the MFMA count)
         load_wrow<DC>(wq[s], p.w_in, min(wave + 4 * s, DC - 1), lane);
         bq[s] = ld4(p.b_in + 16 * min(wave + 4 * s, DC - 1) + 4 * g);
     }
@@ -367,12 +383,10 @@ __global__ __launch_bounds__(256, 2) void enc_layer4_k(const EncK p) {
         // ---- q projection (scaled by d^-1/2 * log2 e: the softmax below works in base 2), exchanged through LDS ----
 #pragma unroll
         for (int s = 0; s < SD; ++s) {
-            const int nt = min(wave + 4 * s, DC - 1);
+            const int nt = wave + 4 * s;
+            if (nt >= DC) continue;
 #pragma unroll
-            for (int u = 0; u < QT; ++u) {
-                const f32x4 a = frag_mm<DC>(wq[s], xq[u], bq[s]) * (p.qscale * 1.4426950408889634f);
-                if (wave + 4 * s < DC) Xs[(nt * QT + u) * 64 + lane] = a;
-            }
+            for (int u = 0; u < QT; ++u) Xs[(nt * QT + u) * 64 + lane] = frag_mm<DC>(wq[s], xq[u], bq[s]) * (p.qscale * 1.4426950408889634f);
         }
     }
     __syncthreads();
@@ -490,7 +504,7 @@ __global__ __launch_bounds__(256, 2) void enc_layer4_k(const EncK p) {
             if constexpr (KS == 2) sc[w] = mw[w] == -__builtin_inff() ? 0.f : sc[w];  // (a half of a short group may leave ALL waves without keys)
             l += MLs[((w * QT + u) * 2 + 1) * 16 + li] * sc[w];
         }
-        float inv = 1.f / l;
+        float inv = __builtin_amdgcn_rcpf(l);
         if constexpr (KS == 2) {
             if (split) inv = 1.f;  // keep the partial state un-normalised for the hand-off below
             m_wg = m;
@@ -533,17 +547,19 @@ __global__ __launch_bounds__(256, 2) void enc_layer4_k(const EncK p) {
             for (int nt = 0; nt < DC; ++nt) ao[nt] = ld_agent(other + nt * 256);
             ml = ld_agent(other + 6 * 256);
             wait_agent_loads<DC>(ao, ml);
-            // combine in a fixed order (half 0, then half 1) whichever workgroup finishes
-            const float m0 = half == 0 ? m_wg : ml[0], m1 = half == 0 ? ml[0] : m_wg;
-            const float l0 = half == 0 ? l_wg : ml[1], l1 = half == 0 ? ml[1] : l_wg;
-            const float m2 = fmaxf(m0, m1);
-            const float s0 = m0 == -__builtin_inff() ? 0.f : __builtin_amdgcn_exp2f(m0 - m2);
-            const float s1 = m1 == -__builtin_inff() ? 0.f : __builtin_amdgcn_exp2f(m1 - m2);
-            const float inv2 = 1.f / (l0 * s0 + l1 * s1);
+            // combine in a fixed order (half 0, then half 1) whichever workgroup finishes: the scales are computed per ROLE (mine / the
+            // other's) and the products are added lower half first -- a scalar branch on `half`, no per-element selects
+            const float m2 = fmaxf(m_wg, ml[0]);
+            const float s_me = m_wg == -__builtin_inff() ? 0.f : __builtin_amdgcn_exp2f(m_wg - m2);
+            const float s_ot = ml[0] == -__builtin_inff() ? 0.f : __builtin_amdgcn_exp2f(ml[0] - m2);
+            if (half == 0) {
+                const float inv2 = __builtin_amdgcn_rcpf(l_wg * s_me + ml[1] * s_ot);
 #pragma unroll
-            for (int nt = 0; nt < DC; ++nt) {
-                const f32x4 x0 = half == 0 ? oc[0][nt] : ao[nt], x1 = half == 0 ? ao[nt] : oc[0][nt];
-                oc[0][nt] = (x0 * s0 + x1 * s1) * inv2;
+                for (int nt = 0; nt < DC; ++nt) oc[0][nt] = (oc[0][nt] * s_me + ao[nt] * s_ot) * inv2;
+            } else {
+                const float inv2 = __builtin_amdgcn_rcpf(ml[1] * s_ot + l_wg * s_me);
+#pragma unroll
+                for (int nt = 0; nt < DC; ++nt) oc[0][nt] = (ao[nt] * s_ot + oc[0][nt] * s_me) * inv2;
             }
         }
     }
@@ -561,12 +577,10 @@ __global__ __launch_bounds__(256, 2) void enc_layer4_k(const EncK p) {
     }
 #pragma unroll
     for (int s = 0; s < SD; ++s) {
-        const int nt = min(wave + 4 * s, DC - 1);
+        const int nt = wave + 4 * s;
+        if (nt >= DC) continue;
 #pragma unroll
-        for (int u = 0; u < QT; ++u) {
-            const f32x4 a = frag_mm<DC>(wo[s], oc[u], ld4(Ps + P_BOUT + 16 * nt + 4 * g)) + res[s][u];
-            if (wave + 4 * s < DC) Xs[(nt * QT + u) * 64 + lane] = a;
-        }
+        for (int u = 0; u < QT; ++u) Xs[(nt * QT + u) * 64 + lane] = frag_mm<DC>(wo[s], oc[u], ld4(Ps + P_BOUT + 16 * nt + 4 * g)) + res[s][u];
     }
     if constexpr (QT != 1) {
 #pragma unroll
@@ -592,29 +606,25 @@ __global__ __launch_bounds__(256, 2) void enc_layer4_k(const EncK p) {
     __syncthreads();  // everyone has read Xs before FFN1 overwrites it
 #pragma unroll
     for (int s = 0; s < SF; ++s) {
-        const int ft = min(wave + 4 * s, FC - 1);
+        const int ft = wave + 4 * s;
+        if (ft >= FC) continue;
 #pragma unroll
         for (int u = 0; u < QT; ++u) {
             f32x4 a = frag_mm<DC>(w1r[s], x1[u], ld4(Ps + P_B1 + 16 * ft + 4 * g));
 #pragma unroll
             for (int r = 0; r < 4; ++r) a[r] = fmaxf(a[r], 0.f);
-            if (wave + 4 * s < FC) Xs[(ft * QT + u) * 64 + lane] = a;
+            Xs[(ft * QT + u) * 64 + lane] = a;
         }
     }
     if constexpr (QT != 1) {
 #pragma unroll
         for (int s = 0; s < SD; ++s) load_wrow<FC>(w2r[s], p.w2, min(wave + 4 * s, DC - 1), lane);
     }
-    f32x4 x1n[SD][QT];  // the residual of FFN2 is only needed for this wave's slots
+    f32x4 x1n[SD][QT];  // the residual of FFN2 is only needed for this wave's slots (wave is scalar: a branch per slot, no selects)
 #pragma unroll
-    for (int s = 0; s < SD; ++s) {
-        const int nt = min(wave + 4 * s, DC - 1);
+    for (int s = 0; s < SD; ++s)
 #pragma unroll
-        for (int u = 0; u < QT; ++u)
-#pragma unroll
-            for (int c = 0; c < DC; ++c)
-                if (c == nt) x1n[s][u] = x1[u][c];
-    }
+        for (int u = 0; u < QT; ++u) x1n[s][u] = pick_frag<DC>(x1[u], wave + 4 * s);
     __syncthreads();
     STAMP(5);
 #pragma unroll
@@ -624,9 +634,9 @@ __global__ __launch_bounds__(256, 2) void enc_layer4_k(const EncK p) {
         for (int c = 0; c < FC; ++c) h[c] = Xs[(c * QT + u) * 64 + lane];
 #pragma unroll
         for (int s = 0; s < SD; ++s) {
-            const int nt = min(wave + 4 * s, DC - 1);
-            const f32x4 a = frag_mm<FC>(w2r[s], h, ld4(Ps + P_B2 + 16 * nt + 4 * g)) + x1n[s][u];
-            if (wave + 4 * s < DC) Ys[(nt * QT + u) * 64 + lane] = a;
+            const int nt = wave + 4 * s;
+            if (nt >= DC) continue;
+            Ys[(nt * QT + u) * 64 + lane] = frag_mm<FC>(w2r[s], h, ld4(Ps + P_B2 + 16 * nt + 4 * g)) + x1n[s][u];
         }
     }
     // K / V rows of the next layer's in_proj for this wave's slots (fragments 0..DC-1: K rows, DC..2DC-1: V rows)
@@ -657,13 +667,7 @@ __global__ __launch_bounds__(256, 2) void enc_layer4_k(const EncK p) {
 #pragma unroll
             for (int s = 0; s < SD; ++s) {
                 const int nt = wave + 4 * s;
-                if (nt < DC) {
-                    f32x4 yn;
-#pragma unroll
-                    for (int c = 0; c < DC; ++c)
-                        if (c == nt) yn = y[u][c];
-                    *reinterpret_cast<f32x4*>(p.out + (size_t)qtok[u] * cs + 16 * nt + 4 * g) = yn;
-                }
+                if (nt < DC) *reinterpret_cast<f32x4*>(p.out + (size_t)qtok[u] * cs + 16 * nt + 4 * g) = pick_frag<DC>(y[u], nt);
             }
         }
     // ---- K / V of the next layer from the layer output still in registers ----
