@@ -32,15 +32,15 @@ OUT = os.path.join(ROOT, "tests", "golden")
 CASES = [
     # tag, config name, length, (H, W), store full output?
     ("w48_l31", "w48_pure_en6", [3, 1], (256, 192), True),
-    ("w48_l44", "w48_pure_en6", [4, 4], (256, 192), False),      # BASELINE config 1 (checksums + samples)
+    ("w48_l44", "w48_pure_en6", [4, 4], (256, 192), True),       # BASELINE config 1: the CPU-runnable case the metric is quoted beside
     ("w48_l1", "w48_pure_en6", [1], (256, 192), False),
     ("w48_l213", "w48_pure_en6", [2, 1, 3], (256, 192), False),
     ("tph_l21", "tph_192_p6_b4", [2, 1], (256, 192), True),
     ("hrt_l21", "hrt_192_p4_b4", [2, 1], (256, 192), True),
-    ("hrt288_l2", "coco_hrt_288_p2_b4", [2], (384, 288), False),     # 96x72 maps, 24x18 inter-human tokens
-    ("tph2s_l12", "coco_tph_192_p4_b4", [1, 2], (256, 192), False),  # interformer_2stage wiring (multiplex deconv, multi-pos)
+    ("hrt288_l2", "coco_hrt_288_p2_b4", [2], (384, 288), True),      # 96x72 maps, 24x18 inter-human tokens
+    ("tph2s_l12", "coco_tph_192_p4_b4", [1, 2], (256, 192), True),   # interformer_2stage wiring (multiplex deconv, multi-pos)
     ("ochtph_l21", "ochuman_tph_192_p3_b8", [2, 1], (256, 192), True),  # multi-position mode 'res' (resnet18 front end)
-    ("bare_l21", "w48_bare_p6", [2, 1], (256, 192), False),          # interformer with MODEL.SINGLEFORMER unset (models/hrnet.py)
+    ("bare_l21", "w48_bare_p6", [2, 1], (256, 192), True),           # interformer with MODEL.SINGLEFORMER unset (models/hrnet.py)
 ]
 
 
