@@ -118,45 +118,49 @@ __global__ __launch_bounds__(256 * HG, HG == 1 ? I2R_ATT_OCC78 : I2R_ATT_OCC156)
 #pragma unroll
         for (int db = 0; db < 3; ++db) wf[slot][db] = src[db * 64];
     };
-#pragma unroll
-    for (int u = 0; u < RB - 1; ++u) fetch(u, u);
-
-    // ---- LayerNorm 1 of the token: features 32 s + 8 g .. + 7 of k-step s (the B operand of the projections) ----
+    // ---- LayerNorm 1 of the token: features 32 s + 8 g .. + 7 of k-step s (the B operand of the projections).  The row loads go out
+    //      FIRST and unconditionally (clamped addresses, selected afterwards: no exec-masked branches), the first weight units behind
+    //      them: loads return in order, and the LayerNorm is what the wave needs first ----
     f32x4 xn[KS];
     {
         f32x4 xa[KS], xb[KS];
+#pragma unroll
+        for (int s = 0; s < KS; ++s) {
+            const int f0 = 32 * s + 8 * g < cs ? 32 * s + 8 * g : cs - 8;  // (cs = 80: lanes g >= 2 of the last k-step hold no channels)
+            xa[s] = *reinterpret_cast<const f32x4*>(p.x + row + f0);
+            xb[s] = *reinterpret_cast<const f32x4*>(p.x + row + f0 + 4);
+        }
+#pragma unroll
+        for (int u = 0; u < RB - 1; ++u) fetch(u, u);
         float s1 = 0.f;
 #pragma unroll
         for (int s = 0; s < KS; ++s) {
             const bool ok = inmap && (32 * s + 8 * g < cs);
-            xa[s] = ok ? *reinterpret_cast<const f32x4*>(p.x + row + 32 * s + 8 * g) : (f32x4){0.f, 0.f, 0.f, 0.f};
-            xb[s] = ok ? *reinterpret_cast<const f32x4*>(p.x + row + 32 * s + 8 * g + 4) : (f32x4){0.f, 0.f, 0.f, 0.f};
+            xa[s] = ok ? xa[s] : (f32x4){0.f, 0.f, 0.f, 0.f};
+            xb[s] = ok ? xb[s] : (f32x4){0.f, 0.f, 0.f, 0.f};
             s1 += ((xa[s][0] + xa[s][1]) + (xa[s][2] + xa[s][3])) + ((xb[s][0] + xb[s][1]) + (xb[s][2] + xb[s][3]));  // pad channels are exact zeros
         }
-        const float mean = xsum4(s1) / (float)p.c;
+        const float inv_c = __builtin_amdgcn_rcpf((float)p.c);
+        const float mean = xsum4(s1) * inv_c;
         float q2 = 0.f;
 #pragma unroll
-        for (int s = 0; s < KS; ++s)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const float da = (32 * s + 8 * g + r < p.c) ? xa[s][r] - mean : 0.f;
-                const float db = (32 * s + 8 * g + 4 + r < p.c) ? xb[s][r] - mean : 0.f;
-                q2 += da * da + db * db;
-            }
-        const float rstd = rsqrtf(xsum4(q2) / (float)p.c + p.eps);
+        for (int s = 0; s < KS; ++s) {
+            // (the zero pad channels inside the row add mean^2 each: subtracted below instead of masking 8 elements per step; the
+            //  channel-less lanes of a partial last step are switched off as a whole)
+            const float keep = 32 * s + 8 * g < cs ? 1.f : 0.f;
+            const f32x4 da = (xa[s] - mean) * keep, db = (xb[s] - mean) * keep;
+            q2 += ((da[0] * da[0] + da[1] * da[1]) + (da[2] * da[2] + da[3] * da[3])) + ((db[0] * db[0] + db[1] * db[1]) + (db[2] * db[2] + db[3] * db[3]));
+        }
+        const float var = (xsum4(q2) - (float)(cs - p.c) * mean * mean) * inv_c;
+        const float rstd = rsqrtf(fmaxf(var, 0.f) + p.eps);
 #pragma unroll
         for (int s = 0; s < KS; ++s) {
             const int f0 = 32 * s + 8 * g < cs ? 32 * s + 8 * g : 0;  // (steps beyond cs: ok is false, any valid address)
             const f32x4 wa = *reinterpret_cast<const f32x4*>(p.ln_w + f0), wb = *reinterpret_cast<const f32x4*>(p.ln_w + f0 + 4);
             const f32x4 ba = *reinterpret_cast<const f32x4*>(p.ln_b + f0), bb = *reinterpret_cast<const f32x4*>(p.ln_b + f0 + 4);
-            const bool ok = inmap && (32 * s + 8 * g < cs);
-            f32x4 va, vb;
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {  // (padded ln_w = ln_b = 0 -> 0 in the pad channels)
-                va[r] = ok ? (xa[s][r] - mean) * rstd * wa[r] + ba[r] : 0.f;
-                vb[r] = ok ? (xb[s][r] - mean) * rstd * wb[r] + bb[r] : 0.f;
-            }
-            xn[s] = pack8<DT>(va, vb);
+            const float keep = (inmap && 32 * s + 8 * g < cs) ? 1.f : 0.f;  // tokens outside the map are exact zeros AFTER the LayerNorm
+            // (padded ln_w = ln_b = 0 -> 0 in the pad channels)
+            xn[s] = pack8<DT>(((xa[s] - mean) * rstd * wa + ba) * keep, ((xb[s] - mean) * rstd * wb + bb) * keep);
         }
     }
 
