@@ -128,7 +128,7 @@ __global__ __launch_bounds__(NBG * 64, NBG == 2 ? 2 : 1) void hrt_mlp_block_k(co
     constexpr int RED_FLOATS = (NBG == 2 ? CB : (CB + 1) / 2) * (NBG - 1) * NPF * 64 * 4;  // partial fc2 sums handed to the finishing wave
     constexpr int SMEM = NBG * WD_WAVE + R1 > RED_FLOATS ? NBG * WD_WAVE + R1 : RED_FLOATS;
     __shared__ __attribute__((aligned(16))) float smem[SMEM];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, li = lane & 15, g = lane >> 4;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), li = lane & 15, g = lane >> 4;  // (wave: scalar)
     float* const Wd = smem + wave * WD_WAVE;                    // this wave's depth-wise weights
     float* const Hs = smem + NBG * WD_WAVE + wave * H_WAVE;     // this wave's hidden tile
     f32x4* const Xs = reinterpret_cast<f32x4*>(smem + NBG * WD_WAVE);  // (prologue only; aliases the H tiles)
@@ -141,6 +141,30 @@ __global__ __launch_bounds__(NBG * 64, NBG == 2 ? 2 : 1) void hrt_mlp_block_k(co
     // hidden block b (0 .. NB-1) of this wave: pair wave + NBG (b >> 1), half b & 1
     auto hblock = [&](int b) { return 2 * (wave + NBG * (b >> 1)) + (b & 1); };
 
+    // ---- LayerNorm 2 of halo fragments wave, wave + NBG, ...: packed B operands -> Xs[fragment][k-step][lane].  Their row loads go out
+    //      FIRST and unconditionally (clamped addresses, zeroed by `keep` afterwards), the depth-wise weights behind them ----
+    float hinf[NF];  // 1 = halo pixel (16 f + li) lies inside the image
+#pragma unroll
+    for (int f = 0; f < NF; ++f) {
+        const int y = y0 + 2 * f + (li >> 3), x = x0 + (li & 7);
+        hinf[f] = (y >= 0 && y < p.h && x >= 0 && x < p.w) ? 1.f : 0.f;
+    }
+    constexpr int NFW = (NF + NBG - 1) / NBG;  // halo fragments per wave
+    f32x4 xra[NFW][KS], xrb[NFW][KS];            // features 32 s + 8 g .. + 3 / + 4 .. + 7
+#pragma unroll
+    for (int i = 0; i < NFW; ++i) {
+        const int f = wave + NBG * i;
+        if (f >= NF) continue;  // (scalar)
+        const int y = y0 + 2 * f + (li >> 3), x = x0 + (li & 7);
+        const bool in = y >= 0 && y < p.h && x >= 0 && x < p.w;
+        const float* row = p.x + (((size_t)img * p.h + (in ? y : 0)) * p.w + (in ? x : 0)) * cs;
+#pragma unroll
+        for (int s = 0; s < KS; ++s) {
+            const int f0 = 32 * s + 8 * g < cs ? 32 * s + 8 * g : cs - 8;  // (cs = 80: the last k-step holds 16 channels, lanes g >= 2 none)
+            xra[i][s] = *reinterpret_cast<const f32x4*>(row + f0);
+            xrb[i][s] = *reinterpret_cast<const f32x4*>(row + f0 + 4);
+        }
+    }
     // ---- depth-wise weights + bias of this wave's blocks -> its LDS region: [block][tap | bias][16] ----
 #pragma unroll
     for (int i0 = 0; i0 < NB * 40; i0 += 64) {
@@ -153,47 +177,42 @@ __global__ __launch_bounds__(NBG * 64, NBG == 2 ? 2 : 1) void hrt_mlp_block_k(co
             *reinterpret_cast<f32x4*>(Wd + blk * 160 + tap * 16 + 4 * q) = v;
         }
     }
-    // ---- LayerNorm 2 of halo fragments wave, wave + NBG, ...: packed B operands -> Xs[fragment][k-step][lane] ----
-    float hinf[NF];  // 1 = halo pixel (16 f + li) lies inside the image
-#pragma unroll
-    for (int f = 0; f < NF; ++f) {
-        const int y = y0 + 2 * f + (li >> 3), x = x0 + (li & 7);
-        hinf[f] = (y >= 0 && y < p.h && x >= 0 && x < p.w) ? 1.f : 0.f;
-    }
     const float npad = (float)(cs - p.c);  // zero pad channels inside the loaded rows: each adds mean^2 to the sum of squares
+    const float inv_c = __builtin_amdgcn_rcpf((float)p.c);
 #pragma unroll
-    for (int f = 0; f < NF; ++f) {
-        if (f % NBG != wave) continue;  // (wave-uniform)
-        const int y = y0 + 2 * f + (li >> 3), x = x0 + (li & 7);
-        const bool in = hinf[f] != 0.f;
-        const float* row = p.x + (((size_t)img * p.h + (in ? y : 0)) * p.w + (in ? x : 0)) * cs;
-        f32x4 xa[KS], xb[KS];  // features 32 s + 8 g .. + 3 / + 4 .. + 7
+    for (int i = 0; i < NFW; ++i) {
+        const int f = wave + NBG * i;
+        if (f >= NF) continue;  // (scalar)
+        float hin = 0.f;        // hinf[f] (f is a scalar: a switch instead of a dynamic register index)
+#pragma unroll
+        for (int ff = 0; ff < NF; ++ff)
+            if (ff == f) hin = hinf[ff];
         float s1 = 0.f;
 #pragma unroll
         for (int s = 0; s < KS; ++s) {
-            const bool ok = 32 * s + 8 * g < cs;  // (cs = 80: the last k-step holds 16 channels, lanes g >= 2 supply zeros)
-            xa[s] = (ok && in) ? *reinterpret_cast<const f32x4*>(row + 32 * s + 8 * g) : (f32x4){0.f, 0.f, 0.f, 0.f};
-            xb[s] = (ok && in) ? *reinterpret_cast<const f32x4*>(row + 32 * s + 8 * g + 4) : (f32x4){0.f, 0.f, 0.f, 0.f};
-            s1 += ((xa[s][0] + xa[s][1]) + (xa[s][2] + xa[s][3])) + ((xb[s][0] + xb[s][1]) + (xb[s][2] + xb[s][3]));
+            const float keep = 32 * s + 8 * g < cs ? hin : 0.f;
+            xra[i][s] *= keep;
+            xrb[i][s] *= keep;
+            s1 += ((xra[i][s][0] + xra[i][s][1]) + (xra[i][s][2] + xra[i][s][3])) + ((xrb[i][s][0] + xrb[i][s][1]) + (xrb[i][s][2] + xrb[i][s][3]));
         }
-        const float mean = xsum4(s1) / (float)p.c;
+        const float mean = xsum4(s1) * inv_c;
         float q2 = 0.f;
 #pragma unroll
         for (int s = 0; s < KS; ++s) {
             const float keep = 32 * s + 8 * g < cs ? 1.f : 0.f;  // (compile-time 1 except in a partial last k-step)
-            const f32x4 da = (xa[s] - mean) * keep, db = (xb[s] - mean) * keep;
+            const f32x4 da = (xra[i][s] - mean) * keep, db = (xrb[i][s] - mean) * keep;
             q2 += ((da[0] * da[0] + da[1] * da[1]) + (da[2] * da[2] + da[3] * da[3])) + ((db[0] * db[0] + db[1] * db[1]) + (db[2] * db[2] + db[3] * db[3]));
         }
-        const float var = (xsum4(q2) - npad * mean * mean) / (float)p.c;
-        const float rstd = in ? rsqrtf(fmaxf(var, 0.f) + p.eps) : 0.f;  // outside the image: zero columns
+        const float var = (xsum4(q2) - npad * mean * mean) * inv_c;
+        const float rstd = rsqrtf(fmaxf(var, 0.f) + p.eps) * hin;  // outside the image: zero columns
 #pragma unroll
         for (int s = 0; s < KS; ++s) {
             const int f0 = 32 * s + 8 * g < cs ? 32 * s + 8 * g : 0;
             const f32x4 wa = *reinterpret_cast<const f32x4*>(p.ln_w + f0), wb = *reinterpret_cast<const f32x4*>(p.ln_w + f0 + 4);
             const f32x4 ba = *reinterpret_cast<const f32x4*>(p.ln_b + f0), bb = *reinterpret_cast<const f32x4*>(p.ln_b + f0 + 4);
-            const float keep = 32 * s + 8 * g < cs ? hinf[f] : 0.f;
+            const float keep = 32 * s + 8 * g < cs ? hin : 0.f;
             // (pad channels: ln_w = ln_b = 0 -> exact zeros)
-            Xs[(f * KS + s) * 64 + lane] = pack8<DT>((xa[s] - mean) * rstd * wa + ba * keep, (xb[s] - mean) * rstd * wb + bb * keep);
+            Xs[(f * KS + s) * 64 + lane] = pack8<DT>((xra[i][s] - mean) * rstd * wa + ba * keep, (xrb[i][s] - mean) * rstd * wb + bb * keep);
         }
     }
     __syncthreads();
