@@ -222,7 +222,20 @@ def _run_one(L, program, i, streams):
     cabi.check(L.i2r_run_program(C.cast(C.byref(program._c_ops, i * C.sizeof(cabi.Op)), C.POINTER(cabi.Op)), 1, streams, None), "op %d" % i)
 
 
-def per_launch_timing(program, precision, reps=3):
+def per_launch_timing(programs, precision, reps=3):
+    """stats of one forward = all of its programs (a forward may run two part-batch programs on two streams, Engine._split_bounds): replayed one after
+    the other on the current stream"""
+    stats = {}
+    for program in (programs if isinstance(programs, (list, tuple)) else [programs]):
+        st, _ = _per_launch_timing_one(program, precision, reps)
+        for k, v in st.items():
+            s = stats.setdefault(k, [0, 0.0, 0.0, 0.0, v[4]])
+            for i in range(4):
+                s[i] += v[i]
+    return stats, reps
+
+
+def _per_launch_timing_one(program, precision, reps=3):
     """Replay the program with HIP events on the launch stream between RUNS of consecutive launches of the same kernel (e.g. the six
     encoder layers, the 8 convs of a branch block) -> per-kernel [launch count, total ms, total flop, total bytes, pipe].  Timing a run
     as a whole keeps the kernels back to back as in the real step; one event pair per launch would add its own few microseconds to
@@ -262,7 +275,11 @@ def per_launch_timing(program, precision, reps=3):
     return stats, reps
 
 
-def stack_timing(program, precision, prefix="enc_", reps=3):
+def stack_timing(programs, precision, prefix="enc_", reps=3):
+    return sum(_stack_timing_one(P, precision, prefix, reps) for P in (programs if isinstance(programs, (list, tuple)) else [programs]))
+
+
+def _stack_timing_one(program, precision, prefix="enc_", reps=3):
     """ms per replay of the ops whose kernel name starts with `prefix`, timed as WHOLE contiguous ranges (one event pair around each
     maximal run of such ops, e.g. enc_kv_k + the six enc_layer4_k launches of an encoder stack): an event pair costs a few
     microseconds of idle queue, which per_launch_timing's pair per KERNEL run would charge twice to a seven-launch stack whose
@@ -585,8 +602,7 @@ def quick_workload(cname, dev, steps=10, warmup=3):
     dt, y = _time_steps(fwd, steps, warmup)
     assert torch.isfinite(y).all()
     eng = net.engine()
-    key = next(k for k in eng.programs if k[3] is False and k[0] == eng.capacity(sum(length)))
-    r = roofline_report(eng.programs[key][0], precision, cname)
+    r = roofline_report(eng.last_programs, precision, cname)  # (the program(s) of the forward just timed)
     gflop = sum(n * wl["gflop"](n) for n in length)
     out = {"workload": wl["label"], "dtype": DTYPE_NAME[precision], "crops_per_step": sum(length), "steps": steps, "warmup": warmup,
            "value": round(sum(length) * steps / dt, 1), "unit": "images/sec", "ms_per_step": round(dt / steps * 1e3, 3),
@@ -849,7 +865,8 @@ def main(argv=None):
                    "crops_per_gpu_step": sum(length),
                    "parallelism": "dp%d (images sharded, one RCCL all-gather of the %s per step, waited for one step later)" % (world, payload)
                                   if world > 1 else "single GPU",
-                   "gflop_per_step_per_gpu": round(gflop_per_step / world, 2)},
+                   "gflop_per_step_per_gpu": round(gflop_per_step / world, 2),
+                   "programs_per_forward": (len(net.engine().last_programs) if (net is not None and getattr(net.engine(), "last_programs", None)) else 1)},
         # SURVEY 8d algorithmic FLOPs of the reference forward (direct convolutions) per second of wall time: a delivered-work figure,
         # NOT a fraction of any pipe (the Winograd launches execute 2.25x fewer multiply-adds); roofline.model_tflops_executed is
         "model_tflops_algorithmic": round(gflop_per_step * (2 if args.pipeline else 1) * args.steps / dt / 1e3, 2),
@@ -868,8 +885,7 @@ def main(argv=None):
     if rank == 0 and not stub:
         eng = net.engine()
         if not args.no_roofline:
-            key = next(k for k in eng.programs if k[3] == bool(args.pipeline) and k[0] == eng.capacity(sum(first)))
-            out["roofline"] = roofline_report(eng.programs[key][0], precision, args.config)
+            out["roofline"] = roofline_report(eng.last_programs, precision, args.config)  # (the program(s) of the last timed forward)
             if not strong and not args.pipeline:  # executed matrix-pipe + element-wise FLOPs of one forward over the step's wall time
                 out["roofline"]["model_tflops_executed"] = round(out["roofline"].pop("_executed_gflop_per_step") * args.steps / dt / 1e3, 2)
             out["roofline"].pop("_executed_gflop_per_step", None)

@@ -108,8 +108,12 @@ __device__ __forceinline__ f32x4 gelu4(f32x4 v, const GeluC& k) {
     return (f32x4){lo[0], lo[1], hi[0], hi[1]};
 }
 
+// fc1 of the next hidden block is issued AFTER the depth-wise phase of the current one.  Issuing it before (round 3's in-wave software
+// pipeline: MFMAs under the vector ALU work) keeps five more accumulators live across that phase: at C = 78 that spills 77 registers
+// (78.8 vs 36 us); at C = 156 it fits (467 registers, one wave per SIMD either way) and is 0.7 us faster stand-alone, but the whole
+// forward measured 2-3 % SLOWER with it (3.35-3.40 vs 3.23-3.28 ms, configs 4 / 5 alike): late everywhere.
 #ifndef I2R_MLP_FC1_LATE
-#define I2R_MLP_FC1_LATE 1   // A/B knob (0 spills 77 registers at C = 78): 1 = fc1 of the next block is issued AFTER the depth-wise phase (its five accumulators are not live across it)
+#define I2R_MLP_FC1_LATE(CB) 1
 #endif
 constexpr int TY = 8, TX = 6;                    // output sub-tile (rows x columns)
 constexpr int HY = TY + 2, HX = TX + 2;          // halo grid 10 x 8 = 80 pixels = 5 fragments (two halo rows each)
@@ -121,6 +125,7 @@ template <int DT, int CB, int NBG>
 __global__ __launch_bounds__(NBG * 64, NBG == 2 ? 2 : 1) void hrt_mlp_block_k(const MlpK p) {
     constexpr int cs = CB * 16, KS = (cs + 31) / 32, HBT = 4 * CB, HID = HBT * 16, NB = HBT / NBG, NP = NB / 2;  // NB hidden blocks = NP pairs per wave
     static_assert(HBT % (2 * NBG) == 0, "whole pairs of hidden blocks per wave");
+    constexpr bool LATE = I2R_MLP_FC1_LATE(CB);
     constexpr int WD_WAVE = NB * 160;                           // floats: per block [10 = 9 taps + bias][16 channels]
     constexpr int H_WAVE = 4 * H_QUAD;                          // floats
     constexpr int X_FLOATS = NF * KS * 64 * 4;                  // packed pixel columns, 16 bytes per lane and (fragment, k-step)
@@ -298,13 +303,13 @@ __global__ __launch_bounds__(NBG * 64, NBG == 2 ? 2 : 1) void hrt_mlp_block_k(co
     for (int pr = 0; pr < NP; ++pr) {
         uint2 d0[NPF], d1[NPF];
         __builtin_amdgcn_wave_barrier();  // (H of block 2 pr is complete in program order; LDS executes a wave's accesses in order)
-        if constexpr (!I2R_MLP_FC1_LATE) fc1();  // block 2 pr + 1 goes to the matrix pipe first
+        if constexpr (!LATE) fc1();  // block 2 pr + 1 goes to the matrix pipe first
         dwconv(2 * pr, d0);
-        if constexpr (I2R_MLP_FC1_LATE) fc1();
+        if constexpr (LATE) fc1();
         fetch1(2 * pr + 2 < NB ? 2 * pr + 2 : 2 * pr + 1);  // (last round: a harmless re-fetch instead of a branch)
         store_h();                        // block 2 pr + 1's hidden tile (block 2 pr's taps have all been read)
         __builtin_amdgcn_wave_barrier();
-        if constexpr (!I2R_MLP_FC1_LATE) { if (pr + 1 < NP) fc1(); }  // block 2 pr + 2 (wave-uniform branch)
+        if constexpr (!LATE) { if (pr + 1 < NP) fc1(); }  // block 2 pr + 2 (wave-uniform branch)
         dwconv(2 * pr + 1, d1);
 #pragma unroll
         for (int ob = 0; ob < CB; ++ob)
@@ -312,7 +317,7 @@ __global__ __launch_bounds__(NBG * 64, NBG == 2 ? 2 : 1) void hrt_mlp_block_k(co
             for (int pf = 0; pf < NPF; ++pf) acc[pf][ob] = mfma32_lp<DT>(w2f[ob], join8(d0[pf], d1[pf]), acc[pf][ob]);
         fetch2(pr + 1 < NP ? pr + 1 : pr);
         if (pr + 1 < NP) {
-            if constexpr (I2R_MLP_FC1_LATE) fc1();
+            if constexpr (LATE) fc1();
             fetch1(2 * pr + 3);
             store_h();
         }

@@ -119,6 +119,7 @@ _HRT_FUSED_MLP = tuple(int(v) for v in _tune("I2R_HRT_FUSED_MLP", "78,156").spli
 PAIR1X1 = _tune("I2R_PAIR1X1", "1") != "0"  # layer1's conv3 + next conv1 as one i2r_conv1x1_pair launch (fp32)
 _PAIR_MT = int(_tune("I2R_PAIR_MT", "0"))  # 16-pixel tiles per wave of that kernel
 WINOGRAD = _tune("I2R_WINOGRAD", "1") != "0"  # fp32 3x3 stride-1 convs on the Winograd F(2x2, 3x3) kernels
+_LANE_CAP = int(_tune("I2R_LANE_CAP", "4"))  # HRFormer-B: branches i >= cap - 1 share stream lane cap - 1 (A/B: fewer, longer lanes)
 
 
 class PackedConv:
@@ -1416,12 +1417,12 @@ class HRFormerB:
         for k in range(max(len(b) for b in mod["blocks"])):
             for i in range(nb):
                 if k < len(mod["blocks"][i]):
-                    xs[i] = cls._emit_block(P, mod["blocks"][i][k], xs[i], lane=i if lanes else 0)
+                    xs[i] = cls._emit_block(P, mod["blocks"][i][k], xs[i], lane=min(i, _LANE_CAP - 1) if lanes else 0)
         if lanes:
             P.xsync((1 << nb) - 1)
         outs = []
         for i in range(mod["n_out"]):
-            ln = i if lanes else 0
+            ln = min(i, _LANE_CAP - 1) if lanes else 0
             P.lane_ctx = ln
             # y = ((t_0 + t_1) + ...) then ReLU (hrformer.py:1716-1731); identity terms ride as residual inputs
             acc, y, j = None, None, 0
@@ -1781,14 +1782,70 @@ class Engine:
         with torch.cuda.device(self.device):  # kernels and events go to the CURRENT device: make it this engine's
             return self._forward(x, pos_mask, list(length), flip_joint_map, S, H, W)
 
+    # Part-batches on separate streams (round 4).  The images of a batch are independent: `_split_bounds` cuts a batch of the HRNet /
+    # TransPose-H towers into SPLIT_PARTS contiguous image groups balanced by crop count (dist.shard_bounds) and `_forward` runs one
+    # program per group -- each with its own arena, keyed by a slot -- on the caller's stream and on side streams, forked and joined with
+    # events.  The launches of the parts interleave on the chip: one part computes while another stages or drains.  Measured
+    # (tools/host_rate.py, bench.py): config 3 bf16 4.36 -> 3.75 ms, the fp32 headline 4.17 -> 3.93 ms, TransPose-H fp32 15.2 -> 14.2 ms.
+    # Not for the four-lane HRFormer-B programs (twice the launches of kernels whose time barely depends on the batch: 5.2 vs 3.8 ms).
+    SPLIT_MIN_CROPS = 24
+    SPLIT_PARTS = int(_tune("I2R_SPLIT_PARTS", "2"))
+
+    def _split_bounds(self, length):
+        """image index cuts [0, b1, ..., n] of the concurrent part-batches, or None (one program)"""
+        from .dist import shard_bounds
+        parts = min(self.SPLIT_PARTS, len(length))
+        if _tune("I2R_SPLIT_BATCH", "1") == "0" or parts < 2 or sum(length) < self.SPLIT_MIN_CROPS:
+            return None
+        if not isinstance(getattr(self, "tower", None), HRNetW48) and _tune("I2R_SPLIT_BATCH", "1") != "2":  # (2: A/B, any tower)
+            return None
+        bounds = shard_bounds(list(length), parts)
+        return bounds if all(bounds[i + 1] > bounds[i] for i in range(parts)) else None
+
     def _forward(self, x, pos_mask, length, flip_joint_map, S, H, W):
+        bounds = self._split_bounds(length)
+        if bounds is None:
+            return self._forward_part(x, pos_mask, length, flip_joint_map, S, H, W, slot=0)
+        parts = len(bounds) - 1
+        offs = [sum(length[:b]) for b in bounds]
+        x = x.to(self.device).contiguous()
+        pm = pos_mask.to(self.device, torch.float32).contiguous() if pos_mask is not None else None
+        cur = torch.cuda.current_stream(self.device)
+        if len(getattr(self, "_part_streams", ())) < parts - 1:
+            self._part_streams = [torch.cuda.Stream(device=self.device) for _ in range(parts - 1)]
+            self._part_events = [torch.cuda.Event() for _ in range(parts)]
+        e_fork = self._part_events[0]
+        e_fork.record(cur)  # (the inputs are ready on the caller's stream)
+        ys, progs = [None] * parts, []
+        for i in range(1, parts):
+            st = self._part_streams[i - 1]
+            x.record_stream(st)
+            if pm is not None:
+                pm.record_stream(st)
+            with torch.cuda.stream(st):
+                st.wait_event(e_fork)
+                ys[i] = self._forward_part(x[offs[i]:offs[i + 1]], pm[offs[i]:offs[i + 1]] if pm is not None else None,
+                                           length[bounds[i]:bounds[i + 1]], flip_joint_map, offs[i + 1] - offs[i], H, W, slot=i)
+                self._part_events[i].record(st)
+            progs += self.last_programs
+        ys[0] = self._forward_part(x[:offs[1]], pm[:offs[1]] if pm is not None else None, length[:bounds[1]], flip_joint_map, offs[1], H, W, slot=0)
+        self.last_programs = self.last_programs + progs
+        for i in range(1, parts):
+            cur.wait_event(self._part_events[i])
+            for t in (ys[i].values() if isinstance(ys[i], dict) else (ys[i],)):
+                t.record_stream(cur)  # (allocated on the side stream, consumed on the caller's)
+        if isinstance(ys[0], dict):
+            return {key: torch.cat([y[key] for y in ys], 0) for key in ys[0]}
+        return torch.cat(ys, 0)
+
+    def _forward_part(self, x, pos_mask, length, flip_joint_map, S, H, W, slot=0):
         M = self.cfg["MODEL"]
         x = x.to(self.device).contiguous()
         flip = flip_joint_map is not None
         # one program per (capacity, H, W, flip): the launch list and every buffer depend on the crop capacity only; the
         # persons-per-image grouping enters through the encoder's offset table, the real crop count through the stem kernels
         cap = self.capacity(S)
-        key = (cap, H, W, flip)
+        key = (cap, H, W, flip) if slot == 0 else (cap, H, W, flip, slot)  # (a Program owns its arena: the concurrent half needs its own)
         if key in self.programs:
             self.programs[key] = self.programs.pop(key)  # most recently used last
         else:
@@ -1797,6 +1854,7 @@ class Engine:
             self.programs[key] = self._build(cap, H, W, list(length) + [1] * (cap - S), flip)
             self.n_builds += 1
         P, patch = self.programs[key]
+        self.last_programs = [P]  # the program(s) of the most recent forward (bench.py's per-launch timing pass replays them; _forward merges the parts')
         glen = list(length) + [1] * (cap - S)
         if flip:
             glen = glen + glen

@@ -296,6 +296,45 @@ def test_config3_ragged_batch_real_size():
         assert d.pow(2).mean().sqrt().item() <= tol_rms * refs[i]["multi"].pow(2).mean().sqrt().item()
 
 
+def test_half_batches_on_two_streams_match_one_program():
+    """Engine._split_bounds: a batch of >= 24 crops of the HRNet / TransPose-H towers runs as two half-batch programs on two HIP streams.  Same images, same kernels: the rows must agree with the single-program forward (split switched off) to
+    rounding, for both outputs of the 2-stage model, in the original image order -- and the split must really have happened."""
+    import bench
+    from i2r_amd import synth
+    length = bench.WORKLOADS["tph_192_p6_b4"]["length"]
+    cfg, sd, _, _, _, _ = setup("tph_l21")
+    net = _net(cfg, sd, "tph_192_p6_b4")
+    x, m, length = synth.make_inputs(length, 256, 192, seed=5)
+    try:
+        net.set_precision("bf16")
+        eng = net.engine()
+        b = eng._split_bounds(length)
+        assert b is not None and len(b) == 3 and abs(2 * sum(length[:b[1]]) - sum(length)) <= max(length)
+        y2 = net(x.cuda(), m.cuda(), length)
+        torch.cuda.synchronize()
+        assert len(eng.last_programs) == 2 and any(len(key) == 5 for key in eng.programs)
+        saved, eng.SPLIT_MIN_CROPS = eng.SPLIT_MIN_CROPS, 10 ** 9
+        try:
+            y1 = net(x.cuda(), m.cuda(), length)
+            torch.cuda.synchronize()
+            assert len(eng.last_programs) == 1
+        finally:
+            eng.SPLIT_MIN_CROPS = saved
+        # Both are valid bf16 evaluations of the same images: the tile / channel-chunk choices follow the batch size, so fp32 partial
+        # sums are added in a different order and bf16-stored activations flip an ulp here and there (16-bit results are tolerance-
+        # stable across batch sizes, not bit-stable: INTEGRATION.md section 4).  A mis-ordered or stale row would be off by O(max).
+        tol_max, tol_rms = LP_TOL["bf16"]
+        for key in ("single", "multi"):
+            assert y2[key].shape == y1[key].shape == (57, 14, 64, 48)
+            d = (y2[key] - y1[key]).float()
+            assert d.abs().max().item() <= tol_max * y1[key].abs().max().item(), key
+            assert d.pow(2).mean().sqrt().item() <= 0.5 * tol_rms * y1[key].pow(2).mean().sqrt().item(), key
+        # small batches and single images stay one program
+        assert eng._split_bounds([4, 4]) is None and eng._split_bounds([30]) is None
+    finally:
+        net.set_precision("fp32")
+
+
 def test_config5_twelve_persons_384x288():
     """BASELINE config 5 at its real size: one image of 12 persons at 384x288 through HRFormer-B; the inter-human encoder sees
     L = 12 * 432 = 5184 tokens of width 78.  fp32 vs the oracle end to end (1e-3); fp16 within the stated tolerance, with the
