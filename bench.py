@@ -222,27 +222,30 @@ def _run_one(L, program, i, streams):
     cabi.check(L.i2r_run_program(C.cast(C.byref(program._c_ops, i * C.sizeof(cabi.Op)), C.POINTER(cabi.Op)), 1, streams, None), "op %d" % i)
 
 
-def per_launch_timing(programs, precision, reps=3):
-    """stats of one forward = all of its programs (a forward may run two part-batch programs on two streams, Engine._split_bounds): replayed one after
-    the other on the current stream"""
+def per_launch_timing(programs, precision, reps=3, concurrent=()):
+    """stats of one forward = all of its programs.  A part-batch forward (Engine._split_bounds) runs several programs SIDE BY SIDE on
+    their own streams: those (`concurrent`) are replayed that way -- run r of every concurrent program is issued on its own stream
+    between a common start and a common end event, so a kernel's time is what it takes with its siblings in flight, and its
+    `launches` / FLOPs count all of them (avg_launch_us = duration / launches in flight) -- the others one after the other."""
     stats = {}
-    for program in (programs if isinstance(programs, (list, tuple)) else [programs]):
-        st, _ = _per_launch_timing_one(program, precision, reps)
+    def merge(st):
         for k, v in st.items():
             s = stats.setdefault(k, [0, 0.0, 0.0, 0.0, v[4]])
             for i in range(4):
                 s[i] += v[i]
+    plist = list(programs) if isinstance(programs, (list, tuple)) else [programs]
+    conc = [P for P in concurrent if any(P is Q for Q in plist)]
+    if len(conc) < 2:
+        conc = []
+    if conc:
+        merge(_per_launch_timing_concurrent(conc, precision, reps))
+    for program in plist:
+        if not any(program is Q for Q in conc):
+            merge(_per_launch_timing_one(program, precision, reps)[0])
     return stats, reps
 
 
-def _per_launch_timing_one(program, precision, reps=3):
-    """Replay the program with HIP events on the launch stream between RUNS of consecutive launches of the same kernel (e.g. the six
-    encoder layers, the 8 convs of a branch block) -> per-kernel [launch count, total ms, total flop, total bytes, pipe].  Timing a run
-    as a whole keeps the kernels back to back as in the real step; one event pair per launch would add its own few microseconds to
-    each.  Single-stream pass: stream lanes collapse onto the current stream (kernels of different lanes do not overlap here)."""
-    L = cabi.lib()
-    cur = torch.cuda.current_stream().cuda_stream
-    streams = (C.c_void_p * 4)(cur, cur, cur, cur)
+def _named_runs(program, precision):
     lens = _enc_lens(program)
     named = []
     for i, kind, st in _launch_ops(program):
@@ -255,6 +258,70 @@ def _per_launch_timing_one(program, precision, reps=3):
             runs[-1][3] += nbytes
         else:
             runs.append([name, [i], flop, nbytes, pipe])
+    return runs
+
+
+def _per_launch_timing_concurrent(programs, precision, reps=3):
+    L = cabi.lib()
+    cur = torch.cuda.current_stream()
+    side = [torch.cuda.Stream() for _ in programs[1:]]
+    sts = [cur] + side
+    arrs = [(C.c_void_p * 4)(s.cuda_stream, s.cuda_stream, s.cuda_stream, s.cuda_stream) for s in sts]
+    # the part-batch programs are the same launch list over different crop counts: run r = the op indices of program 0's r-th run of
+    # equal kernels; the siblings' launches of the same indices go with it (an instantiation name may differ with the crop count --
+    # the run is filed under program 0's -- the FLOPs / bytes are each program's own)
+    runs0 = _named_runs(programs[0], precision)
+    pos = {i: n for n, (i, _, _) in enumerate(_launch_ops(programs[0]))}
+    runs = [runs0]
+    for P in programs[1:]:
+        ops = _launch_ops(P)
+        assert len(ops) == len(pos), "concurrent programs are the same launch list"
+        lens = _enc_lens(P)
+        rr = []
+        for name, idx, _, _, pipe in runs0:
+            mine = [ops[pos[i]] for i in idx]
+            models = [op_model(kind, st, precision, lens.get(C.addressof(st)) if kind in (cabi.OP_ENC_KV, cabi.OP_ENC_LAYER) else None) for _, kind, st in mine]
+            rr.append([name, [i for i, _, _ in mine], sum(m[1] for m in models), sum(m[2] for m in models), pipe])
+        runs.append(rr)
+    stats = {}
+    for rep in range(reps + 1):
+        evs = []
+        for r in range(len(runs[0])):
+            e0, e2 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record(cur)
+            for s in side:
+                s.wait_event(e0)
+            for p, P in enumerate(programs):
+                for i in runs[p][r][1]:
+                    _run_one(L, P, i, arrs[p])
+            for s in side:
+                e1 = torch.cuda.Event()
+                e1.record(s)
+                cur.wait_event(e1)
+            e2.record(cur)
+            evs.append((e0, e2))
+        torch.cuda.synchronize()
+        if rep == 0:
+            continue
+        for r, (e0, e2) in enumerate(evs):
+            name, pipe = runs[0][r][0], runs[0][r][4]
+            s = stats.setdefault(name, [0, 0.0, 0.0, 0.0, pipe])
+            s[0] += sum(len(rr[r][1]) for rr in runs)
+            s[1] += e0.elapsed_time(e2)
+            s[2] += sum(rr[r][2] for rr in runs)
+            s[3] += sum(rr[r][3] for rr in runs)
+    return stats
+
+
+def _per_launch_timing_one(program, precision, reps=3):
+    """Replay the program with HIP events on the launch stream between RUNS of consecutive launches of the same kernel (e.g. the six
+    encoder layers, the 8 convs of a branch block) -> per-kernel [launch count, total ms, total flop, total bytes, pipe].  Timing a run
+    as a whole keeps the kernels back to back as in the real step; one event pair per launch would add its own few microseconds to
+    each.  Single-stream pass: stream lanes collapse onto the current stream (kernels of different lanes do not overlap here)."""
+    L = cabi.lib()
+    cur = torch.cuda.current_stream().cuda_stream
+    streams = (C.c_void_p * 4)(cur, cur, cur, cur)
+    runs = _named_runs(program, precision)
     stats = {}
     for rep in range(reps + 1):
         evs = [torch.cuda.Event(enable_timing=True) for _ in range(len(runs) + 1)]
@@ -369,8 +436,8 @@ def _kernel_view(name, s, reps, total_ms, precision):
     return out
 
 
-def roofline_report(prog, precision, cname):
-    stats, reps = per_launch_timing(prog, precision)
+def roofline_report(prog, precision, cname, concurrent=()):
+    stats, reps = per_launch_timing(prog, precision, concurrent=concurrent)
     total_ms = sum(s[1] for s in stats.values())
     order = sorted(stats, key=lambda k: -stats[k][1])
     dom = order[0]  # the kernel with the largest share of the step's kernel time, whatever it is
@@ -391,6 +458,10 @@ def roofline_report(prog, precision, cname):
         for drop in ("hbm_view", "mfma_view", "machine_balance_flop_per_byte", "gbytes_per_launch"):
             kv.pop(drop, None)
     r["per_kernel_ms_per_step"] = {k: round(stats[k][1] / reps, 3) for k in order}
+    if len(concurrent) >= 2:
+        r["concurrency"] = ("%d part-batch programs run side by side on their own streams (Engine._split_bounds); their kernels are timed that way: "
+                            "launches_per_step / FLOPs count all of them, avg_launch_us = time of a run / launches in flight "
+                            "(a rocprofv3 trace shows each launch lasting about %d x avg_launch_us)" % (len(concurrent), len(concurrent)))
     r["_executed_gflop_per_step"] = sum(stats[k][2] / (WINO_CUT if k.startswith("conv_wino") else 1.0) for k in stats) / reps / 1e9
     att_k = sorted(k for k in stats if k.startswith("enc_"))
     att_flop = sum(stats[k][2] for k in att_k) / reps
@@ -602,7 +673,7 @@ def quick_workload(cname, dev, steps=10, warmup=3):
     dt, y = _time_steps(fwd, steps, warmup)
     assert torch.isfinite(y).all()
     eng = net.engine()
-    r = roofline_report(eng.last_programs, precision, cname)  # (the program(s) of the forward just timed)
+    r = roofline_report(eng.last_programs, precision, cname, concurrent=eng.last_concurrent)  # (the program(s) of the forward just timed)
     gflop = sum(n * wl["gflop"](n) for n in length)
     out = {"workload": wl["label"], "dtype": DTYPE_NAME[precision], "crops_per_step": sum(length), "steps": steps, "warmup": warmup,
            "value": round(sum(length) * steps / dt, 1), "unit": "images/sec", "ms_per_step": round(dt / steps * 1e3, 3),
@@ -885,7 +956,7 @@ def main(argv=None):
     if rank == 0 and not stub:
         eng = net.engine()
         if not args.no_roofline:
-            out["roofline"] = roofline_report(eng.last_programs, precision, args.config)  # (the program(s) of the last timed forward)
+            out["roofline"] = roofline_report(eng.last_programs, precision, args.config, concurrent=eng.last_concurrent)  # (the program(s) of the last timed forward)
             if not strong and not args.pipeline:  # executed matrix-pipe + element-wise FLOPs of one forward over the step's wall time
                 out["roofline"]["model_tflops_executed"] = round(out["roofline"].pop("_executed_gflop_per_step") * args.steps / dt / 1e3, 2)
             out["roofline"].pop("_executed_gflop_per_step", None)

@@ -62,6 +62,16 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void* base, un
 __device__ __forceinline__ f32x4 buf_ld16(const __amdgpu_buffer_rsrc_t& rs, unsigned voff, int soff) {
     return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, voff, soff, 0));
 }
+// 16-byte store with a SCALAR offset.  A buffer_store_dwordx4 reads its data registers a little after it issues; the compiler keeps
+// two wait states before a VALU write of those registers only when the store has no SGPR soffset and lets the very next instruction
+// overwrite them when it has one.  On MI355X that lost data whenever other waves shared the SIMD (conv1x1_pair_k beside a second
+// program: 16 lanes of a fragment stored the NEXT fragment's value; tools/race_bisect.py, DESIGN.md "store-data hazard").  The asm
+// keeps the data registers alive for two more wait states; tools/isa_store_hazard.py (tests/test_host.py) scans every kernel of
+// the built library for stores left with fewer.
+__device__ __forceinline__ void buf_st16(const __amdgpu_buffer_rsrc_t& rs, unsigned voff, int soff, f32x4 v) {
+    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), rs, voff, soff, 0);
+    asm volatile("s_nop 1" ::"v"(v));
+}
 
 constexpr int kMaxPP = 5;  // patch pixels per thread (256 threads) -> patches up to 1280 pixels
 

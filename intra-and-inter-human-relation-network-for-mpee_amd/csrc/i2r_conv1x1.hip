@@ -92,7 +92,7 @@ __global__ __launch_bounds__(256) void conv1x1_pair_k(const PairK p) {
 #pragma unroll
                 for (int s = 0; s < 4; ++s) acc = mfma16(t.a[c][s], xb[mt][c][s], acc);  // Y^T[16 f + 4 g + r][pixel li]
             acc = floor4(acc, p.lo_a);
-            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, acc), rs_y, yo[mt], f * 64, 0);
+            buf_st16(rs_y, yo[mt], f * 64, acc);
             if constexpr (NB > 0) {
 #pragma unroll
                 for (int nb = 0; nb < NB; ++nb)
@@ -119,7 +119,7 @@ __global__ __launch_bounds__(256) void conv1x1_pair_k(const PairK p) {
         for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
             for (int nb = 0; nb < NB; ++nb)
-                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, floor4(zacc[mt][nb], p.lo_b)), rs_z, zo[mt], nb * 64, 0);
+                buf_st16(rs_z, zo[mt], nb * 64, floor4(zacc[mt][nb], p.lo_b));
     }
 }
 

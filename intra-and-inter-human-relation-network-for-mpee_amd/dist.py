@@ -16,20 +16,17 @@ def shard_bounds(length, world):
     crops).  Every rank gets at least one image whenever there are at least as many images as ranks (a rank with an empty shard
     would skip the forward and hang the collective); with fewer images than ranks the trailing ranks are empty."""
     n = len(length)
-    total = sum(length)
-    bounds, acc = [0], 0
-    for i, l in enumerate(length):
-        acc += l
-        nxt = len(bounds)                     # the next cut to place (1 .. world-1)
-        if nxt >= world:
-            break
-        left_imgs, left_ranks = n - (i + 1), world - nxt
-        # at most ONE cut per image: after image i when the running crop count has reached the next equal share, or when the
-        # images left are just enough to give every remaining rank one
-        if left_imgs >= left_ranks and (acc * world >= total * nxt) or left_imgs == left_ranks:
-            bounds.append(i + 1)
-    while len(bounds) < world:
-        bounds.append(n)
+    prefix = [0]
+    for l in length:
+        prefix.append(prefix[-1] + l)
+    total = prefix[-1]
+    bounds = [0]
+    for k in range(1, world):
+        lo = min(bounds[-1] + 1, n)            # a chunk holds at least one image ...
+        hi = max(lo, n - (world - k))          # ... and leaves one for every rank behind it (when there are enough images)
+        hi = min(hi, n)
+        # the image boundary whose crop prefix is nearest to k equal shares (the earlier one on a tie)
+        bounds.append(min(range(lo, hi + 1), key=lambda j: (abs(prefix[j] * world - total * k), j)))
     bounds.append(n)
     return bounds
 

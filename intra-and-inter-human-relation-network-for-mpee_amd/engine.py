@@ -1665,9 +1665,12 @@ class Engine:
             b = c
         return b, pe_args
 
-    def _build(self, S, H, W, length, flip=False):
+    def _build(self, S, H, W, length, flip=False, part=None):
         """flip: the flip test of validate() (lib/core/function.py:142-162) batched into the same forward -- crops S..2S-1 are
-        the mirrored copies (mirroring happens inside the stem kernels), every image appears twice as a token group."""
+        the mirrored copies (mirroring happens inside the stem kernels), every image appears twice as a token group.
+        part (models whose first stage is the bare HRNet tower): "tower" = the per-crop tower + reduce only -> (P, patch, features Act);
+        "tail" = everything behind it (position branch, inter-human encoder, deconvs, head) reading a feature buffer that tower
+        programs fill (patch["feat"]) -- the two halves of a part-batch forward (_forward_split)."""
         M = self.cfg["MODEL"]
         P = Program(self.device, multi_lane=self.multi_lane)
         P.store_dt = self.store_dt
@@ -1675,11 +1678,21 @@ class Engine:
         n_src = S
         if flip:
             S, length = 2 * S, list(length) + list(length)
-        if self.name == "interformer_pureMulti" or not self.singleformer:
+        bare = self.name == "interformer_pureMulti" or not self.singleformer
+        assert part is None or bare
+        if bare and part == "tail":
+            down = 4 * 2 ** (M["EXTRA"]["STAGE3"]["NUM_BRANCHES"] - 1)  # the lowest branch of the tower (interformer_pureMulti.py:702)
+            f = patch["feat"] = P.alloc(S, H // down, W // down, self.reduce.cout)
+            f.t.zero_()  # (capacity slots nobody fills must hold finite rows)
+            single_feat = None
+        elif bare:
             xs, patch["x"] = self.tower.emit(P, S, H, W, n_src=n_src)
             f = P.conv(xs[-1], self.reduce, out_dt=0)
             P.release(*xs)
             single_feat = None
+            if part == "tower":
+                P.finalize()
+                return P, patch, f
         else:
             g, patch["x"] = self._emit_single(P, S, H, W, n_src)
             single_feat = g
@@ -1769,7 +1782,7 @@ class Engine:
         step = 2 if S <= 32 else (4 if S <= 64 else 8)
         return -(-S // step) * step
 
-    MAX_PROGRAMS = 16  # least-recently-used programs beyond this are dropped (each owns ~20 MB of activations per crop)
+    MAX_PROGRAMS = 48  # least-recently-used programs beyond this are dropped (each owns ~20 MB of activations per crop; a part-batch forward keeps a tower program per stream and capacity next to the tail's)
 
     def forward(self, x, pos_mask, length, flip_joint_map=None):
         """flip_joint_map (device int32 [J], see caller.joint_map): run the flip test in the same forward and return the merged
@@ -1806,6 +1819,8 @@ class Engine:
         bounds = self._split_bounds(length)
         if bounds is None:
             return self._forward_part(x, pos_mask, length, flip_joint_map, S, H, W, slot=0)
+        if self.name == "interformer_pureMulti" or not self.singleformer:
+            return self._forward_split(x, pos_mask, length, flip_joint_map, S, H, W, bounds)
         parts = len(bounds) - 1
         offs = [sum(length[:b]) for b in bounds]
         x = x.to(self.device).contiguous()
@@ -1830,6 +1845,7 @@ class Engine:
             progs += self.last_programs
         ys[0] = self._forward_part(x[:offs[1]], pm[:offs[1]] if pm is not None else None, length[:bounds[1]], flip_joint_map, offs[1], H, W, slot=0)
         self.last_programs = self.last_programs + progs
+        self.last_concurrent = list(self.last_programs)
         for i in range(1, parts):
             cur.wait_event(self._part_events[i])
             for t in (ys[i].values() if isinstance(ys[i], dict) else (ys[i],)):
@@ -1837,6 +1853,90 @@ class Engine:
         if isinstance(ys[0], dict):
             return {key: torch.cat([y[key] for y in ys], 0) for key in ys[0]}
         return torch.cat(ys, 0)
+
+    def _program(self, key, build):
+        """LRU cache of programs: most recently used last"""
+        if key in self.programs:
+            self.programs[key] = self.programs.pop(key)
+        else:
+            while len(self.programs) >= self.MAX_PROGRAMS:
+                self.programs.pop(next(iter(self.programs)))
+            self.programs[key] = build()
+            self.n_builds += 1
+        return self.programs[key]
+
+    def _forward_split(self, x, pos_mask, length, flip_joint_map, S, H, W, bounds):
+        """Models whose first stage is the bare HRNet tower (vanilla I2R-Net): the per-crop TOWER of every image group runs as its own
+        program on its own stream, the rest of the forward -- position branch, inter-human encoder over ALL images (one launch per
+        layer: 384 query tiles with the partial key split instead of two launches of 192), deconvs, head -- as one tail program on
+        the caller's stream behind the join.  The towers hand their features over with a row copy into the tail's buffer."""
+        M = self.cfg["MODEL"]
+        parts = len(bounds) - 1
+        flip = flip_joint_map is not None
+        offs = [sum(length[:b]) for b in bounds]
+        x = x.to(self.device).contiguous()
+        cur = torch.cuda.current_stream(self.device)
+        if len(getattr(self, "_part_streams", ())) < parts - 1:
+            self._part_streams = [torch.cuda.Stream(device=self.device) for _ in range(parts - 1)]
+            self._part_events = [torch.cuda.Event() for _ in range(parts)]
+        cap = self.capacity(S)
+        Pt, patch = self._program((cap, H, W, flip, "tail"), lambda: self._build(cap, H, W, list(length) + [1] * (cap - S), flip, part="tail"))
+        feat = patch["feat"].view()  # [cap (x 2 with the flip test), h, w, cs]
+        e_fork = self._part_events[0]
+        e_fork.record(cur)  # (the inputs are ready, and the tail of the previous forward has read the feature buffer)
+        progs = []
+        for i in range(parts - 1, -1, -1):  # (the caller's stream takes part 0 last: its launches queue behind the side streams')
+            sp = offs[i + 1] - offs[i]
+            capp = self.capacity(sp)
+            st = self._part_streams[i - 1] if i else cur
+            if i:
+                x.record_stream(st)
+            with torch.cuda.stream(st):
+                if i:
+                    st.wait_event(e_fork)
+                Pw, pw, f = self._program((capp, H, W, flip, "tower", i), lambda: self._build(capp, H, W, [1] * capp, flip, part="tower"))
+                xi = x[offs[i]:offs[i + 1]]
+                pw["x"].in_ = xi.data_ptr()
+                pw["x"].n_valid = sp
+                Pw.run()
+                fv = f.view()
+                feat[offs[i]:offs[i + 1]].copy_(fv[:sp])
+                if flip:
+                    feat[cap + offs[i]:cap + offs[i + 1]].copy_(fv[capp:capp + sp])
+                if i:
+                    self._part_events[i].record(st)
+            progs.append(Pw)
+        for i in range(1, parts):
+            cur.wait_event(self._part_events[i])
+        # ---- the tail, as _forward_part runs a whole program ----
+        glen = list(length) + [1] * (cap - S)
+        if flip:
+            glen = glen + glen
+        for grouping, tok in Pt.groupings:
+            go = [0]
+            for n in glen:
+                go.append(go[-1] + n * tok)
+            Pt.set_groups(grouping, go)
+        J = M["NUM_JOINTS"]
+        keep = [x]
+        if "pos_mask" in patch:
+            pm = pos_mask.to(self.device, torch.float32).contiguous()
+            assert pm.shape == (S, 1, H, W)
+            patch["pos_mask"].in_ = pm.data_ptr()
+            patch["pos_mask"].n_valid = S
+            keep.append(pm)
+        n_out = 2 * cap if flip else cap
+        out = torch.empty(n_out, J, H // 4, W // 4, dtype=torch.float32, device=self.device)
+        patch["multi"].out = out.data_ptr()
+        Pt.run()
+        self.last_programs = progs[::-1] + [Pt]
+        self.last_concurrent = progs[::-1]  # (ran side by side on their own streams: bench.py times them that way)
+        if flip:
+            merged = torch.empty(S, J, H // 4, W // 4, dtype=torch.float32, device=self.device)
+            cabi.check(cabi.lib().i2r_flip_merge(out.data_ptr(), out[cap:].data_ptr(), flip_joint_map.data_ptr(), merged.data_ptr(),
+                                                 S, J, H // 4, W // 4, cur.cuda_stream), "i2r_flip_merge")
+            return merged
+        return out[:S]
 
     def _forward_part(self, x, pos_mask, length, flip_joint_map, S, H, W, slot=0):
         M = self.cfg["MODEL"]
@@ -1854,6 +1954,7 @@ class Engine:
             self.programs[key] = self._build(cap, H, W, list(length) + [1] * (cap - S), flip)
             self.n_builds += 1
         P, patch = self.programs[key]
+        self.last_concurrent = []
         self.last_programs = [P]  # the program(s) of the most recent forward (bench.py's per-launch timing pass replays them; _forward merges the parts')
         glen = list(length) + [1] * (cap - S)
         if flip:

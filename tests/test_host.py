@@ -4,6 +4,7 @@ import glob
 import os
 import re
 import subprocess
+import sys
 
 import numpy as np
 import pytest
@@ -114,6 +115,28 @@ def test_cabi_library_exports_every_declared_symbol():
     e = cabi.EncoderDesc()
     assert L.i2r_encoder_layer(ctypes.byref(e), None) == -1
     assert L.i2r_run_program(None, 0, None, None) == -1
+
+
+def test_no_wide_store_has_its_data_registers_overwritten_early():
+    """Every buffer / global store of >= 12 bytes in the gfx950 code of the built library keeps its data VGPRs untouched for two wait
+    states (tools/isa_store_hazard.py: the compiler allows zero behind a store with an SGPR soffset, which lost data on MI355X as soon as
+    two programs shared the chip -- csrc/i2r_conv.h buf_st16)."""
+    if not os.path.exists(cabi.LIB_PATH):
+        import __graft_entry__
+        __graft_entry__.build()
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import isa_store_hazard
+    import tempfile
+    with tempfile.TemporaryDirectory() as td:
+        cos = isa_store_hazard.code_objects(cabi.LIB_PATH, td)
+        assert len(cos) >= 10, "one gfx950 code object per HIP source"
+        n_stores, bad = 0, []
+        for co in cos:
+            n, b = isa_store_hazard.scan(co, 2)
+            n_stores += n
+            bad += b
+    assert n_stores > 1000
+    assert not bad, bad[:3]
 
 
 def test_struct_layouts_match_header():

@@ -335,6 +335,32 @@ def test_half_batches_on_two_streams_match_one_program():
         net.set_precision("fp32")
 
 
+def test_first_part_batch_forward_beside_a_running_program_fp32():
+    """fp32, 2-stage TransPose-H model: a one-program forward, then the FIRST part-batch forward of the same engine -- part A's tower starts
+    while part B's encoder kernels occupy the chip -- and the steady state after it, every image against the oracle at the fp32
+    tolerance.  Before csrc/i2r_conv.h buf_st16 this failed every time (0.01 .. 0.05 on part A's images): conv1x1_pair_k overwrote a
+    store's data register in the next instruction, which MI355X tolerates only while the wave has the SIMD to itself
+    (tools/race_bisect.py, tools/isa_store_hazard.py)."""
+    from i2r_amd import synth
+    cfg, sd, _, _, _, _ = setup("tph_l21")
+    length = [6, 4, 4, 2, 2, 1, 1, 1, 2, 5]
+    x, m, _ = synth.make_inputs(length, 256, 192, seed=3)
+    ref = i2r_cpu.forward(sd, cfg, x, m, length)
+    net = _net(cfg, sd, "tph_l21 (an engine of its own: no program built yet)")
+    eng = net.engine()
+    saved = eng.SPLIT_MIN_CROPS
+    try:
+        for split, n_prog in ((False, 1), (True, 2), (True, 2), (False, 1), (True, 2)):
+            eng.SPLIT_MIN_CROPS = 24 if split else 10 ** 9
+            y = net(x.cuda(), m.cuda(), length)
+            torch.cuda.synchronize()
+            assert len(eng.last_programs) == n_prog
+            for key in ("single", "multi"):
+                assert (y[key].cpu() - ref[key]).abs().max().item() < TOL, (key, split)
+    finally:
+        eng.SPLIT_MIN_CROPS = saved
+
+
 def test_config5_twelve_persons_384x288():
     """BASELINE config 5 at its real size: one image of 12 persons at 384x288 through HRFormer-B; the inter-human encoder sees
     L = 12 * 432 = 5184 tokens of width 78.  fp32 vs the oracle end to end (1e-3); fp16 within the stated tolerance, with the
