@@ -17,6 +17,13 @@ for c in tph_192_p6_b4 hrt_192_p4_b4 coco_hrt_288_p2_b4; do
   pmc $O/pmc_${c}_sq SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU SQ_INSTS_MFMA -- $B
   python tools/pmc_summary.py $O/pmc_${c}_fetch,$O/pmc_${c}_write,$O/pmc_${c}_sq > $O/pmc_$c.json 2>&1
 done
+# the headline's dominant kernel INSIDE the default bench command (per-dispatch means over all launches of the instantiation: the forward
+# runs it on 16-crop part-batches since round 4), and the isolated grouped stage-3 launch at 32 crops as in rounds 2-3
+B="python bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-roofline --no-parity --no-other-workloads"
+pmc $O/pmc_w48_fetch FETCH_SIZE -- $B
+pmc $O/pmc_w48_write WRITE_SIZE -- $B
+pmc $O/pmc_w48_sq SQ_INSTS_MFMA SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU -- $B
+python tools/pmc_summary.py $O/pmc_w48_fetch,$O/pmc_w48_write,$O/pmc_w48_sq > $O/pmc_w48.json 2>&1
 G="python tools/one_conv.py 32 5 group"
 pmc $O/pmc_wino_fetch FETCH_SIZE -- $G
 pmc $O/pmc_wino_write WRITE_SIZE -- $G

@@ -18,14 +18,28 @@ eng = engine.Engine(cfg, sd, DEV, precision=sys.argv[2] if len(sys.argv) > 2 els
 length = wl["length"]
 x, pm, _ = synth.make_inputs(length, cfg.MODEL.IMAGE_SIZE[1], cfg.MODEL.IMAGE_SIZE[0], 0)
 eng.forward(x.to(DEV), pm.to(DEV), length)
-P = next(iter(eng.programs.values()))[0]
+PI = int(os.environ.get("PROGRAM", "0"))  # which program of the forward (a part-batch forward has several: towers first, tail last)
+print("forward = %d program(s); listing program %d" % (len(eng.last_programs), PI))
+P = eng.last_programs[PI]
 L = cabi.lib()
 cur = torch.cuda.current_stream().cuda_stream
 streams = (C.c_void_p * 4)(cur, cur, cur, cur)
 tot = 0.0
 per_lane, per_name = {}, {}
+region, crit_sum, regions = {}, 0.0, []
+def close_region(i):
+    """between two sync ops the lanes run side by side: with perfect overlap the region costs its longest lane"""
+    global crit_sum
+    if region:
+        crit = max(region.values())
+        crit_sum += crit
+        regions.append((i, dict(region), crit))
+        print("      == region ends at op %d: per lane %s -> longest %.1f us (running sum of longest lanes %.3f ms)"
+              % (i, {l: round(v * 1e3, 1) for l, v in sorted(region.items())}, crit * 1e3, crit_sum))
+        region.clear()
 for i, (kind, lane, st) in enumerate(P.ops):
     if kind in cabi.SYNC_OPS:
+        close_region(i)
         print("%4d  lane %s  -- sync op %d" % (i, lane, kind))
         continue
     ms = 0.0
@@ -53,9 +67,11 @@ for i, (kind, lane, st) in enumerate(P.ops):
     elif kind in (cabi.OP_DWCONV,):
         shp = "C=%d @%dx%d s%d" % (st.c, st.in_h, st.in_w, st.stride)
     per_lane[lane] = per_lane.get(lane, 0.0) + ms
+    region[lane] = region.get(lane, 0.0) + ms
     per_name[(lane, nm)] = per_name.get((lane, nm), 0.0) + ms
     print("%4d  lane %s  %7.1f us  %6.1f TF  %-30s %s" % (i, lane, ms * 1e3, fl / ms / 1e9 if ms else 0, nm, shp))
-print("sum of stand-alone launch times: %.3f ms" % tot)
+close_region(len(P.ops))
+print("sum of stand-alone launch times: %.3f ms; sum of the longest lane of every region (perfect overlap): %.3f ms" % (tot, crit_sum))
 for lane in sorted(per_lane):
     print("lane %d: %.3f ms" % (lane, per_lane[lane]))
     for (l, nm), v in sorted(per_name.items(), key=lambda kv: -kv[1]):

@@ -63,9 +63,13 @@ if __name__ == "__main__":
         for extra in ("hrt_mlp_block_k", "hrt_attn_block_k", "conv1x1_lp_k"):
             if c.startswith(("hrt", "coco")) and extra != dom:
                 traffic("pmc_%s.json" % c, extra, "%s_hbm_traffic_%s_%s.json" % (tag, c, extra), extra + " inside bench.py --config " + c)
-    t = traffic("pmc_wino.json", "conv_wino_f32", tag + "_hbm_traffic.json",
-                "grouped stage-3 conv: 48@64x48 + 96@32x24 + 192@16x12, 3x3, S=32, +residual +ReLU (tools/one_conv.py 32 5 group)")
-    print("headline", head["value"], "wino traffic %.1f MB" % (t["hbm_bytes_per_launch"] / 1e6))
+    dom = head["roofline"]["kernel"]
+    t = traffic("pmc_w48.json", dom, tag + "_hbm_traffic.json", "dominant kernel inside the default bench.py command (all its launches of a forward: "
+                "the grouped stage-2 / stage-3 3x3 convs of the 16-crop tower programs)")
+    t2 = traffic("pmc_wino.json", "conv_wino_f32", tag + "_hbm_traffic_grouped_conv_s32.json",
+                 "isolated grouped stage-3 conv: 48@64x48 + 96@32x24 + 192@16x12, 3x3, S=32, +residual +ReLU (tools/one_conv.py 32 5 group)")
+    print("headline", head["value"], dom, "traffic per launch in the forward %.1f MB; isolated S=32 grouped launch %.1f MB"
+          % (t["hbm_bytes_per_launch"] / 1e6, t2["hbm_bytes_per_launch"] / 1e6))
     shutil.copy(os.path.join(O, "pmc_enc.json"), os.path.join(P, tag + "_pmc_encoder_layer.json"))
     copy_json("bench_ragged.json", tag + "_bench_ragged.json")
     copy_json("bench_ragged_hrt_192_p4_b4.json", tag + "_bench_ragged_hrt_192_p4_b4.json")
