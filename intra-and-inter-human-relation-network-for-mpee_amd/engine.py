@@ -119,6 +119,7 @@ _HRT_FUSED_MLP = tuple(int(v) for v in _tune("I2R_HRT_FUSED_MLP", "78,156").spli
 PAIR1X1 = _tune("I2R_PAIR1X1", "1") != "0"  # layer1's conv3 + next conv1 as one i2r_conv1x1_pair launch (fp32)
 _PAIR_MT = int(_tune("I2R_PAIR_MT", "0"))  # 16-pixel tiles per wave of that kernel
 WINOGRAD = _tune("I2R_WINOGRAD", "1") != "0"  # fp32 3x3 stride-1 convs on the Winograd F(2x2, 3x3) kernels
+_FUSE_PRE = int(_tune("I2R_FUSE_PRE", "1"))  # A/B: 0 = the fuse layers' down paths run entirely on the output's lane, after the xsync
 _LANE_CAP = int(_tune("I2R_LANE_CAP", "4"))  # HRFormer-B: branches i >= cap - 1 share stream lane cap - 1 (A/B: fewer, longer lanes)
 
 
@@ -1418,6 +1419,27 @@ class HRFormerB:
             for i in range(nb):
                 if k < len(mod["blocks"][i]):
                     xs[i] = cls._emit_block(P, mod["blocks"][i][k], xs[i], lane=min(i, _LANE_CAP - 1) if lanes else 0)
+        # Down paths of the fuse layers (output i > source j: hops of dw 3x3 s2 + 1x1 conv, hrformer.py:1656-1700) read only branch j
+        # until their last 1x1 conv, which adds the running sum of output i.  Everything before that conv runs on lane j BEFORE the
+        # all-to-all xsync: the high-resolution lanes finish their blocks early (fused kernels) while the low-resolution lanes, with
+        # eight small launches per block, are the longest of every region (tools/op_list.py) -- and would otherwise also run the
+        # down paths' dw convs over the big maps.
+        pre = {}
+        if lanes and _FUSE_PRE:
+            for i in range(mod["n_out"]):
+                for j in range(min(i, nb)):
+                    lj = min(j, _LANE_CAP - 1)
+                    P.lane_ctx = lj
+                    cur = xs[j]
+                    hops = mod["fuse"][(i, j)]
+                    for k, (dw, pc) in enumerate(hops):
+                        d = P.dwconv(cur, dw, 2, act=0, lane=lj)
+                        if cur is not xs[j]:
+                            P.release(cur)
+                        if k < len(hops) - 1:
+                            cur = P.conv(d, pc, relu=True, lane=lj)
+                            P.release(d)
+                    pre[(i, j)] = d
         if lanes:
             P.xsync((1 << nb) - 1)
         outs = []
@@ -1445,9 +1467,14 @@ class HRFormerB:
                     cur = xs[j]
                     hops = mod["fuse"][(i, j)]
                     for k, (dw, pc) in enumerate(hops):
-                        d = P.dwconv(cur, dw, 2, act=0, lane=ln)
-                        if cur is not xs[j]:
-                            P.release(cur)
+                        if (i, j) in pre:  # (everything up to the last dw conv ran on lane j before the xsync)
+                            if k < len(hops) - 1:
+                                continue
+                            d = pre[(i, j)]
+                        else:
+                            d = P.dwconv(cur, dw, 2, act=0, lane=ln)
+                            if cur is not xs[j]:
+                                P.release(cur)
                         if k < len(hops) - 1:
                             cur = P.conv(d, pc, relu=True, lane=ln)
                             P.release(d)
