@@ -119,6 +119,7 @@ _HRT_FUSED_MLP = tuple(int(v) for v in _tune("I2R_HRT_FUSED_MLP", "78,156").spli
 PAIR1X1 = _tune("I2R_PAIR1X1", "1") != "0"  # layer1's conv3 + next conv1 as one i2r_conv1x1_pair launch (fp32)
 _PAIR_MT = int(_tune("I2R_PAIR_MT", "0"))  # 16-pixel tiles per wave of that kernel
 WINOGRAD = _tune("I2R_WINOGRAD", "1") != "0"  # fp32 3x3 stride-1 convs on the Winograd F(2x2, 3x3) kernels
+_S2_MT = int(_tune("I2R_S2_MT", "1"))  # pixel fragments per wave of the stride-2 convs of the direct kernels (A/B: 0 = cost model's choice)
 _FUSE_PRE = int(_tune("I2R_FUSE_PRE", "1"))  # A/B: 0 = the fuse layers' down paths run entirely on the output's lane, after the xsync
 _LANE_CAP = int(_tune("I2R_LANE_CAP", "4"))  # HRFormer-B: branches i >= cap - 1 share stream lane cap - 1 (A/B: fewer, longer lanes)
 
@@ -703,7 +704,10 @@ class Program:
             nt, wn = conv_split(pc.cout_pad)
             n_cblk = (pc.cout_pad // 16) // (nt * wn)
             max_d = max(max(t) for t in pc.taps)
-            th, tw, mt = choose_tile(conv_h, conv_w, 4 // wn, pc.stride, max_d, x.n, n_cblk)
+            # stride-2 convs stage four input pixels per output pixel: one fragment per wave and three or more workgroups per CU
+            # hide that staging (tools/sweep_conv.py at 16 crops: 64->64 s2 82 -> 43 us, 256->96 s2 77 -> 67 us); the cost model's
+            # rounds-of-256-workgroups term was fitted on stride-1 shapes
+            th, tw, mt = choose_tile(conv_h, conv_w, 4 // wn, pc.stride, max_d, x.n, n_cblk, force_mt=_S2_MT if pc.stride == 2 else 0)
             d.tile_h, d.tile_w, d.mt, d.wn, d.ck = th, tw, mt, wn, 0
             geo = (conv_h, conv_w, 4 // wn, pc.stride, max_d, x.n, n_cblk)
             key = nt
@@ -719,7 +723,9 @@ class Program:
     def _group_tiles(group):
         """common mt + per-member tiles of a grouped launch (cost model: workgroups of all members share the chip)"""
         best = None
-        for mt in (2, 3, 4, 1):
+        # (all members: with 1x1 members in the group -- the fuse layers' second launch -- forcing it measured -0.7 % on the fp32 tower, +1.5 % on the bf16 one)
+        s2 = _S2_MT and all(geo[3] == 2 for _, geo, _ in group)
+        for mt in ((_S2_MT,) if s2 else (2, 3, 4, 1)):
             try:
                 tiles = [choose_tile(*geo, force_mt=mt, want_cost=True) for _, geo, _ in group]
             except AssertionError:

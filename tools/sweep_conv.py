@@ -34,6 +34,8 @@ def main():
     S = int(sys.argv[1]) if len(sys.argv) > 1 else 32
     shapes = [(48, 48, 3, 1, 64, 48), (96, 96, 3, 1, 32, 24), (192, 192, 3, 1, 16, 12), (64, 64, 3, 1, 64, 48),
               (256, 64, 1, 1, 64, 48), (64, 256, 1, 1, 64, 48)]
+    if len(sys.argv) > 2:  # shapes as cin,cout,k,stride,h,w (input map) ...
+        shapes = [tuple(int(v) for v in a.split(",")) for a in sys.argv[2:]]
     for (cin, cout, k, stride, h, w) in shapes:
         sd = {"c.weight": torch.from_numpy(synth._sym(1, "w", (cout, cin, k, k), 0.05))}
         pc = engine.Packer(sd, DEV).conv("c", None, stride=stride)
