@@ -38,10 +38,13 @@ def main():
         shapes = [tuple(int(v) for v in a.split(",")) for a in sys.argv[2:]]
     for (cin, cout, k, stride, h, w) in shapes:
         sd = {"c.weight": torch.from_numpy(synth._sym(1, "w", (cout, cin, k, k), 0.05))}
-        pc = engine.Packer(sd, DEV).conv("c", None, stride=stride)
+        prec = os.environ.get("PRECISION", "fp32")  # (16-bit: the lp kernels with 16-bit maps, as the towers of configs 3-5 run them)
+        dt = {"fp32": 0, "bf16": 1, "fp16": 2}[prec]
+        pc = engine.Packer(sd, DEV, precision=prec).conv("c", None, stride=stride)
         P = engine.Program(DEV)
-        x = P.alloc(S, h, w, cin)
-        x.t.normal_()
+        P.store_dt = dt
+        x = P.alloc(S, h, w, cin, dt)
+        x.view().normal_()
         P.conv(x, pc, relu=True)
         d = P.ops[-1][2]
         flop = 2.0 * S * d.conv_h * d.conv_w * cout * cin * k * k
@@ -70,7 +73,8 @@ def main():
                         if ms:
                             res.append((flop / ms / 1e9, wn, mt, th, tw, ck, ms))
         res.sort(reverse=True)
-        print("== conv %d->%d k%d s%d @%dx%d S=%d  (%.2f GFLOP) engine default tile=%s" % (cin, cout, k, stride, h, w, S, flop / 1e9, base))
+        d.tile_h, d.tile_w, d.mt, d.wn, d.ck = base + (0,)
+        print("== conv %d->%d k%d s%d @%dx%d S=%d %s (%.2f GFLOP) engine default tile=%s: %.1f us" % (cin, cout, k, stride, h, w, S, prec, flop / 1e9, base, (time_desc(d) or 0) * 1e3))
         for r in res[:8]:
             print("   %7.1f TF  wn=%d mt=%d tile=%dx%d ck=%d  %.1f us" % (r[0], r[1], r[2], r[3], r[4], r[5], r[6] * 1e3))
         worst = res[-1]
