@@ -44,6 +44,7 @@ struct ConvK {
     // Winograd F(2x2, 3x3) kernels (i2r_conv_wino.hip; algo == 1): tiles_y / tiles_x count FRAGMENTS (16 Winograd tiles, 2^w_fwlog across)
     // per crop, ph / pw / plane describe one fragment's raw patch, whose rows have w_pitch slots with the odd columns at + w_half
     int algo, w_fwlog, w_pitch, w_half, w_nfrag, w_rcp;  // w_rcp = ceil(65536 / pw): patch row of a pixel index without a division
+    int w_band;                                          // fragment groups per XCD band (launches without a dispatch table, i2r_conv_wino.hip)
     unsigned w_m_cblk, w_m_img, w_m_tx;                  // ceil(2^32 / d) for d = n_cblk, fragments per crop, fragments per row (item decode)
 };
 

@@ -394,7 +394,7 @@ static void copy_desc(const i2r_conv_desc* d, ConvK& k) {
     k.out_step = d->out_step; k.out_off_y = d->out_off_y; k.out_off_x = d->out_off_x; k.rep = d->rep; k.relu = d->relu;
     k.dtype = d->dtype;
     k.in16 = d->in_f16; k.out16 = d->out_f16;
-    k.algo = d->algo; k.w_fwlog = k.w_pitch = k.w_half = k.w_nfrag = k.w_rcp = 0;
+    k.algo = d->algo; k.w_fwlog = k.w_pitch = k.w_half = k.w_nfrag = k.w_rcp = k.w_band = 0;
     k.w_m_cblk = k.w_m_img = k.w_m_tx = 0; k.in_bytes = k.w_bytes = k.out_bytes = 0;
     k.m_cblk = k.m_tx = k.m_ty = k.m_pw = k.m_tw = 0; k.wn_log = 0; k.npass = 0;
     k.dbg = 0;
@@ -625,7 +625,7 @@ static int prepare(const i2r_conv_desc* d, int force_mt, int force_cap, int forc
 }
 
 static int resolve(const i2r_conv_desc* const* descs, int32_t n, ConvGroupK& grp, int* nt0_, int* mt0_, int* cap0_, int* pf0_,
-                   size_t* lds_, long long* total_) {
+                   size_t* lds_, long long* total_, bool table = true) {
     I2R_CHECK_ARG(descs && n >= 1 && n <= kMaxGroups, "i2r_conv_grouped: 1..%d descriptors", kMaxGroups);
     int nt0 = 0, mt0 = 0, pf0 = -1, cap0 = 4;
     size_t lds_max = 0;
@@ -661,6 +661,11 @@ static int resolve(const i2r_conv_desc* const* descs, int32_t n, ConvGroupK& grp
         I2R_CHECK_ARG(nt == nt0 && mt == mt0, "i2r_conv_grouped: descriptor %d has fragment blocking (%d,%d) != (%d,%d)", i, mt, nt, mt0, nt0);
         I2R_CHECK_ARG(descs[i]->dtype == descs[0]->dtype, "i2r_conv_grouped: members mix compute dtypes");
         if (lds > lds_max) lds_max = lds;
+        if (descs[i]->algo == 1 && !table) {  // XCD-aware item numbering of the Winograd kernels (i2r_conv_wino.hip): whole rounds of 8 fragment groups
+            const long long groups = nblk / grp.g[i].n_cblk;
+            grp.g[i].w_band = (int)((groups + 7) / 8);
+            nblk = (long long)grp.g[i].w_band * 8 * grp.g[i].n_cblk;
+        }
         total += nblk;
         grp.blk_end[i] = (int)total;
     }
@@ -677,7 +682,7 @@ extern "C" int i2r_conv_grouped(const i2r_conv_desc* const* descs, int32_t n, co
     int nt0, mt0, cap0, pf0;
     size_t lds_max;
     long long total;
-    int rc = resolve(descs, n, grp, &nt0, &mt0, &cap0, &pf0, &lds_max, &total);
+    int rc = resolve(descs, n, grp, &nt0, &mt0, &cap0, &pf0, &lds_max, &total, block_map != nullptr);
     if (rc) return rc;
     grp.blk_map = block_map;
     I2R_CHECK_ARG(block_map == nullptr || map_len == (int32_t)total, "i2r_conv_grouped: block_map has %d entries, grid has %lld", map_len, total);
