@@ -55,14 +55,8 @@ full = [0xFFFFFFFF] * 8
 run("default streams", None, None)
 run("default streams (again)", None, None)
 run("all lanes on full-mask ExternalStreams", masked_stream(full), [masked_stream(full) for _ in range(3)])
-for reserve in (2, 4, 8):
-    # layout A: the reserved CUs are the top bits of every 32-bit word; layout B: whole trailing words' worth spread as every 32/reserve-th bit
-    a = [0xFFFFFFFF >> reserve] * 8
-    step = 32 // reserve
-    bmask = 0xFFFFFFFF
-    for k in range(reserve):
-        bmask &= ~(1 << (k * step))
-    b = [bmask] * 8
-    for lname, words in (("top bits", a), ("every %dth bit" % step, b)):
-        run("lanes 0/1 without %d CUs per word (%s)" % (reserve, lname), masked_stream(words), [masked_stream(words), torch.cuda.Stream(), torch.cuda.Stream()])
+# one 32-bit word: is the mask applied per XCC (32 CUs each) and replicated?
+for words, tag in (([0xFFFFFFFF], "1 word, full"), ([0x0FFFFFFF], "1 word, 28 of 32"), ([0xFFFFFFFF, 0xFFFFFFFF], "2 words, full"),
+                   ([0x0FFFFFFF] * 8, "8 words, 28 of 32 each")):
+    run("lanes 0/1 masked: " + tag, masked_stream(words), [masked_stream(words), torch.cuda.Stream(), torch.cuda.Stream()])
 run("default streams (end)", None, None)
