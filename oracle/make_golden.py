@@ -33,8 +33,8 @@ CASES = [
     # tag, config name, length, (H, W), store full output?
     ("w48_l31", "w48_pure_en6", [3, 1], (256, 192), True),
     ("w48_l44", "w48_pure_en6", [4, 4], (256, 192), True),       # BASELINE config 1: the CPU-runnable case the metric is quoted beside
-    ("w48_l1", "w48_pure_en6", [1], (256, 192), False),
-    ("w48_l213", "w48_pure_en6", [2, 1, 3], (256, 192), False),
+    ("w48_l1", "w48_pure_en6", [1], (256, 192), True),
+    ("w48_l213", "w48_pure_en6", [2, 1, 3], (256, 192), True),
     ("tph_l21", "tph_192_p6_b4", [2, 1], (256, 192), True),
     ("hrt_l21", "hrt_192_p4_b4", [2, 1], (256, 192), True),
     ("hrt288_l2", "coco_hrt_288_p2_b4", [2], (384, 288), True),      # 96x72 maps, 24x18 inter-human tokens
