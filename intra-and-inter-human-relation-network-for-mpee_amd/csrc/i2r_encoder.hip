@@ -763,27 +763,33 @@ __device__ __forceinline__ f32x4 load_xblk(const float* row, const float* prow, 
     return pack8<DT>(a0, a1);
 }
 
-// K / V projection, one 32-token block of ONE group per workgroup (blocks are numbered group by group, like the 16-key fragments of
-// the fp32 kernels: block b of group g sits at index sum_{g' < g} ceil(len_g' / 32) + b, so group offsets need no alignment)
-template <int DC, int CSR, int DT>
+// K / V projection, TB consecutive 32-token blocks of ONE group per workgroup (blocks are numbered group by group, like the 16-key
+// fragments of the fp32 kernels: block b of group g sits at index sum_{g' < g} ceil(len_g' / 32) + b, so group offsets need no
+// alignment).  TB = 2 (round 4): the 36 KB of K / V projection rows stream from L2 once per 64 tokens instead of once per 32 -- every
+// wave of the launch re-reads them, which was more L2 traffic than the launch's HBM traffic -- and K is projected and stored before V
+// so the two sets of accumulators never live together.
+#ifndef I2R_KV_TB
+#define I2R_KV_TB 2
+#endif
+template <int DC, int CSR, int DT, int TB>
 __global__ __launch_bounds__(64) void enc_kv_lp_k(const EncK p) {
-    constexpr int KC = DC / 2, cs = CSR * 16, csp = DC * 16;
+    constexpr int KC = DC / 2, cs = CSR * 16, csp = DC * 16, TF = 2 * TB;
     const int lane = threadIdx.x, li = lane & 15, g = lane >> 4;
     int b = blockIdx.x, gs = 0, ge = 0, base32 = 0;
     for (int grp = 0; grp < p.n_grp; ++grp) {
         gs = p.grp_off[grp];
         ge = p.grp_off[grp + 1];
-        const int nb = (ge - gs + 31) >> 5;
-        if (b < nb) break;
-        b -= nb;
+        const int nb = (ge - gs + 31) >> 5, nw = (nb + TB - 1) / TB;
+        if (b < nw) break;
+        b -= nw;
         base32 += nb;
     }
-    const int t0 = gs + b * 32;
-    // B operands of the two 16-token fragments: src + pos (keys) and src (values), packed to 16 bit like every GEMM input here
-    f32x4 xq[2][KC], xs[2][KC];
-    bool valid[2];
+    const int t0 = gs + b * 32 * TB;
+    // B operands of the 16-token fragments: src + pos (keys) and src (values), packed to 16 bit like every GEMM input here
+    f32x4 xq[TF][KC], xs[TF][KC];
+    bool valid[TF];
 #pragma unroll
-    for (int tf = 0; tf < 2; ++tf) {
+    for (int tf = 0; tf < TF; ++tf) {
         const int tok = t0 + tf * 16 + li;
         valid[tf] = tok < ge;
         const int row = valid[tf] ? tok : ge - 1;  // (rows past the group: finite duplicates, masked as keys, zeroed as values)
@@ -797,28 +803,45 @@ __global__ __launch_bounds__(64) void enc_kv_lp_k(const EncK p) {
     // K rows of the in_proj: row blocks [DC, 2DC) of the fragment-packed 16-bit matrix, V rows: [2DC, 3DC)
     const unsigned short* w16 = reinterpret_cast<const unsigned short*>(p.w_in_lp);
     const float* bin = p.vec_lp;  // LpVec::BIN = 0
-    f32x4 ak[2][DC], av[2][DC];
-    gemm_T_lp<DC, KC, 2, DT>(w16 + (size_t)DC * KC * 512, bin + csp, csp, xq, li, g, [&](int nt, int tf, f32x4 a) { ak[tf][nt] = a; });
-    gemm_T_lp<DC, KC, 2, DT>(w16 + (size_t)2 * DC * KC * 512, bin + 2 * csp, csp, xs, li, g, [&](int nt, int tf, f32x4 a) {
-        av[tf][nt] = valid[tf] ? a : (f32x4){0.f, 0.f, 0.f, 0.f};
-    });
-    // fragment-packed 16-bit operand images of this 32-token block, one 16-byte store per lane:
+    // fragment-packed 16-bit operand images of a 32-token block, one 16-byte store per lane:
     //   K:   [(blk*2 + tf)*KC + c][lane][8]      lane (li, g): key 16tf + li, the 8 permuted features g*8.. of 32-block c
     //   V^T: [blk*DC + nt][lane'][8]              lane' (li' = feature in fragment nt, g' = key quad): 8 keys in the block's
     //        permuted order (position 8*((k%16)/4) + 4*(k/16) + k%4); a 4x4 quad transpose turns (key li, features 4g+r) into
     //        (feature 4g + (li&3), keys 4(li>>2) + r') so both 16-key halves pack into the destination lane's 16 bytes
     unsigned short* k16 = reinterpret_cast<unsigned short*>(p.kbuf);
     unsigned short* v16 = reinterpret_cast<unsigned short*>(p.vbuf);
-    const size_t blk = (size_t)(base32 + b);
+    const size_t blk0 = (size_t)base32 + (size_t)b * TB;
+    bool bok[TB];  // (wave-uniform: the group may end inside the workgroup's run of blocks -- a block that does not exist is not stored,
+                   //  its index belongs to the next group)
 #pragma unroll
-    for (int c = 0; c < KC; ++c)
+    for (int h = 0; h < TB; ++h) bok[h] = t0 + 32 * h < ge;
+    {
+        f32x4 ak[TF][DC];
+        gemm_T_lp<DC, KC, TF, DT>(w16 + (size_t)DC * KC * 512, bin + csp, csp, xq, li, g, [&](int nt, int tf, f32x4 a) { ak[tf][nt] = a; });
 #pragma unroll
-        for (int tf = 0; tf < 2; ++tf)
-            *reinterpret_cast<f32x4*>(k16 + ((((blk * 2 + tf) * KC + c) * 64 + lane) * 8)) = pack8<DT>(ak[tf][2 * c], ak[tf][2 * c + 1]);
+        for (int h = 0; h < TB; ++h) {
+            if (!bok[h]) continue;
 #pragma unroll
-    for (int nt = 0; nt < DC; ++nt) {
-        const f32x4 pv = pack8<DT>(quad_transpose(av[0][nt], li & 3), quad_transpose(av[1][nt], li & 3));
-        *reinterpret_cast<f32x4*>(v16 + (((blk * DC + nt) * 64 + 4 * g + (li & 3) + 16 * (li >> 2)) * 8)) = pv;
+            for (int c = 0; c < KC; ++c)
+#pragma unroll
+                for (int tf = 0; tf < 2; ++tf)
+                    *reinterpret_cast<f32x4*>(k16 + (((((blk0 + h) * 2 + tf) * KC + c) * 64 + lane) * 8)) = pack8<DT>(ak[2 * h + tf][2 * c], ak[2 * h + tf][2 * c + 1]);
+        }
+    }
+    {
+        f32x4 av[TF][DC];
+        gemm_T_lp<DC, KC, TF, DT>(w16 + (size_t)2 * DC * KC * 512, bin + 2 * csp, csp, xs, li, g, [&](int nt, int tf, f32x4 a) {
+            av[tf][nt] = valid[tf] ? a : (f32x4){0.f, 0.f, 0.f, 0.f};
+        });
+#pragma unroll
+        for (int h = 0; h < TB; ++h) {
+            if (!bok[h]) continue;
+#pragma unroll
+            for (int nt = 0; nt < DC; ++nt) {
+                const f32x4 pv = pack8<DT>(quad_transpose(av[2 * h][nt], li & 3), quad_transpose(av[2 * h + 1][nt], li & 3));
+                *reinterpret_cast<f32x4*>(v16 + ((((blk0 + h) * DC + nt) * 64 + 4 * g + (li & 3) + 16 * (li >> 2)) * 8)) = pv;
+            }
+        }
     }
 }
 
@@ -1087,14 +1110,17 @@ extern "C" int i2r_encoder_kv(const i2r_encoder_desc* d, void* stream) {
     int rc = fill(d, k);
     if (rc) return rc;
     if (d->dtype != 0) {
-        const unsigned nblk = (unsigned)d->n_qtiles32;  // one 32-token block of a group per workgroup
+        // one workgroup per I2R_KV_TB consecutive 32-token blocks of a group (n_qtiles64 = sum of ceil(len / 64) = sum of ceil(blocks / 2))
+        constexpr int TB = I2R_KV_TB;
+        const unsigned nblk = (unsigned)(TB == 2 ? d->n_qtiles64 : d->n_qtiles32);
+        I2R_CHECK_ARG(nblk > 0, "i2r_encoder_kv: n_qtiles%d", TB == 2 ? 64 : 32);
         const bool c6 = d->cs == 96;
         if (d->dtype == 1) {
-            if (c6) hipLaunchKernelGGL((enc_kv_lp_k<6, 6, 1>), dim3(nblk), dim3(64), 0, (hipStream_t)stream, k);
-            else hipLaunchKernelGGL((enc_kv_lp_k<6, 5, 1>), dim3(nblk), dim3(64), 0, (hipStream_t)stream, k);
+            if (c6) hipLaunchKernelGGL((enc_kv_lp_k<6, 6, 1, TB>), dim3(nblk), dim3(64), 0, (hipStream_t)stream, k);
+            else hipLaunchKernelGGL((enc_kv_lp_k<6, 5, 1, TB>), dim3(nblk), dim3(64), 0, (hipStream_t)stream, k);
         } else {
-            if (c6) hipLaunchKernelGGL((enc_kv_lp_k<6, 6, 2>), dim3(nblk), dim3(64), 0, (hipStream_t)stream, k);
-            else hipLaunchKernelGGL((enc_kv_lp_k<6, 5, 2>), dim3(nblk), dim3(64), 0, (hipStream_t)stream, k);
+            if (c6) hipLaunchKernelGGL((enc_kv_lp_k<6, 6, 2, TB>), dim3(nblk), dim3(64), 0, (hipStream_t)stream, k);
+            else hipLaunchKernelGGL((enc_kv_lp_k<6, 5, 2, TB>), dim3(nblk), dim3(64), 0, (hipStream_t)stream, k);
         }
     } else {
         I2R_CHECK_ARG(d->n_qtiles16 > 0, "i2r_encoder_kv: n_qtiles16");
