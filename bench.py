@@ -30,7 +30,7 @@ One JSON line is printed by rank 0:
                (MI355X_MICROARCH.md: fp32 MFMA 157.3 TFLOP/s, bf16/fp16 2500 TFLOP/s, HBM 8 TB/s);
                `kernels` = the same figures for the five largest kernels; attention_blocks = the encoder kernels
   other_workloads  (default single-GPU line only) BASELINE configs[2..4] at their own batch shapes and dtypes, the ragged stream and the
-               pipeline, ~10 steps each, measured in this process after the headline's timed region: value, ms_per_step, dominant kernel
+               pipeline, 10-30 steps each, measured in this process after the headline's timed region: value, ms_per_step, dominant kernel
                with its roofline fraction, parity against the CPU oracle
   parity       max-abs difference of the first image of the timed batch against the CPU oracle (fp32: the 1e-3 bar of BASELINE.json)
   cpu_baseline the CPU oracle (oracle/i2r_cpu.py, a port of the reference forward) timed on this host, rank 0, N = 1 only
@@ -655,7 +655,7 @@ def _brief(kv):
     return out
 
 
-def quick_workload(cname, dev, steps=10, warmup=3):
+def quick_workload(cname, dev, steps=30, warmup=5):
     """One of the other BASELINE workloads at its own batch shape and dtype, measured like the headline but short: `steps` timed forwards
     (inputs resident), the per-launch roofline pass (dominant kernel + the next two, attention blocks), parity of image 0 against the
     CPU oracle.  Everything it allocates is released on return."""
@@ -973,7 +973,7 @@ def main(argv=None):
                         and args.precision in (None, "fp32"))
         if default_line and not args.no_other_workloads:
             # the driver only runs `bench.py --gpus 1`: BASELINE configs[2..4] at their own batch shapes / dtypes, the ragged stream and
-            # the pipeline are measured in the same process right after the headline's timed region, ~10 steps each
+            # the pipeline are measured in the same process right after the headline's timed region, 10-30 steps each
             t_other = time.perf_counter()
             out["other_workloads"] = other_workloads(net, cfg, dev)
             out["other_workloads"]["wall_s"] = round(time.perf_counter() - t_other, 1)
