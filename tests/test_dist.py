@@ -39,6 +39,11 @@ def test_shard_images_never_starves_a_rank():
         if n >= world:
             assert all(b[i] < b[i + 1] for i in range(world)), (length, world, b)
             assert max(sum(length[b[i]:b[i + 1]]) for i in range(world)) <= sum(length) / world + max(length)
+        if world == 2 and n >= 2:  # two part-batches (Engine._split_bounds): the cut is the image boundary nearest to half of the crops
+            half = sum(length) / 2.0
+            best = min(abs(sum(length[:j]) - half) for j in range(1, n))
+            assert abs(sum(length[:b[1]]) - half) == best, (length, b)
+    assert i2r_dist.shard_bounds([6, 4, 4, 2, 2, 1, 1, 1, 2, 5, 4, 6, 4, 4, 6, 5], 2) == [0, 10, 16]  # 28 / 29 crops (bench config 3)
 
 
 def _worker(rank, world, port, length):

@@ -361,6 +361,18 @@ def test_first_part_batch_forward_beside_a_running_program_fp32():
         eng.SPLIT_MIN_CROPS = saved
 
 
+def test_engines_share_the_lane_streams():
+    """engine.lane_streams: every engine of the process runs its lanes / part-batches on the same side streams (an engine with streams of
+    its own, made after other engines', got lanes on a shared hardware queue: -7 % on the four-lane HRFormer forward)"""
+    from i2r_amd import engine
+    cfg_a, sd_a, _, _, _, _ = setup("tph_l21")
+    cfg_b, sd_b, _, _, _, _ = setup("hrt_l21")
+    ea = _net(cfg_a, sd_a, "tph_192_p6_b4").engine()
+    eb = _net(cfg_b, sd_b, "hrt_192_p4_b4").engine()
+    assert len(ea.side_streams) == 3 and all(a is b for a, b in zip(ea.side_streams, eb.side_streams))
+    assert engine.lane_streams(ea.device, 4)[:3] == ea.side_streams
+
+
 def test_config5_twelve_persons_384x288():
     """BASELINE config 5 at its real size: one image of 12 persons at 384x288 through HRFormer-B; the inter-human encoder sees
     L = 12 * 432 = 5184 tokens of width 78.  fp32 vs the oracle end to end (1e-3); fp16 within the stated tolerance, with the
