@@ -26,7 +26,11 @@
 extern "C" {
 #endif
 
-#define I2R_ABI_VERSION 8
+#define I2R_ABI_VERSION 9
+
+/* The library is built with -fvisibility=hidden: the entry points declared in this header (marked I2R_API) are its ONLY exported
+ * symbols (tests/test_host.py holds the header, the dynamic symbol table and cabi.EXPORTS equal). */
+#define I2R_API __attribute__((visibility("default")))
 
 #define I2R_OK 0
 #define I2R_E_ARG (-1)      /* bad argument (shape / alignment / unsupported combination) */
@@ -90,7 +94,7 @@ typedef struct i2r_conv_desc {
                                       workgroup (1 or 2, 0 = 1; 2 only for cout_pad / 16 a multiple of 3).  2.25x fewer matrix-pipe operations than algo 0 for the same sum. */
 } i2r_conv_desc;
 
-int i2r_conv(const i2r_conv_desc* d, void* stream);
+I2R_API int i2r_conv(const i2r_conv_desc* d, void* stream);
 
 /* i2r_conv_grouped -- up to I2R_MAX_GROUP independent convolutions in ONE launch ("horizontal fusion"): the
  * parallel branches of a HighResolutionModule (interformer_pureMulti.py:396-397) and the same-depth terms of its
@@ -100,7 +104,7 @@ int i2r_conv(const i2r_conv_desc* d, void* stream);
 /* block_map (optional, device int32[map_len]): dispatch order of the workgroups, entry = (member << 24) | index of
  * the workgroup within that member; map_len must equal the total workgroup count
  * (sum over members of n_img * ceil(conv_h/tile_h) * ceil(conv_w/tile_w) * cout_blocks). */
-int i2r_conv_grouped(const i2r_conv_desc* const* descs, int32_t n, const int32_t* block_map, int32_t map_len,
+I2R_API int i2r_conv_grouped(const i2r_conv_desc* const* descs, int32_t n, const int32_t* block_map, int32_t map_len,
                      void* stream);
 
 /* i2r_conv_chain (EXPERIMENTAL: correct and tested, but measured slower than one i2r_conv_grouped per layer on MI355X at 32 crops;
@@ -130,8 +134,8 @@ typedef struct i2r_conv_chain_args {
     int32_t n_flags, kdesc_bytes, capacity, nt, mt, cap, pf, lds_bytes;
     int32_t tiles[I2R_MAX_GROUP][4];  /* per member: tiles_y, tiles_x, cout blocks, workgroups per layer */
 } i2r_conv_chain_args;
-int i2r_conv_chain_pack(i2r_conv_chain_args* a, void* host_buf, int64_t host_bytes);
-int i2r_conv_chain(const i2r_conv_chain_args* a, void* stream);
+I2R_API int i2r_conv_chain_pack(i2r_conv_chain_args* a, void* host_buf, int64_t host_bytes);
+I2R_API int i2r_conv_chain(const i2r_conv_chain_args* a, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * i2r_stem_conv -- first 3x3 stride-2 pad-1 conv of a tower (cin = 1..4) + folded BN + ReLU, reading the
@@ -143,7 +147,7 @@ int i2r_conv_chain(const i2r_conv_chain_args* a, void* stream);
  * n_valid (1..n_src): the input tensor really holds n_valid images; output slots n_valid..n_src-1 (capacity padding of a
  * pre-built launch program) are computed from image n_valid-1 and are the caller's to drop.
  * ------------------------------------------------------------------------------------------------ */
-int i2r_stem_conv(const float* in_nchw, const float* w, const float* bias, float* out_nhwc, int32_t n_img,
+I2R_API int i2r_stem_conv(const float* in_nchw, const float* w, const float* bias, float* out_nhwc, int32_t n_img,
                   int32_t cin, int32_t in_h, int32_t in_w, int32_t cout, int32_t out_cs, int32_t n_src, int32_t n_valid,
                   int32_t out_dt /* storage of out: 0 fp32, 1 bf16, 2 f16 (see i2r_conv_desc.in_f16) */, void* stream);
 
@@ -152,29 +156,29 @@ int i2r_stem_conv(const float* in_nchw, const float* w, const float* bias, float
  * no bias) + bn1 (eval, folded by the host) + ReLU, reading the boundary NCHW bbox mask [n_src, 1, in_h, in_w] and writing NHWC
  * [n_img, in_h/2, in_w/2, out_cs].  w_pre: float[9][3] (tap-major), w7: float[49][3][64] (tap, cin, cout) with the BN scale
  * folded in, bias[64].  n_src / n_valid as in i2r_stem_conv (mirrored copies for the flip test, capacity padding). */
-int i2r_pe_res_stem(const float* mask_nchw, const float* w_pre, const float* w7, const float* bias, float* out_nhwc,
+I2R_API int i2r_pe_res_stem(const float* mask_nchw, const float* w_pre, const float* w7, const float* bias, float* out_nhwc,
                     int32_t n_img, int32_t in_h, int32_t in_w, int32_t cout, int32_t out_cs, int32_t n_src, int32_t n_valid, void* stream);
 
 /* i2r_maxpool3x3s2 -- nn.MaxPool2d(kernel_size=3, stride=2, padding=1) on NHWC
  * (interformer.py:162,260-264; position_embedding.py:9,106-109).  c % 4 == 0. */
-int i2r_maxpool3x3s2(const float* in, float* out, int32_t n_img, int32_t in_h, int32_t in_w, int32_t c,
+I2R_API int i2r_maxpool3x3s2(const float* in, float* out, int32_t n_img, int32_t in_h, int32_t in_w, int32_t c,
                      int32_t in_cs, int32_t out_cs, void* stream);
 
 /* i2r_head -- final 1x1 conv (with bias) NHWC -> boundary NCHW heatmaps
  * (final_layer, interformer_pureMulti.py:486-492,776; interformer.py:176-182,317).
  * w: float[cout][cin] (the nn.Conv2d weight as is), bias[cout]. out: [n_img, cout, h, w]. */
-int i2r_head(const float* in, const float* w, const float* bias, float* out_nchw, int32_t n_img, int32_t h,
+I2R_API int i2r_head(const float* in, const float* w, const float* bias, float* out_nchw, int32_t n_img, int32_t h,
              int32_t w_, int32_t cin, int32_t in_cs, int32_t cout, void* stream);
 
 /* i2r_conv_kernel_name -- which instantiation conv_igemm_f32<MT, NT, CAP, PF> a (grouped) launch resolves to, as it
  * appears in rocprofv3 kernel traces (used by bench.py to key its per-kernel roofline numbers). No launch happens. */
-int i2r_conv_kernel_name(const i2r_conv_desc* const* descs, int32_t n, char* buf, int32_t buflen);
+I2R_API int i2r_conv_kernel_name(const i2r_conv_desc* const* descs, int32_t n, char* buf, int32_t buflen);
 
 /* ---- after the forward: flip-test merge and keypoint decode -------------------------------- */
 /* i2r_flip_merge -- out = (y + flip_back(y_flipped)) * 0.5  with flip_back = reverse W + swap left/right joints
  * (lib/core/function.py:142-162, lib/utils/transforms.py:16-30). joint_map: device int32[joints], the joint whose mirrored
  * heatmap lands in channel j (identity for unpaired joints). NCHW fp32 [n, joints, h, w]. */
-int i2r_flip_merge(const float* y, const float* y_flipped, const int32_t* joint_map, float* out, int32_t n, int32_t joints,
+I2R_API int i2r_flip_merge(const float* y, const float* y_flipped, const int32_t* joint_map, float* out, int32_t n, int32_t joints,
                    int32_t h, int32_t w, void* stream);
 
 /* i2r_decode -- get_final_preds (lib/core/inference.py:90-112): arg-max (:20-48), Gaussian blur with kernel TEST.BLUR_KERNEL
@@ -182,7 +186,7 @@ int i2r_flip_merge(const float* y, const float* y_flipped, const int32_t* joint_
  * 0.3*((k-1)*0.5-1)+0.8), log(max(.,1e-10)), second-order Taylor refinement (:51-70), inverse crop affine with rot 0
  * (lib/utils/transforms.py:50-101: scale about the centres by (scale[0]*200-1)/(w-1)).
  * heatmaps [n, joints, h, w]; center, scale [n, 2] (unused when transform_back == 0); preds [n, joints, 2]; maxvals [n, joints]. */
-int i2r_decode(const float* heatmaps, const float* center, const float* scale, float* preds, float* maxvals, int32_t n,
+I2R_API int i2r_decode(const float* heatmaps, const float* center, const float* scale, float* preds, float* maxvals, int32_t n,
                int32_t joints, int32_t h, int32_t w, int32_t blur_kernel, int32_t transform_back, void* stream);
 
 /* ---- input side (reference lib/dataset/JointsDataset.py:296-333) ------------------------
@@ -192,13 +196,13 @@ int i2r_decode(const float* heatmaps, const float* center, const float* scale, f
  * inv_trans: device float [n, 6] = the INVERSE (input pixel -> image pixel) of get_affine_transform(center, scale, 0, size)
  * (lib/utils/transforms.py:61-96); out: [n, 3, oh, ow] fp32.  fp32 interpolation, NOT cv2's fixed-point one (parity unpinned:
  * cv2 is not available to pin it; deviation bounded by cv2's 1/32-pixel / 8-bit quantisation). */
-int i2r_crop_affine(const unsigned char* img, int32_t ih, int32_t iw, int32_t row_bytes, int32_t swap_rb, const float* inv_trans,
+I2R_API int i2r_crop_affine(const unsigned char* img, int32_t ih, int32_t iw, int32_t row_bytes, int32_t swap_rb, const float* inv_trans,
                     const float* mean, const float* inv_std, float* out, int32_t n, int32_t oh, int32_t ow, void* stream);
 
 /* i2r_box_mask -- get_position(shape, box, 'single') + rotate_bound(., 0) + cv2.resize(., IMAGE_SIZE) + ToTensor
  * (JointsDataset.py:165-177,323-331): the filled inclusive rectangle boxes[p] = (int(x), int(y), int(x+w), int(y+h)) at image
  * resolution, resized bilinearly (half-pixel centres) to [n, 1, oh, ow], values in [0, 1].  Same parity note as above. */
-int i2r_box_mask(const int32_t* boxes, int32_t ih, int32_t iw, float* out, int32_t n, int32_t oh, int32_t ow, void* stream);
+I2R_API int i2r_box_mask(const int32_t* boxes, int32_t ih, int32_t iw, float* out, int32_t n, int32_t oh, int32_t ow, void* stream);
 
 /* i2r_crop_affine_cv2 / i2r_box_mask_cv2 -- the same two steps in cv2's OWN arithmetic, restated from OpenCV's published algorithm
  * (imgwarp.cpp warpAffine -> remap with the 1/32-pixel fixed-point bilinear table, 15-bit weights, 8-bit result; resize.cpp 8-bit
@@ -206,15 +210,18 @@ int i2r_box_mask(const int32_t* boxes, int32_t ih, int32_t iw, float* out, int32
  * inv_m: device double [n, 6] = the INVERSE of get_affine_transform(...) computed in double precision the way cv2.warpAffine does.
  * Default of the host side (input.person_inputs); still "parity unpinned": cv2 is absent from the build image, nothing could be
  * compared with a cv2 output (oracle/input_cpu.py carries the same restatement in numpy). */
-int i2r_crop_affine_cv2(const unsigned char* img, int32_t ih, int32_t iw, int32_t row_bytes, int32_t swap_rb, const double* inv_m,
+I2R_API int i2r_crop_affine_cv2(const unsigned char* img, int32_t ih, int32_t iw, int32_t row_bytes, int32_t swap_rb, const double* inv_m,
                         const float* mean, const float* inv_std, float* out, int32_t n, int32_t oh, int32_t ow, void* stream);
-int i2r_box_mask_cv2(const int32_t* boxes, int32_t ih, int32_t iw, float* out, int32_t n, int32_t oh, int32_t ow, void* stream);
+I2R_API int i2r_box_mask_cv2(const int32_t* boxes, int32_t ih, int32_t iw, float* out, int32_t n, int32_t oh, int32_t ow, void* stream);
 
 /* i2r_person_inputs_cv2 -- the input side of a whole validate() BATCH in one launch: for every person crop p of every image,
  * i2r_crop_affine_cv2 and i2r_box_mask_cv2 (same arithmetic, bit-identical results) written straight into the collated tensors
  * x_out [n_crops, 3, oh, ow] and mask_out [n_crops, 1, oh, ow] that collater.__call__ would build (lib/dataset/collater.py:14-26).
  * images / crops: DEVICE tables (the caller uploads both in one pinned, stream-ordered copy); crops[p].image indexes `images`;
  * the crops of an image must be consecutive for the model's `length` list to describe them, the kernel itself does not care.
+ * The tables are device memory the host entry point cannot read: a crop whose `image` index lies outside [0, n_images) or whose
+ * image entry is empty (null pointer, ih / iw <= 0) gets ZEROS in x_out / mask_out instead of an out-of-bounds read (the call
+ * still returns I2R_OK); `reserved` fields are ignored.
  * mean / inv_std: HOST float[3] (passed on as kernel arguments). */
 typedef struct {
     const unsigned char* img;      /* device uint8 [ih, iw, 3], channel order as cv2.imread delivers it */
@@ -226,13 +233,13 @@ typedef struct {
     int32_t image;                 /* index into the image table */
     int32_t reserved[3];
 } i2r_crop_ref;                    /* 80 bytes */
-int i2r_person_inputs_cv2(const i2r_image_ref* images, int32_t n_images, const i2r_crop_ref* crops, int32_t n_crops, int32_t swap_rb,
+I2R_API int i2r_person_inputs_cv2(const i2r_image_ref* images, int32_t n_images, const i2r_crop_ref* crops, int32_t n_crops, int32_t swap_rb,
                           const float* mean, const float* inv_std, float* x_out, float* mask_out, int32_t oh, int32_t ow, void* stream);
 
 /* ---- HRFormer-B glue (reference lib/models/hrformer.py) ---------------------------------------------------- */
 /* i2r_layernorm -- nn.LayerNorm(c, eps) over the channels of every pixel/token of an NHWC tensor
  * (GeneralTransformerBlock.norm1/norm2, hrformer.py:1198,1235-1237). w, b: [cs] zero-padded. */
-int i2r_layernorm(const float* in, const float* w, const float* b, float* out, int32_t npix, int32_t c, int32_t cs,
+I2R_API int i2r_layernorm(const float* in, const float* w, const float* b, float* out, int32_t npix, int32_t c, int32_t cs,
                   float eps, int32_t out_dt /* storage of out: 0 fp32, 1 bf16, 2 f16 */, void* stream);
 
 /* i2r_window_attn -- the softmax(q k^T) v core of InterlacedPoolAttention / MHA_ over 7x7 windows
@@ -244,14 +251,17 @@ int i2r_layernorm(const float* in, const float* w, const float* b, float* out, i
  * bias_qkv: [3*hs] = the projections of a zero token in the same layout (what padded tokens contribute).
  * out: [n, h, w, hs] attention output BEFORE out_proj, same head-padded channel order (out_proj gets zero columns there).
  * 36 < head_dim <= 40 (HRFormer-B: 39).  Runs on the fp32 matrix pipe: one workgroup per (crop, window, head). */
-int i2r_window_attn(const float* qkv, const float* bias_qkv, float* out, int32_t n_img, int32_t h, int32_t w, int32_t c,
+I2R_API int i2r_window_attn(const float* qkv, const float* bias_qkv, float* out, int32_t n_img, int32_t h, int32_t w, int32_t c,
                     int32_t hs, int32_t heads, void* stream);
 
 /* i2r_hrt_attn_block -- 16-bit modes only: the attention half of a GeneralTransformerBlock in ONE launch,
  *     out = x + out_proj(window_attention(q|k|v_proj(LayerNorm(x))))      (hrformer.py:1230-1236; same semantics as
  * i2r_layernorm + i2r_conv(q|k|v) + i2r_window_attn + i2r_conv(out_proj, res1 = x)), one workgroup per 7x7 window, on
  * v_mfma_f32_16x16x32_{bf16,f16} with fp32 LayerNorm / softmax / accumulation; x and out are fp32 NHWC [n, h, w, cs] (may not alias).
- * Built for the two high-resolution HRFormer-B branches: (c, heads, cs) = (78, 2, 80) or (156, 4, 160); head_dim 39 padded to 48.
+ * Built for the four HRFormer-B branches: (c, heads, cs) = (78, 2, 80), (156, 4, 160), (312, 8, 320), (624, 16, 624); head_dim 39 padded
+ * to 48.  variant: 0 = the library's choice; 1 = one wave per 16-token tile of the window, K / V^T through LDS (rounds 3-4; 78 / 156
+ * only); 2 = one wave per HEAD over all 64 token rows, the whole attention of a head in registers, every weight fragment feeding four
+ * matrix instructions (round 5; all four widths).  Same operands, same arithmetic, results agree to fp32 summation order.
  * Operand images (16-bit, fragment-packed for the 32-deep MFMA: element e of lane l of a fragment = M[16*rowblk + (l & 15)][32*kstep +
  * 8*(l >> 4) + e], 16 bytes per lane, 1 KB per fragment):
  *   wqkv  [head][q, k, v][cs/32 rounded up k-steps][3 dim blocks][64 lanes][8]: rows = the head's 39 output dims (+ 9 zero rows) of
@@ -261,9 +271,9 @@ int i2r_window_attn(const float* qkv, const float* bias_qkv, float* out, int32_t
  *         re-ordered inside every 32-column k-step to the kernel's slot order: slot 8g + 4h + r <- column 16 (2 kstep + h) + 4g + r
  *         (g < 4, h < 2, r < 4): the B operand of that GEMM is two 16-dim accumulator fragments packed side by side;
  *   bo float [cs];   ln_w, ln_b float [cs] zero-padded. */
-int i2r_hrt_attn_block(const float* x, float* out, const float* ln_w, const float* ln_b, const void* wqkv, const float* bqkv,
+I2R_API int i2r_hrt_attn_block(const float* x, float* out, const float* ln_w, const float* ln_b, const void* wqkv, const float* bqkv,
                        const void* wo, const float* bo, int32_t n_img, int32_t h, int32_t w, int32_t c, int32_t cs, int32_t heads,
-                       float eps, int32_t dtype, void* stream);
+                       float eps, int32_t dtype, int32_t variant, void* stream);
 
 /* i2r_hrt_mlp_block -- 16-bit modes only: the MLP half of a GeneralTransformerBlock in ONE launch,
  *     out = x + GELU(BN3(fc2( GELU(BN2(dw3x3( GELU(BN1(fc1( LayerNorm(x) ))) ))) )))      (hrformer.py:1237, MlpDWBN :1094-1119; same
@@ -275,35 +285,35 @@ int i2r_hrt_attn_block(const float* x, float* out, const float* ln_w, const floa
  * in i2r_hrt_attn_block; columns zero beyond cs), b1 float [hidden_pad]; wdw float [9][hidden_pad] tap-major BN-folded depth-wise
  * weights, bdw [hidden_pad]; w2: fragments [cs/16][hidden_pad/32][64][8] of the BN-folded fc2 matrix [c, hidden] with the hidden columns
  * of every 32-column k-step in slot order (slot 8g + 4h + r <- column 16 (2 kstep + h) + 4g + r), b2 float [cs]. */
-int i2r_hrt_mlp_block(const float* x, float* out, const float* ln_w, const float* ln_b, const void* w1, const float* b1,
+I2R_API int i2r_hrt_mlp_block(const float* x, float* out, const float* ln_w, const float* ln_b, const void* w1, const float* b1,
                       const float* wdw, const float* bdw, const void* w2, const float* b2, int32_t n_img, int32_t h, int32_t w,
                       int32_t c, int32_t cs, int32_t hidden_pad, float eps, int32_t dtype, void* stream);
 
 /* i2r_dwconv3x3 -- depth-wise 3x3 conv, pad 1, stride 1|2, + bias (eval BN folded) + activation (0 none, 1 ReLU,
  * 2 GELU): MlpDWBN.dw3x3+norm2+act2 (hrformer.py:1070-1080,1106-1108) and the DW down-sampling hops of the fuse
  * layers (:1651-1704). w: [9][cs] (tap-major), bias [cs]. */
-int i2r_dwconv3x3(const float* in, const float* w, const float* bias, float* out, int32_t n_img, int32_t in_h, int32_t in_w,
+I2R_API int i2r_dwconv3x3(const float* in, const float* w, const float* bias, float* out, int32_t n_img, int32_t in_h, int32_t in_w,
                   int32_t c, int32_t cs, int32_t stride, int32_t act, int32_t dt /* storage of in and out: 0 fp32, 1 bf16, 2 f16 (stride 1) */,
                   void* stream);
 
 /* i2r_upsample_bilinear_add -- out = act(res + F.interpolate(low, scale_factor=scale, mode='bilinear',
  * align_corners=False)): the up-sampling terms of HighResolutionTransformerModule.forward (hrformer.py:1629-1646,
  * 1718-1730). res may alias out. */
-int i2r_upsample_bilinear_add(const float* low, const float* res, float* out, int32_t n_img, int32_t low_h, int32_t low_w,
+I2R_API int i2r_upsample_bilinear_add(const float* low, const float* res, float* out, int32_t n_img, int32_t low_h, int32_t low_w,
                               int32_t scale, int32_t c, int32_t cs, int32_t act, void* stream);
 /* the same with up to three up-sampled terms added in ONE pass, in the order given (a->low2 / a->low3 may be null): the sum of
  * HighResolutionTransformerModule.forward over the lower-resolution branches j > i (hrformer.py:1718-1730) without handing the partial
  * sums through memory; bit-identical to successive i2r_upsample_bilinear_add calls.  All terms share n_img, c, cs; the output is
  * low_h * scale x low_w * scale and every scale divides it.  (i2r_up_args: below, with the program runner's structs.) */
 struct i2r_up_args;
-int i2r_upsample_bilinear_add_multi(const struct i2r_up_args* a, void* stream);
+I2R_API int i2r_upsample_bilinear_add_multi(const struct i2r_up_args* a, void* stream);
 
 /* i2r_fuse_up_add -- out = act(base + up(t1, s1) [+ up(t2, s2)]), up = nearest-neighbour up-sampling by s (a power of two; t_k is
  * [n, h/s_k, w/s_k, cs]).  The closing step of the HRNet fuse sum for the outputs that receive lower-resolution terms
  * (interformer_pureMulti.py:392-410: y_i = ReLU(x_i + sum_j Upsample(BN(conv1x1(x_j))))): the 1x1 convs write their small maps once
  * and this HBM-bound pass adds them, instead of s x s read-modify-write scatters from the conv epilogues.  The sum is evaluated
  * left to right ((base + t1) + t2).  base may alias out; t2 may be null.  dt: storage type of all tensors (0 fp32, 1 bf16, 2 f16). */
-int i2r_fuse_up_add(const float* base, const float* t1, int32_t s1, const float* t2, int32_t s2, float* out, int32_t n_img,
+I2R_API int i2r_fuse_up_add(const float* base, const float* t1, int32_t s1, const float* t2, int32_t s2, float* out, int32_t n_img,
                     int32_t h, int32_t w, int32_t cs, int32_t act, int32_t dt, void* stream);
 
 /* i2r_conv1x1_pair -- two chained 1x1 convolutions over NHWC rows in one launch (fp32):
@@ -319,7 +329,7 @@ typedef struct i2r_conv1x1_pair_args {
     const float* w_b; const float* b_b; float* z;
     int32_t n_pix, k_a, ca_out, cb_out, x_cs, y_cs, z_cs, relu_a, relu_b, mt;
 } i2r_conv1x1_pair_args;
-int i2r_conv1x1_pair(const i2r_conv1x1_pair_args* a, void* stream);
+I2R_API int i2r_conv1x1_pair(const i2r_conv1x1_pair_args* a, void* stream);
 
 /* i2r_conv1x1_lp -- 1x1 convolution (+ folded BN) over a small number of NHWC pixel rows on the 16-bit matrix pipe, operands straight
  * from global memory, K split over the four waves of a workgroup:
@@ -334,7 +344,7 @@ typedef struct i2r_conv1x1_lp_args {
     const void* x; const void* w; const float* bias; const void* res1; const void* res_post; void* out;
     int32_t n_pix, cin_pad, cout_pad, x_cs, out_cs, act, dtype, in_16, out_16, mt;
 } i2r_conv1x1_lp_args;
-int i2r_conv1x1_lp(const i2r_conv1x1_lp_args* a, void* stream);
+I2R_API int i2r_conv1x1_lp(const i2r_conv1x1_lp_args* a, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * i2r_encoder_desc -- one DETR-style post-norm encoder layer over variable-length token groups
@@ -408,8 +418,8 @@ typedef struct i2r_encoder_desc {
     float* split_ws; int32_t* split_cnt;
 } i2r_encoder_desc;
 
-int i2r_encoder_kv(const i2r_encoder_desc* d, void* stream);
-int i2r_encoder_layer(const i2r_encoder_desc* d, void* stream);
+I2R_API int i2r_encoder_kv(const i2r_encoder_desc* d, void* stream);
+I2R_API int i2r_encoder_layer(const i2r_encoder_desc* d, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Program runner: replay a pre-built list of launches from one C call (no per-op host overhead, and
@@ -459,7 +469,7 @@ typedef struct i2r_winattn_args {
 
 typedef struct i2r_hrt_attn_args {
     const float* x; float* out; const float* ln_w; const float* ln_b; const void* wqkv; const float* bqkv; const void* wo; const float* bo;
-    int32_t n_img, h, w_, c, cs, heads; float eps; int32_t dtype;
+    int32_t n_img, h, w_, c, cs, heads; float eps; int32_t dtype, variant;
 } i2r_hrt_attn_args;
 
 typedef struct i2r_hrt_mlp_args {
@@ -501,12 +511,12 @@ typedef struct i2r_op {
 
 /* streams: array of 4 hipStream_t (lane 0 = the caller's stream); events: array of >= 8 hipEvent_t
  * created by the caller with hipEventDisableTiming.  Both may be NULL when every op uses lane 0. */
-int i2r_run_program(const i2r_op* ops, int32_t n_ops, void* const* streams, void* const* events);
+I2R_API int i2r_run_program(const i2r_op* ops, int32_t n_ops, void* const* streams, void* const* events);
 
-int i2r_abi_version(void);
-const char* i2r_last_error(void);
+I2R_API int i2r_abi_version(void);
+I2R_API const char* i2r_last_error(void);
 /* device sanity: returns 0 when device `dev` is gfx950, fills cu_count / lds_bytes if non-NULL */
-int i2r_device_check(int32_t dev, int32_t* cu_count, int32_t* lds_bytes);
+I2R_API int i2r_device_check(int32_t dev, int32_t* cu_count, int32_t* lds_bytes);
 
 #ifdef __cplusplus
 }

@@ -14,7 +14,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libi2r_hip.so")
 
 MAX_TAPS = 9
-ABI_VERSION = 8  # I2R_ABI_VERSION of include/i2r_hip.h
+ABI_VERSION = 9  # I2R_ABI_VERSION of include/i2r_hip.h
 OP_CONV, OP_STEM, OP_MAXPOOL, OP_HEAD, OP_ENC_KV, OP_ENC_LAYER, OP_FORK, OP_JOIN, OP_CONV_GROUP = 1, 2, 3, 4, 5, 6, 7, 8, 9
 MAX_GROUP = 4
 OP_LAYERNORM, OP_WINATTN, OP_DWCONV, OP_UPSAMPLE = 10, 11, 12, 13
@@ -91,7 +91,8 @@ class WinAttnArgs(C.Structure):
 
 class HrtAttnArgs(C.Structure):
     _fields_ = [("x", _fp), ("out", _fp), ("ln_w", _fp), ("ln_b", _fp), ("wqkv", _fp), ("bqkv", _fp), ("wo", _fp), ("bo", _fp),
-                ("n_img", _i32), ("h", _i32), ("w_", _i32), ("c", _i32), ("cs", _i32), ("heads", _i32), ("eps", C.c_float), ("dtype", _i32)]
+                ("n_img", _i32), ("h", _i32), ("w_", _i32), ("c", _i32), ("cs", _i32), ("heads", _i32), ("eps", C.c_float), ("dtype", _i32),
+                ("variant", _i32)]
 
 
 class HrtMlpArgs(C.Structure):
@@ -191,7 +192,7 @@ def load_library(path=LIB_PATH):
     L.i2r_head.argtypes = [_fp, _fp, _fp, _fp, _i32, _i32, _i32, _i32, _i32, _i32, C.c_void_p]
     L.i2r_layernorm.argtypes = [_fp, _fp, _fp, _fp, _i32, _i32, _i32, C.c_float, _i32, C.c_void_p]
     L.i2r_window_attn.argtypes = [_fp, _fp, _fp, _i32, _i32, _i32, _i32, _i32, _i32, C.c_void_p]
-    L.i2r_hrt_attn_block.argtypes = [_fp, _fp, _fp, _fp, _fp, _fp, _fp, _fp, _i32, _i32, _i32, _i32, _i32, _i32, C.c_float, _i32, C.c_void_p]
+    L.i2r_hrt_attn_block.argtypes = [_fp, _fp, _fp, _fp, _fp, _fp, _fp, _fp, _i32, _i32, _i32, _i32, _i32, _i32, C.c_float, _i32, _i32, C.c_void_p]
     L.i2r_hrt_mlp_block.argtypes = [_fp] * 10 + [_i32] * 6 + [C.c_float, _i32, C.c_void_p]
     L.i2r_dwconv3x3.argtypes = [_fp, _fp, _fp, _fp, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, C.c_void_p]
     L.i2r_upsample_bilinear_add_multi.argtypes = [C.POINTER(UpArgs), C.c_void_p]

@@ -130,7 +130,7 @@ extern "C" int i2r_run_program(const i2r_op* ops, int32_t n_ops, void* const* st
             case I2R_OP_HRT_ATTN: {
                 const i2r_hrt_attn_args* a = (const i2r_hrt_attn_args*)op.args;
                 rc = i2r_hrt_attn_block(a->x, a->out, a->ln_w, a->ln_b, a->wqkv, a->bqkv, a->wo, a->bo, a->n_img, a->h, a->w_, a->c, a->cs, a->heads,
-                                        a->eps, a->dtype, st);
+                                        a->eps, a->dtype, a->variant, st);
                 break;
             }
             case I2R_OP_HRT_MLP: {

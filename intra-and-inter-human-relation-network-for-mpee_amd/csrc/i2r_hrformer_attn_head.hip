@@ -1,0 +1,309 @@
+// HRFormer-B transformer block, attention half, FUSED for the 16-bit modes -- the HEAD-PER-WAVE form (round 5):
+//     x1 = x + out_proj( window_attention( q|k|v_proj( LayerNorm1(x) ) ) )          (reference lib/models/hrformer.py:1230-1236,
+//     InterlacedPoolAttention :1164-1180, PadBlock :937-966, LocalPermuteModule :969-1001, MHA_ :692-935)
+// Same C-ABI entry point, operand images and arithmetic as i2r_hrformer_lp.hip (one wave per 16-token tile of the window); what
+// changes is the decomposition, and with it the traffic: there a weight fragment (1 KB through the CU's 64 B/clk vector-memory path)
+// feeds ONE matrix instruction, so the four SIMDs ask for four times what that path delivers and the kernel waits on its weight
+// stream (DESIGN.md, round-4 ablation: 8 us of arithmetic in a 25 us launch).
+//
+// Workgroup = one 7x7 window (49 tokens + 15 padding rows = four 16-token tiles); wave = ONE HEAD (HPW heads one after the other for
+// the 16-head branch) over ALL four tiles:
+//   * a q / k / v weight fragment is fetched once per wave and feeds FOUR matrix instructions (one per token tile);
+//   * the whole attention of a head stays in the wave's registers -- no K / V^T staging through LDS, no barrier per head:
+//       Q^T, K^T = W . X^T   (A = weight fragment, B = LayerNorm-ed token columns): D = [dim rows][token column];
+//       two 16-dim D fragments packed to 16 bit are at once the A operand "K rows" (lane = key) and the B operand "Q^T" (lane = query)
+//       of  S^T = K Q^T  with the k-slot order 8g + 4h + r <-> dim 16 (2s + h) + 4g + r  (the permutation of i2r_hrformer_lp.hip);
+//       V = X . Wv^T  with the operands SWAPPED (A = token columns, B = weight fragment: the same two register images):
+//       D = [token rows][dim column], and two token tiles packed side by side are the A operand "V^T rows" of  O^T = V^T P^T
+//       in exactly the key-slot order in which the packed softmax output P^T arrives as B operand;
+//   * LayerNorm 1 is computed once per window (the waves split tiles / channel slices, statistics through LDS) and written to LDS as
+//     the packed operand image every head reads;
+//   * O^T of all heads meets in LDS (the LayerNorm area, dead by then) for the out-proj: wave w finishes token-tile pair w & 1 of the
+//     output blocks (w >> 1) + i NW/2 -- a weight fragment feeds two matrix instructions, + bias + residual (re-read), fp32 store.
+// Tokens outside the map are exact zeros after the LayerNorm (their q / k / v are the projection biases, hrformer.py:947-956), rows
+// 49..63 are masked keys; head_dim 39 padded to 48; q carries head_dim^-0.5 * log2(e), softmax in base 2; fp32 accumulation.
+#include <type_traits>
+
+#include "i2r_hrformer_attn.h"
+
+namespace {
+
+#ifndef I2R_XCD_BAND
+#define I2R_XCD_BAND 1
+#endif
+
+template <int DT, int CB, int HEADS, int HPW, int OCC>
+__global__ __launch_bounds__(64 * (HEADS / HPW), OCC) void hrt_attn_head_k(const I2rAttnK p) {
+    constexpr int NW = HEADS / HPW, cs = CB * 16, KS = (cs + 31) / 32, OSG = 3 * HEADS / 2;
+    constexpr int KP = NW >= 4 ? NW / 4 : 1;      // channel slices of the LayerNorm (waves w, w + 4, ... share token tile w & 3)
+    constexpr int TPW = NW >= 4 ? 1 : 4 / NW;     // token tiles a wave normalises
+    constexpr int KSL = KS / KP;
+    static_assert(KS % KP == 0 && HEADS % HPW == 0 && (NW & 1) == 0, "LayerNorm slices / waves");
+    constexpr int XS = 4 * KS * 64, OBN = 4 * OSG * 64;
+    __shared__ __attribute__((aligned(16))) f32x4 smem[XS > OBN ? XS : OBN];  // LayerNorm-ed tokens [tile][k-step][lane]; later O^T [tile][k-step][lane]
+    __shared__ float stat[2][KP > 1 ? KP * 64 : 1];
+    const int tid = threadIdx.x, lane = tid & 63, li = lane & 15, g = lane >> 4;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    int bid = I2R_XCD_BAND ? xcd_band_item(blockIdx.x, p.total) : (int)blockIdx.x;  // (workgroup-uniform)
+    if (bid < 0 || bid >= p.total) return;
+    const int wx = bid % p.nwx; bid /= p.nwx;
+    const int wy = bid % p.nwy;
+    const int img = bid / p.nwy;
+    const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
+
+    // ---- LayerNorm 1 -> smem as packed operand image: lane (li, g) of (tile t, k-step s) holds features 32 s + 8 g .. + 7 of token 16 t + li ----
+    {
+        const float inv_c = __builtin_amdgcn_rcpf((float)p.c);
+        const float npad = (float)(cs - p.c);  // zero pad channels inside the row: each adds mean^2 to the sum of squares
+#pragma unroll
+        for (int i = 0; i < TPW; ++i) {
+            const int t = NW >= 4 ? (wave & 3) : wave + i * NW;
+            const int kh = NW >= 4 ? (wave >> 2) : 0;
+            const int tt = 16 * t + li;
+            const int ty = tt / 7, tx = tt - ty * 7;
+            const int y = wy * 7 + ty - p.pad_top, x = wx * 7 + tx - p.pad_left;
+            const bool inmap = tt < 49 && y >= 0 && y < p.h && x >= 0 && x < p.w;
+            const float* row = p.x + (((size_t)img * p.h + (inmap ? y : 0)) * p.w + (inmap ? x : 0)) * cs;
+            f32x4 xa[KSL], xb[KSL];
+#pragma unroll
+            for (int k = 0; k < KSL; ++k) {  // (unconditional loads from clamped addresses, selected afterwards)
+                const int s = kh * KSL + k;
+                const int f0 = 32 * s + 8 * g < cs ? 32 * s + 8 * g : cs - 8;
+                xa[k] = *reinterpret_cast<const f32x4*>(row + f0);
+                xb[k] = *reinterpret_cast<const f32x4*>(row + f0 + 4);
+            }
+            float s1 = 0.f;
+#pragma unroll
+            for (int k = 0; k < KSL; ++k) {
+                const bool ok = inmap && (32 * (kh * KSL + k) + 8 * g < cs);
+                xa[k] = ok ? xa[k] : zero4;
+                xb[k] = ok ? xb[k] : zero4;
+                s1 += ((xa[k][0] + xa[k][1]) + (xa[k][2] + xa[k][3])) + ((xb[k][0] + xb[k][1]) + (xb[k][2] + xb[k][3]));
+            }
+            s1 = i2r_xsum4(s1);
+            if constexpr (KP > 1) {  // the slices' partial sums meet in a fixed order
+                if (g == 0) stat[0][(kh * 4 + t) * 16 + li] = s1;
+                __syncthreads();
+                s1 = 0.f;
+#pragma unroll
+                for (int kk = 0; kk < KP; ++kk) s1 += stat[0][(kk * 4 + t) * 16 + li];
+            }
+            const float mean = s1 * inv_c;
+            float q2 = 0.f;
+#pragma unroll
+            for (int k = 0; k < KSL; ++k) {
+                const float keep = 32 * (kh * KSL + k) + 8 * g < cs ? 1.f : 0.f;
+                const f32x4 da = (xa[k] - mean) * keep, db = (xb[k] - mean) * keep;
+                q2 += ((da[0] * da[0] + da[1] * da[1]) + (da[2] * da[2] + da[3] * da[3])) + ((db[0] * db[0] + db[1] * db[1]) + (db[2] * db[2] + db[3] * db[3]));
+            }
+            q2 = i2r_xsum4(q2);
+            if constexpr (KP > 1) {
+                if (g == 0) stat[1][(kh * 4 + t) * 16 + li] = q2;
+                __syncthreads();
+                q2 = 0.f;
+#pragma unroll
+                for (int kk = 0; kk < KP; ++kk) q2 += stat[1][(kk * 4 + t) * 16 + li];
+            }
+            const float var = (q2 - npad * mean * mean) * inv_c;
+            const float rstd = rsqrtf(fmaxf(var, 0.f) + p.eps);
+#pragma unroll
+            for (int k = 0; k < KSL; ++k) {
+                const int s = kh * KSL + k;
+                const bool has = 32 * s + 8 * g < cs;
+                const int f0 = has ? 32 * s + 8 * g : 0;
+                const f32x4 wa = *reinterpret_cast<const f32x4*>(p.ln_w + f0), wb = *reinterpret_cast<const f32x4*>(p.ln_w + f0 + 4);
+                const f32x4 ba = *reinterpret_cast<const f32x4*>(p.ln_b + f0), bb = *reinterpret_cast<const f32x4*>(p.ln_b + f0 + 4);
+                const float keep = (inmap && has) ? 1.f : 0.f;  // tokens outside the map are exact zeros AFTER the LayerNorm
+                smem[(t * KS + s) * 64 + lane] = pack8<DT>(((xa[k] - mean) * rstd * wa + ba) * keep, ((xb[k] - mean) * rstd * wb + bb) * keep);
+            }
+        }
+    }
+    __syncthreads();
+
+    // ---- q / k / v of one head over the four token tiles: 3 dim blocks x 4 tiles accumulators, weight fragments one k-step ahead ----
+    auto project = [&](const int head, const int part, auto swap_c, f32x4 (&acc)[4][3]) {
+        constexpr bool SWAP = decltype(swap_c)::value;
+        const float* bsrc = p.bqkv + (head * 3 + part) * 48;
+#pragma unroll
+        for (int db = 0; db < 3; ++db) {
+            f32x4 b4;
+            if constexpr (SWAP) {  // D = [token rows][dim column li]
+                const float b = bsrc[16 * db + li];
+                b4 = (f32x4){b, b, b, b};
+            } else {               // D = [dim rows 4g + r][token column]
+                b4 = *reinterpret_cast<const f32x4*>(bsrc + 16 * db + 4 * g);
+            }
+#pragma unroll
+            for (int t = 0; t < 4; ++t) acc[t][db] = b4;
+        }
+        const f32x4* wsrc = p.wqkv + (size_t)(head * 3 + part) * KS * 192 + lane;
+        f32x4 wn[3];
+#pragma unroll
+        for (int db = 0; db < 3; ++db) wn[db] = wsrc[db * 64];
+        // (a ROLLED loop: fully unrolled, the scheduler hoists the fragment loads of all k-steps to the top and spills)
+#pragma unroll 1
+        for (int s = 0; s < KS; ++s) {
+            f32x4 wf[3];
+#pragma unroll
+            for (int db = 0; db < 3; ++db) wf[db] = wn[db];
+            const int sn = s + 1 < KS ? s + 1 : s;  // (last step: a harmless re-fetch instead of a branch)
+#pragma unroll
+            for (int db = 0; db < 3; ++db) wn[db] = wsrc[sn * 192 + db * 64];
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                const f32x4 xt = smem[(t * KS + s) * 64 + lane];
+#pragma unroll
+                for (int db = 0; db < 3; ++db)
+                    acc[t][db] = SWAP ? mfma32_lp<DT>(xt, wf[db], acc[t][db]) : mfma32_lp<DT>(wf[db], xt, acc[t][db]);
+            }
+        }
+    };
+
+    uint2 opk[HPW][4][3];  // O^T of this wave's heads, packed: [head][query tile][dim block] = dims 16 db + 4g + r of query li
+#pragma unroll
+    for (int j = 0; j < HPW; ++j) {
+        const int head = wave * HPW + j;
+        f32x4 qpk[4][2], kpk[4][2], vpk[3][2];
+        // (v first, q last: the accumulators of the widest phase then sit beside the fewest packed operands)
+        {
+            f32x4 acc[4][3];
+            project(head, 2, std::true_type{}, acc);
+#pragma unroll
+            for (int db = 0; db < 3; ++db) { vpk[db][0] = pack8<DT>(acc[0][db], acc[1][db]); vpk[db][1] = pack8<DT>(acc[2][db], acc[3][db]); }
+        }
+        {
+            f32x4 acc[4][3];
+            project(head, 1, std::false_type{}, acc);
+#pragma unroll
+            for (int t = 0; t < 4; ++t) { kpk[t][0] = pack8<DT>(acc[t][0], acc[t][1]); kpk[t][1] = pack8<DT>(acc[t][2], zero4); }
+        }
+        {
+            f32x4 acc[4][3];
+            project(head, 0, std::false_type{}, acc);
+#pragma unroll
+            for (int t = 0; t < 4; ++t) { qpk[t][0] = pack8<DT>(acc[t][0], acc[t][1]); qpk[t][1] = pack8<DT>(acc[t][2], zero4); }
+        }
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            // S^T[key][query] of query tile t against the 64 keys, softmax over the 49 real ones (base 2)
+            f32x4 st[4];
+#pragma unroll
+            for (int kf = 0; kf < 4; ++kf) st[kf] = mfma32_lp<DT>(kpk[kf][0], qpk[t][0], zero4);
+#pragma unroll
+            for (int kf = 0; kf < 4; ++kf) st[kf] = mfma32_lp<DT>(kpk[kf][1], qpk[t][1], st[kf]);
+            float mx = -__builtin_inff();
+#pragma unroll
+            for (int kf = 0; kf < 4; ++kf)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    if (16 * kf + 4 * g + r >= 49) st[kf][r] = -__builtin_inff();
+                    mx = fmaxf(mx, st[kf][r]);
+                }
+            mx = i2r_xmax4(mx);
+            float sum = 0.f;
+#pragma unroll
+            for (int kf = 0; kf < 4; ++kf)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    st[kf][r] = __builtin_amdgcn_exp2f(st[kf][r] - mx);
+                    sum += st[kf][r];
+                }
+            const f32x4 pB0 = pack8<DT>(st[0], st[1]), pB1 = pack8<DT>(st[2], st[3]);
+            const float inv = 1.f / i2r_xsum4(sum);
+            f32x4 o[3];
+#pragma unroll
+            for (int db = 0; db < 3; ++db) o[db] = mfma32_lp<DT>(vpk[db][0], pB0, zero4);
+#pragma unroll
+            for (int db = 0; db < 3; ++db) o[db] = mfma32_lp<DT>(vpk[db][1], pB1, o[db]);
+#pragma unroll
+            for (int db = 0; db < 3; ++db) opk[j][t][db] = i2r_pack4<DT>(o[db] * inv);
+        }
+    }
+
+    // ---- O^T of all heads -> LDS as the out-proj's B operand: 16-dim block bi = 3 head + db is half bi & 1 of k-step bi >> 1 ----
+    __syncthreads();  // every wave has read its last LayerNorm-ed column: the area becomes the exchange buffer
+#pragma unroll
+    for (int j = 0; j < HPW; ++j)
+#pragma unroll
+        for (int db = 0; db < 3; ++db) {
+            const int bi = (wave * HPW + j) * 3 + db;
+#pragma unroll
+            for (int t = 0; t < 4; ++t)
+                reinterpret_cast<uint2*>(smem + (t * OSG + (bi >> 1)) * 64 + lane)[bi & 1] = opk[j][t][db];
+        }
+    __syncthreads();
+
+    // ---- out-proj + bias + residual: this wave's token-tile pair, output blocks (wave >> 1) + i NW / 2 ----
+    const int tp = wave & 1;
+    size_t rowT[2];
+    bool inT[2];
+#pragma unroll
+    for (int tt = 0; tt < 2; ++tt) {
+        const int tk = 16 * (2 * tp + tt) + li;
+        const int ty = tk / 7, tx = tk - ty * 7;
+        const int y = wy * 7 + ty - p.pad_top, x = wx * 7 + tx - p.pad_left;
+        inT[tt] = tk < 49 && y >= 0 && y < p.h && x >= 0 && x < p.w;
+        rowT[tt] = (((size_t)img * p.h + (inT[tt] ? y : 0)) * p.w + (inT[tt] ? x : 0)) * cs;
+    }
+    constexpr int UN = (CB + NW / 2 - 1) / (NW / 2);  // output blocks per wave (the last one may not exist)
+    constexpr int UC = UN < 5 ? UN : 5;               // ... in chunks of at most five (accumulators + fragments + residuals in registers)
+#pragma unroll
+    for (int c0 = 0; c0 < UN; c0 += UC) {
+        f32x4 acc[UC][2], xres[UC][2];
+        int ob[UC];
+#pragma unroll
+        for (int i = 0; i < UC; ++i) {
+            const int o_ = (wave >> 1) + (c0 + i) * (NW / 2);
+            ob[i] = o_ < CB ? o_ : CB - 1;  // (a block that does not exist: recomputed, not stored)
+            const f32x4 b = *reinterpret_cast<const f32x4*>(p.bo + 16 * ob[i] + 4 * g);
+#pragma unroll
+            for (int tt = 0; tt < 2; ++tt) {
+                acc[i][tt] = b;
+                xres[i][tt] = *reinterpret_cast<const f32x4*>(p.x + rowT[tt] + 16 * ob[i] + 4 * g);  // (clamped row: always readable)
+            }
+        }
+        f32x4 wn[UC];
+#pragma unroll
+        for (int i = 0; i < UC; ++i) wn[i] = p.wo[(size_t)ob[i] * OSG * 64 + lane];
+#pragma unroll 1
+        for (int s = 0; s < OSG; ++s) {
+            f32x4 wv[UC];
+#pragma unroll
+            for (int i = 0; i < UC; ++i) wv[i] = wn[i];
+            const int sn = s + 1 < OSG ? s + 1 : s;
+#pragma unroll
+            for (int i = 0; i < UC; ++i) wn[i] = p.wo[((size_t)ob[i] * OSG + sn) * 64 + lane];
+            const f32x4 b0 = smem[((2 * tp) * OSG + s) * 64 + lane], b1 = smem[((2 * tp + 1) * OSG + s) * 64 + lane];
+#pragma unroll
+            for (int i = 0; i < UC; ++i) {
+                acc[i][0] = mfma32_lp<DT>(wv[i], b0, acc[i][0]);
+                acc[i][1] = mfma32_lp<DT>(wv[i], b1, acc[i][1]);
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < UC; ++i) {
+            const bool exists = (wave >> 1) + (c0 + i) * (NW / 2) < CB;  // (wave-uniform)
+            if (!exists) continue;
+#pragma unroll
+            for (int tt = 0; tt < 2; ++tt)
+                if (inT[tt]) *reinterpret_cast<f32x4*>(p.out + rowT[tt] + 16 * ob[i] + 4 * g) = acc[i][tt] + xres[i][tt];
+        }
+    }
+}
+
+template <int DT>
+bool launch(const I2rAttnK& k, int cs, int heads, long long nblk, hipStream_t stream) {
+    const dim3 grid((unsigned)((nblk + 7) / 8 * 8));
+    if (cs == 80 && heads == 2) hipLaunchKernelGGL((hrt_attn_head_k<DT, 5, 2, 1, 3>), grid, dim3(128), 0, stream, k);
+    else if (cs == 160 && heads == 4) hipLaunchKernelGGL((hrt_attn_head_k<DT, 10, 4, 1, 3>), grid, dim3(256), 0, stream, k);
+    else if (cs == 320 && heads == 8) hipLaunchKernelGGL((hrt_attn_head_k<DT, 20, 8, 1, 2>), grid, dim3(512), 0, stream, k);
+    else if (cs == 624 && heads == 16) hipLaunchKernelGGL((hrt_attn_head_k<DT, 39, 16, 2, 2>), grid, dim3(512), 0, stream, k);
+    else return false;
+    return true;
+}
+
+}  // namespace
+
+bool i2r_attn_head_launch(const I2rAttnK& k, int dtype, int cs, int heads, long long nblk, hipStream_t stream) {
+    return dtype == 1 ? launch<1>(k, cs, heads, nblk, stream) : launch<2>(k, cs, heads, nblk, stream);
+}

@@ -27,7 +27,7 @@
 //     the half it does not own over through LDS (the K / V^T area, dead by then) and finishes the other half: + bias + residual.
 //   * fp32 residual and output (the HRFormer tower keeps its maps in fp32); operands are bf16 / f16, accumulation fp32.  The residual
 //     x is re-read for the epilogue (issued before the out-proj MFMAs) instead of being carried through the kernel in registers.
-#include "i2r_common.h"
+#include "i2r_hrformer_attn.h"
 
 namespace {
 
@@ -59,14 +59,7 @@ __device__ __forceinline__ float xmax4(float v) {
     return v;
 }
 
-struct AttnK {
-    const float* x; float* out;
-    const float* ln_w; const float* ln_b;
-    const f32x4* wqkv; const float* bqkv;   // [head][q,k,v][KS k-steps][3 dim blocks][64 lanes] 16-byte fragments; [head][3][48] biases
-    const f32x4* wo; const float* bo;       // [CB out blocks][HEADS*3/2 k-steps][64 lanes] (columns in slot order); [cs]
-    int n_img, h, w, c, nwy, nwx, pad_top, pad_left, total;
-    float eps;
-};
+using AttnK = I2rAttnK;  // (i2r_hrformer_attn.h: shared with the head-per-wave kernel)
 
 // tuning knobs of the A/B library variants (tools/ab/): ring depth per branch width, minimum waves per SIMD
 #ifndef I2R_ATT_RB78
@@ -83,6 +76,10 @@ struct AttnK {
 #endif
 #ifndef I2R_XCD_BAND
 #define I2R_XCD_BAND 1   // A/B knob: 0 = windows in plain blockIdx order
+#endif
+// which kernel `variant` 0 selects per channel stride (measured): 2 = wave per head, 1 = wave per token tile
+#ifndef I2R_ATTN_DEFAULT_VARIANT
+#define I2R_ATTN_DEFAULT_VARIANT(cs) 2
 #endif
 constexpr int ROW = 64;  // 16-bit elements per LDS row (K: key x 64 dim slots; V^T: dim x 64 key slots) = 8 chunks of 16 bytes
 
@@ -316,11 +313,15 @@ int launch(const AttnK& k, int heads, long long nblk, hipStream_t stream) {
 
 extern "C" int i2r_hrt_attn_block(const float* x, float* out, const float* ln_w, const float* ln_b, const void* wqkv, const float* bqkv,
                                   const void* wo, const float* bo, int32_t n_img, int32_t h, int32_t w, int32_t c, int32_t cs,
-                                  int32_t heads, float eps, int32_t dtype, void* stream) {
+                                  int32_t heads, float eps, int32_t dtype, int32_t variant, void* stream) {
     I2R_CHECK_ARG(x && out && x != out && ln_w && ln_b && wqkv && bqkv && wo && bo, "i2r_hrt_attn_block: null pointer / out aliases x");
     I2R_CHECK_ARG(dtype == 1 || dtype == 2, "i2r_hrt_attn_block: dtype %d (1 bf16, 2 f16; the fp32 path is i2r_layernorm + i2r_conv + i2r_window_attn)", dtype);
-    I2R_CHECK_ARG(heads > 0 && c == heads * 39 && cs % 16 == 0 && c <= cs && ((cs == 80 && heads == 2) || (cs == 160 && heads == 4)),
-                  "i2r_hrt_attn_block: c=%d cs=%d heads=%d (built for the two high-resolution HRFormer-B branches: 78 / 2, 156 / 4)", c, cs, heads);
+    const bool narrow = (cs == 80 && heads == 2) || (cs == 160 && heads == 4), wide = (cs == 320 && heads == 8) || (cs == 624 && heads == 16);
+    I2R_CHECK_ARG(heads > 0 && c == heads * 39 && cs % 16 == 0 && c <= cs && (narrow || wide),
+                  "i2r_hrt_attn_block: c=%d cs=%d heads=%d (built for the HRFormer-B branches: 78 / 2, 156 / 4, 312 / 8, 624 / 16)", c, cs, heads);
+    I2R_CHECK_ARG(variant >= 0 && variant <= 2 && (variant != 1 || narrow),
+                  "i2r_hrt_attn_block: variant %d (0 default, 1 wave per token tile: 78 / 156 only, 2 wave per head)", variant);
+    I2R_CHECK_ARG((long long)n_img * h * w * cs < (1ll << 31), "i2r_hrt_attn_block: tensor too large");
     AttnK k;
     k.x = x; k.out = out; k.ln_w = ln_w; k.ln_b = ln_b; k.wqkv = (const f32x4*)wqkv; k.bqkv = bqkv; k.wo = (const f32x4*)wo; k.bo = bo;
     k.n_img = n_img; k.h = h; k.w = w; k.c = c; k.eps = eps;
@@ -329,8 +330,15 @@ extern "C" int i2r_hrt_attn_block(const float* x, float* out, const float* ln_w,
     const long long nblk = (long long)n_img * k.nwy * k.nwx;
     I2R_CHECK_ARG(nblk > 0 && nblk < (1ll << 30), "i2r_hrt_attn_block: grid");
     k.total = (int)nblk;
-    if (dtype == 1) launch<1>(k, heads, nblk, (hipStream_t)stream);
-    else launch<2>(k, heads, nblk, (hipStream_t)stream);
+    if (variant == 0) variant = I2R_ATTN_DEFAULT_VARIANT(cs);
+    if (variant == 2 || wide) {
+        const bool ok = i2r_attn_head_launch(k, dtype, cs, heads, nblk, (hipStream_t)stream);
+        I2R_CHECK_ARG(ok, "i2r_hrt_attn_block: no head-per-wave kernel for cs=%d heads=%d", cs, heads);
+    } else if (dtype == 1) {
+        launch<1>(k, heads, nblk, (hipStream_t)stream);
+    } else {
+        launch<2>(k, heads, nblk, (hipStream_t)stream);
+    }
     I2R_CHECK_LAUNCH("i2r_hrt_attn_block");
     return I2R_OK;
 }

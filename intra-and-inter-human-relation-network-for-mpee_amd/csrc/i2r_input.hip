@@ -155,14 +155,21 @@ __global__ __launch_bounds__(256) void box_mask_cv2_k(const int* __restrict__ bo
 // the whole batch of a validate() step in ONE launch: every person crop of every image + its box mask, written straight into the
 // collated [S, 3, oh, ow] / [S, 1, oh, ow] tensors (collater.py:14-26); images and crops are described by two device tables
 __global__ __launch_bounds__(256) void person_inputs_cv2_k(const i2r_image_ref* __restrict__ images, const i2r_crop_ref* __restrict__ crops,
-                                                           int swap_rb, Norm3 nm, float* __restrict__ x_out, float* __restrict__ m_out, int n,
-                                                           int oh, int ow) {
+                                                           int n_images, int swap_rb, Norm3 nm, float* __restrict__ x_out,
+                                                           float* __restrict__ m_out, int n, int oh, int ow) {
     const long long gid = (long long)blockIdx.x * 256 + threadIdx.x;
     if (gid >= (long long)n * oh * ow) return;
     const int x = (int)(gid % ow);
     const int y = (int)((gid / ow) % oh);
     const int p = (int)(gid / ((long long)ow * oh));
     const i2r_crop_ref* cr = crops + p;
+    // the tables live on the device: the host entry point cannot validate them, so a crop whose image index lies outside the image
+    // table (or whose image entry is empty) writes zeros instead of reading out of bounds
+    if ((unsigned)cr->image >= (unsigned)n_images || images[cr->image].img == nullptr || images[cr->image].ih <= 0 || images[cr->image].iw <= 0) {
+        for (int c = 0; c < 3; ++c) x_out[(((size_t)p * 3 + c) * oh + y) * ow + x] = 0.f;
+        m_out[((size_t)p * oh + y) * ow + x] = 0.f;
+        return;
+    }
     const i2r_image_ref im = images[cr->image];
     crop_pixel_cv2(im.img, im.ih, im.iw, im.row_bytes, swap_rb, cr->inv_m, nm, x_out + (size_t)p * 3 * oh * ow, x, y, oh, ow);
     m_out[((size_t)p * oh + y) * ow + x] = mask_pixel_cv2(cr->box, im.ih, im.iw, x, y, oh, ow);
@@ -177,8 +184,8 @@ extern "C" int i2r_person_inputs_cv2(const i2r_image_ref* images, int32_t n_imag
     Norm3 nm;
     for (int c = 0; c < 3; ++c) { nm.mean[c] = mean[c]; nm.inv_std[c] = inv_std[c]; }  // (HOST arrays: they travel as kernel arguments)
     const long long nthr = (long long)n_crops * oh * ow;
-    hipLaunchKernelGGL(person_inputs_cv2_k, dim3((unsigned)((nthr + 255) / 256)), dim3(256), 0, (hipStream_t)stream, images, crops, swap_rb, nm,
-                       x_out, mask_out, n_crops, oh, ow);
+    hipLaunchKernelGGL(person_inputs_cv2_k, dim3((unsigned)((nthr + 255) / 256)), dim3(256), 0, (hipStream_t)stream, images, crops, n_images, swap_rb,
+                       nm, x_out, mask_out, n_crops, oh, ow);
     I2R_CHECK_LAUNCH("i2r_person_inputs_cv2");
     return I2R_OK;
 }

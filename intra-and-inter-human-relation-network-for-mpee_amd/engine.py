@@ -114,7 +114,8 @@ LP1X1 = _tune("I2R_LP1X1", "1") != "0"  # 16-bit modes: single 1x1 convs over fe
 LP1X1_MAX_PIX = int(_tune("I2R_LP1X1_MAX_PIX", "65536"))  # beyond that the implicit-GEMM kernel has enough workgroups to hide its staging
 _LP1X1_MT = int(_tune("I2R_LP1X1_MT", "0"))
 # branch widths whose transformer-block halves run as the fused 16-bit kernels (i2r_hrt_attn_block / i2r_hrt_mlp_block)
-_HRT_FUSED_ATTN = tuple(int(v) for v in _tune("I2R_HRT_FUSED_ATTN", "78,156").split(",") if v)
+_HRT_FUSED_ATTN = tuple(int(v) for v in _tune("I2R_HRT_FUSED_ATTN", "78,156,312").split(",") if v)
+_HRT_ATTN_VARIANT = int(_tune("I2R_HRT_ATTN_VARIANT", "0"))  # i2r_hrt_attn_block: 0 the library's choice, 1 wave per token tile, 2 wave per head
 _HRT_FUSED_MLP = tuple(int(v) for v in _tune("I2R_HRT_FUSED_MLP", "78,156").split(",") if v)
 PAIR1X1 = _tune("I2R_PAIR1X1", "1") != "0"  # layer1's conv3 + next conv1 as one i2r_conv1x1_pair launch (fp32)
 _PAIR_MT = int(_tune("I2R_PAIR_MT", "0"))  # 16-pixel tiles per wave of that kernel
@@ -940,13 +941,16 @@ class Program:
         self.ops.append((cabi.OP_WINATTN, lane, a))
         return out
 
-    def hrt_attn(self, x, ab, eps=1e-6, lane=0):
-        """fused x + out_proj(window_attn(qkv(LN1 x))) (16-bit modes, i2r_hrt_attn_block)"""
+    def hrt_attn(self, x, ab, eps=1e-6, lane=0, variant=None):
+        """fused x + out_proj(window_attn(qkv(LN1 x))) (16-bit modes, i2r_hrt_attn_block); variant: None = the library's choice"""
         assert x.dt == 0 and x.c == ab["c"] and x.cs == ab["cs"]
+        variant = _HRT_ATTN_VARIANT if variant is None else variant
+        if variant == 0 or (variant == 1 and ab["c"] not in (78, 156)):
+            variant = 2  # measured (tools/time_hrt_attn.py, 16 crops bf16): wave per head 20.4 / 19.3 us against 25.6 / 30.2 us (C = 78 / 156)
         out = self.alloc(x.n, x.h, x.w, x.c)
         self.keep.append(ab)
         a = cabi.HrtAttnArgs(x.ptr, out.ptr, ab["ln"]["w"].data_ptr(), ab["ln"]["b"].data_ptr(), ab["wqkv"].data_ptr(), ab["bqkv"].data_ptr(),
-                             ab["wo"].data_ptr(), ab["bo"].data_ptr(), x.n, x.h, x.w, x.c, x.cs, ab["heads"], eps, ab["dtype"])
+                             ab["wo"].data_ptr(), ab["bo"].data_ptr(), x.n, x.h, x.w, x.c, x.cs, ab["heads"], eps, ab["dtype"], variant)
         self.ops.append((cabi.OP_HRT_ATTN, lane, a))
         return out
 
@@ -1051,6 +1055,7 @@ class Program:
         split_ws = torch.empty(256 * 2 * 1792, dtype=torch.float32, device=self.device)
         split_cnt = torch.zeros(256, dtype=torch.int32, device=self.device)
         self.keep += kbufs + vbufs + [goff, split_ws, split_cnt]
+        self.nbytes += sum(t.numel() * t.element_size() for t in kbufs + vbufs + [goff, split_ws, split_cnt])
         self.split_counters.append(split_cnt)
         cur = x
         self.keep.append(layers)
@@ -1780,15 +1785,15 @@ class Engine:
         x = x.to(self.device).contiguous()
         key = (S, H, W, "backbone")
         with torch.cuda.device(self.device):
-            if key not in self.programs:
+            def build():
                 P = Program(self.device)
                 P.store_dt = self.store_dt
                 xs, px = self.tower.emit(P, S, H, W, n_src=S)
                 f = P.conv(xs[-1], self.reduce, out_dt=0)
                 P.release(*xs)
                 P.finalize()
-                self.programs[key] = (P, px, f)
-            P, px, f = self.programs[key]
+                return (P, px, f)
+            P, px, f = self._program(key, build)
             px.in_ = x.data_ptr()
             P.run()
             # (NHWC arena buffer -> the reference's NCHW tensor: a torch view + copy, boundary plumbing only)
@@ -1802,14 +1807,14 @@ class Engine:
         x = x.to(self.device).contiguous()
         key = (S, H, W, "single")
         with torch.cuda.device(self.device):
-            if key not in self.programs:
+            def build():
                 P = Program(self.device)
                 P.store_dt = self.store_dt
                 g, px = self._emit_single(P, S, H, W, S)
                 hd = P.head(g, self.single_head)
                 P.finalize()
-                self.programs[key] = (P, px, g, hd)
-            P, px, g, hd = self.programs[key]
+                return (P, px, g, hd)
+            P, px, g, hd = self._program(key, build)
             px.in_ = x.data_ptr()
             J = self.cfg["MODEL"]["NUM_JOINTS"]
             hm = torch.empty(S, J, g.h, g.w, dtype=torch.float32, device=self.device)
@@ -1831,7 +1836,11 @@ class Engine:
         step = 2 if S <= 32 else (4 if S <= 64 else 8)
         return -(-S // step) * step
 
-    MAX_PROGRAMS = 48  # least-recently-used programs beyond this are dropped (each owns ~20 MB of activations per crop; a part-batch forward keeps a tower program per stream and capacity next to the tail's)
+    # Program cache: least-recently-used programs are dropped beyond MAX_PROGRAMS entries OR beyond MAX_PROGRAM_BYTES of arena memory
+    # (each program owns ~20 MB of activations per crop; a part-batch forward keeps a tower program per stream and capacity next to the
+    # tail's, and a ragged validate() stream touches one capacity per batch size: a count alone does not bound the memory).
+    MAX_PROGRAMS = 48
+    MAX_PROGRAM_BYTES = 32 << 30
 
     def forward(self, x, pos_mask, length, flip_joint_map=None):
         """flip_joint_map (device int32 [J], see caller.joint_map): run the flip test in the same forward and return the merged
@@ -1851,21 +1860,30 @@ class Engine:
     # (tools/host_rate.py, bench.py): config 3 bf16 4.36 -> 3.75 ms, the fp32 headline 4.17 -> 3.93 ms, TransPose-H fp32 15.2 -> 14.2 ms.
     # Not for the four-lane HRFormer-B programs (twice the launches of kernels whose time barely depends on the batch: 5.2 vs 3.8 ms).
     SPLIT_MIN_CROPS = 24
+    SPLIT_MIN_PART = 8   # crops of the smallest part: a [23, 1] batch would double the launches for nothing to overlap with
     SPLIT_PARTS = int(_tune("I2R_SPLIT_PARTS", "2"))
 
-    def _split_bounds(self, length):
-        """image index cuts [0, b1, ..., n] of the concurrent part-batches, or None (one program)"""
+    def _split_bounds(self, length, H=None, W=None):
+        """image index cuts [0, b1, ..., n] of the concurrent part-batches, or None (one program): every part needs >= SPLIT_MIN_PART
+        crops, and the tower / tail split hands features over between programs whose map sizes must agree (H, W multiples of the
+        tower's total stride; any other size takes the one-program path, which handles it)"""
         from .dist import shard_bounds
         parts = min(self.SPLIT_PARTS, len(length))
         if _tune("I2R_SPLIT_BATCH", "1") == "0" or parts < 2 or sum(length) < self.SPLIT_MIN_CROPS:
             return None
         if not isinstance(getattr(self, "tower", None), HRNetW48) and _tune("I2R_SPLIT_BATCH", "1") != "2":  # (2: A/B, any tower)
             return None
+        if H is not None and (H % 16 or W % 16):
+            return None
         bounds = shard_bounds(list(length), parts)
-        return bounds if all(bounds[i + 1] > bounds[i] for i in range(parts)) else None
+        if not all(bounds[i + 1] > bounds[i] for i in range(parts)):
+            return None
+        if min(sum(length[bounds[i]:bounds[i + 1]]) for i in range(parts)) < self.SPLIT_MIN_PART:
+            return None
+        return bounds
 
     def _forward(self, x, pos_mask, length, flip_joint_map, S, H, W):
-        bounds = self._split_bounds(length)
+        bounds = self._split_bounds(length, H, W)
         if bounds is None:
             return self._forward_part(x, pos_mask, length, flip_joint_map, S, H, W, slot=0)
         if self.name == "interformer_pureMulti" or not self.singleformer:
@@ -1903,15 +1921,19 @@ class Engine:
             return {key: torch.cat([y[key] for y in ys], 0) for key in ys[0]}
         return torch.cat(ys, 0)
 
+    def program_bytes(self):
+        """arena + workspace bytes held by the cached programs (bench.py --ragged-stream reports it)"""
+        return sum(v[0].nbytes for v in self.programs.values())
+
     def _program(self, key, build):
-        """LRU cache of programs: most recently used last"""
+        """LRU cache of programs, most recently used last; bounded by entries and by bytes (the newest program always stays)"""
         if key in self.programs:
             self.programs[key] = self.programs.pop(key)
         else:
-            while len(self.programs) >= self.MAX_PROGRAMS:
-                self.programs.pop(next(iter(self.programs)))
             self.programs[key] = build()
             self.n_builds += 1
+            while len(self.programs) > 1 and (len(self.programs) > self.MAX_PROGRAMS or self.program_bytes() > self.MAX_PROGRAM_BYTES):
+                self.programs.pop(next(iter(self.programs)))
         return self.programs[key]
 
     def _forward_split(self, x, pos_mask, length, flip_joint_map, S, H, W, bounds):
@@ -1995,14 +2017,7 @@ class Engine:
         # persons-per-image grouping enters through the encoder's offset table, the real crop count through the stem kernels
         cap = self.capacity(S)
         key = (cap, H, W, flip) if slot == 0 else (cap, H, W, flip, slot)  # (a Program owns its arena: the concurrent half needs its own)
-        if key in self.programs:
-            self.programs[key] = self.programs.pop(key)  # most recently used last
-        else:
-            while len(self.programs) >= self.MAX_PROGRAMS:
-                self.programs.pop(next(iter(self.programs)))
-            self.programs[key] = self._build(cap, H, W, list(length) + [1] * (cap - S), flip)
-            self.n_builds += 1
-        P, patch = self.programs[key]
+        P, patch = self._program(key, lambda: self._build(cap, H, W, list(length) + [1] * (cap - S), flip))
         self.last_concurrent = []
         self.last_programs = [P]  # the program(s) of the most recent forward (bench.py's per-launch timing pass replays them; _forward merges the parts')
         glen = list(length) + [1] * (cap - S)

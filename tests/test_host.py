@@ -96,14 +96,18 @@ def test_synth_is_key_addressed_and_deterministic():
     assert abs(x.std() - 1.0) < 0.02 and m.sum() > 0
 
 
-def test_cabi_library_exports_every_declared_symbol():
-    """include/i2r_hip.h <-> libi2r_hip.so <-> cabi.EXPORTS agree (no compute call: no GPU here)."""
+def test_cabi_library_exports_exactly_the_declared_symbols():
+    """include/i2r_hip.h == dynamic symbol table of libi2r_hip.so == cabi.EXPORTS (the library is built with -fvisibility=hidden: an
+    internal helper that leaks into the table, or an entry point that loses its I2R_API mark, fails here).  No compute call: no GPU here."""
+    import __graft_entry__
     header = open(os.path.join(ROOT, "include", "i2r_hip.h")).read()
-    declared = set(re.findall(r"^(?:int|const char\*)\s+(i2r_\w+)\s*\(", header, flags=re.M))
+    declared = set(re.findall(r"^I2R_API\s+(?:int|const char\*)\s+(i2r_\w+)\s*\(", header, flags=re.M))
+    unmarked = set(re.findall(r"^(?:int|const char\*)\s+(i2r_\w+)\s*\(", header, flags=re.M))
+    assert not unmarked, "declarations without I2R_API: %s" % sorted(unmarked)
     assert declared == set(cabi.EXPORTS), declared ^ set(cabi.EXPORTS)
     if not os.path.exists(cabi.LIB_PATH):
-        import __graft_entry__
         __graft_entry__.build()
+    assert set(__graft_entry__.exported_symbols(cabi.LIB_PATH)) == declared
     L = cabi.load_library()
     for name in cabi.EXPORTS:
         assert hasattr(L, name)
@@ -137,6 +141,19 @@ def test_no_wide_store_has_its_data_registers_overwritten_early():
             bad += b
     assert n_stores > 1000
     assert not bad, bad[:3]
+
+
+def test_build_records_mode_and_runs_the_library_checks():
+    """__graft_entry__.build() writes libi2r_hip.build.json (build_mode compiled | reused, per-source hashes, the post-link checks'
+    summary) and runs check_library() -- export list + ISA store-hazard scan -- on every link, not only from pytest."""
+    import json
+    import __graft_entry__
+    __graft_entry__.build()
+    info = json.load(open(__graft_entry__.BUILD_INFO))
+    assert info["build_mode"] in ("compiled", "reused")
+    assert set(info["objects"]) == set(__graft_entry__.SOURCES)
+    assert info["checks"]["store_hazards"] == 0 and info["checks"]["exports"] == len(cabi.EXPORTS)
+    assert __graft_entry__.check_library(cabi.LIB_PATH)["wide_stores"] == info["checks"]["wide_stores"]
 
 
 def test_struct_layouts_match_header():

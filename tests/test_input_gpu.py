@@ -82,6 +82,31 @@ def test_person_inputs_batch_is_bit_identical_to_per_image_path():
     assert np.array_equal(scl.cpu().numpy(), np.concatenate([np.stack(sc[2]) for sc in scenes]).astype(np.float32))
 
 
+def test_person_inputs_malformed_crop_table_writes_zeros():
+    """raw C-ABI: a crop whose image index lies outside the image table (device memory the host entry point cannot validate) gets zero
+    rows instead of an out-of-bounds read; the well-formed crop next to it is untouched (include/i2r_hip.h, i2r_person_inputs_cv2)"""
+    import ctypes as C
+    from i2r_amd import cabi
+    img, centers, scales, boxes = _scene(21, 120, 160, 2)
+    im = torch.from_numpy(img).cuda()
+    x_ref, m_ref, _, _, _ = inp.person_inputs_batch([im], [centers], [scales], [boxes], (192, 256))
+    tab = x_ref._i2r_keep[0].clone()          # [crop table (2 x 80 bytes) | image table | ...]
+    tab_h = tab.cpu()
+    tab_h.numpy()[:160].view(inp._CROP_DT)["image"][1] = 7   # only one image in the table
+    tab = tab_h.cuda()
+    x = torch.full_like(x_ref, 5.0)
+    m = torch.full_like(m_ref, 5.0)
+    mean_c = (C.c_float * 3)(*inp.IMAGENET_MEAN)
+    istd_c = (C.c_float * 3)(*[1.0 / v for v in inp.IMAGENET_STD])
+    st = torch.cuda.current_stream().cuda_stream
+    cabi.check(cabi.lib().i2r_person_inputs_cv2(tab.data_ptr() + 160, 1, tab.data_ptr(), 2, 0, mean_c, istd_c, x.data_ptr(), m.data_ptr(), 256, 192, st),
+               "i2r_person_inputs_cv2")
+    torch.cuda.synchronize()
+    assert torch.equal(x[0], x_ref[0]) and torch.equal(m[0], m_ref[0])
+    assert (x[1] == 0).all() and (m[1] == 0).all()
+    assert cabi.lib().i2r_person_inputs_cv2(tab.data_ptr() + 160, 0, tab.data_ptr(), 2, 0, mean_c, istd_c, x.data_ptr(), m.data_ptr(), 256, 192, st) == -1
+
+
 def test_image_to_heatmaps_chain():
     """image bytes -> device crops / masks -> collate -> model: the crops of one image, collated with a second image's, give the same
     heat maps as running that image alone (and the forward accepts what the input side produces)."""

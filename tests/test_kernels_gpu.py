@@ -788,13 +788,8 @@ def test_window_attention_block_matches_oracle(c, heads, h, w):
     assert err < 2e-4, "window attention c=%d max-abs %.3e" % (c, err)
 
 
-@pytest.mark.parametrize("precision", ["bf16", "fp16"])
-@pytest.mark.parametrize("c,heads,h,w", [(78, 2, 64, 48), (156, 4, 32, 24), (78, 2, 24, 18), (156, 4, 9, 12)])
-def test_fused_attention_block_16bit(precision, c, heads, h, w):
-    """i2r_hrt_attn_block (one launch: LN1 + q|k|v + window attention + out_proj + residual, 16-bit MFMA) vs the fp32 oracle
-    x + attn(LN1 x); tolerance = 16-bit operand rounding of a residual branch (|x| ~ 1, branch ~ 1)."""
+def _attn_block_case(c, heads, h, w, tag):
     import i2r_cpu_hrformer as H
-    tag = "fa%d_%d" % (c, h)
     p = "b.attn.attn"
     sd = {"b.norm1.weight": _rand((c,), "n1w" + tag, 0.3) + 1.0, "b.norm1.bias": _rand((c,), "n1b" + tag, 0.2)}
     for n in ("q_proj", "k_proj", "v_proj", "out_proj"):
@@ -804,15 +799,63 @@ def test_fused_attention_block_16bit(precision, c, heads, h, w):
     t = x.permute(0, 2, 3, 1)
     n1 = F.layer_norm(t, (c,), sd["b.norm1.weight"], sd["b.norm1.bias"], 1e-6)
     ref = (t + H.window_attention(sd, p, n1, heads)).permute(0, 3, 1, 2)
+    return sd, x, ref
+
+
+@pytest.mark.parametrize("precision", ["bf16", "fp16"])
+@pytest.mark.parametrize("c,heads,h,w,variant", [(78, 2, 64, 48, 1), (156, 4, 32, 24, 1), (78, 2, 24, 18, 1), (156, 4, 9, 12, 1),
+                                                  (78, 2, 64, 48, 2), (156, 4, 32, 24, 2), (78, 2, 24, 18, 2), (156, 4, 9, 12, 2),
+                                                  (312, 8, 16, 12, 2), (624, 16, 8, 6, 2), (312, 8, 24, 18, 2), (624, 16, 12, 9, 2),
+                                                  (312, 8, 5, 9, 2), (156, 4, 32, 24, 0)])
+def test_fused_attention_block_16bit(precision, c, heads, h, w, variant):
+    """i2r_hrt_attn_block (one launch: LN1 + q|k|v + window attention + out_proj + residual, 16-bit MFMA) vs the fp32 oracle
+    x + attn(LN1 x); tolerance = 16-bit operand rounding of a residual branch (|x| ~ 1, branch ~ 1).  variant 1 = one wave per 16-token
+    tile (rounds 3-4), 2 = one wave per head (round 5: all four branch widths), 0 = the library's choice."""
+    sd, x, ref = _attn_block_case(c, heads, h, w, "fa%d_%d" % (c, h))
     P = engine.Program(torch.device(DEV))
     pk = engine.Packer(sd, torch.device(DEV), precision)
-    out = P.hrt_attn(to_act(P, x), pk.attn_block_lp("b", c, heads))
+    out = P.hrt_attn(to_act(P, x), pk.attn_block_lp("b", c, heads), variant=variant)
     run(P)
     d = from_act(out) - ref
     tol_max, tol_rms = (6e-2, 2e-2) if precision == "bf16" else (1e-2, 3e-3)   # relative, like LP_TOL of the model tests
     rel_max, rel_rms = d.abs().max().item() / ref.abs().max().item(), d.pow(2).mean().sqrt().item() / ref.pow(2).mean().sqrt().item()
     assert rel_max < tol_max and rel_rms < tol_rms, (rel_max, rel_rms)
-    assert out.view()[..., c:].abs().max().item() == 0.0
+    assert out.cs == c or out.view()[..., c:].abs().max().item() == 0.0
+
+
+@pytest.mark.parametrize("c,heads,h,w", [(78, 2, 64, 48), (156, 4, 20, 24)])
+def test_fused_attention_variants_agree(c, heads, h, w):
+    """the two decompositions of i2r_hrt_attn_block run the same arithmetic on the same packed operands: they differ by fp32 summation
+    order and by where 16-bit roundings of equal values fall -- an order of magnitude below the distance of either to the fp32 oracle"""
+    sd, x, ref = _attn_block_case(c, heads, h, w, "fv%d_%d" % (c, h))
+    outs = []
+    for variant in (1, 2):
+        P = engine.Program(torch.device(DEV))
+        pk = engine.Packer(sd, torch.device(DEV), "bf16")
+        out = P.hrt_attn(to_act(P, x), pk.attn_block_lp("b", c, heads), variant=variant)
+        run(P)
+        outs.append(from_act(out))
+    d12 = (outs[0] - outs[1]).pow(2).mean().sqrt().item()
+    d1r = (outs[0] - ref).pow(2).mean().sqrt().item()
+    assert d12 < 0.5 * d1r, (d12, d1r)
+
+
+def test_fused_attention_block_rejects_bad_variant():
+    """raw C-ABI: variant 1 exists for the 78 / 156 branches only; unknown variants are I2R_E_ARG"""
+    sd, x, _ = _attn_block_case(312, 8, 7, 7, "fe")
+    P = engine.Program(torch.device(DEV))
+    pk = engine.Packer(sd, torch.device(DEV), "bf16")
+    xa = to_act(P, x)
+    ab = pk.attn_block_lp("b", 312, 8)
+    out = P.alloc(xa.n, xa.h, xa.w, xa.c)
+    from i2r_amd import cabi
+    L = cabi.lib()
+    args = [xa.ptr, out.ptr, ab["ln"]["w"].data_ptr(), ab["ln"]["b"].data_ptr(), ab["wqkv"].data_ptr(), ab["bqkv"].data_ptr(), ab["wo"].data_ptr(),
+            ab["bo"].data_ptr(), xa.n, xa.h, xa.w, 312, 320, 8, 1e-6, 1]
+    assert L.i2r_hrt_attn_block(*args, 1, None) == -1 and b"variant" in L.i2r_last_error()
+    assert L.i2r_hrt_attn_block(*args, 3, None) == -1
+    assert L.i2r_hrt_attn_block(*args, 2, None) == 0
+    torch.cuda.synchronize()
 
 
 @pytest.mark.parametrize("precision", ["bf16", "fp16"])

@@ -223,8 +223,13 @@ def test_full_size_batch_properties():
 #                                          fp16: max-abs <= 0.6 % of max|ref| and rms error <= 0.2 % of rms(ref)
 # (measured on MI355X, tools/lp_error.py, round 3: bf16 0.8-3.1 % / 0.7-1.2 % -- the 3.1 % is the first-stage `single` head of the
 #  3-crop HRFormer case, the `multi` outputs stay below 1.9 %; fp16 0.14-0.39 % / 0.10-0.15 %).
-LP_TOL = {"bf16": (4e-2, 1.5e-2), "fp16": (6e-3, 2e-3)}
-HRFORMER_FUSED_WIDTHS = (78, 156)  # branches whose transformer blocks run as one attention + one MLP launch in the 16-bit modes
+# Round 5 (variant 2 of the fused attention kernel, three fused branch widths): `multi` bf16 1.0-1.9 % / 0.7-1.0 %, the HRFormer `single`
+# heads 2.9-3.0 % / 0.9-1.2 %; fp16 0.12-0.44 % / 0.08-0.16 %.  The bars: the final (`multi`) heat maps 3 % (worst case + 50 %), the
+# first-stage `single` heads keep 4 %.
+LP_TOL = {"bf16": (3e-2, 1.5e-2), "fp16": (6e-3, 2e-3)}
+LP_TOL_SINGLE = {"bf16": (4e-2, 1.5e-2), "fp16": (6e-3, 2e-3)}
+HRFORMER_FUSED_ATTN = (78, 156, 312)  # branches whose attention half runs as ONE launch in the 16-bit modes (i2r_hrt_attn_block)
+HRFORMER_FUSED_MLP = (78, 156)        # ... and whose MLP half does (i2r_hrt_mlp_block)
 
 
 @pytest.mark.parametrize("tag,precision", [("tph_l21", "bf16"), ("hrt_l21", "bf16"), ("hrt288_l2", "fp16"), ("w48_l213", "bf16")])
@@ -239,8 +244,8 @@ def test_low_precision_modes_within_stated_tolerance(tag, precision):
     outs = y if isinstance(y, dict) else {"multi": y}
     zs = i2r_cpu.forward(sd, cfg, x, m, length)
     zs = zs if isinstance(zs, dict) else {"multi": zs}
-    tol_max, tol_rms = LP_TOL[precision]
     for k, t in outs.items():
+        tol_max, tol_rms = (LP_TOL_SINGLE if k == "single" else LP_TOL)[precision]
         d = t.cpu() - zs[k]
         assert torch.isfinite(t).all()
         assert d.abs().max().item() <= tol_max * zs[k].abs().max().item(), (tag, k, d.abs().max().item())
@@ -335,6 +340,59 @@ def test_half_batches_on_two_streams_match_one_program():
         net.set_precision("fp32")
 
 
+@pytest.mark.parametrize("precision", ["fp32", "bf16"])
+def test_tower_tail_split_flip_forward_matches_one_program(precision):
+    """Engine._forward_split with the flip test, fp32 and bf16: 27 crops of the vanilla model over 7 ragged images -> S = 27 <
+    cap = 28 and a part of 13 crops < its capacity 14, so the padding rows of the tail's feature buffer and of the tower programs are
+    exercised, and the mirrored half is copied with the hand-written row offsets feat[cap + offs[i] : cap + offs[i + 1]] <-
+    tower rows [capp : capp + sp].  The split forward must agree with the one-program forward (split off): fp32 1e-4, bf16 within the
+    16-bit tolerance; one image is checked against two oracle forwards (plain + mirrored, merged as function.py:142-162 does)."""
+    import post_cpu
+    from i2r_amd import caller, synth
+    cfg, sd, _, _, _, _ = setup("w48_l1")
+    net = _net(cfg, sd, "w48_pure_en6")
+    length = [5, 3, 6, 1, 4, 2, 6]
+    x, m, length = synth.make_inputs(length, 256, 192, seed=11)
+    pairs = caller.FLIP_PAIRS["crowdpose"]
+    eng = None
+    try:
+        net.set_precision(precision)
+        eng = net.engine()
+        b = eng._split_bounds(length, 256, 192)
+        assert b is not None and eng.capacity(27) == 28
+        sp = [sum(length[b[i]:b[i + 1]]) for i in range(2)]
+        assert any(eng.capacity(v) > v for v in sp), sp
+        y2 = net.forward_flip(x.cuda(), m.cuda(), length, pairs)
+        torch.cuda.synchronize()
+        assert len(eng.last_programs) == 3 and len(eng.last_concurrent) == 2  # two towers + the tail
+        saved, eng.SPLIT_MIN_CROPS = eng.SPLIT_MIN_CROPS, 10 ** 9
+        try:
+            y1 = net.forward_flip(x.cuda(), m.cuda(), length, pairs)
+            torch.cuda.synchronize()
+            assert len(eng.last_programs) == 1
+        finally:
+            eng.SPLIT_MIN_CROPS = saved
+        assert y1.shape == y2.shape == (27, 14, 64, 48) and torch.isfinite(y2).all()
+        d = (y2 - y1).float()
+        if precision == "fp32":
+            assert d.abs().max().item() < 1e-4
+        else:
+            tol_max, tol_rms = LP_TOL[precision]
+            assert d.abs().max().item() <= tol_max * y1.abs().max().item()
+            assert d.pow(2).mean().sqrt().item() <= 0.5 * tol_rms * y1.pow(2).mean().sqrt().item()
+        # image 3 (one person) and image 5 (two persons) against the oracle's flip test
+        for i in (3, 5):
+            o, n = sum(length[:i]), length[i]
+            ref = post_cpu.flip_test(lambda a, bb, c: i2r_cpu.forward(sd, cfg, a, bb, c), x[o:o + n], m[o:o + n], [n], pairs)
+            e = (y2[o:o + n].cpu() - ref).abs().max().item()
+            assert e < (TOL if precision == "fp32" else LP_TOL[precision][0] * ref.abs().max().item()), (i, e)
+    finally:
+        net.set_precision("fp32")
+    # unbalanced batches and sizes the tower / tail hand-over does not cover stay one program
+    assert eng._split_bounds([23, 1], 256, 192) is None and eng._split_bounds([20, 7], 256, 192) is None
+    assert eng._split_bounds(length, 250, 192) is None and eng._split_bounds(length, 256, 192) is not None
+
+
 def test_first_part_batch_forward_beside_a_running_program_fp32():
     """fp32, 2-stage TransPose-H model: a one-program forward, then the FIRST part-batch forward of the same engine -- part A's tower starts
     while part B's encoder kernels occupy the chip -- and the steady state after it, every image against the oracle at the fp32
@@ -425,11 +483,11 @@ def test_config4_real_batch_bf16_fused_blocks():
     assert ym.shape == (16, 14, 64, 48) and torch.isfinite(ym).all()
     assert (yp - ym[idx]).abs().max().item() < 1e-4 * max(1.0, ym.abs().max().item())
     assert var and all(d == 78 and dt == 1 for d, dt in var), "bf16 mode must run the 16-bit inter-human encoder: %r" % (var,)
-    fused_c = HRFORMER_FUSED_WIDTHS
-    want = sum(st["num_modules"] * st["num_blocks"][i] for st in STAGES.values() for i, c in enumerate(st["num_channels"]) if c in fused_c)
+    want_a, want_m = (sum(st["num_modules"] * st["num_blocks"][i] for st in STAGES.values() for i, c in enumerate(st["num_channels"]) if c in fused_c)
+                      for fused_c in (HRFORMER_FUSED_ATTN, HRFORMER_FUSED_MLP))
     for P in progs:
         kinds = [k for k, _, _ in P.ops]
-        assert kinds.count(cabi.OP_HRT_ATTN) == want and kinds.count(cabi.OP_HRT_MLP) == want, (kinds.count(cabi.OP_HRT_ATTN), kinds.count(cabi.OP_HRT_MLP), want)
+        assert kinds.count(cabi.OP_HRT_ATTN) == want_a and kinds.count(cabi.OP_HRT_MLP) == want_m, (kinds.count(cabi.OP_HRT_ATTN), kinds.count(cabi.OP_HRT_MLP))
         stem = [st for k, _, st in P.ops if k == cabi.OP_STEM][0]
         assert stem.out_dt == 1, "bf16 mode: the HRFormer stem stores bf16"
     ref = i2r_cpu.forward(sd, cfg, x[8:12], m[8:12], [4])["multi"]

@@ -1,4 +1,5 @@
-"""GPU tuning aid: time the fused HRFormer attention-block kernel (i2r_hrt_attn_block) on the two high-resolution branch shapes."""
+"""GPU tuning aid: time the fused HRFormer attention-block kernel (i2r_hrt_attn_block), both variants, on the branch shapes of configs 4 / 5.
+usage: time_hrt_attn.py [bf16|fp16] [crops] [192|288]"""
 import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
@@ -10,7 +11,9 @@ if os.environ.get("I2R_TOOL_LIB"):  # an A/B library variant (tools/ab/build_var
 DEV = torch.device("cuda:0")
 prec = sys.argv[1] if len(sys.argv) > 1 else "bf16"
 n = int(sys.argv[2]) if len(sys.argv) > 2 else 16
-for c, heads, h, w in ((78, 2, 64, 48), (156, 4, 32, 24)):
+big = len(sys.argv) > 3 and sys.argv[3] == "288"
+shapes = ((78, 2, 96, 72), (156, 4, 48, 36), (312, 8, 24, 18), (624, 16, 12, 9)) if big else ((78, 2, 64, 48), (156, 4, 32, 24), (312, 8, 16, 12), (624, 16, 8, 6))
+for c, heads, h, w, variant in [sh + (v,) for sh in shapes for v in (1, 2) if v == 2 or sh[0] <= 156]:
     sd = {"b.norm1.weight": torch.ones(c), "b.norm1.bias": torch.zeros(c)}
     for k in ("q_proj", "k_proj", "v_proj", "out_proj"):
         sd["b.attn.attn.%s.weight" % k] = torch.from_numpy(synth._sym(1, k + str(c), (c, c), 0.1))
@@ -21,7 +24,7 @@ for c, heads, h, w in ((78, 2, 64, 48), (156, 4, 32, 24)):
     x.t.normal_()
     y = x
     for _ in range(4):
-        y = P.hrt_attn(y, ab)
+        y = P.hrt_attn(y, ab, variant=variant)
     P.finalize()
     for _ in range(3):
         P.run()
@@ -32,4 +35,4 @@ for c, heads, h, w in ((78, 2, 64, 48), (156, 4, 32, 24)):
         P.run()
     e1.record()
     torch.cuda.synchronize()
-    print("C=%d %dx%d n=%d: %.1f us per launch" % (c, h, w, n, e0.elapsed_time(e1) / 40 * 1e3))
+    print("C=%d %dx%d n=%d variant %d: %.1f us per launch" % (c, h, w, n, variant, e0.elapsed_time(e1) / 40 * 1e3))
