@@ -161,7 +161,7 @@ def op_model(kind, st, precision, enc_lens=None):
         return ("hrt_attn_head_k" if st.variant == 2 else "hrt_attn_block_k", nwin * (8.0 * c * c * 49 + 4.0 * c * 49 * 49), float(2 * st.n_img * st.h * st.w_ * st.cs * 4 + 4 * c * c * 2), lp)
     if kind == cabi.OP_HRT_MLP:
         npix, c = st.n_img * st.h * st.w_, st.c
-        return ("hrt_mlp_block_k", npix * (16.0 * c * c + 18.0 * 4 * c), float(2 * npix * st.cs * 4 + 8 * c * c * 2 + 10 * 4 * c * 4), lp)
+        return ("hrt_mlp_wide_k" if st.variant == 2 else "hrt_mlp_block_k", npix * (16.0 * c * c + 18.0 * 4 * c), float(2 * npix * st.cs * 4 + 8 * c * c * 2 + 10 * 4 * c * 4), lp)
     if kind == cabi.OP_WINATTN:
         nwin = st.n_img * ((st.h + 6) // 7) * ((st.w_ + 6) // 7)
         return "window_attn_k", nwin * 4.0 * st.c * 49 * 49, float(st.n_img * st.h * st.w_ * st.cs * 4 * 4), "fp32"  # (cs = hs; q|k|v in, o out)

@@ -280,14 +280,17 @@ I2R_API int i2r_hrt_attn_block(const float* x, float* out, const float* ln_w, co
  * semantics as i2r_layernorm + i2r_conv(fc1, GELU) + i2r_dwconv3x3(GELU) + i2r_conv(fc2, GELU, res_post = x)), one workgroup per 8x6
  * pixel tile (+ halo of 1, recomputed) on v_mfma_f32_16x16x32_{bf16,f16}; the 4C-wide hidden tensor only exists in LDS, 16 channels per
  * wave at a time.  x and out: fp32 NHWC [n, h, w, cs], distinct buffers; pad channels of x must be zero (they are everywhere in this library).
- * (c, cs) = (78, 80) or (156, 160); hidden_pad = 4 cs (zero weights / biases beyond 4c).
+ * (c, cs) = (78, 80), (156, 160) or (312, 320); hidden_pad = 4 cs (zero weights / biases beyond 4c).
+ * variant: 0 = the library's choice; 1 = every wave accumulates fc2 over its own hidden blocks for all output blocks, partial sums meet
+ * once through LDS (rounds 3-4; 78 / 156); 2 = ten waves per tile, the hidden dimension in rounds of ten block pairs whose packed
+ * depth-wise outputs meet in LDS, every wave accumulating ITS output blocks (round 5; 156 / 312).  Same operands and arithmetic.
  * w1: 16-bit 32-deep fragments [hidden_pad/16][cs/32 rounded up][64 lanes][8] of the BN-folded fc1 matrix [hidden, c] (fragment layout as
  * in i2r_hrt_attn_block; columns zero beyond cs), b1 float [hidden_pad]; wdw float [9][hidden_pad] tap-major BN-folded depth-wise
  * weights, bdw [hidden_pad]; w2: fragments [cs/16][hidden_pad/32][64][8] of the BN-folded fc2 matrix [c, hidden] with the hidden columns
  * of every 32-column k-step in slot order (slot 8g + 4h + r <- column 16 (2 kstep + h) + 4g + r), b2 float [cs]. */
 I2R_API int i2r_hrt_mlp_block(const float* x, float* out, const float* ln_w, const float* ln_b, const void* w1, const float* b1,
                       const float* wdw, const float* bdw, const void* w2, const float* b2, int32_t n_img, int32_t h, int32_t w,
-                      int32_t c, int32_t cs, int32_t hidden_pad, float eps, int32_t dtype, void* stream);
+                      int32_t c, int32_t cs, int32_t hidden_pad, float eps, int32_t dtype, int32_t variant, void* stream);
 
 /* i2r_dwconv3x3 -- depth-wise 3x3 conv, pad 1, stride 1|2, + bias (eval BN folded) + activation (0 none, 1 ReLU,
  * 2 GELU): MlpDWBN.dw3x3+norm2+act2 (hrformer.py:1070-1080,1106-1108) and the DW down-sampling hops of the fuse
@@ -475,7 +478,7 @@ typedef struct i2r_hrt_attn_args {
 typedef struct i2r_hrt_mlp_args {
     const float* x; float* out; const float* ln_w; const float* ln_b; const void* w1; const float* b1; const float* wdw; const float* bdw;
     const void* w2; const float* b2;
-    int32_t n_img, h, w_, c, cs, hidden_pad; float eps; int32_t dtype;
+    int32_t n_img, h, w_, c, cs, hidden_pad; float eps; int32_t dtype, variant;
 } i2r_hrt_mlp_args;
 
 typedef struct i2r_dw_args {

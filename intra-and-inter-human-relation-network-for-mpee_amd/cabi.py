@@ -98,7 +98,7 @@ class HrtAttnArgs(C.Structure):
 class HrtMlpArgs(C.Structure):
     _fields_ = [("x", _fp), ("out", _fp), ("ln_w", _fp), ("ln_b", _fp), ("w1", _fp), ("b1", _fp), ("wdw", _fp), ("bdw", _fp), ("w2", _fp),
                 ("b2", _fp), ("n_img", _i32), ("h", _i32), ("w_", _i32), ("c", _i32), ("cs", _i32), ("hidden_pad", _i32), ("eps", C.c_float),
-                ("dtype", _i32)]
+                ("dtype", _i32), ("variant", _i32)]
 
 
 class DwArgs(C.Structure):
@@ -193,7 +193,7 @@ def load_library(path=LIB_PATH):
     L.i2r_layernorm.argtypes = [_fp, _fp, _fp, _fp, _i32, _i32, _i32, C.c_float, _i32, C.c_void_p]
     L.i2r_window_attn.argtypes = [_fp, _fp, _fp, _i32, _i32, _i32, _i32, _i32, _i32, C.c_void_p]
     L.i2r_hrt_attn_block.argtypes = [_fp, _fp, _fp, _fp, _fp, _fp, _fp, _fp, _i32, _i32, _i32, _i32, _i32, _i32, C.c_float, _i32, _i32, C.c_void_p]
-    L.i2r_hrt_mlp_block.argtypes = [_fp] * 10 + [_i32] * 6 + [C.c_float, _i32, C.c_void_p]
+    L.i2r_hrt_mlp_block.argtypes = [_fp] * 10 + [_i32] * 6 + [C.c_float, _i32, _i32, C.c_void_p]
     L.i2r_dwconv3x3.argtypes = [_fp, _fp, _fp, _fp, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, C.c_void_p]
     L.i2r_upsample_bilinear_add_multi.argtypes = [C.POINTER(UpArgs), C.c_void_p]
     L.i2r_upsample_bilinear_add.argtypes = [_fp, _fp, _fp, _i32, _i32, _i32, _i32, _i32, _i32, _i32, C.c_void_p]

@@ -136,7 +136,7 @@ extern "C" int i2r_run_program(const i2r_op* ops, int32_t n_ops, void* const* st
             case I2R_OP_HRT_MLP: {
                 const i2r_hrt_mlp_args* a = (const i2r_hrt_mlp_args*)op.args;
                 rc = i2r_hrt_mlp_block(a->x, a->out, a->ln_w, a->ln_b, a->w1, a->b1, a->wdw, a->bdw, a->w2, a->b2, a->n_img, a->h, a->w_, a->c, a->cs,
-                                       a->hidden_pad, a->eps, a->dtype, st);
+                                       a->hidden_pad, a->eps, a->dtype, a->variant, st);
                 break;
             }
             case I2R_OP_DWCONV: {

@@ -51,70 +51,75 @@ __global__ __launch_bounds__(64 * (HEADS / HPW), OCC) void hrt_attn_head_k(const
     const int img = bid / p.nwy;
     const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
 
-    // ---- LayerNorm 1 -> smem as packed operand image: lane (li, g) of (tile t, k-step s) holds features 32 s + 8 g .. + 7 of token 16 t + li ----
+    // ---- LayerNorm 1 -> smem as packed operand image: lane (li, g) of (tile t, k-step s) holds features 32 s + 8 g .. + 7 of token 16 t + li.
+    //      The rows are READ quad-coalesced: lane n takes token n >> 2 of the tile and the 16-byte pieces (n & 3) + 4 k of its row, so the
+    //      four lanes of a quad cover 64 contiguous bytes (a 64-lane access whose quads straddle rows takes four times the addresser
+    //      cycles, DESIGN.md "quad rule"); statistics: in-lane, then over the quad; piece pi lands in half pi & 1 of lane
+    //      (g = (pi & 7) >> 1, li = token) of k-step pi >> 3. ----
     {
+        constexpr int NP = cs / 4;               // 16-byte pieces of a row
+        constexpr int KQ = 2 * KS / KP;          // pieces per lane and slice (all 8 KS pieces of the operand image: beyond the row, zeros)
+        static_assert((2 * KS) % KP == 0, "pieces per LayerNorm slice");
         const float inv_c = __builtin_amdgcn_rcpf((float)p.c);
         const float npad = (float)(cs - p.c);  // zero pad channels inside the row: each adds mean^2 to the sum of squares
+        const int tl = lane >> 2, q = lane & 3;
 #pragma unroll
         for (int i = 0; i < TPW; ++i) {
             const int t = NW >= 4 ? (wave & 3) : wave + i * NW;
             const int kh = NW >= 4 ? (wave >> 2) : 0;
-            const int tt = 16 * t + li;
+            const int tt = 16 * t + tl;
             const int ty = tt / 7, tx = tt - ty * 7;
             const int y = wy * 7 + ty - p.pad_top, x = wx * 7 + tx - p.pad_left;
             const bool inmap = tt < 49 && y >= 0 && y < p.h && x >= 0 && x < p.w;
             const float* row = p.x + (((size_t)img * p.h + (inmap ? y : 0)) * p.w + (inmap ? x : 0)) * cs;
-            f32x4 xa[KSL], xb[KSL];
+            f32x4 xv[KQ];
 #pragma unroll
-            for (int k = 0; k < KSL; ++k) {  // (unconditional loads from clamped addresses, selected afterwards)
-                const int s = kh * KSL + k;
-                const int f0 = 32 * s + 8 * g < cs ? 32 * s + 8 * g : cs - 8;
-                xa[k] = *reinterpret_cast<const f32x4*>(row + f0);
-                xb[k] = *reinterpret_cast<const f32x4*>(row + f0 + 4);
+            for (int k = 0; k < KQ; ++k) {  // (unconditional loads from clamped addresses, selected afterwards)
+                const int pi = q + 4 * (kh * KQ + k);
+                xv[k] = *reinterpret_cast<const f32x4*>(row + 4 * (pi < NP ? pi : 0));
             }
             float s1 = 0.f;
 #pragma unroll
-            for (int k = 0; k < KSL; ++k) {
-                const bool ok = inmap && (32 * (kh * KSL + k) + 8 * g < cs);
-                xa[k] = ok ? xa[k] : zero4;
-                xb[k] = ok ? xb[k] : zero4;
-                s1 += ((xa[k][0] + xa[k][1]) + (xa[k][2] + xa[k][3])) + ((xb[k][0] + xb[k][1]) + (xb[k][2] + xb[k][3]));
+            for (int k = 0; k < KQ; ++k) {
+                const bool ok = inmap && q + 4 * (kh * KQ + k) < NP;
+                xv[k] = ok ? xv[k] : zero4;
+                s1 += (xv[k][0] + xv[k][1]) + (xv[k][2] + xv[k][3]);
             }
-            s1 = i2r_xsum4(s1);
+            s1 += __shfl_xor(s1, 1);
+            s1 += __shfl_xor(s1, 2);
             if constexpr (KP > 1) {  // the slices' partial sums meet in a fixed order
-                if (g == 0) stat[0][(kh * 4 + t) * 16 + li] = s1;
+                if (q == 0) stat[0][(kh * 4 + t) * 16 + tl] = s1;
                 __syncthreads();
                 s1 = 0.f;
 #pragma unroll
-                for (int kk = 0; kk < KP; ++kk) s1 += stat[0][(kk * 4 + t) * 16 + li];
+                for (int kk = 0; kk < KP; ++kk) s1 += stat[0][(kk * 4 + t) * 16 + tl];
             }
             const float mean = s1 * inv_c;
             float q2 = 0.f;
 #pragma unroll
-            for (int k = 0; k < KSL; ++k) {
-                const float keep = 32 * (kh * KSL + k) + 8 * g < cs ? 1.f : 0.f;
-                const f32x4 da = (xa[k] - mean) * keep, db = (xb[k] - mean) * keep;
-                q2 += ((da[0] * da[0] + da[1] * da[1]) + (da[2] * da[2] + da[3] * da[3])) + ((db[0] * db[0] + db[1] * db[1]) + (db[2] * db[2] + db[3] * db[3]));
+            for (int k = 0; k < KQ; ++k) {
+                const float keep = q + 4 * (kh * KQ + k) < NP ? 1.f : 0.f;
+                const f32x4 d = (xv[k] - mean) * keep;
+                q2 += (d[0] * d[0] + d[1] * d[1]) + (d[2] * d[2] + d[3] * d[3]);
             }
-            q2 = i2r_xsum4(q2);
+            q2 += __shfl_xor(q2, 1);
+            q2 += __shfl_xor(q2, 2);
             if constexpr (KP > 1) {
-                if (g == 0) stat[1][(kh * 4 + t) * 16 + li] = q2;
+                if (q == 0) stat[1][(kh * 4 + t) * 16 + tl] = q2;
                 __syncthreads();
                 q2 = 0.f;
 #pragma unroll
-                for (int kk = 0; kk < KP; ++kk) q2 += stat[1][(kk * 4 + t) * 16 + li];
+                for (int kk = 0; kk < KP; ++kk) q2 += stat[1][(kk * 4 + t) * 16 + tl];
             }
             const float var = (q2 - npad * mean * mean) * inv_c;
             const float rstd = rsqrtf(fmaxf(var, 0.f) + p.eps);
 #pragma unroll
-            for (int k = 0; k < KSL; ++k) {
-                const int s = kh * KSL + k;
-                const bool has = 32 * s + 8 * g < cs;
-                const int f0 = has ? 32 * s + 8 * g : 0;
-                const f32x4 wa = *reinterpret_cast<const f32x4*>(p.ln_w + f0), wb = *reinterpret_cast<const f32x4*>(p.ln_w + f0 + 4);
-                const f32x4 ba = *reinterpret_cast<const f32x4*>(p.ln_b + f0), bb = *reinterpret_cast<const f32x4*>(p.ln_b + f0 + 4);
-                const float keep = (inmap && has) ? 1.f : 0.f;  // tokens outside the map are exact zeros AFTER the LayerNorm
-                smem[(t * KS + s) * 64 + lane] = pack8<DT>(((xa[k] - mean) * rstd * wa + ba) * keep, ((xb[k] - mean) * rstd * wb + bb) * keep);
+            for (int k = 0; k < KQ; ++k) {
+                const int pi = q + 4 * (kh * KQ + k);
+                const bool has = pi < NP;
+                const f32x4 wa = *reinterpret_cast<const f32x4*>(p.ln_w + 4 * (has ? pi : 0)), ba = *reinterpret_cast<const f32x4*>(p.ln_b + 4 * (has ? pi : 0));
+                const float keep = (inmap && has) ? 1.f : 0.f;  // tokens outside the map are exact zeros AFTER the LayerNorm; so is the image beyond the row
+                reinterpret_cast<uint2*>(smem + (t * KS + (pi >> 3)) * 64 + ((pi & 7) >> 1) * 16 + tl)[pi & 1] = i2r_pack4<DT>(((xv[k] - mean) * rstd * wa + ba) * keep);
             }
         }
     }
@@ -233,17 +238,21 @@ __global__ __launch_bounds__(64 * (HEADS / HPW), OCC) void hrt_attn_head_k(const
         }
     __syncthreads();
 
-    // ---- out-proj + bias + residual: this wave's token-tile pair, output blocks (wave >> 1) + i NW / 2 ----
+    // ---- out-proj + bias + residual: this wave's token-tile pair, output blocks (wave >> 1) + i NW / 2.  The D fragments (lane (li, g):
+    //      features 4g + r of token li) are re-numbered with one ds_bpermute per register so that lane n holds piece n & 3 of token
+    //      n >> 2: residual loads and stores are quad-coalesced like the LayerNorm's loads ----
     const int tp = wave & 1;
+    const int tl = lane >> 2, pq = lane & 3;
+    const int srcl = tl + 16 * pq;       // the lane that holds this lane's new data
     size_t rowT[2];
     bool inT[2];
 #pragma unroll
     for (int tt = 0; tt < 2; ++tt) {
-        const int tk = 16 * (2 * tp + tt) + li;
+        const int tk = 16 * (2 * tp + tt) + tl;
         const int ty = tk / 7, tx = tk - ty * 7;
         const int y = wy * 7 + ty - p.pad_top, x = wx * 7 + tx - p.pad_left;
         inT[tt] = tk < 49 && y >= 0 && y < p.h && x >= 0 && x < p.w;
-        rowT[tt] = (((size_t)img * p.h + (inT[tt] ? y : 0)) * p.w + (inT[tt] ? x : 0)) * cs;
+        rowT[tt] = (((size_t)img * p.h + (inT[tt] ? y : 0)) * p.w + (inT[tt] ? x : 0)) * cs + 4 * pq;
     }
     constexpr int UN = (CB + NW / 2 - 1) / (NW / 2);  // output blocks per wave (the last one may not exist)
     constexpr int UC = UN < 5 ? UN : 5;               // ... in chunks of at most five (accumulators + fragments + residuals in registers)
@@ -259,7 +268,7 @@ __global__ __launch_bounds__(64 * (HEADS / HPW), OCC) void hrt_attn_head_k(const
 #pragma unroll
             for (int tt = 0; tt < 2; ++tt) {
                 acc[i][tt] = b;
-                xres[i][tt] = *reinterpret_cast<const f32x4*>(p.x + rowT[tt] + 16 * ob[i] + 4 * g);  // (clamped row: always readable)
+                xres[i][tt] = *reinterpret_cast<const f32x4*>(p.x + rowT[tt] + 16 * ob[i]);  // (clamped row: always readable)
             }
         }
         f32x4 wn[UC];
@@ -285,8 +294,12 @@ __global__ __launch_bounds__(64 * (HEADS / HPW), OCC) void hrt_attn_head_k(const
             const bool exists = (wave >> 1) + (c0 + i) * (NW / 2) < CB;  // (wave-uniform)
             if (!exists) continue;
 #pragma unroll
-            for (int tt = 0; tt < 2; ++tt)
-                if (inT[tt]) *reinterpret_cast<f32x4*>(p.out + rowT[tt] + 16 * ob[i] + 4 * g) = acc[i][tt] + xres[i][tt];
+            for (int tt = 0; tt < 2; ++tt) {
+                f32x4 v;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) v[r] = __shfl(acc[i][tt][r], srcl);  // (ds_bpermute_b32; NOT __builtin_bit_cast on a vector element: hipcc 7.2 folds the four into one)
+                if (inT[tt]) *reinterpret_cast<f32x4*>(p.out + rowT[tt] + 16 * ob[i]) = v + xres[i][tt];
+            }
         }
     }
 }

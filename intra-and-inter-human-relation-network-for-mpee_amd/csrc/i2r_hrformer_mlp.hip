@@ -26,94 +26,23 @@
 // that slot order, as for the attention kernel's out-proj) -- and the per-element masks of the prologue / epilogue are gone: pad
 // channels are exact zeros on both sides (zero weights and biases, GELU(0) = 0), the LayerNorm variance subtracts their (cs - c)
 // mean^2 instead of masking them.
-#include "i2r_common.h"
+#include "i2r_hrformer_mlp.h"
 
 namespace {
 
 #ifndef I2R_XCD_BAND
 #define I2R_XCD_BAND 1   // A/B knob: 0 = tiles in plain blockIdx order
 #endif
-template <int DT>
-__device__ __forceinline__ uint2 pack4(f32x4 v) {
-    if constexpr (DT == 1) {
-        typedef __bf16 b16x4 __attribute__((ext_vector_type(4)));
-        const b16x4 b = {(__bf16)v[0], (__bf16)v[1], (__bf16)v[2], (__bf16)v[3]};
-        return __builtin_bit_cast(uint2, b);
-    } else {
-        typedef _Float16 h16x4 __attribute__((ext_vector_type(4)));
-        const h16x4 h = {(_Float16)v[0], (_Float16)v[1], (_Float16)v[2], (_Float16)v[3]};
-        return __builtin_bit_cast(uint2, h);
-    }
-}
-__device__ __forceinline__ f32x4 join8(uint2 lo, uint2 hi) {  // two packed 4-element halves -> one 8-element MFMA operand
-    const uint4 v = {lo.x, lo.y, hi.x, hi.y};
-    return __builtin_bit_cast(f32x4, v);
-}
-__device__ __forceinline__ float xsum4(float v) {  // over the 4 lanes that share l & 15
-    v += __shfl_xor(v, 16);
-    v += __shfl_xor(v, 32);
-    return v;
-}
-
-struct MlpK {
-    const float* x; float* out;
-    const float* ln_w; const float* ln_b;
-    const f32x4* w1; const float* b1;     // fc1 (+BN1): 32-deep fragments [hidden block][KS k-steps][64 lanes]; bias [hidden_pad]
-    const float* wdw; const float* bdw;   // depth-wise 3x3 (+BN2): [9][hidden_pad] tap-major; bias [hidden_pad]
-    const f32x4* w2; const float* b2;     // fc2 (+BN3): 32-deep fragments [CB out blocks][hidden block pairs][64 lanes] (slot order); bias [cs]
-    int n_img, h, w, c, tiles_y, tiles_x, total;
-    float eps;
-};
-
-// exact-erf GELU (nn.GELU, hrformer.py:1197) with ONE transcendental:  GELU(x) = max(x, 0) - |x| Phi(-|x|), and the normal tail
-// Phi(-a) = erfc(a / sqrt 2) / 2 = 2^-Q(a), Q(0) = 1, Q a polynomial in a = min(|x|, 8) evaluated by Horner (minimax fit of the error of
-// the GELU VALUE, tools/fit_gelu.py; beyond 8 the tail term is below 1e-14 |x|, so the clamped a also serves as |x| in the product).
-// DEG 4: |error| < 9e-6 (hidden activations: two orders below one bf16 / f16 rounding); DEG 5: |error| < 1e-6 (the block output, added to
-// the fp32 residual stream).  The VALU retires one wave64 instruction per 4 cycles, packed fp32 ones (v_pk_fma_f32) included, so the
-// Horner steps and the final product run on PAIRS: 5.5 (6) issue slots per element: min, exp2, max + 5 (6) packed FMAs per pair.
-// The fp32 parity kernels keep libm's erff.
-typedef float f32x2 __attribute__((ext_vector_type(2)));
-struct GeluC {  // the coefficients as opaque SGPR pairs: literals would make the compiler pick scalar fmaak / fmamk over the packed FMAs
-    f32x2 c1, c2, c3, c4, d1, d2, d3, d4, d5, one;
-    __device__ __forceinline__ GeluC() {
-        auto splat = [](float v) { f32x2 r = {v, v}; asm("" : "+s"(r)); return r; };
-        c1 = splat(1.14955728e+00f); c2 = splat(4.64952799e-01f); c3 = splat(4.57202931e-02f); c4 = splat(-4.15856780e-03f);
-        d1 = splat(1.15100107e+00f); d2 = splat(4.59593681e-01f); d3 = splat(5.21493605e-02f); d4 = splat(-7.20005350e-03f);
-        d5 = splat(4.88322604e-04f); one = splat(1.f);
-    }
-};
-template <int DEG>
-__device__ __forceinline__ f32x2 gelu2(f32x2 x, const GeluC& k) {
-    // (v_med3_f32: clamp without the NaN-canonicalising v_max the IEEE fminf / fmaxf forms cost)
-    const f32x2 a = {__builtin_amdgcn_fmed3f(__builtin_fabsf(x[0]), 0.f, 8.f), __builtin_amdgcn_fmed3f(__builtin_fabsf(x[1]), 0.f, 8.f)};
-    f32x2 t;
-    if constexpr (DEG == 4) {
-        t = a * k.c4 + k.c3;
-        t = t * a + k.c2;
-        t = t * a + k.c1;
-    } else {
-        t = a * k.d5 + k.d4;
-        t = t * a + k.d3;
-        t = t * a + k.d2;
-        t = t * a + k.d1;
-    }
-    const f32x2 q = t * a + k.one;
-    const f32x2 e = {__builtin_amdgcn_exp2f(-q[0]), __builtin_amdgcn_exp2f(-q[1])};
-    const f32x2 r = {__builtin_amdgcn_fmed3f(x[0], 0.f, 3.0e38f), __builtin_amdgcn_fmed3f(x[1], 0.f, 3.0e38f)};
-    return r - a * e;
-}
-template <int DEG>
-__device__ __forceinline__ f32x4 gelu4(f32x4 v, const GeluC& k) {
-    const f32x2 lo = gelu2<DEG>(v.xy, k), hi = gelu2<DEG>(v.zw, k);
-    return (f32x4){lo[0], lo[1], hi[0], hi[1]};
-}
-
 // fc1 of the next hidden block is issued AFTER the depth-wise phase of the current one.  Issuing it before (round 3's in-wave software
 // pipeline: MFMAs under the vector ALU work) keeps five more accumulators live across that phase: at C = 78 that spills 77 registers
 // (78.8 vs 36 us); at C = 156 it fits (467 registers, one wave per SIMD either way) and is 0.7 us faster stand-alone, but the whole
 // forward measured 2-3 % SLOWER with it (3.35-3.40 vs 3.23-3.28 ms, configs 4 / 5 alike): late everywhere.
 #ifndef I2R_MLP_FC1_LATE
 #define I2R_MLP_FC1_LATE(CB) 1
+#endif
+// which kernel `variant` 0 selects for cs = 80 / 160 (measured): 1 = fc2 accumulated per wave, 2 = by output-block ownership
+#ifndef I2R_MLP_DEFAULT_VARIANT
+#define I2R_MLP_DEFAULT_VARIANT(cs) 1
 #endif
 constexpr int TY = 8, TX = 6;                    // output sub-tile (rows x columns)
 constexpr int HY = TY + 2, HX = TX + 2;          // halo grid 10 x 8 = 80 pixels = 5 fragments (two halo rows each)
@@ -373,11 +302,15 @@ __global__ __launch_bounds__(NBG * 64, NBG == 2 ? 2 : 1) void hrt_mlp_block_k(co
 
 extern "C" int i2r_hrt_mlp_block(const float* x, float* out, const float* ln_w, const float* ln_b, const void* w1, const float* b1,
                                  const float* wdw, const float* bdw, const void* w2, const float* b2, int32_t n_img, int32_t h, int32_t w,
-                                 int32_t c, int32_t cs, int32_t hidden_pad, float eps, int32_t dtype, void* stream) {
+                                 int32_t c, int32_t cs, int32_t hidden_pad, float eps, int32_t dtype, int32_t variant, void* stream) {
     I2R_CHECK_ARG(x && out && x != out && ln_w && ln_b && w1 && b1 && wdw && bdw && w2 && b2, "i2r_hrt_mlp_block: null pointer / out aliases x");
     I2R_CHECK_ARG(dtype == 1 || dtype == 2, "i2r_hrt_mlp_block: dtype %d (1 bf16, 2 f16; the fp32 path is i2r_layernorm + i2r_conv + i2r_dwconv3x3)", dtype);
-    I2R_CHECK_ARG((cs == 80 || cs == 160) && c <= cs && c > cs - 16 && hidden_pad >= 4 * c && hidden_pad == 4 * cs,
-                  "i2r_hrt_mlp_block: c=%d cs=%d hidden_pad=%d (built for the two high-resolution HRFormer-B branches; hidden padded to 4 cs)", c, cs, hidden_pad);
+    I2R_CHECK_ARG((cs == 80 || cs == 160 || cs == 320) && c <= cs && c > cs - 16 && hidden_pad >= 4 * c && hidden_pad == 4 * cs,
+                  "i2r_hrt_mlp_block: c=%d cs=%d hidden_pad=%d (built for the HRFormer-B branches 78 / 156 / 312; hidden padded to 4 cs)", c, cs, hidden_pad);
+    if (variant == 0) variant = cs == 320 ? 2 : I2R_MLP_DEFAULT_VARIANT(cs);
+    I2R_CHECK_ARG((variant == 1 && cs <= 160) || variant == 2,
+                  "i2r_hrt_mlp_block: variant %d for cs=%d (1 = fc2 accumulated per wave: 78 / 156; 2 = fc2 by output-block ownership)", variant, cs);
+    I2R_CHECK_ARG((long long)n_img * h * w * cs < (1ll << 31), "i2r_hrt_mlp_block: tensor too large");
     MlpK k;
     k.x = x; k.out = out; k.ln_w = ln_w; k.ln_b = ln_b; k.w1 = (const f32x4*)w1; k.b1 = b1; k.wdw = wdw; k.bdw = bdw; k.w2 = (const f32x4*)w2; k.b2 = b2;
     k.n_img = n_img; k.h = h; k.w = w; k.c = c; k.eps = eps;
@@ -386,7 +319,10 @@ extern "C" int i2r_hrt_mlp_block(const float* x, float* out, const float* ln_w, 
     I2R_CHECK_ARG(nblk > 0 && nblk < (1ll << 30), "i2r_hrt_mlp_block: grid");
     k.total = (int)nblk;
     const dim3 grid((unsigned)((nblk + 7) / 8 * 8));
-    if (dtype == 1) {
+    if (variant == 2) {
+        const bool ok = i2r_mlp_wide_launch(k, dtype, cs, nblk, (hipStream_t)stream);
+        I2R_CHECK_ARG(ok, "i2r_hrt_mlp_block: no output-block-ownership kernel for cs=%d", cs);
+    } else if (dtype == 1) {
         if (cs == 80) hipLaunchKernelGGL((hrt_mlp_block_k<1, 5, 2>), grid, dim3(128), 0, (hipStream_t)stream, k);
         else hipLaunchKernelGGL((hrt_mlp_block_k<1, 10, 4>), grid, dim3(256), 0, (hipStream_t)stream, k);
     } else {

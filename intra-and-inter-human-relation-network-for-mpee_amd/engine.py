@@ -116,7 +116,9 @@ _LP1X1_MT = int(_tune("I2R_LP1X1_MT", "0"))
 # branch widths whose transformer-block halves run as the fused 16-bit kernels (i2r_hrt_attn_block / i2r_hrt_mlp_block)
 _HRT_FUSED_ATTN = tuple(int(v) for v in _tune("I2R_HRT_FUSED_ATTN", "78,156,312").split(",") if v)
 _HRT_ATTN_VARIANT = int(_tune("I2R_HRT_ATTN_VARIANT", "0"))  # i2r_hrt_attn_block: 0 the library's choice, 1 wave per token tile, 2 wave per head
-_HRT_FUSED_MLP = tuple(int(v) for v in _tune("I2R_HRT_FUSED_MLP", "78,156").split(",") if v)
+_HRT_FUSED_MLP = tuple(int(v) for v in _tune("I2R_HRT_FUSED_MLP", "78,156,312").split(",") if v)
+_HRT_MLP_VARIANT = int(_tune("I2R_HRT_MLP_VARIANT", "0"))  # i2r_hrt_mlp_block: 0 the table below, 1 fc2 accumulated per wave, 2 fc2 by output-block ownership
+_MLP_VARIANT = {78: 1, 156: 2, 312: 2}  # measured (tools/time_hrt_mlp.py, host_rate.py): C = 156 29.0 -> 22.0 us, config 5 forward 4.19 -> 3.87 ms
 PAIR1X1 = _tune("I2R_PAIR1X1", "1") != "0"  # layer1's conv3 + next conv1 as one i2r_conv1x1_pair launch (fp32)
 _PAIR_MT = int(_tune("I2R_PAIR_MT", "0"))  # 16-pixel tiles per wave of that kernel
 WINOGRAD = _tune("I2R_WINOGRAD", "1") != "0"  # fp32 3x3 stride-1 convs on the Winograd F(2x2, 3x3) kernels
@@ -954,14 +956,17 @@ class Program:
         self.ops.append((cabi.OP_HRT_ATTN, lane, a))
         return out
 
-    def hrt_mlp(self, x, mb, eps=1e-6, lane=0):
-        """fused x + mlp(LN2 x) (16-bit modes, i2r_hrt_mlp_block)"""
+    def hrt_mlp(self, x, mb, eps=1e-6, lane=0, variant=None):
+        """fused x + mlp(LN2 x) (16-bit modes, i2r_hrt_mlp_block); variant: None = the measured choice per width"""
         assert x.dt == 0 and x.c == mb["c"] and x.cs == mb["cs"]
+        variant = _HRT_MLP_VARIANT if variant is None else variant
+        if variant == 0 or (variant == 1 and mb["c"] > 156):
+            variant = _MLP_VARIANT[mb["c"]]
         out = self.alloc(x.n, x.h, x.w, x.c)
         self.keep.append(mb)
         a = cabi.HrtMlpArgs(x.ptr, out.ptr, mb["ln"]["w"].data_ptr(), mb["ln"]["b"].data_ptr(), mb["w1"].data_ptr(), mb["b1"].data_ptr(),
                             mb["wdw"].data_ptr(), mb["bdw"].data_ptr(), mb["w2"].data_ptr(), mb["b2"].data_ptr(), x.n, x.h, x.w, x.c, x.cs,
-                            mb["hidden_pad"], eps, mb["dtype"])
+                            mb["hidden_pad"], eps, mb["dtype"], variant)
         self.ops.append((cabi.OP_HRT_MLP, lane, a))
         return out
 

@@ -859,10 +859,13 @@ def test_fused_attention_block_rejects_bad_variant():
 
 
 @pytest.mark.parametrize("precision", ["bf16", "fp16"])
-@pytest.mark.parametrize("c,h,w", [(78, 64, 48), (156, 32, 24), (78, 13, 9), (156, 36, 27)])
-def test_fused_mlp_block_16bit(precision, c, h, w):
+@pytest.mark.parametrize("c,h,w,variant", [(78, 64, 48, 1), (156, 32, 24, 1), (78, 13, 9, 1), (156, 36, 27, 1),
+                                           (312, 16, 12, 2), (312, 24, 18, 2), (312, 7, 5, 2), (156, 32, 24, 2), (156, 13, 9, 2), (312, 16, 12, 0),
+                                           (78, 64, 48, 2), (78, 13, 9, 2)])
+def test_fused_mlp_block_16bit(precision, c, h, w, variant):
     """i2r_hrt_mlp_block (one launch: LN2 + fc1/BN/GELU + DW3x3/BN/GELU + fc2/BN/GELU + residual, hidden tensor only in LDS) vs the fp32
-    oracle x + mlp(LN2 x); maps that are not multiples of the 8x8 tile included"""
+    oracle x + mlp(LN2 x); maps that are not multiples of the 8x6 tile included.  variant 1 = fc2 accumulated per wave (rounds 3-4),
+    2 = fc2 by output-block ownership over rounds of hidden pairs (round 5: the 312-channel branch), 0 = the library's choice."""
     import i2r_cpu_hrformer as H
     tag = "fm%d_%d" % (c, h)
     hid = 4 * c
@@ -880,7 +883,7 @@ def test_fused_mlp_block_16bit(precision, c, h, w):
     ref = x + H.mlp_dwbn(sd, "b.mlp", n2.permute(0, 3, 1, 2))
     P = engine.Program(torch.device(DEV))
     pk = engine.Packer(sd, torch.device(DEV), precision)
-    out = P.hrt_mlp(to_act(P, x), pk.mlp_block_lp("b", c))
+    out = P.hrt_mlp(to_act(P, x), pk.mlp_block_lp("b", c), variant=variant)
     run(P)
     d = from_act(out) - ref
     tol_max, tol_rms = (6e-2, 2e-2) if precision == "bf16" else (1e-2, 3e-3)

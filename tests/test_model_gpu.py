@@ -229,7 +229,7 @@ def test_full_size_batch_properties():
 LP_TOL = {"bf16": (3e-2, 1.5e-2), "fp16": (6e-3, 2e-3)}
 LP_TOL_SINGLE = {"bf16": (4e-2, 1.5e-2), "fp16": (6e-3, 2e-3)}
 HRFORMER_FUSED_ATTN = (78, 156, 312)  # branches whose attention half runs as ONE launch in the 16-bit modes (i2r_hrt_attn_block)
-HRFORMER_FUSED_MLP = (78, 156)        # ... and whose MLP half does (i2r_hrt_mlp_block)
+HRFORMER_FUSED_MLP = (78, 156, 312)        # ... and whose MLP half does (i2r_hrt_mlp_block)
 
 
 @pytest.mark.parametrize("tag,precision", [("tph_l21", "bf16"), ("hrt_l21", "bf16"), ("hrt288_l2", "fp16"), ("w48_l213", "bf16")])

@@ -1,4 +1,5 @@
-"""GPU tuning aid: time the fused HRFormer MLP-block kernel (i2r_hrt_mlp_block) on the two high-resolution branch shapes."""
+"""GPU tuning aid: time the fused HRFormer MLP-block kernel (i2r_hrt_mlp_block), both variants, on the branch shapes of configs 4 / 5.
+usage: time_hrt_mlp.py [bf16|fp16] [crops] [192|288]"""
 import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
@@ -10,7 +11,9 @@ if os.environ.get("I2R_TOOL_LIB"):  # an A/B library variant (tools/ab/build_var
 DEV = torch.device("cuda:0")
 prec = sys.argv[1] if len(sys.argv) > 1 else "bf16"
 n = int(sys.argv[2]) if len(sys.argv) > 2 else 16
-for c, h, w in ((78, 64, 48), (156, 32, 24)):
+big = len(sys.argv) > 3 and sys.argv[3] == "288"
+shapes = ((78, 96, 72), (156, 48, 36), (312, 24, 18)) if big else ((78, 64, 48), (156, 32, 24), (312, 16, 12))
+for c, h, w, variant in [sh + (v,) for sh in shapes for v in (1, 2) if v == 2 or sh[0] <= 156]:
     hid = 4 * c
     sd = {"b.norm2.weight": torch.ones(c), "b.norm2.bias": torch.zeros(c),
           "b.mlp.fc1.weight": torch.from_numpy(synth._sym(1, "f1%d" % c, (hid, c, 1, 1), 0.1)), "b.mlp.fc1.bias": torch.zeros(hid),
@@ -25,7 +28,7 @@ for c, h, w in ((78, 64, 48), (156, 32, 24)):
     x.t.normal_()
     y = x
     for _ in range(4):
-        y = P.hrt_mlp(y, mb)
+        y = P.hrt_mlp(y, mb, variant=variant)
     P.finalize()
     for _ in range(3):
         P.run()
@@ -36,4 +39,4 @@ for c, h, w in ((78, 64, 48), (156, 32, 24)):
         P.run()
     e1.record()
     torch.cuda.synchronize()
-    print("C=%d %dx%d n=%d: %.1f us per launch" % (c, h, w, n, e0.elapsed_time(e1) / 40 * 1e3))
+    print("C=%d %dx%d n=%d variant %d: %.1f us per launch" % (c, h, w, n, variant, e0.elapsed_time(e1) / 40 * 1e3))
