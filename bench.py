@@ -230,8 +230,8 @@ def per_launch_timing(programs, precision, reps=3, concurrent=()):
     stats = {}
     def merge(st):
         for k, v in st.items():
-            s = stats.setdefault(k, [0, 0.0, 0.0, 0.0, v[4]])
-            for i in range(4):
+            s = stats.setdefault(k, [0, 0.0, 0.0, 0.0, v[4], 0])  # [launches, ms, flop, bytes, pipe, launches one after the other on a stream]
+            for i in (0, 1, 2, 3, 5):
                 s[i] += v[i]
     plist = list(programs) if isinstance(programs, (list, tuple)) else [programs]
     conc = [P for P in concurrent if any(P is Q for Q in plist)]
@@ -305,11 +305,12 @@ def _per_launch_timing_concurrent(programs, precision, reps=3):
             continue
         for r, (e0, e2) in enumerate(evs):
             name, pipe = runs[0][r][0], runs[0][r][4]
-            s = stats.setdefault(name, [0, 0.0, 0.0, 0.0, pipe])
+            s = stats.setdefault(name, [0, 0.0, 0.0, 0.0, pipe, 0])
             s[0] += sum(len(rr[r][1]) for rr in runs)
             s[1] += e0.elapsed_time(e2)
             s[2] += sum(rr[r][2] for rr in runs)
             s[3] += sum(rr[r][3] for rr in runs)
+            s[5] += len(runs[0][r][1])  # (the siblings' launches of the run are in flight beside these, not behind them)
     return stats
 
 
@@ -334,11 +335,12 @@ def _per_launch_timing_one(program, precision, reps=3):
         if rep == 0:
             continue  # warm-up pass
         for r, (name, idx, flop, nbytes, pipe) in enumerate(runs):
-            s = stats.setdefault(name, [0, 0.0, 0.0, 0.0, pipe])
+            s = stats.setdefault(name, [0, 0.0, 0.0, 0.0, pipe, 0])
             s[0] += len(idx)
             s[1] += evs[r].elapsed_time(evs[r + 1])
             s[2] += flop
             s[3] += nbytes
+            s[5] += len(idx)
     return stats, reps
 
 
@@ -380,16 +382,31 @@ def _stack_timing_one(program, precision, prefix="enc_", reps=3):
     return total / reps
 
 
-def hbm_traffic(cname):
-    """HBM bytes per launch of the dominant kernel from the committed PMC passes (separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE
-    runs, FETCH_SIZE doubled per MI355X_MICROARCH.md).  bench.py itself cannot collect PMC counters: this is a constant read from
-    profiles/ (named in traffic_source), together with the kernel it was measured on; null when no profile exists for the workload."""
-    for rnd in ("round4", "round3", "round2", "round1"):
+def _kbase(name):
+    """kernel name without template arguments / operand-type suffix: conv_igemm_lp<3, 3, 8, 1>/bf16 -> conv_igemm_lp"""
+    return name.split("<")[0].split("/")[0]
+
+
+def hbm_traffic(cname, kernel):
+    """HBM bytes per launch of `kernel` from the committed PMC passes (separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE runs of the
+    workload's own bench command, FETCH_SIZE doubled per MI355X_MICROARCH.md).  bench.py itself cannot collect PMC counters: this is a
+    constant read from profiles/ (named in traffic_source).  Round-5 files hold every kernel of the workload by BASE name, the bytes
+    being the launch-weighted mean over all instantiations that ran (what `algorithmic_bytes` -- the launch-weighted mean of bench's
+    own byte model over the same launches -- compares with); older files hold one instantiation.  -> (bytes, source, what) or Nones."""
+    base = _kbase(kernel)
+    for rnd in ("round5", "round4", "round3", "round2", "round1"):
         path = os.path.join(ROOT, "profiles", "%s_hbm_traffic%s.json" % (rnd, "" if cname == "w48_pure_en6" else "_" + cname))
         try:
             with open(path) as f:
                 j = json.load(f)
-                return round(j["hbm_bytes_per_launch"]), os.path.relpath(path, ROOT), j.get("kernel")
+            if "by_kernel" in j:
+                e = j["by_kernel"].get(base)
+                if e is None:
+                    continue
+                return round(e["hbm_bytes_per_launch"]), os.path.relpath(path, ROOT), "launch-weighted mean over %d launches of %d instantiation(s) of %s" % (
+                    e["launches_averaged"], len(e["instantiations"]), base)
+            if _kbase(j.get("kernel", "")) == base:
+                return round(j["hbm_bytes_per_launch"]), os.path.relpath(path, ROOT), "one instantiation: " + j["kernel"]
         except (OSError, KeyError, ValueError):
             continue
     return None, None, None
@@ -401,13 +418,17 @@ def _kernel_view(name, s, reps, total_ms, precision):
     tile and (cin, cout) pair where the direct convolution of SURVEY 8d (2 pixels cout cin 9) needs 36: its executed FLOPs are the
     algorithmic ones / 2.25 (checked against PMC SQ_INSTS_MFMA x 2048 FLOP in profiles/round3_pmc_sq_grouped_conv.json); the
     direct-convolution FLOPs it DELIVERS per second are reported separately as `direct_equivalent` and are not a pipe fraction."""
-    cnt, ms, flop, nbytes, pipe = s
+    cnt, ms, flop, nbytes, pipe, seq = s
     wino = name.startswith("conv_wino")
     flop_exec = flop / WINO_CUT if wino else flop
     tf = flop_exec / (ms * 1e-3) / 1e12
     gbs = nbytes / (ms * 1e-3) / 1e9
     out = {"kernel": name,  # (16-bit conv instantiations carry their operand type in the name: conv_igemm_lp<..>/bf16)
-           "launches_per_step": cnt // reps, "avg_launch_us": round(ms / cnt * 1e3, 2), "ms_per_step": round(ms / reps, 3),
+           # avg_launch_us = event-bracketed time of the kernel's runs / ALL its launches (with part-batch programs side by side: launches
+           # in flight together share that time -- this is the figure `achieved` uses); avg_launch_us_on_stream = the same time / the
+           # launches that follow each other on ONE stream = what a rocprofv3 kernel trace shows per launch (equal when nothing is concurrent)
+           "launches_per_step": cnt // reps, "avg_launch_us": round(ms / cnt * 1e3, 2), "avg_launch_us_on_stream": round(ms / seq * 1e3, 2),
+           "launches_in_flight": round(cnt / seq, 2), "ms_per_step": round(ms / reps, 3),
            "share_of_step_kernel_time": round(ms / total_ms, 3), "gflop_per_launch": round(flop_exec / cnt / 1e9, 4),
            "gbytes_per_launch": round(nbytes / cnt / 1e9, 4)}
     peak = MFMA_PEAK_TFLOPS[pipe] if pipe else None
@@ -442,10 +463,12 @@ def roofline_report(prog, precision, cname, concurrent=()):
     order = sorted(stats, key=lambda k: -stats[k][1])
     dom = order[0]  # the kernel with the largest share of the step's kernel time, whatever it is
     r = _kernel_view(dom, stats[dom], reps, total_ms, precision)
-    traffic, traffic_src, traffic_kernel = hbm_traffic(cname)
-    if traffic_kernel is not None and r["kernel"].split("<")[0].split("/")[0] != traffic_kernel.split("<")[0].split("/")[0]:
-        traffic, traffic_src = None, None  # (the committed PMC pass was made on another kernel)
-    r["traffic"], r["traffic_source"] = traffic, traffic_src
+    # `traffic` (PMC, per launch) next to `algorithmic_bytes` (bench's byte model, per launch, same launch-weighted mean over the kernel's
+    # launches): their ratio is computable from the line
+    traffic, traffic_src, traffic_what = hbm_traffic(cname, r["kernel"])
+    r["traffic"], r["traffic_source"], r["traffic_what"] = traffic, traffic_src, traffic_what
+    r["algorithmic_bytes"] = round(stats[dom][3] / stats[dom][0])
+    r["traffic_over_algorithmic"] = round(traffic / r["algorithmic_bytes"], 3) if traffic and r["algorithmic_bytes"] else None
     conv = [k for k in stats if k.startswith("conv_")]
     if conv:
         t_conv = sum(stats[k][1] for k in conv) * 1e-3
@@ -458,10 +481,16 @@ def roofline_report(prog, precision, cname, concurrent=()):
         for drop in ("hbm_view", "mfma_view", "machine_balance_flop_per_byte", "gbytes_per_launch"):
             kv.pop(drop, None)
     r["per_kernel_ms_per_step"] = {k: round(stats[k][1] / reps, 3) for k in order}
+    # The per-kernel times are event-bracketed replays of every run of equal launches (lanes collapsed onto one stream, part-batch
+    # programs side by side): their SUM is the kernel time of a step with nothing overlapping across runs, and exceeds the wall time of
+    # the real step by what lanes / streams overlap minus what the event pairs add.  kernel_time_overlap = that sum / ms_per_step is
+    # filled in by the caller, which knows the step's wall time.
+    r["kernel_time_sum_ms_per_step"] = round(total_ms / reps, 3)
     if len(concurrent) >= 2:
         r["concurrency"] = ("%d part-batch programs run side by side on their own streams (Engine._split_bounds); their kernels are timed that way: "
-                            "launches_per_step / FLOPs count all of them, avg_launch_us = time of a run / launches in flight "
-                            "(a rocprofv3 trace shows each launch lasting about %d x avg_launch_us)" % (len(concurrent), len(concurrent)))
+                            "launches_per_step / FLOPs count all of them, avg_launch_us = time of a run / launches in flight, "
+                            "avg_launch_us_on_stream = time of a run / launches one after the other on a stream (what a rocprofv3 kernel trace "
+                            "shows per launch)" % len(concurrent))
     r["_executed_gflop_per_step"] = sum(stats[k][2] / (WINO_CUT if k.startswith("conv_wino") else 1.0) for k in stats) / reps / 1e9
     att_k = sorted(k for k in stats if k.startswith("enc_"))
     att_flop = sum(stats[k][2] for k in att_k) / reps
@@ -541,6 +570,31 @@ def cpu_baseline(cfg, sd, H, W, length, budget_s=20.0):
             "sample": "%d forwards of %s at %dx%d, fp32, oracle/i2r_cpu.py on torch %s CPU, %d threads "
                       "(%d cores visible; seconds per 2-crop forward by thread count: %s)"
                       % (n, what, H, W, torch.__version__, threads, cores, ", ".join("%d: %.2f" % (t, v) for t, v in sorted(tried.items())))}
+
+
+def cpu_baseline_short(cfg, sd, H, W, length, threads=32, budget_s=3.0):
+    """The CPU oracle on ONE image of the workload (its largest, capped at 4 persons) for a few seconds: the `cpu_baseline` of an
+    other_workloads entry (the headline's own leg probes thread counts and runs the whole batch; this one must stay short)."""
+    import i2r_cpu
+    try:
+        cores = len(os.sched_getaffinity(0))
+    except AttributeError:
+        cores = os.cpu_count() or 1
+    threads = min(threads, cores)
+    torch.set_num_threads(threads)
+    n_p = min(max(length), 4)
+    x, m, ls = synth.make_inputs([n_p], H, W)
+    i2r_cpu.forward(sd, cfg, x, m, ls)  # warm-up
+    n, t0 = 0, time.perf_counter()
+    while True:
+        i2r_cpu.forward(sd, cfg, x, m, ls)
+        n += 1
+        if time.perf_counter() - t0 > budget_s * 0.5 or n >= 10:
+            break
+    dt = time.perf_counter() - t0
+    return {"value": round(n * n_p / dt, 3), "unit": "images/sec", "cores": threads, "kind": "port",
+            "sample": "%d forward(s) of 1 image x %d person(s) at %dx%d, fp32, oracle/i2r_cpu.py on torch %s CPU, %d threads (%d cores visible)"
+                      % (n, n_p, H, W, torch.__version__, threads, cores)}
 
 
 def make_pipeline(net, cfg, length, H, W, dev, seed):
@@ -647,7 +701,8 @@ def _time_steps(fn, steps, warmup):
 
 def _brief(kv):
     """the figures of a _kernel_view that identify the kernel and its roofline fraction"""
-    keep = ("kernel", "launches_per_step", "avg_launch_us", "share_of_step_kernel_time", "bound", "achieved", "peak", "unit", "frac")
+    keep = ("kernel", "launches_per_step", "avg_launch_us", "avg_launch_us_on_stream", "launches_in_flight", "share_of_step_kernel_time", "bound", "achieved",
+            "peak", "unit", "frac")
     out = {k: kv[k] for k in keep if k in kv}
     for view in ("mfma_view", "hbm_view"):
         if view in kv:
@@ -679,10 +734,14 @@ def quick_workload(cname, dev, steps=30, warmup=5):
            "value": round(sum(length) * steps / dt, 1), "unit": "images/sec", "ms_per_step": round(dt / steps * 1e3, 3),
            "model_tflops_algorithmic": round(gflop * steps / dt / 1e3, 2),
            "dominant_kernel": _brief(r), "next_kernels": [_brief(k) for k in r["kernels"][1:3]],
-           "traffic": r.get("traffic"), "traffic_source": r.get("traffic_source")}
+           "traffic": r.get("traffic"), "algorithmic_bytes": r.get("algorithmic_bytes"), "traffic_over_algorithmic": r.get("traffic_over_algorithmic"),
+           "traffic_source": r.get("traffic_source"), "traffic_what": r.get("traffic_what"),
+           "kernel_time_sum_ms_per_step": r["kernel_time_sum_ms_per_step"],
+           "kernel_time_overlap": round(r["kernel_time_sum_ms_per_step"] / (dt / steps * 1e3), 3)}
     if "attention_blocks" in r:
         out["attention_blocks"] = {k: r["attention_blocks"][k] for k in ("kernels", "ms_per_step", "achieved", "peak", "frac")}
     out["parity"] = oracle_parity(cfg, sd, x, m, length, fwd(), precision)
+    out["cpu_baseline"] = cpu_baseline_short(cfg, sd, H_, W_, length)
     return out
 
 
@@ -762,6 +821,10 @@ def parse_args(argv=None):
     ap.add_argument("--no-other-workloads", action="store_true",
                     help="default single-GPU run only: skip the short runs of BASELINE configs[2..4], the ragged stream and the pipeline that are "
                          "embedded in the line as other_workloads")
+    ap.add_argument("--world1-collective", action="store_true",
+                    help="--gpus 1 only: create a ONE-rank process group and run the per-step all-gather, the barriers and the max-over-ranks "
+                         "reduction exactly as the N > 1 ranks do (the N = 1 end of the scaling line with the collective in place; "
+                         "tests/test_dist_gpu.py checks it against the plain N = 1 line)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--no-parity", action="store_true")
@@ -785,14 +848,23 @@ def main(argv=None):
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     assert world == args.gpus, "WORLD_SIZE=%d but --gpus %d" % (world, args.gpus)
     stub = args.selftest_stub
-    if world > 1:
+    if args.world1_collective and world != 1:
+        raise SystemExit("--world1-collective is the N = 1 form of the multi-GPU step (use it with --gpus 1)")
+    coll = world > 1 or args.world1_collective  # the step ends in the collective
+    if coll:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        kw = {}
+        if world == 1 and "RANK" not in os.environ:  # (no launcher: a one-rank group on a free loopback port)
+            with socket.socket() as sk:
+                sk.bind(("127.0.0.1", 0))
+                os.environ.setdefault("MASTER_PORT", str(sk.getsockname()[1]))
+            kw = dict(rank=0, world_size=1)
         if args.backend == "nccl" and torch.cuda.is_available():  # "nccl" IS RCCL on ROCm; bind the communicator to this rank's GPU
             torch.cuda.set_device(local_rank)
-            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank), **kw)
         else:  # (gloo self-test; or no GPU at all: ProcessGroupNCCL then says so itself)
-            dist.init_process_group(args.backend)
+            dist.init_process_group(args.backend, **kw)
     if stub:
         dev = torch.device("cpu")
     else:
@@ -849,13 +921,13 @@ def main(argv=None):
             h = None
             if stub:
                 y = stub_y
-                if world > 1:
+                if coll:
                     h = (i2r_dist.gather_keypoints(y[:, :, :1, 0].expand(-1, -1, 2), y[:, :, :1, 0], counts, async_op=True)
                          if gather == "keypoints" else i2r_dist.gather_heatmaps_async(y, counts))
             elif pipe is not None:
                 preds, maxv = pipe()
                 y = torch.cat([preds, maxv], 2)
-                if world > 1:
+                if coll:
                     h = i2r_dist.gather_heatmaps_async(y, counts)
             else:
                 ys = []
@@ -864,13 +936,13 @@ def main(argv=None):
                     ys.append(yb["multi"] if isinstance(yb, dict) else yb)
                 # (strong scaling: a rank's forwards of one step are gathered together -- ranks run different numbers of forwards)
                 y = ys[0] if len(ys) == 1 else (torch.cat(ys, 0) if ys else torch.zeros(0, J, H_ // 4, W_ // 4, device=dev))
-                if world > 1:
+                if coll:
                     if gather == "keypoints":  # decode on the device, gather [S, J, 3] (168 B/crop) instead of 172 KB/crop
                         preds, maxv = caller.decode(y, None, None, cfg.TEST.BLUR_KERNEL, transform_back=False)
                         h = i2r_dist.gather_keypoints(preds, maxv, counts, async_op=True)
                     else:
                         h = i2r_dist.gather_heatmaps_async(y, counts)
-            if world > 1:
+            if coll:
                 if pending[0] is not None:
                     pending[0].wait()
                 pending[0] = h
@@ -892,7 +964,7 @@ def main(argv=None):
             y = step()
         drain()
         sync()
-        if world > 1:
+        if coll:
             dist.barrier()
         sync()
         t0 = time.perf_counter()
@@ -900,11 +972,11 @@ def main(argv=None):
             y = step()
         drain()
         sync()
-        if world > 1:
+        if coll:
             dist.barrier()
         sync()
         dt = time.perf_counter() - t0
-        if world > 1:
+        if coll:
             t = torch.tensor([dt], dtype=torch.float64, device=dev)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             dt = t.item()
@@ -913,7 +985,7 @@ def main(argv=None):
     dt, y = timed(make_step(args.gather), args.steps, args.warmup)
     assert torch.isfinite(y).all()
     alt = None
-    if world > 1 and pipe is None:
+    if coll and pipe is None:
         other = "keypoints" if args.gather == "heatmaps" else "heatmaps"
         dt2, _ = timed(make_step(other), args.steps, min(args.warmup, 3))
         alt = {"payload": other, "ms_per_step": round(dt2 / args.steps * 1e3, 4), "value": round(sum(length_all) * args.steps / dt2, 2)}
@@ -935,7 +1007,7 @@ def main(argv=None):
                    "images_per_gpu": len(length), "persons_per_image": length if len(set(length)) > 1 else (length[0] if length else 0),
                    "crops_per_gpu_step": sum(length),
                    "parallelism": "dp%d (images sharded, one RCCL all-gather of the %s per step, waited for one step later)" % (world, payload)
-                                  if world > 1 else "single GPU",
+                                  if coll else "single GPU",
                    "gflop_per_step_per_gpu": round(gflop_per_step / world, 2),
                    "programs_per_forward": (len(net.engine().last_programs) if (net is not None and getattr(net.engine(), "last_programs", None)) else 1)},
         # SURVEY 8d algorithmic FLOPs of the reference forward (direct convolutions) per second of wall time: a delivered-work figure,
@@ -960,6 +1032,7 @@ def main(argv=None):
             if not strong and not args.pipeline:  # executed matrix-pipe + element-wise FLOPs of one forward over the step's wall time
                 out["roofline"]["model_tflops_executed"] = round(out["roofline"].pop("_executed_gflop_per_step") * args.steps / dt / 1e3, 2)
             out["roofline"].pop("_executed_gflop_per_step", None)
+            out["roofline"]["kernel_time_overlap"] = round(out["roofline"]["kernel_time_sum_ms_per_step"] / (dt / args.steps * 1e3), 3)
         if not args.no_parity and not args.pipeline:
             y1 = net(x, m, first)
             y1 = y1["multi"] if isinstance(y1, dict) else y1
@@ -981,7 +1054,7 @@ def main(argv=None):
             out["cpu_baseline"] = cpu_baseline(cfg, sd, H_, W_, first)
     if rank == 0:
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if coll:
         dist.barrier()
         dist.destroy_process_group()
 

@@ -83,20 +83,25 @@ __global__ __launch_bounds__(NBG * 64, NBG == 2 ? 2 : 1) void hrt_mlp_block_k(co
         const int y = y0 + 2 * f + (li >> 3), x = x0 + (li & 7);
         hinf[f] = (y >= 0 && y < p.h && x >= 0 && x < p.w) ? 1.f : 0.f;
     }
+    // Round 5: the rows are read QUAD-COALESCED -- lane n takes halo pixel n >> 2 of the fragment and the 16-byte pieces (n & 3) + 4 k of
+    // its row, so a quad covers 64 contiguous bytes (one row per lane costs four times the addresser cycles, DESIGN.md "quad rule");
+    // statistics in-lane + over the quad; piece pi lands in half pi & 1 of lane (g = (pi & 7) >> 1, li = pixel) of k-step pi >> 3.
     constexpr int NFW = (NF + NBG - 1) / NBG;  // halo fragments per wave
-    f32x4 xra[NFW][KS], xrb[NFW][KS];            // features 32 s + 8 g .. + 3 / + 4 .. + 7
+    constexpr int NPC = cs / 4, KQ = 2 * KS;     // 16-byte pieces of a row / pieces per lane (the whole operand image: beyond the row, zeros)
+    const int tl = lane >> 2, q4 = lane & 3;
+    f32x4 xv[NFW][KQ];
+    bool pin[NFW];
 #pragma unroll
     for (int i = 0; i < NFW; ++i) {
         const int f = wave + NBG * i;
         if (f >= NF) continue;  // (scalar)
-        const int y = y0 + 2 * f + (li >> 3), x = x0 + (li & 7);
-        const bool in = y >= 0 && y < p.h && x >= 0 && x < p.w;
-        const float* row = p.x + (((size_t)img * p.h + (in ? y : 0)) * p.w + (in ? x : 0)) * cs;
+        const int y = y0 + 2 * f + (tl >> 3), x = x0 + (tl & 7);
+        pin[i] = y >= 0 && y < p.h && x >= 0 && x < p.w;
+        const float* row = p.x + (((size_t)img * p.h + (pin[i] ? y : 0)) * p.w + (pin[i] ? x : 0)) * cs;
 #pragma unroll
-        for (int s = 0; s < KS; ++s) {
-            const int f0 = 32 * s + 8 * g < cs ? 32 * s + 8 * g : cs - 8;  // (cs = 80: the last k-step holds 16 channels, lanes g >= 2 none)
-            xra[i][s] = *reinterpret_cast<const f32x4*>(row + f0);
-            xrb[i][s] = *reinterpret_cast<const f32x4*>(row + f0 + 4);
+        for (int k = 0; k < KQ; ++k) {
+            const int pi = q4 + 4 * k;
+            xv[i][k] = *reinterpret_cast<const f32x4*>(row + 4 * (pi < NPC ? pi : 0));
         }
     }
     // ---- depth-wise weights + bias of this wave's blocks -> its LDS region: [block][tap | bias][16] ----
@@ -117,36 +122,34 @@ __global__ __launch_bounds__(NBG * 64, NBG == 2 ? 2 : 1) void hrt_mlp_block_k(co
     for (int i = 0; i < NFW; ++i) {
         const int f = wave + NBG * i;
         if (f >= NF) continue;  // (scalar)
-        float hin = 0.f;        // hinf[f] (f is a scalar: a switch instead of a dynamic register index)
-#pragma unroll
-        for (int ff = 0; ff < NF; ++ff)
-            if (ff == f) hin = hinf[ff];
         float s1 = 0.f;
 #pragma unroll
-        for (int s = 0; s < KS; ++s) {
-            const float keep = 32 * s + 8 * g < cs ? hin : 0.f;
-            xra[i][s] *= keep;
-            xrb[i][s] *= keep;
-            s1 += ((xra[i][s][0] + xra[i][s][1]) + (xra[i][s][2] + xra[i][s][3])) + ((xrb[i][s][0] + xrb[i][s][1]) + (xrb[i][s][2] + xrb[i][s][3]));
+        for (int k = 0; k < KQ; ++k) {
+            const bool ok = pin[i] && q4 + 4 * k < NPC;
+            xv[i][k] = ok ? xv[i][k] : (f32x4){0.f, 0.f, 0.f, 0.f};
+            s1 += (xv[i][k][0] + xv[i][k][1]) + (xv[i][k][2] + xv[i][k][3]);
         }
-        const float mean = xsum4(s1) * inv_c;
+        s1 += __shfl_xor(s1, 1);
+        s1 += __shfl_xor(s1, 2);
+        const float mean = s1 * inv_c;
         float q2 = 0.f;
 #pragma unroll
-        for (int s = 0; s < KS; ++s) {
-            const float keep = 32 * s + 8 * g < cs ? 1.f : 0.f;  // (compile-time 1 except in a partial last k-step)
-            const f32x4 da = (xra[i][s] - mean) * keep, db = (xrb[i][s] - mean) * keep;
-            q2 += ((da[0] * da[0] + da[1] * da[1]) + (da[2] * da[2] + da[3] * da[3])) + ((db[0] * db[0] + db[1] * db[1]) + (db[2] * db[2] + db[3] * db[3]));
+        for (int k = 0; k < KQ; ++k) {
+            const float keep = q4 + 4 * k < NPC ? 1.f : 0.f;  // (compile-time 1 except beyond the row)
+            const f32x4 d = (xv[i][k] - mean) * keep;
+            q2 += (d[0] * d[0] + d[1] * d[1]) + (d[2] * d[2] + d[3] * d[3]);
         }
-        const float var = (xsum4(q2) - npad * mean * mean) * inv_c;
-        const float rstd = rsqrtf(fmaxf(var, 0.f) + p.eps) * hin;  // outside the image: zero columns
+        q2 += __shfl_xor(q2, 1);
+        q2 += __shfl_xor(q2, 2);
+        const float var = (q2 - npad * mean * mean) * inv_c;
+        const float rstd = rsqrtf(fmaxf(var, 0.f) + p.eps);
 #pragma unroll
-        for (int s = 0; s < KS; ++s) {
-            const int f0 = 32 * s + 8 * g < cs ? 32 * s + 8 * g : 0;
-            const f32x4 wa = *reinterpret_cast<const f32x4*>(p.ln_w + f0), wb = *reinterpret_cast<const f32x4*>(p.ln_w + f0 + 4);
-            const f32x4 ba = *reinterpret_cast<const f32x4*>(p.ln_b + f0), bb = *reinterpret_cast<const f32x4*>(p.ln_b + f0 + 4);
-            const float keep = 32 * s + 8 * g < cs ? hin : 0.f;
-            // (pad channels: ln_w = ln_b = 0 -> exact zeros)
-            Xs[(f * KS + s) * 64 + lane] = pack8<DT>((xra[i][s] - mean) * rstd * wa + ba * keep, (xrb[i][s] - mean) * rstd * wb + bb * keep);
+        for (int k = 0; k < KQ; ++k) {
+            const int pi = q4 + 4 * k;
+            const bool has = pi < NPC;
+            const f32x4 wa = *reinterpret_cast<const f32x4*>(p.ln_w + 4 * (has ? pi : 0)), ba = *reinterpret_cast<const f32x4*>(p.ln_b + 4 * (has ? pi : 0));
+            const float keep = (pin[i] && has) ? 1.f : 0.f;  // outside the image: zero columns; beyond the row: zeros (pad channels: ln_w = ln_b = 0)
+            reinterpret_cast<uint2*>(Xs + (f * KS + (pi >> 3)) * 64 + ((pi & 7) >> 1) * 16 + tl)[pi & 1] = pack4<DT>(((xv[i][k] - mean) * rstd * wa + ba) * keep);
         }
     }
     __syncthreads();
@@ -252,16 +255,19 @@ __global__ __launch_bounds__(NBG * 64, NBG == 2 ? 2 : 1) void hrt_mlp_block_k(co
         }
     }
 
-    // ---- the waves' partial sums meet: output block ob is finished by wave ob % NBG ----
-    const int gy = sy * TY + oy;
+    // ---- the waves' partial sums meet: output block ob is finished by wave ob % NBG.  Round 5: the finished D fragment (lane (li, g):
+    //      channels 4g + r of pixel li) is re-numbered with one ds_bpermute per register so that lane n holds piece n & 3 of pixel n >> 2:
+    //      residual loads and stores are quad-coalesced ----
+    const int srcl = tl + 16 * q4;
+    const int gy = sy * TY + (tl & 7);
     const bool rowin = gy < p.h;
     size_t prow[NPF];
     bool oin[NPF];
 #pragma unroll
     for (int pf = 0; pf < NPF; ++pf) {
-        const int gx = sx * TX + 3 * xb + pf;
+        const int gx = sx * TX + 3 * (tl >> 3) + pf;
         oin[pf] = rowin && gx < p.w;
-        prow[pf] = (((size_t)img * p.h + (rowin ? gy : 0)) * p.w + (gx < p.w ? gx : 0)) * cs;
+        prow[pf] = (((size_t)img * p.h + (rowin ? gy : 0)) * p.w + (gx < p.w ? gx : 0)) * cs + 4 * q4;
     }
     // (partials of OBC output blocks at a time, so the exchange area fits the loop's LDS footprint)
     constexpr int OBC = NBG == 2 ? CB : (CB + 1) / 2;
@@ -289,10 +295,14 @@ __global__ __launch_bounds__(NBG * 64, NBG == 2 ? 2 : 1) void hrt_mlp_block_k(co
 #pragma unroll
                 for (int s = 1; s < NBG; ++s)  // fixed order: waves owner + 1, owner + 2, ... (mod NBG)
                     v += Red[(((ob - ob0) * (NBG - 1) + (s - 1)) * NPF + pf) * 64 + lane];
-                if (!oin[pf]) continue;
-                const f32x4 xres = *reinterpret_cast<const f32x4*>(p.x + prow[pf] + 16 * ob + 4 * g);
                 // (pad channels: zero W2 rows and bias -> GELU(0) = 0 exactly, + the residual's zero: no mask)
-                *reinterpret_cast<f32x4*>(p.out + prow[pf] + 16 * ob + 4 * g) = gelu4<5>(v + b, gk) + xres;
+                v = gelu4<5>(v + b, gk);
+                f32x4 vn;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) vn[e] = __shfl(v[e], srcl);  // (ds_bpermute_b32; all lanes take part)
+                if (!oin[pf]) continue;
+                const f32x4 xres = *reinterpret_cast<const f32x4*>(p.x + prow[pf] + 16 * ob);
+                *reinterpret_cast<f32x4*>(p.out + prow[pf] + 16 * ob) = vn + xres;
             }
         }
     }

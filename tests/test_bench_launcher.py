@@ -31,6 +31,24 @@ def test_gpus2_self_launch_gloo_stub():
     assert "STUB" in out["data"] and out["value"] == 0.0  # a stub run can never be mistaken for a measurement
 
 
+def test_gpus1_world1_collective_strong_gloo_stub():
+    """--world1-collective: the N = 1 step with the collective in place (a ONE-rank process group: gather, barriers, max-over-ranks
+    reduction) -- here on gloo with the stub step; tests/test_dist_gpu.py runs the real model over RCCL.  Strong scaling: the line
+    carries `shards` (all 64 images on the one rank, 4 forwards of uneven crop counts per step, gathered together)."""
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "2", "--warmup", "1", "--backend", "gloo",
+                        "--selftest-stub", "--world1-collective", "--scaling", "strong"], cwd=ROOT, env=_env(), capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-4000:]
+    (line,) = [l for l in p.stdout.splitlines() if l.startswith("{")]
+    out = json.loads(line)
+    assert out["n_gpus"] == 1 and out["scaling"] == "strong" and "dp1" in out["config"]["parallelism"]
+    sh = out["shards"]
+    assert sh["images_total"] == 64 and sh["crops_per_rank"] == [sh["crops_total"]] and sh["forwards_per_rank_step"] == [4]
+    assert out["gather_alt"]["payload"] == "keypoints"
+    bad = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--world1-collective", "--backend", "gloo", "--selftest-stub"],
+                         cwd=ROOT, env=_env(), capture_output=True, text=True, timeout=600)
+    assert bad.returncode != 0 and "world1-collective" in (bad.stdout + bad.stderr)
+
+
 def test_gpus2_without_launcher_reaches_process_group_init():
     """On a GPU-less box the real (nccl) path must get as far as creating the process group -- not exit at argument time."""
     import torch

@@ -54,3 +54,39 @@ def test_rccl_gather_after_real_forward(nccl_world1):
     t = torch.ones(1, device="cuda")
     dist.all_reduce(t)                                       # bench.py's max-over-ranks timing reduction
     assert t.item() == 1.0
+
+
+def _bench(*args, timeout=900):
+    """bench.py as the driver runs it (a process of its own), -> its one JSON line"""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT") and not k.startswith("I2R_")}
+    p = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--no-cpu-baseline", "--no-roofline", "--no-other-workloads"] + list(args),
+                       cwd=root, env=env, capture_output=True, text=True, timeout=timeout)
+    assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-4000:]
+    (line,) = [l for l in p.stdout.splitlines() if l.startswith("{")]
+    return json.loads(line)
+
+
+def test_bench_strong_scaling_end_to_end_on_one_gpu():
+    """`bench.py --gpus 1 --scaling strong --world1-collective`: the real model over the FIXED 64-image job (4 forwards of uneven crop
+    counts per step), their rows gathered together through an RCCL process group of one rank -- every piece of the N > 1 strong-scaling
+    step except the second GPU.  The line carries `shards`, the parity of image 0 holds, the value is positive."""
+    out = _bench("--gpus", "1", "--scaling", "strong", "--steps", "3", "--warmup", "1", "--world1-collective")
+    sh = out["shards"]
+    assert out["scaling"] == "strong" and sh["images_total"] == 64 and sh["crops_per_rank"] == [sh["crops_total"]] and sh["forwards_per_rank_step"] == [4]
+    assert "dp1" in out["config"]["parallelism"] and out["gather_alt"]["payload"] == "keypoints"
+    assert out["value"] > 1000 and out["parity"]["ok"]
+
+
+def test_bench_config4_with_collective_matches_plain_line():
+    """BASELINE configs[3] (HRFormer-B bf16, 16 crops per GPU -- the workload BASELINE quotes on 8 GPUs) at N = 1 with the per-step
+    heat-map all-gather, barriers and max-over-ranks reduction in place (one-rank RCCL group) against the plain N = 1 line: the collective
+    path may not cost more than 5 % (it is waited for one step later), and both agree with the oracle."""
+    plain = _bench("--config", "hrt_192_p4_b4", "--gpus", "1", "--steps", "30", "--warmup", "10")
+    coll = _bench("--config", "hrt_192_p4_b4", "--gpus", "1", "--steps", "30", "--warmup", "10", "--world1-collective")
+    assert plain["parity"]["ok"] and coll["parity"]["ok"]
+    assert "dp1" in coll["config"]["parallelism"] and coll["config"]["crops_per_gpu_step"] == 16
+    assert abs(coll["value"] - plain["value"]) <= 0.05 * plain["value"], (coll["value"], plain["value"])

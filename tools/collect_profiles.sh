@@ -1,10 +1,10 @@
 #!/bin/bash
-# GPU box: regenerate the artefacts under profiles/ (job body for tools/gpu_job.sh: `gpurun -- 'bash tools/gpu_job.sh prof4'` with
-# tools/jobs/prof4.sh = `bash tools/collect_profiles.sh`; outputs land in $O = gpurun_out/<tag>, condensed by tools/summarize_round4.py).
+# GPU box: regenerate the artefacts under profiles/ (job body for tools/gpu_job.sh: `gpurun -- 'bash tools/gpu_job.sh prof5'` with
+# tools/jobs/prof5.sh = `bash tools/collect_profiles.sh`; outputs land in $O = gpurun_out/<tag>, condensed by tools/summarize_round5.py).
 #  1. the default bench line (headline + other_workloads), 2. the same command under rocprofv3 --kernel-trace --stats, 3. every other
 #  BASELINE workload: bench line + kernel stats, 4. PMC passes (counters only, separate runs): HBM traffic + SQ counters of the dominant
 #  kernels of every workload, the grouped Winograd launch and the encoder layer, 5. ragged stream / pipeline lines.
-O=${O:-gpurun_out/prof4}; mkdir -p $O
+O=${O:-gpurun_out/prof5}; mkdir -p $O
 python bench.py > $O/bench.json 2> $O/bench.err
 stats $O/stats_w48 -- python bench.py --no-cpu-baseline --no-parity --no-other-workloads
 cp $O/stats_w48.log $O/bench_under_rocprof.json 2>/dev/null
