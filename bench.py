@@ -154,7 +154,8 @@ def op_model(kind, st, precision, enc_lens=None):
         if st.next_w_in:
             flop += 4.0 * d * d * n  # the NEXT layer's k / v projection, fused into this launch
         nbytes = n * cs * 4 * (3 if st.pos else 2) + 2 * n * cs * kv_e * (2 if st.next_w_in else 1) + (4 * d * d + 2 * d * dff) * kv_e
-        return "enc_layer_lp_k" if islp else "enc_layer4_k", flop, float(nbytes), lp if islp else "fp32"
+        name = ("enc_layer_lp4_k" if (st.n_qtiles192 > 0 and st.n_qtiles64 >= 512) else "enc_layer_lp_k") if islp else "enc_layer4_k"
+        return name, flop, float(nbytes), lp if islp else "fp32"
     if kind == cabi.OP_HRT_ATTN:
         nwin = st.n_img * ((st.h + 6) // 7) * ((st.w_ + 6) // 7)
         c = st.c
@@ -497,7 +498,7 @@ def roofline_report(prog, precision, cname, concurrent=()):
     att_ms = stack_timing(prog, precision)  # (each encoder stack timed as one unit; the per-kernel split stays in per_kernel_ms_per_step)
     if att_flop and att_ms:
         att = att_flop / (att_ms * 1e-3) / 1e12
-        att_peak = MFMA_PEAK_TFLOPS["fp32" if "enc_layer4_k" in att_k and "enc_layer_lp_k" not in att_k else precision]
+        att_peak = MFMA_PEAK_TFLOPS["fp32" if "enc_layer4_k" in att_k and not any(k_.startswith("enc_layer_lp") for k_ in att_k) else precision]
         r["attention_blocks"] = {"kernels": " + ".join(att_k), "gflop_per_step": round(att_flop / 1e9, 3), "ms_per_step": round(att_ms, 3),
                                  "achieved": round(att, 2), "peak": att_peak, "frac": round(att / att_peak, 4)}
     return r

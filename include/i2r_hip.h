@@ -419,6 +419,9 @@ typedef struct i2r_encoder_desc {
      * must be stream-ordered; replaying the same list concurrently on two streams pairs partials of different forwards.
      * Both null = one workgroup per tile. */
     float* split_ws; int32_t* split_cnt;
+    /* 16-bit mode, long groups (n_qtiles64 >= 512): sum over groups of ceil(group_len / 192) = workgroups of the kernel whose four waves
+     * share the K / V stream through LDS (192 queries each); 0 = use the one-wave-per-64-queries kernel */
+    int32_t n_qtiles192;
 } i2r_encoder_desc;
 
 I2R_API int i2r_encoder_kv(const i2r_encoder_desc* d, void* stream);

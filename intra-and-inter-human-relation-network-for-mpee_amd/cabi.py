@@ -54,7 +54,7 @@ class EncoderDesc(C.Structure):
         ("n_qtiles32", _i32), ("ln_eps", C.c_float), ("dtype", _i32), ("n_qtiles16", _i32), ("n_qtiles64", _i32),
         ("w_in_lp", _fp), ("w_out_lp", _fp), ("w1_lp", _fp), ("w2_lp", _fp),
         ("next_w_in", _fp), ("next_b_in", _fp), ("next_kbuf", _fp), ("next_vbuf", _fp), ("vec_lp", _fp),
-        ("split_ws", _fp), ("split_cnt", _fp),
+        ("split_ws", _fp), ("split_cnt", _fp), ("n_qtiles192", _i32),
     ]
 
 

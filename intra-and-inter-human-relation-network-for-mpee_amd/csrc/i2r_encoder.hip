@@ -18,6 +18,7 @@
 // i.e. one load instruction = 1 KB contiguous.  Weights are packed like this by the host (engine.pack_frag); the K rows
 // and V^T rows of the attention are WRITTEN like this by the kernels that produce them (per 16-key fragment of a group).
 #include <stdlib.h>
+#include <type_traits>
 
 #include "i2r_common.h"
 
@@ -851,7 +852,10 @@ __global__ __launch_bounds__(64) void enc_layer_lp_k(const EncK p) {
     typedef LpVec<DC, FC> V;
     const int lane = threadIdx.x, li = lane & 15, g = lane >> 4;
     constexpr int QT = QF * 16;
-    int b = blockIdx.x, gs = 0, ge = 0, base32 = 0;
+    // XCD x (= workgroup index % 8, MI355X_MICROARCH.md) takes a CONTIGUOUS eighth of the work items: the waves of a group then stream its
+    // K / V through ONE 4 MB L2.  In launch order every XCD touched every group -- 57 crops x 1.2 MB of K / V per layer, all L2 misses.
+    int b = xcd_band_item(blockIdx.x, p.n_qblk), gs = 0, ge = 0, base32 = 0;
+    if (b < 0) return;
     for (int grp = 0; grp < p.n_grp; ++grp) {
         gs = p.grp_off[grp];
         ge = p.grp_off[grp + 1];
@@ -1069,6 +1073,235 @@ __global__ __launch_bounds__(64) void enc_layer_lp_k(const EncK p) {
     }
 }
 
+// =====================================================================================================================
+// enc_layer_lp4_k (round 5): the same 16-bit layer with the K / V stream SHARED by the four waves of a workgroup.
+// ---------------------------------------------------------------------------------------------------------------------
+// enc_layer_lp_k above is one wave per 64 queries that streams every 32-key block (6 K + 6 V^T fragments = 12 KB) from L2 into its own
+// registers: 12 KB through the CU's 64 B/clk vector-memory path per 52 matrix instructions -- with a wave on each of the four SIMDs that
+// is 59 B/clk, the whole path -- and the double-buffered block (96 registers) is what pins the kernel at one wave per SIMD, where the
+// softmax of a block and its matrix instructions serialise (0.29 of the 16-bit peak for two rounds).  Here
+//   * a workgroup = 4 waves x QF = 3 query fragments = 192 consecutive queries of ONE group; every wave fetches 3 of the 12 fragments
+//     of a block (one block ahead, through registers) and puts them into a two-slot LDS ring; one barrier per block; all four waves
+//     read their A operands from LDS -- a fragment crosses the vector-memory path once per 156 matrix instructions;
+//   * without the register-resident K / V blocks a wave needs < 256 registers: TWO workgroups per CU = two waves per SIMD, one
+//     wave's softmax beside the other's matrix instructions;
+//   * everything else (q projection, lazy-reference online softmax in base 2, row sums from the matrix pipe, out-proj / LN / FFN tail)
+//     is the code of enc_layer_lp_k, per wave.
+template <int DC, int FC, int DT, int CSR>
+__global__ __launch_bounds__(256, 2) void enc_layer_lp4_k(const EncK p) {
+    constexpr int QF = 3, cs = CSR * 16, csp = DC * 16, dff = FC * 16, KC = DC / 2, FKC = FC / 2, NFR = 2 * KC + DC;  // fragments of a 32-key block
+    static_assert(NFR == 12, "three fragments per wave");
+    typedef LpVec<DC, FC> V;
+    constexpr int NS = 4, PD = 3;  // LDS ring slots (12 KB each) / prefetch distance in blocks
+    static_assert(PD <= NS - 1 && PD >= 2, "ring");
+    __shared__ __attribute__((aligned(16))) f32x4 kvs[NS][NFR * 64];
+    const int tid = threadIdx.x, lane = tid & 63, li = lane & 15, g = lane >> 4;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    constexpr int QW = QF * 16, QT = 4 * QW;  // queries per wave / per workgroup
+    int b = xcd_band_item(blockIdx.x, p.n_qblk), gs = 0, ge = 0, base32 = 0;  // (XCD-banded like enc_layer_lp_k; workgroup-uniform)
+    if (b < 0) return;
+    for (int grp = 0; grp < p.n_grp; ++grp) {
+        gs = p.grp_off[grp];
+        ge = p.grp_off[grp + 1];
+        const int nq = (ge - gs + QT - 1) / QT;
+        if (b < nq) break;
+        b -= nq;
+        base32 += (ge - gs + 31) >> 5;
+    }
+    const int q0 = gs + b * QT + wave * QW;
+    int qrow[QF];
+#pragma unroll
+    for (int qf = 0; qf < QF; ++qf) qrow[qf] = min(q0 + qf * 16 + li, ge - 1);
+    const float* vec = p.vec_lp;
+
+    // ---- this wave's share of a block: fragments 3 wave .. 3 wave + 2 of [K (kf, c) | V^T nt] go from global memory STRAIGHT into an LDS
+    //      slot (global_load_lds_dwordx4: 16 bytes per lane to M0 + 16 lane, i.e. the 1 KB fragment image as it is; no staging
+    //      registers).  Nothing but the issuing wave's vmcnt orders a later ds_read behind such a load: `landed()` + the barrier. ----
+    auto gload = [&](int blk, int slot) {
+        const size_t bb = (size_t)base32 + blk;
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+            const int f = wave * 3 + i;  // (wave-uniform: waves 0, 1 fetch K, waves 2, 3 V^T)
+            const unsigned short* src = f < 2 * KC ? reinterpret_cast<const unsigned short*>(p.kbuf) + ((bb * 2 * KC + f) * 64 + lane) * 8
+                                                   : reinterpret_cast<const unsigned short*>(p.vbuf) + ((bb * DC + (f - 2 * KC)) * 64 + lane) * 8;
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                             (__attribute__((address_space(3))) void*)&kvs[slot][f * 64], 16, 0, 0);
+        }
+    };
+    auto landed = [&]() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); };
+    const int nblk = (ge - gs + 31) >> 5;
+#pragma unroll
+    for (int jb = 0; jb < PD; ++jb)
+        if (jb < nblk) gload(jb, jb);
+
+    // ---- q projection: B operand = packed (src + pos) ----
+    f32x4 qB[QF][KC];
+    {
+        f32x4 xB[QF][KC];
+#pragma unroll
+        for (int qf = 0; qf < QF; ++qf) {
+            const int prow = p.pos_period > 0 ? qrow[qf] % p.pos_period : qrow[qf];
+#pragma unroll
+            for (int c = 0; c < KC; ++c)
+                xB[qf][c] = load_xblk<CSR, DT>(p.src + (size_t)qrow[qf] * cs, p.pos ? p.pos + (size_t)prow * cs : nullptr, c, g);
+        }
+        f32x4 q32[QF][DC];
+        gemm_T_lp<DC, KC, QF, DT>(p.w_in_lp, vec + V::BIN, csp, xB, li, g, [&](int nt, int qf, f32x4 a) { q32[qf][nt] = a * (p.qscale * 1.4426950408889634f); });
+#pragma unroll
+        for (int qf = 0; qf < QF; ++qf)
+#pragma unroll
+            for (int c = 0; c < KC; ++c) qB[qf][c] = pack8<DT>(q32[qf][2 * c], q32[qf][2 * c + 1]);
+    }
+    landed();
+    __syncthreads();
+
+    f32x4 o[QF][DC], ol[QF], negm[QF];  // negm: -reference of the lane's query column in all four elements (the S accumulators start from it)
+#pragma unroll
+    for (int qf = 0; qf < QF; ++qf) {
+        negm[qf] = ol[qf] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int nt = 0; nt < DC; ++nt) o[qf][nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    }
+    const f32x4 one4 = (f32x4){1.f, 1.f, 1.f, 1.f};
+    const f32x4 onesA = li == 0 ? pack8<DT>(one4, one4) : (f32x4){0.f, 0.f, 0.f, 0.f};  // A fragment: row 0 = ones over the block's 32 keys
+    auto max3 = [](float x, float y, float z) { return fmaxf(fmaxf(x, y), z); };
+    // one 32-key block out of LDS slot `sl`; general = the group's first block (sets the reference) or its ragged last one
+    auto attend = [&](const int sl, const int k0, const bool general) {
+        const f32x4* ks = kvs[sl];
+        f32x4 st[QF][2];
+#pragma unroll
+        for (int qf = 0; qf < QF; ++qf) st[qf][0] = st[qf][1] = negm[qf];
+        // The twelve A fragments of the block come out of LDS through a short register pipeline: fragment i + LA is read before the
+        // matrix instructions of fragment i are issued (fences keep that order).  Read -> wait -> use per fragment left ~1700 of a
+        // block's 3300 wave cycles parked on lgkmcnt (PMC); reading all twelve up front does not fit two waves per SIMD.
+        constexpr int LA = 2;
+        f32x4 fr[LA + 1];
+        auto frag_at = [&](int i) { return ks[i * 64 + lane]; };  // fragment order in a slot: K (c-major below: kf * KC + c), then V^T nt
+        auto kidx = [&](int i) { return (i & 1) * KC + (i >> 1); };  // S phase visits (c, kf) = (i >> 1, i & 1)
+#pragma unroll
+        for (int i = 0; i < LA; ++i) fr[i] = frag_at(kidx(i));
+#pragma unroll
+        for (int i = 0; i < 2 * KC; ++i) {
+            const int c = i >> 1, kf = i & 1;
+            if (i + LA < 2 * KC) fr[(i + LA) % (LA + 1)] = frag_at(kidx(i + LA));
+            else fr[(i + LA) % (LA + 1)] = frag_at(2 * KC + (i + LA - 2 * KC));  // (runs on into the first V^T fragments)
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int qf = 0; qf < QF; ++qf) st[qf][kf] = mfma32_lp<DT>(fr[i % (LA + 1)], qB[qf][c], st[qf][kf]);  // S^T[key 16kf+4g+r][query li] - m
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        const bool first = general && k0 == gs;
+        if (general && k0 + 32 > ge) {  // (wave-uniform)
+#pragma unroll
+            for (int qf = 0; qf < QF; ++qf)
+#pragma unroll
+                for (int kf = 0; kf < 2; ++kf)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+                        if (k0 + 16 * kf + 4 * g + r >= ge) st[qf][kf][r] = -__builtin_inff();
+        }
+        float mx[QF], mxa = -__builtin_inff();
+#pragma unroll
+        for (int qf = 0; qf < QF; ++qf) {
+            mx[qf] = max3(max3(max3(st[qf][0][0], st[qf][0][1], st[qf][0][2]), st[qf][0][3], st[qf][1][0]), max3(st[qf][1][1], st[qf][1][2], st[qf][1][3]), st[qf][1][1]);
+            mxa = fmaxf(mxa, mx[qf]);
+        }
+        if (first || __any(mxa > 10.f)) {
+#pragma unroll
+            for (int qf = 0; qf < QF; ++qf) {
+                if (!first && !__any(mx[qf] > 10.f)) continue;
+                float d = xmax(mx[qf]);          // how far the block's maximum lies above the reference
+                if (!first) {
+                    d = fmaxf(d, 0.f);           // (the reference only rises afterwards)
+                    const float alpha = __builtin_amdgcn_exp2f(-d);
+                    ol[qf] *= alpha;
+#pragma unroll
+                    for (int nt = 0; nt < DC; ++nt) o[qf][nt] *= alpha;
+                }
+                negm[qf] -= d;
+                st[qf][0] -= d;
+                st[qf][1] -= d;
+            }
+        }
+        f32x4 pB[QF];
+#pragma unroll
+        for (int qf = 0; qf < QF; ++qf) {
+#pragma unroll
+            for (int kf = 0; kf < 2; ++kf)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) st[qf][kf][r] = __builtin_amdgcn_exp2f(st[qf][kf][r]);
+            pB[qf] = pack8<DT>(st[qf][0], st[qf][1]);  // keys {4g+r} U {16+4g+r} of the block: the order V^T blocks are stored in
+        }
+#pragma unroll
+        for (int nt = 0; nt < DC; ++nt) {
+            const int i = 2 * KC + nt;
+            if (nt + LA < DC) fr[(i + LA) % (LA + 1)] = frag_at(i + LA);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int qf = 0; qf < QF; ++qf) o[qf][nt] = mfma32_lp<DT>(fr[i % (LA + 1)], pB[qf], o[qf][nt]);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+#pragma unroll
+        for (int qf = 0; qf < QF; ++qf) ol[qf] = mfma32_lp<DT>(onesA, pB[qf], ol[qf]);  // row 0: l[query li] += sum of the block's (16-bit rounded) weights
+    };
+    // ---- the group's blocks through a ring of NS LDS slots, fetched PD blocks ahead (one block ahead the landing of a fetch -- a
+    //      microsecond under load -- was exposed behind every block: 52 % of the wave cycles waiting, PMC).  Block j is read from slot
+    //      j % NS while block j + PD lands in slot (j + PD) % NS, whose last readers (block j + PD - NS <= j - 1) are all behind the
+    //      previous barrier; ONE barrier per block.  The first and the last block (reference set-up / ragged keys) are peeled off so
+    //      that the loop body is one straight path ----
+    auto step = [&](const int j, auto general_c) {
+        if (j + PD < nblk) gload(j + PD, (j + PD) % NS);
+        attend(j % NS, gs + 32 * j, decltype(general_c)::value);
+        // block j + 1 must have landed: the fetches of blocks j + 2 .. j + PD issued behind it may still be in flight (3 loads each)
+        const int rem = nblk - 1 - j;
+        if (rem >= PD) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(3 * (PD - 1)) : "memory");
+        else if (rem == PD - 1 && PD >= 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PD >= 2 ? 3 * (PD - 2) : 0) : "memory");
+        else landed();
+        __syncthreads();
+    };
+    step(0, std::true_type{});
+#pragma unroll 1
+    for (int j = 1; j < nblk - 1; ++j) step(j, std::false_type{});
+    if (nblk > 1) step(nblk - 1, std::true_type{});
+
+    // ---- out-proj + residual + LN1, FFN, + residual + LN2, ONE query fragment at a time: all three side by side (as enc_layer_lp_k runs
+    //      its four) need 316 registers; the weights (90 KB) are re-read per fragment, 1 % of what the key loop streams ----
+#pragma unroll
+    for (int qf = 0; qf < QF; ++qf) {
+        f32x4 oB[1][KC];
+        {
+            const float inv = 1.f / xsum(ol[qf][0]);  // l sits in row 0 of the ones tile (lane g = 0, register 0); rows 4g of g > 0 are zero
+#pragma unroll
+            for (int c = 0; c < KC; ++c) oB[0][c] = pack8<DT>(o[qf][2 * c] * inv, o[qf][2 * c + 1] * inv);
+        }
+        f32x4 x1[DC];
+        gemm_T_lp<DC, KC, 1, DT>(p.w_out_lp, vec + V::BOUT, csp, oB, li, g, [&](int nt, int, f32x4 a) {
+            x1[nt] = nt < CSR ? ld4(p.src + (size_t)qrow[qf] * cs + 16 * nt + 4 * g) + a : a;  // (features >= cs: zero weights -> a = 0)
+        });
+        f32x4 x1B[1][KC];
+        layer_norm<DC>(x1, vec + V::LN1W, vec + V::LN1B, p.d, p.ln_eps, g);
+#pragma unroll
+        for (int c = 0; c < KC; ++c) x1B[0][c] = pack8<DT>(x1[2 * c], x1[2 * c + 1]);
+        f32x4 hB[1][FKC];
+        {
+            f32x4 hprev;
+            gemm_T_lp<FC, KC, 1, DT>(p.w1_lp, vec + V::B1, csp, x1B, li, g, [&](int ft, int, f32x4 a) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) a[r] = fmaxf(a[r], 0.f);
+                if (ft & 1) hB[0][ft >> 1] = pack8<DT>(hprev, a); else hprev = a;
+            });
+        }
+        gemm_T_lp<DC, FKC, 1, DT>(p.w2_lp, vec + V::B2, dff, hB, li, g, [&](int nt, int, f32x4 a) { x1[nt] += a; });
+        layer_norm<DC>(x1, vec + V::LN2W, vec + V::LN2B, p.d, p.ln_eps, g);
+        const int qtok = q0 + qf * 16 + li;
+        if (qtok < ge) {
+#pragma unroll
+            for (int nt = 0; nt < CSR; ++nt) *reinterpret_cast<f32x4*>(p.out + (size_t)qtok * cs + 16 * nt + 4 * g) = x1[nt];
+        }
+        __builtin_amdgcn_sched_barrier(0);
+    }
+}
+
 int fill(const i2r_encoder_desc* d, EncK& k) {
     I2R_CHECK_ARG(d && d->src && d->kbuf && d->vbuf && d->out && d->grp_off && d->w_in && d->b_in && d->w_out && d->b_out &&
                       d->ln1_w && d->ln1_b && d->w1 && d->b1 && d->w2 && d->b2 && d->ln2_w && d->ln2_b,
@@ -1148,17 +1381,30 @@ extern "C" int i2r_encoder_layer(const i2r_encoder_desc* d, void* stream) {
     if (d->dtype != 0) {
         // 64 queries per wave when that still gives >= 2 waves per SIMD-pair of the chip, else 16 (more, shorter waves)
         const bool big = d->n_qtiles64 >= 512;
-        const unsigned grid = (unsigned)(big ? d->n_qtiles64 : d->n_qtiles16);
+        k.n_qblk = big ? d->n_qtiles64 : d->n_qtiles16;
+        const unsigned grid = (unsigned)((k.n_qblk + 7) / 8 * 8);  // (XCD-banded work items inside the kernel)
         const bool c6 = d->cs == 96;
 #ifdef I2R_TUNING
         static const int qf_env = getenv("I2R_ENC_QF") ? atoi(getenv("I2R_ENC_QF")) : 0;  // tuning switch: 2 = 32 queries per wave
         if (qf_env == 2 && big) {
-            if (d->dtype == 1) launch_lp<2, 1>(k, c6, (unsigned)d->n_qtiles32, (hipStream_t)stream); else launch_lp<2, 2>(k, c6, (unsigned)d->n_qtiles32, (hipStream_t)stream);
+            k.n_qblk = d->n_qtiles32;
+            const unsigned g2 = (unsigned)((d->n_qtiles32 + 7) / 8 * 8);
+            if (d->dtype == 1) launch_lp<2, 1>(k, c6, g2, (hipStream_t)stream); else launch_lp<2, 2>(k, c6, g2, (hipStream_t)stream);
             I2R_CHECK_LAUNCH("i2r_encoder_layer");
             return I2R_OK;
         }
 #endif
-        if (d->dtype == 1) {
+        if (big && d->n_qtiles192 > 0) {  // long groups: four waves per workgroup share the K / V stream through LDS (two workgroups per CU)
+            k.n_qblk = d->n_qtiles192;
+            const unsigned g4 = (unsigned)((d->n_qtiles192 + 7) / 8 * 8);
+            if (d->dtype == 1) {
+                if (c6) hipLaunchKernelGGL((enc_layer_lp4_k<6, 12, 1, 6>), dim3(g4), dim3(256), 0, (hipStream_t)stream, k);
+                else hipLaunchKernelGGL((enc_layer_lp4_k<6, 12, 1, 5>), dim3(g4), dim3(256), 0, (hipStream_t)stream, k);
+            } else {
+                if (c6) hipLaunchKernelGGL((enc_layer_lp4_k<6, 12, 2, 6>), dim3(g4), dim3(256), 0, (hipStream_t)stream, k);
+                else hipLaunchKernelGGL((enc_layer_lp4_k<6, 12, 2, 5>), dim3(g4), dim3(256), 0, (hipStream_t)stream, k);
+            }
+        } else if (d->dtype == 1) {
             if (big) launch_lp<4, 1>(k, c6, grid, (hipStream_t)stream); else launch_lp<1, 1>(k, c6, grid, (hipStream_t)stream);
         } else {
             if (big) launch_lp<4, 2>(k, c6, grid, (hipStream_t)stream); else launch_lp<1, 2>(k, c6, grid, (hipStream_t)stream);

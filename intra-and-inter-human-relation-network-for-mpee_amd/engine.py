@@ -117,6 +117,7 @@ _LP1X1_MT = int(_tune("I2R_LP1X1_MT", "0"))
 _HRT_FUSED_ATTN = tuple(int(v) for v in _tune("I2R_HRT_FUSED_ATTN", "78,156,312").split(",") if v)
 _HRT_ATTN_VARIANT = int(_tune("I2R_HRT_ATTN_VARIANT", "0"))  # i2r_hrt_attn_block: 0 the library's choice, 1 wave per token tile, 2 wave per head
 _HRT_FUSED_MLP = tuple(int(v) for v in _tune("I2R_HRT_FUSED_MLP", "78,156,312").split(",") if v)
+_ENC_LP4 = _tune("I2R_ENC_LP4", "1") != "0"  # 16-bit encoder, long groups: four waves per workgroup share the K / V stream through LDS
 _HRT_MLP_VARIANT = int(_tune("I2R_HRT_MLP_VARIANT", "0"))  # i2r_hrt_mlp_block: 0 the table below, 1 fc2 accumulated per wave, 2 fc2 by output-block ownership
 _MLP_VARIANT = {78: 1, 156: 2, 312: 2}  # measured (tools/time_hrt_mlp.py, host_rate.py): C = 156 29.0 -> 22.0 us, config 5 forward 4.19 -> 3.87 ms
 PAIR1X1 = _tune("I2R_PAIR1X1", "1") != "0"  # layer1's conv3 + next conv1 as one i2r_conv1x1_pair launch (fp32)
@@ -1104,12 +1105,13 @@ class Program:
         assert len(offs) <= grouping["goff"].numel()
         lens = [offs[i + 1] - offs[i] for i in range(len(offs) - 1)]
         assert all(l > 0 for l in lens)
-        nq, nq16, nq64 = (sum(-(-l // t) for l in lens) for t in (32, 16, 64))
+        nq, nq16, nq64, nq192 = (sum(-(-l // t) for l in lens) for t in (32, 16, 64, 192))
         # (pinned staging + stream-ordered copy: a pageable source would make every regroup of the validate() loop a blocking copy; torch's
         #  caching host allocator keeps the pinned block alive until the copy has run)
         grouping["goff"][:len(offs)].copy_(torch.tensor(offs, dtype=torch.int32).pin_memory(), non_blocking=True)
         for d, dt in grouping["descs"]:
             d.n_grp, d.n_qtiles32, d.n_qtiles16, d.n_qtiles64 = len(offs) - 1, nq, nq16, nq64
+            d.n_qtiles192 = nq192 if _ENC_LP4 else 0
             d.dtype = dt  # (both kernel families take any group offsets: K / V blocks are numbered group by group)
         grouping["current"] = offs
 
@@ -1572,17 +1574,62 @@ def validate_config(cfg, name=None):
 _LANE_STREAMS = {}  # device -> side streams shared by every Engine of the process
 
 
+def _streams_overlap(a, b, cycles=400000):
+    """True if work queued on streams a and b runs side by side (different hardware queues): a spin kernel on each, timed together.
+    HIP maps streams onto a handful of hardware queues in creation order; two streams on one queue serialise."""
+    def once(both):
+        e0, e1, e2 = (torch.cuda.Event(enable_timing=True) for _ in range(3))
+        e0.record(a)
+        b.wait_event(e0)
+        with torch.cuda.stream(a):
+            torch.cuda._sleep(cycles)
+        if both:
+            with torch.cuda.stream(b):
+                torch.cuda._sleep(cycles)
+        e1.record(b)
+        a.wait_event(e1)
+        e2.record(a)
+        e2.synchronize()
+        return e0.elapsed_time(e2)
+    once(True)  # (first use of a stream binds its queue)
+    t1 = min(once(False) for _ in range(2))
+    t2 = min(once(True) for _ in range(2))
+    return t2 < 1.5 * t1
+
+
 def lane_streams(device, n):
-    """The first n side streams of the device, created once per process and shared by all engines (lanes 1..3 of the multi-lane programs,
-    then the part-batch streams).  HIP spreads streams over a handful of hardware queues in the order they are first used: an engine
-    that made its own streams after other engines had made theirs got lanes that shared a hardware queue, and its four-lane HRFormer
-    forward ran 7 % slower than in a fresh process (bench.py other_workloads: 3.39 vs 3.15 ms).  Engines of one process issue their
-    forwards one after the other, so sharing the streams costs nothing; it only adds ordering if they ever did not."""
+    """The first n side streams of the device, created once per process and shared by all engines (lanes 1..3 of the multi-lane programs;
+    the part-batch forwards run their second part on lane stream 0).  HIP spreads streams over a handful of hardware queues in the order
+    they are created, and work on two streams of one queue does not overlap: an engine whose lanes landed on the caller's queue ran its
+    four-lane HRFormer forward 7-16 % slower, and a process that had created an RCCL communicator first (its streams shift the order)
+    lost the whole part-batch overlap (w48 fp32 3.75 -> 5.09 ms per step, tools/gather_cost.py).  So every candidate stream is PROBED:
+    it becomes a lane only if a spin kernel on it runs side by side with one on the current stream and on every lane chosen so far
+    (_streams_overlap); candidates that share a queue are kept aside.  Engines of one process issue their forwards one after the
+    other, so sharing the streams costs nothing; it only adds ordering if they ever did not."""
     key = str(device)
     lst = _LANE_STREAMS.setdefault(key, [])
-    while len(lst) < n:
-        lst.append(torch.cuda.Stream(device=device))
+    if len(lst) < n:
+        with torch.cuda.device(device):
+            cur = torch.cuda.current_stream(device)
+            spare = _LANE_SPARE.setdefault(key, [])
+            for _ in range(int(_tune("I2R_STREAM_SKIP", "0"))):  # (A/B: shift the creation order)
+                spare.append(torch.cuda.Stream(device=device))
+            tries = 0
+            while len(lst) < n and tries < 24:
+                tries += 1
+                st = torch.cuda.Stream(device=device)
+                try:
+                    ok = _streams_overlap(cur, st) and all(_streams_overlap(o, st) for o in lst)
+                except Exception:  # (no spin kernel on this build: take the stream as it comes)
+                    ok = True
+                (lst if ok else spare).append(st)
+            while len(lst) < n:  # (fewer independent queues than lanes: the remaining lanes share)
+                lst.append(spare.pop() if spare else torch.cuda.Stream(device=device))
+            torch.cuda.synchronize(device)
     return lst[:n]
+
+
+_LANE_SPARE = {}  # device -> probed streams that share a hardware queue with the caller's stream or with a lane (kept alive, unused)
 
 
 class Engine:
@@ -1899,7 +1946,7 @@ class Engine:
         pm = pos_mask.to(self.device, torch.float32).contiguous() if pos_mask is not None else None
         cur = torch.cuda.current_stream(self.device)
         if len(getattr(self, "_part_streams", ())) < parts - 1:
-            self._part_streams = lane_streams(self.device, 3 + parts - 1)[3:]
+            self._part_streams = lane_streams(self.device, max(3, parts - 1))[:parts - 1]  # (programs that split use no lanes: the lane streams serve)
             self._part_events = [torch.cuda.Event() for _ in range(parts)]
         e_fork = self._part_events[0]
         e_fork.record(cur)  # (the inputs are ready on the caller's stream)
@@ -1953,7 +2000,7 @@ class Engine:
         x = x.to(self.device).contiguous()
         cur = torch.cuda.current_stream(self.device)
         if len(getattr(self, "_part_streams", ())) < parts - 1:
-            self._part_streams = lane_streams(self.device, 3 + parts - 1)[3:]
+            self._part_streams = lane_streams(self.device, max(3, parts - 1))[:parts - 1]
             self._part_events = [torch.cuda.Event() for _ in range(parts)]
         cap = self.capacity(S)
         Pt, patch = self._program((cap, H, W, flip, "tail"), lambda: self._build(cap, H, W, list(length) + [1] * (cap - S), flip, part="tail"))

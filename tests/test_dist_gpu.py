@@ -89,4 +89,7 @@ def test_bench_config4_with_collective_matches_plain_line():
     coll = _bench("--config", "hrt_192_p4_b4", "--gpus", "1", "--steps", "30", "--warmup", "10", "--world1-collective")
     assert plain["parity"]["ok"] and coll["parity"]["ok"]
     assert "dp1" in coll["config"]["parallelism"] and coll["config"]["crops_per_gpu_step"] == 16
-    assert abs(coll["value"] - plain["value"]) <= 0.05 * plain["value"], (coll["value"], plain["value"])
+    # (the first version of this test caught a 15 % loss: with an RCCL communicator created first the engine's lane streams landed on
+    #  the caller's hardware queue -- engine.lane_streams now probes every stream for overlap before using it)
+    assert coll["value"] >= 0.95 * plain["value"], (coll["value"], plain["value"])
+    assert coll["value"] <= 1.15 * plain["value"], (coll["value"], plain["value"])

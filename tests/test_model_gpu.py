@@ -429,6 +429,10 @@ def test_engines_share_the_lane_streams():
     eb = _net(cfg_b, sd_b, "hrt_192_p4_b4").engine()
     assert len(ea.side_streams) == 3 and all(a is b for a, b in zip(ea.side_streams, eb.side_streams))
     assert engine.lane_streams(ea.device, 4)[:3] == ea.side_streams
+    # every lane was probed: work on it overlaps work on the caller's stream and on the other lanes (distinct hardware queues)
+    cur = torch.cuda.current_stream()
+    assert all(engine._streams_overlap(cur, st) for st in ea.side_streams)
+    assert engine._streams_overlap(ea.side_streams[0], ea.side_streams[1])
 
 
 def test_config5_twelve_persons_384x288():
