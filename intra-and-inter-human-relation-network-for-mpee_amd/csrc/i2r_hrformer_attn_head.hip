@@ -169,6 +169,63 @@ __global__ __launch_bounds__(64 * (HEADS / HPW), OCC) void hrt_attn_head_k(const
     for (int j = 0; j < HPW; ++j) {
         const int head = wave * HPW + j;
         f32x4 qpk[4][2], kpk[4][2], vpk[3][2];
+        if constexpr (KS <= 10) {
+            // Narrow branches (C = 78 / 156: 3 / 5 k-steps per projection): the 3 KS (part, k-step) units of a head form ONE fully unrolled
+            // sequence whose weight fragments come through a ring fetched RD units ahead ACROSS the part boundaries -- with one k-step
+            // of look-ahead inside a rolled loop per part (below) every step waited for an L2 round trip that 12 matrix instructions
+            // do not cover.  A fence per unit keeps the ring a ring (unfenced, the scheduler hoists all fetches to the top and spills).
+            constexpr int NU = 3 * KS, RD = 2;
+            f32x4 wr[RD + 1][3];
+            auto ufetch = [&](const int n) {  // unit n: part 2 - n / KS (v, k, q), k-step n % KS
+                const f32x4* a = p.wqkv + ((size_t)(head * 3 + (2 - n / KS)) * KS + n % KS) * 192 + lane;
+#pragma unroll
+                for (int db = 0; db < 3; ++db) wr[n % (RD + 1)][db] = a[db * 64];
+            };
+#pragma unroll
+            for (int n = 0; n < RD; ++n) ufetch(n);
+#pragma unroll
+            for (int pi = 0; pi < 3; ++pi) {
+                const int part = 2 - pi;
+                f32x4 acc[4][3];
+                const float* bsrc = p.bqkv + (head * 3 + part) * 48;
+#pragma unroll
+                for (int db = 0; db < 3; ++db) {
+                    f32x4 b4;
+                    if (part == 2) {  // V: D = [token rows][dim column li]
+                        const float b = bsrc[16 * db + li];
+                        b4 = (f32x4){b, b, b, b};
+                    } else {          // Q^T, K^T: D = [dim rows 4g + r][token column]
+                        b4 = *reinterpret_cast<const f32x4*>(bsrc + 16 * db + 4 * g);
+                    }
+#pragma unroll
+                    for (int t = 0; t < 4; ++t) acc[t][db] = b4;
+                }
+#pragma unroll
+                for (int sk = 0; sk < KS; ++sk) {
+                    const int n = pi * KS + sk;
+                    if (n + RD < NU) ufetch(n + RD);
+                    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                    for (int t = 0; t < 4; ++t) {
+                        const f32x4 xt = smem[(t * KS + sk) * 64 + lane];
+#pragma unroll
+                        for (int db = 0; db < 3; ++db)
+                            acc[t][db] = part == 2 ? mfma32_lp<DT>(xt, wr[n % (RD + 1)][db], acc[t][db]) : mfma32_lp<DT>(wr[n % (RD + 1)][db], xt, acc[t][db]);
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+                if (part == 2) {
+#pragma unroll
+                    for (int db = 0; db < 3; ++db) { vpk[db][0] = pack8<DT>(acc[0][db], acc[1][db]); vpk[db][1] = pack8<DT>(acc[2][db], acc[3][db]); }
+                } else if (part == 1) {
+#pragma unroll
+                    for (int t = 0; t < 4; ++t) { kpk[t][0] = pack8<DT>(acc[t][0], acc[t][1]); kpk[t][1] = pack8<DT>(acc[t][2], zero4); }
+                } else {
+#pragma unroll
+                    for (int t = 0; t < 4; ++t) { qpk[t][0] = pack8<DT>(acc[t][0], acc[t][1]); qpk[t][1] = pack8<DT>(acc[t][2], zero4); }
+                }
+            }
+        } else {
         // (v first, q last: the accumulators of the widest phase then sit beside the fewest packed operands)
         {
             f32x4 acc[4][3];
@@ -187,6 +244,7 @@ __global__ __launch_bounds__(64 * (HEADS / HPW), OCC) void hrt_attn_head_k(const
             project(head, 0, std::false_type{}, acc);
 #pragma unroll
             for (int t = 0; t < 4; ++t) { qpk[t][0] = pack8<DT>(acc[t][0], acc[t][1]); qpk[t][1] = pack8<DT>(acc[t][2], zero4); }
+        }
         }
 #pragma unroll
         for (int t = 0; t < 4; ++t) {
@@ -271,6 +329,28 @@ __global__ __launch_bounds__(64 * (HEADS / HPW), OCC) void hrt_attn_head_k(const
                 xres[i][tt] = *reinterpret_cast<const f32x4*>(p.x + rowT[tt] + 16 * ob[i]);  // (clamped row: always readable)
             }
         }
+        if constexpr (OSG <= 12) {  // narrow branches: all k-steps unrolled, fragments through a ring two steps ahead (as the projections)
+            constexpr int RD = 2;
+            f32x4 wr[RD + 1][UC];
+            auto ofetch = [&](const int sn) {
+#pragma unroll
+                for (int i = 0; i < UC; ++i) wr[sn % (RD + 1)][i] = p.wo[((size_t)ob[i] * OSG + sn) * 64 + lane];
+            };
+#pragma unroll
+            for (int sn = 0; sn < RD; ++sn) ofetch(sn);
+#pragma unroll
+            for (int sk = 0; sk < OSG; ++sk) {
+                if (sk + RD < OSG) ofetch(sk + RD);
+                __builtin_amdgcn_sched_barrier(0);
+                const f32x4 b0 = smem[((2 * tp) * OSG + sk) * 64 + lane], b1 = smem[((2 * tp + 1) * OSG + sk) * 64 + lane];
+#pragma unroll
+                for (int i = 0; i < UC; ++i) {
+                    acc[i][0] = mfma32_lp<DT>(wr[sk % (RD + 1)][i], b0, acc[i][0]);
+                    acc[i][1] = mfma32_lp<DT>(wr[sk % (RD + 1)][i], b1, acc[i][1]);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        } else {
         f32x4 wn[UC];
 #pragma unroll
         for (int i = 0; i < UC; ++i) wn[i] = p.wo[(size_t)ob[i] * OSG * 64 + lane];
@@ -288,6 +368,7 @@ __global__ __launch_bounds__(64 * (HEADS / HPW), OCC) void hrt_attn_head_k(const
                 acc[i][0] = mfma32_lp<DT>(wv[i], b0, acc[i][0]);
                 acc[i][1] = mfma32_lp<DT>(wv[i], b1, acc[i][1]);
             }
+        }
         }
 #pragma unroll
         for (int i = 0; i < UC; ++i) {
