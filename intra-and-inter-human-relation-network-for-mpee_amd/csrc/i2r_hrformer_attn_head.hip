@@ -51,6 +51,19 @@ __global__ __launch_bounds__(64 * (HEADS / HPW), OCC) void hrt_attn_head_k(const
     const int img = bid / p.nwy;
     const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
 
+    // the first weight fragments of this wave's (first) head go out before anything else: they fly under the LayerNorm's row loads
+    constexpr int RDQ = 2;  // ring depth of the q / k / v weight stream (narrow branches, see below)
+    f32x4 wr[RDQ + 1][3];
+    auto ufetch = [&](const int head, const int n) {  // unit n of a head: part 2 - n / KS (v, k, q), k-step n % KS
+        const f32x4* a = p.wqkv + ((size_t)(head * 3 + (2 - n / KS)) * KS + n % KS) * 192 + lane;
+#pragma unroll
+        for (int db = 0; db < 3; ++db) wr[n % (RDQ + 1)][db] = a[db * 64];
+    };
+    if constexpr (KS <= 10) {
+#pragma unroll
+        for (int n = 0; n < RDQ; ++n) ufetch(wave * HPW, n);
+    }
+
     // ---- LayerNorm 1 -> smem as packed operand image: lane (li, g) of (tile t, k-step s) holds features 32 s + 8 g .. + 7 of token 16 t + li.
     //      The rows are READ quad-coalesced: lane n takes token n >> 2 of the tile and the 16-byte pieces (n & 3) + 4 k of its row, so the
     //      four lanes of a quad cover 64 contiguous bytes (a 64-lane access whose quads straddle rows takes four times the addresser
@@ -174,15 +187,11 @@ __global__ __launch_bounds__(64 * (HEADS / HPW), OCC) void hrt_attn_head_k(const
             // sequence whose weight fragments come through a ring fetched RD units ahead ACROSS the part boundaries -- with one k-step
             // of look-ahead inside a rolled loop per part (below) every step waited for an L2 round trip that 12 matrix instructions
             // do not cover.  A fence per unit keeps the ring a ring (unfenced, the scheduler hoists all fetches to the top and spills).
-            constexpr int NU = 3 * KS, RD = 2;
-            f32x4 wr[RD + 1][3];
-            auto ufetch = [&](const int n) {  // unit n: part 2 - n / KS (v, k, q), k-step n % KS
-                const f32x4* a = p.wqkv + ((size_t)(head * 3 + (2 - n / KS)) * KS + n % KS) * 192 + lane;
+            constexpr int NU = 3 * KS, RD = RDQ;
+            if (j > 0) {
 #pragma unroll
-                for (int db = 0; db < 3; ++db) wr[n % (RD + 1)][db] = a[db * 64];
-            };
-#pragma unroll
-            for (int n = 0; n < RD; ++n) ufetch(n);
+                for (int n = 0; n < RD; ++n) ufetch(head, n);
+            }
 #pragma unroll
             for (int pi = 0; pi < 3; ++pi) {
                 const int part = 2 - pi;
@@ -203,7 +212,7 @@ __global__ __launch_bounds__(64 * (HEADS / HPW), OCC) void hrt_attn_head_k(const
 #pragma unroll
                 for (int sk = 0; sk < KS; ++sk) {
                     const int n = pi * KS + sk;
-                    if (n + RD < NU) ufetch(n + RD);
+                    if (n + RD < NU) ufetch(head, n + RD);
                     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                     for (int t = 0; t < 4; ++t) {

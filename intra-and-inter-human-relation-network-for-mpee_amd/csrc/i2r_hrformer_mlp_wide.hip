@@ -49,6 +49,16 @@ __global__ __launch_bounds__(64 * W, (W + 3) / 4) void hrt_mlp_wide_k(const I2rM
     const int y0 = sy * TY - 1, x0 = sx * TX - 1;               // image coordinate of halo pixel (0, 0)
     const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
 
+    // Weight fragments are fetched a whole BLOCK ahead (all KS fc1 fragments of the next hidden block fly under the GELU / depth-wise
+    // phase of the current one; fc2's three pairs ahead): with one fragment of look-ahead a wave paid an L2 round trip per k-step.
+    // The first block's go out before anything else: they fly under the LayerNorm's row loads.
+    f32x4 w1f[KS];
+    auto fetch1 = [&](int hb) {
+#pragma unroll
+        for (int s = 0; s < KS; ++s) w1f[s] = p.w1[((size_t)hb * KS + s) * 64 + lane];
+    };
+    fetch1(2 * wave);
+
     // ---- LayerNorm 2 of halo fragment wave % NF, channel slice wave / NF -> Xs (rows read quad-coalesced: lane n = pixel n >> 2 of the
     //      fragment, 16-byte pieces (n & 3) + 4 k; piece pi is half pi & 1 of lane (g = (pi & 7) >> 1, li = pixel) of k-step pi >> 3) ----
     {
@@ -175,14 +185,6 @@ __global__ __launch_bounds__(64 * W, (W + 3) / 4) void hrt_mlp_wide_k(const I2rM
 #pragma unroll
         for (int pf = 0; pf < NPF; ++pf) acc[o][pf] = zero4;
 
-    // Weight fragments are fetched a whole BLOCK ahead (all KS fc1 fragments of the next hidden block fly under the GELU / depth-wise
-    // phase of the current one; fc2's three pairs ahead): with one fragment of look-ahead a wave paid an L2 round trip per k-step.
-    f32x4 w1f[KS];
-    auto fetch1 = [&](int hb) {
-#pragma unroll
-        for (int s = 0; s < KS; ++s) w1f[s] = p.w1[((size_t)hb * KS + s) * 64 + lane];
-    };
-    fetch1(2 * wave);
 #pragma unroll 1
     for (int r = 0; r < R; ++r) {
         const int gp = wave + W * r;  // this wave's pair of hidden blocks 2 gp, 2 gp + 1 in this round
