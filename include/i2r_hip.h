@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define I2R_ABI_VERSION 9
+#define I2R_ABI_VERSION 10
 
 /* The library is built with -fvisibility=hidden: the entry points declared in this header (marked I2R_API) are its ONLY exported
  * symbols (tests/test_host.py holds the header, the dynamic symbol table and cabi.EXPORTS equal). */
@@ -427,6 +427,24 @@ typedef struct i2r_encoder_desc {
 I2R_API int i2r_encoder_kv(const i2r_encoder_desc* d, void* stream);
 I2R_API int i2r_encoder_layer(const i2r_encoder_desc* d, void* stream);
 
+/* i2r_mh_attention -- softmax(q k^T) v of nn.MultiheadAttention with ANY head count over the same variable-length token groups
+ * (MODEL.N_HEAD > 1: interformer_pureMulti.py:461,473, transpose_h.py:457,467, interformer_2stage.py:221,233, attention.py:1039; the yacs
+ * default is 8, lib/config/default.py:63) -- the attention core of the general encoder layer the host composes for configs the fused
+ * single-head post-norm kernels above do not cover (N_HEAD > 1, NORMALIZE_BEFORE with MODEL.NAME interformer: forward_pre,
+ * attention.py:84-103): q|k and v come from 1x1 i2r_conv launches over the token rows, out-proj / FFN / LayerNorms likewise.
+ *   qk  [n_tok, qk_cs] fp32: q of head h at channels [h*hp, h*hp + hp), k of head h at k_off + the same; q ALREADY scaled by
+ *       head_dim^-0.5 (folded into the q rows by the host); hp = head_dim rounded up to a multiple of 16 (<= 256), pad dims exactly 0
+ *   v   [n_tok, v_cs], out [n_tok, out_cs]: head h at channels [h*hp, h*hp + hp); out's channels behind heads*hp are written as zeros
+ *   grp_off device int32 [n_grp + 1]: group g owns token rows [grp_off[g], grp_off[g+1]) (keys of other groups are never seen: the
+ *       reference's pad + key_padding_mask, interformer_pureMulti.py:706-750)
+ *   n_qtiles16 = sum over groups of ceil(len / 16) (the host knows the lengths)
+ * fp32 matrix pipe, one wave per (16-query tile, head), no workspace. */
+typedef struct i2r_mh_attn_args {
+    const float* qk; const float* v; float* out; const int32_t* grp_off;
+    int32_t n_grp, heads, hp, k_off, qk_cs, v_cs, out_cs, n_qtiles16;
+} i2r_mh_attn_args;
+I2R_API int i2r_mh_attention(const i2r_mh_attn_args* a, void* stream);
+
 /* ------------------------------------------------------------------------------------------------
  * Program runner: replay a pre-built list of launches from one C call (no per-op host overhead, and
  * capturable into a hipGraph by the caller).  Streams: ops carry a lane id 0..3; lane 0 is `stream`,
@@ -440,7 +458,7 @@ enum {
     I2R_OP_ENC_KV = 5, I2R_OP_ENC_LAYER = 6, I2R_OP_FORK = 7, I2R_OP_JOIN = 8, I2R_OP_CONV_GROUP = 9,
     I2R_OP_LAYERNORM = 10, I2R_OP_WINATTN = 11, I2R_OP_DWCONV = 12, I2R_OP_UPSAMPLE = 13, I2R_OP_CONV_CHAIN = 14,
     I2R_OP_PE_RES_STEM = 15, I2R_OP_HRT_ATTN = 16, I2R_OP_HRT_MLP = 17, I2R_OP_XSYNC = 18, I2R_OP_FUSE_UP = 19,
-    I2R_OP_CONV1X1_PAIR = 20, I2R_OP_CONV1X1_LP = 21
+    I2R_OP_CONV1X1_PAIR = 20, I2R_OP_CONV1X1_LP = 21, I2R_OP_MH_ATTN = 22
 };
 
 typedef struct i2r_stem_args {

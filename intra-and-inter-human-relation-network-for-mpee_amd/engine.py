@@ -357,6 +357,40 @@ class Packer:
         t.update(d=d, cs=cs, dff_pad=fs, dtype=self.dtype if lp else 0)
         return t
 
+    @staticmethod
+    def mh_width(heads, hd):
+        """(hp, hs): head dim padded to a multiple of 16 (csrc/i2r_encoder_mh.hip) and the width of a q / k / v / attention-output part,
+        heads*hp rounded up to a fragment count the conv kernels split (conv_split: a multiple of 3, 4 or 5 sixteen-channel blocks)"""
+        hp = _r16(hd)
+        f = heads * hp // 16
+        while not any(f % k == 0 for k in (3, 4, 5)):
+            f += 1
+        return hp, 16 * f
+
+    def encoder_layer_mh(self, p, d, dff, heads):
+        """General form of a DETR encoder layer (any MODEL.N_HEAD, post- or pre-norm; interformer_pureMulti.py:171-243, attention.py:37-112)
+        as 1x1 convs around i2r_mh_attention: q|k (head hh's dim j at channel hh*hp + j, k part hs further; head_dim^-0.5 folded into the q
+        rows), v, out-proj (zero columns for the head pads), linear1, linear2 and the two LayerNorms."""
+        assert self.dtype == 0, "the general encoder layer runs in fp32 (use a Packer(..., 'fp32'))"
+        s = self.sd
+        hd = d // heads
+        assert hd * heads == d, "nn.MultiheadAttention: embed_dim %d must be divisible by num_heads %d" % (d, heads)
+        hp, hs = self.mh_width(heads, hd)
+        rows = torch.tensor([hh * hp + j for hh in range(heads) for j in range(hd)])
+        wi, bi = s[p + ".self_attn.in_proj_weight"].double(), s[p + ".self_attn.in_proj_bias"].double()
+        wqk, bqk = torch.zeros(2 * hs, d, dtype=torch.float64), torch.zeros(2 * hs, dtype=torch.float64)
+        wqk[rows], bqk[rows] = wi[:d] * float(hd) ** -0.5, bi[:d] * float(hd) ** -0.5
+        wqk[hs + rows], bqk[hs + rows] = wi[d:2 * d], bi[d:2 * d]
+        wv, bv = torch.zeros(hs, d, dtype=torch.float64), torch.zeros(hs, dtype=torch.float64)
+        wv[rows], bv[rows] = wi[2 * d:], bi[2 * d:]
+        wo = torch.zeros(d, hs, dtype=torch.float64)
+        wo[:, rows] = s[p + ".self_attn.out_proj.weight"].double()
+        return dict(mh=True, heads=heads, hp=hp, hs=hs, d=d, cs=_r16(d),
+                    qk=self.linear_as_conv(wqk, bqk), v=self.linear_as_conv(wv, bv), o=self.linear_as_conv(wo, s[p + ".self_attn.out_proj.bias"]),
+                    w1=self.linear_as_conv(s[p + ".linear1.weight"], s[p + ".linear1.bias"]),
+                    w2=self.linear_as_conv(s[p + ".linear2.weight"], s[p + ".linear2.bias"]),
+                    ln1=self.ln(p + ".norm1", d), ln2=self.ln(p + ".norm2", d))
+
     def dw(self, conv_key, bn_key, eps=1e-5):
         """depth-wise 3x3 [C,1,3,3] (+bias) + BN -> tap-major [9][cs] weights + [cs] bias."""
         w = self.sd[conv_key + ".weight"]
@@ -504,6 +538,14 @@ class Act:
     @property
     def ptr(self):
         return self.t.data_ptr()
+
+
+class _RawAct:
+    """a device buffer laid out like the Act `like` that the program does not own (a conv's second input)"""
+    __slots__ = ("ptr", "n", "h", "w", "c", "cs", "dt")
+
+    def __init__(self, ptr, like):
+        self.ptr, self.n, self.h, self.w, self.c, self.cs, self.dt = ptr, like.n, like.h, like.w, like.c, like.cs, 0
 
 
 _MT_EFF = {1: 0.62, 2: 0.9, 3: 1.0, 4: 0.9}  # measured on MI355X (tools/sweep_conv.py): B-fragment reuse per wave
@@ -698,7 +740,7 @@ class Program:
             fw, fh = wino_fragment(conv_h, conv_w)
             d.algo, d.w = 1, pc.w_wino.data_ptr()
             mt = 1  # one fragment per item: 114 registers = 4 waves per SIMD (measured faster than two fragments at 2 waves per SIMD)
-            if _WINO_MT:
+            if _WINO_MT and nt == 3:  # (A/B; <2, 4> is not instantiated)
                 mt = _WINO_MT
             d.tile_h, d.tile_w, d.mt, d.wn, d.ck = fh, fw, mt, 1, 0
             n_frag = x.n * -(-conv_h // fh) * -(-conv_w // fw)
@@ -1039,11 +1081,15 @@ class Program:
         self.ops.append((cabi.OP_HEAD, lane, a))
         return a
 
-    def encoder(self, x, layers, grp_off_host, pos=None, pos_period=0, lane=0, regroupable=False):
+    def encoder(self, x, layers, grp_off_host, pos=None, pos_period=0, lane=0, regroupable=False, pre_norm=False, pos_table=None):
         """x: Act viewed as tokens [n*h*w, cs]; grp_off_host: python list of token offsets per group.
         regroupable: the grouping (persons per image) may be changed later with set_groups() without rebuilding the program:
         the offset table gets capacity for one group per crop."""
         assert x.dt == 0, "the encoder kernels read fp32 token rows"
+        if layers and layers[0].get("mh"):
+            return self.encoder_mh(x, layers, grp_off_host, pos=pos, pos_period=pos_period, lane=lane, regroupable=regroupable, pre_norm=pre_norm,
+                                   pos_table=pos_table)
+        assert not pre_norm, "the fused layer kernels are post-norm"
         n_tok = x.n * x.h * x.w
         cs = x.cs
         n_pad = (n_tok + 63) // 64 * 64 + 64
@@ -1097,6 +1143,62 @@ class Program:
             self.groupings.append((grouping, x.h * x.w))
         return cur
 
+    def encoder_mh(self, x, layers, grp_off_host, pos=None, pos_period=0, lane=0, regroupable=False, pre_norm=False, pos_table=None):
+        """The general encoder stack (Packer.encoder_layer_mh): per layer, post-norm (forward_post, attention.py:61-82)
+            q|k = (src + pos) Wqk ; v = src Wv ; a = mh_attention ; x = LN1(src + a Wo) ; out = LN2(x + W2 relu(W1 x))
+        or pre-norm (forward_pre, attention.py:84-103: q and k from LN1(src) + pos, the VALUE from src itself)
+            q|k = (LN1(src) + pos) Wqk ; v = src Wv ; x = src + a Wo ; out = x + W2 relu(W1 LN2(x)).
+        pos: device address of per-token rows laid out like x, or of a [pos_period, cs] table (TransPose-H), or 0."""
+        pos_act = None
+        if pos:
+            if pos_period:  # the conv kernel adds a second INPUT of the same geometry: the table repeated per crop, built once
+                assert x.h * x.w == pos_period and pos_table is not None and pos_table.data_ptr() == pos and tuple(pos_table.shape) == (pos_period, x.cs)
+                rep = pos_table.unsqueeze(0).expand(x.n, pos_period, x.cs).contiguous()
+                self.keep.append(rep)
+                self.nbytes += rep.numel() * 4
+                pos = rep.data_ptr()
+            pos_act = _RawAct(pos, x)
+        goff = torch.zeros(x.n + 1, dtype=torch.int32, device=self.device)
+        self.keep += [goff, layers]
+        self.nbytes += goff.numel() * 4
+        cur, mh_args = x, []
+        for L in layers:
+            assert L["cs"] == x.cs
+            qk_in = self.layernorm(cur, L["ln1"], eps=1e-5, lane=lane) if pre_norm else cur
+            qk = self.conv(qk_in, L["qk"], in2=pos_act, lane=lane)
+            v = self.conv(cur, L["v"], lane=lane)
+            if pre_norm:
+                self.release(qk_in)
+            att = self.alloc(x.n, x.h, x.w, L["hs"])
+            a = cabi.MhAttnArgs(qk.ptr, v.ptr, att.ptr, goff.data_ptr(), 0, L["heads"], L["hp"], L["hs"], qk.cs, v.cs, att.cs, 0)
+            self.ops.append((cabi.OP_MH_ATTN, lane, a))
+            mh_args.append(a)
+            self.release(qk, v)
+            x1 = self.conv(att, L["o"], res1=cur, lane=lane)  # src + attention
+            self.release(att)
+            if cur is not x:
+                self.release(cur)
+            if pre_norm:
+                n2 = self.layernorm(x1, L["ln2"], eps=1e-5, lane=lane)
+                hdn = self.conv(n2, L["w1"], relu=True, lane=lane)
+                self.release(n2)
+                cur = self.conv(hdn, L["w2"], res1=x1, lane=lane)
+                self.release(hdn, x1)
+            else:
+                n1 = self.layernorm(x1, L["ln1"], eps=1e-5, lane=lane)
+                self.release(x1)
+                hdn = self.conv(n1, L["w1"], relu=True, lane=lane)
+                y = self.conv(hdn, L["w2"], res1=n1, lane=lane)
+                self.release(hdn, n1)
+                cur = self.layernorm(y, L["ln2"], eps=1e-5, lane=lane)
+                self.release(y)
+        grouping = dict(descs=[], mh=mh_args, goff=goff, current=None)
+        self.set_groups(grouping, grp_off_host)
+        self.enc_stacks.append(grouping)
+        if regroupable:
+            self.groupings.append((grouping, x.h * x.w))
+        return cur
+
     def set_groups(self, grouping, grp_off_host):
         """(Re)define the token groups of an encoder stack: uploads the offset table and patches the per-layer descriptors."""
         offs = tuple(int(o) for o in grp_off_host)
@@ -1113,6 +1215,8 @@ class Program:
             d.n_grp, d.n_qtiles32, d.n_qtiles16, d.n_qtiles64 = len(offs) - 1, nq, nq16, nq64
             d.n_qtiles192 = nq192 if _ENC_LP4 else 0
             d.dtype = dt  # (both kernel families take any group offsets: K / V blocks are numbered group by group)
+        for a in grouping.get("mh", ()):
+            a.n_grp, a.n_qtiles16 = len(offs) - 1, nq16
         grouping["current"] = offs
 
     def fork(self, mask):
@@ -1545,10 +1649,12 @@ def validate_config(cfg, name=None):
     reference experiments/*.yaml).  Raises NotImplementedError for a combination the reference can express but no shipped yaml uses."""
     M = cfg["MODEL"]
     name = name or M["NAME"]
-    if M["N_HEAD"] != 1:
-        raise NotImplementedError("MODEL.N_HEAD=%r: the shipped configs use single-head inter-human attention" % (M["N_HEAD"],))
-    if M["NORMALIZE_BEFORE"]:
-        raise NotImplementedError("NORMALIZE_BEFORE: every shipped config is post-norm")
+    if name not in ("hrnet", "hrformer"):  # (every other model builds DETR-style encoder layers from these two keys)
+        heads, d = M["N_HEAD"], M["DIM_MODEL"]
+        if heads < 1 or d % heads:  # (nn.MultiheadAttention asserts the same)
+            raise ValueError("MODEL.DIM_MODEL=%r must be divisible by MODEL.N_HEAD=%r" % (d, heads))
+        if _r16(d // heads) > 256:
+            raise NotImplementedError("head dim %d > 256 (i2r_mh_attention)" % (d // heads,))
     if name not in ("hrnet", "transpose_h", "hrformer", "interformer_pureMulti", "interformer", "interformer_2stage"):
         raise NotImplementedError("MODEL.NAME=%r" % (name,))
     if name in ("hrnet", "transpose_h", "hrformer"):
@@ -1654,6 +1760,10 @@ class Engine:
         self.name = name or M["NAME"]
         pk = Packer(state_dict, self.device, precision)
         d, dff = M["DIM_MODEL"], M["DIM_FEEDFORWARD"]
+        self._pk = pk
+        # forward_pre exists in every copy of the layer class, but only attention.py:1040 (get_default_encoder: the inter-human stack of
+        # MODEL.NAME interformer) passes cfg.MODEL.NORMALIZE_BEFORE on; the other constructors leave the default False
+        self.pre_norm = bool(M["NORMALIZE_BEFORE"]) and self.name == "interformer"
         self.singleformer = None
         if self.name == "hrnet":  # stand-alone backbone (models/hrnet.py): tower + reduce, see forward_backbone()
             self.tower = HRNetW48(pk, "", M["EXTRA"])
@@ -1667,7 +1777,7 @@ class Engine:
             self.use_pos = bool(M["USE_MULTI_POS"])
             if self.use_pos:
                 self._pack_pos(pk, "position_embedding", M["MULTI_POS_EMBEDDING"])
-            self.layers = [pk.encoder_layer("global_encoder.layers.%d" % l, d, dff) for l in range(M["ENCODER_LAYERS"])]
+            self.layers = [self._enc_layer("global_encoder.layers.%d" % l) for l in range(M["ENCODER_LAYERS"])]
             self.deconvs = [pk.deconv("deconv_layers.0", "deconv_layers.1")] * 2  # the same layer twice (:774-775)
             self.head = pk.head("final_layer")
         elif self.name in ("interformer", "interformer_2stage"):
@@ -1682,8 +1792,7 @@ class Engine:
             self.use_pos = bool(M["USE_MULTI_POS"])
             if self.use_pos:
                 self._pack_pos(pk, "multi_position_embedding", M["MULTI_POS_EMBEDDING"])
-            self.layers = [pk.encoder_layer("multi_global_encoder.layers.%d" % l, d, dff)
-                           for l in range(M["ENCODER_MULTI_LAYERS"])]
+            self.layers = [self._enc_layer("multi_global_encoder.layers.%d" % l, self.pre_norm) for l in range(M["ENCODER_MULTI_LAYERS"])]
             up = M["UPSAMPLE_TYPE"]
             if up == "deconv" and self.name == "interformer_2stage":  # deconv_layers1..3, as many as pooling steps (:366-379)
                 w4 = M["IMAGE_SIZE"][0] // 4
@@ -1702,6 +1811,17 @@ class Engine:
         else:
             raise NotImplementedError("MODEL.NAME=%r" % self.name)
 
+    def _enc_layer(self, p, pre_norm=False):
+        """One encoder layer under state-dict prefix p: the fused single-head post-norm kernels (i2r_encoder_layer) for what every shipped
+        yaml asks for, else the general layer around i2r_mh_attention (any N_HEAD, pre-norm, other widths), always in fp32."""
+        M = self.cfg["MODEL"]
+        d, dff, heads = M["DIM_MODEL"], M["DIM_FEEDFORWARD"], M["N_HEAD"]
+        if heads == 1 and not pre_norm and _r16(d) in (96, 80) and _r16(dff) == 192:
+            return self._pk.encoder_layer(p, d, dff)
+        if getattr(self, "_pk32", None) is None:
+            self._pk32 = self._pk if self._pk.dtype == 0 else Packer(self._pk.sd, self.device, "fp32")
+        return self._pk32.encoder_layer_mh(p, d, dff, heads)
+
     def _pack_single(self, pk, sf, p):
         """first (intra-human) stage under key prefix p: transpose_h.TransPoseH (:418-480) or hrformer.HRFormer (:2470-2476)"""
         M = self.cfg["MODEL"]
@@ -1713,7 +1833,7 @@ class Engine:
             w, h = M["IMAGE_SIZE"]
             self.single_tokens = (h // 2 ** self.res_layer // 4) * (w // 2 ** self.res_layer // 4)
             self.single_pos = pk.table(p + "pos_embedding", self.single_tokens, d) if M["POS_EMBEDDING"] != "none" else None
-            self.single_layers = [pk.encoder_layer("%sglobal_encoder.layers.%d" % (p, l), d, dff) for l in range(M["ENCODER_LAYERS"])]
+            self.single_layers = [self._enc_layer("%sglobal_encoder.layers.%d" % (p, l)) for l in range(M["ENCODER_LAYERS"])]
             self.single_head = pk.head(p + "final_layer")
         else:
             self.tower = HRFormerB(pk, p)
@@ -1729,7 +1849,7 @@ class Engine:
         tok = f.h * f.w
         assert tok == self.single_tokens, "input size does not match MODEL.IMAGE_SIZE (pos_embedding rows)"
         g = P.encoder(f, self.single_layers, [i * tok for i in range(S + 1)],
-                      pos=self.single_pos.data_ptr() if self.single_pos is not None else 0, pos_period=tok)
+                      pos=self.single_pos.data_ptr() if self.single_pos is not None else 0, pos_period=tok, pos_table=self.single_pos)
         P.release(f)
         return g, stem_args
 
@@ -1819,7 +1939,7 @@ class Engine:
         offs = [0]
         for n in length:
             offs.append(offs[-1] + n * tok)
-        e = P.encoder(f, self.layers, offs, pos=pos_ptr, regroupable=True)
+        e = P.encoder(f, self.layers, offs, pos=pos_ptr, regroupable=True, pre_norm=self.pre_norm)
         for i, dc in enumerate(self.deconvs):
             last = i == len(self.deconvs) - 1
             # 2-stage models add the first-stage features AFTER the deconv's ReLU (x = single_res + x, interformer.py:315)

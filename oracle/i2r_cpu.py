@@ -134,15 +134,17 @@ def hrnet_w48_stages(sd, p, x, extra, collect=None):
 
 
 # --------------------------------------------------------------------------------------------------
-# DETR-style post-norm encoder layer (interformer_pureMulti.py:192-213, attention.py:61-82,
-# transpose_h.py:189-210); nn.MultiheadAttention with one head (or n_head heads)
+# DETR-style encoder layer: post-norm (forward_post: interformer_pureMulti.py:192-213, attention.py:61-82,
+# transpose_h.py:189-210) or pre-norm (forward_pre: attention.py:84-103 -- q and k from norm1(src) + pos, the VALUE from src
+# itself, no norm after the residuals); nn.MultiheadAttention with n_head heads
 # --------------------------------------------------------------------------------------------------
-def encoder_layer(sd, p, src, pos, key_mask, n_head=1):
+def encoder_layer(sd, p, src, pos, key_mask, n_head=1, pre_norm=False):
     """src [B, L, d]; pos [B or 1, L, d] or None; key_mask bool [B, L] (True = padded key) or None."""
     B, L, d = src.shape
     hd = d // n_head
     w, b = sd[p + ".self_attn.in_proj_weight"], sd[p + ".self_attn.in_proj_bias"]
-    qk_in = src if pos is None else src + pos
+    qk_in = F.layer_norm(src, (d,), sd[p + ".norm1.weight"], sd[p + ".norm1.bias"], 1e-5) if pre_norm else src
+    qk_in = qk_in if pos is None else qk_in + pos
     q = F.linear(qk_in, w[:d], b[:d]) * (hd ** -0.5)
     k = F.linear(qk_in, w[d:2 * d], b[d:2 * d])
     v = F.linear(src, w[2 * d:], b[2 * d:])
@@ -155,6 +157,11 @@ def encoder_layer(sd, p, src, pos, key_mask, n_head=1):
     a = torch.softmax(s, dim=-1) @ v
     a = a.transpose(1, 2).reshape(B, L, d)
     a = F.linear(a, sd[p + ".self_attn.out_proj.weight"], sd[p + ".self_attn.out_proj.bias"])
+    if pre_norm:
+        src = src + a
+        f = F.layer_norm(src, (d,), sd[p + ".norm2.weight"], sd[p + ".norm2.bias"], 1e-5)
+        f = F.linear(F.relu(F.linear(f, sd[p + ".linear1.weight"], sd[p + ".linear1.bias"])), sd[p + ".linear2.weight"], sd[p + ".linear2.bias"])
+        return src + f
     src = F.layer_norm(src + a, (d,), sd[p + ".norm1.weight"], sd[p + ".norm1.bias"], 1e-5)
     f = F.linear(F.relu(F.linear(src, sd[p + ".linear1.weight"], sd[p + ".linear1.bias"])),
                  sd[p + ".linear2.weight"], sd[p + ".linear2.bias"])
@@ -177,7 +184,7 @@ def _unpad_persons(t, length):
     return torch.cat([t[b, :n] for b, n in enumerate(length)], dim=0)
 
 
-def inter_human_encoder(sd, p, n_layers, feat, pos, length, n_head=1, collect=None):
+def inter_human_encoder(sd, p, n_layers, feat, pos, length, n_head=1, collect=None, pre_norm=False):
     """feat [S, d, h, w] (+ pos [S, d, h, w] or None) -> [S, d, h, w].
 
     Reference: pad persons per image to N=max(length), tokens ordered (n, y, x), key_padding_mask on the
@@ -195,7 +202,7 @@ def inter_human_encoder(sd, p, n_layers, feat, pos, length, n_head=1, collect=No
         mask[b, n:] = True
     mask = mask.view(B, N * h * w)
     for l in range(n_layers):
-        tok = encoder_layer(sd, "%s.layers.%d" % (p, l), tok, ptok, mask, n_head)
+        tok = encoder_layer(sd, "%s.layers.%d" % (p, l), tok, ptok, mask, n_head, pre_norm)
         if collect is not None:
             collect["%s.layers.%d" % (p, l)] = _unpad_persons(tok.view(B, N, h * w, d), length)
     out = tok.view(B, N, h, w, d).permute(0, 1, 4, 2, 3)
@@ -327,8 +334,9 @@ def forward_two_stage(sd, cfg, x, pos_mask, length, collect=None):
         pos = multi_position_embedding(sd, "multi_position_embedding", pos_mask, M["TRANS_SIZE"][-1], M["MULTI_POS_EMBEDDING"])
         if collect is not None:
             collect["pos"] = pos
+    # (only attention.py:1040 -- the inter-human stack of MODEL.NAME interformer -- hands NORMALIZE_BEFORE to its layers)
     f = inter_human_encoder(sd, "multi_global_encoder", M["ENCODER_MULTI_LAYERS"], f, pos, length,
-                            M["N_HEAD"], collect)
+                            M["N_HEAD"], collect, pre_norm=bool(M["NORMALIZE_BEFORE"]) and M["NAME"] == "interformer")
     if collect is not None:
         collect["encoder"] = f
     up = M["UPSAMPLE_TYPE"]

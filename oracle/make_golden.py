@@ -44,6 +44,17 @@ CASES = [
 ]
 
 
+# Reference-expressible settings no shipped yaml uses (the config keys of the path): base config + KEY VALUE overrides.
+# The same table lives in tests/_golden.py (VARIANTS); a variant whose overrides change the parameter inventory gets its own <tag>_keys.json.
+VARIANTS = [
+    # tag, config name, overrides, length, (H, W)
+    ("w48_nh8_l21", "w48_pure_en6", ["MODEL.N_HEAD", 8], [2, 1], (256, 192)),                 # vanilla, 8 heads of 12 dims, conv position embedding
+    ("tph_nh4_l11", "tph_192_p6_b4", ["MODEL.N_HEAD", 4], [1, 1], (256, 192)),                # both encoder stacks multi-head (sine table in stage 1)
+    ("bare_pre_l21", "w48_bare_p6", ["MODEL.NORMALIZE_BEFORE", True], [2, 1], (256, 192)),    # forward_pre, one head of 96 dims
+    ("hrt_pre_nh2_l21", "hrt_192_p4_b4", ["MODEL.NORMALIZE_BEFORE", True, "MODEL.N_HEAD", 2], [2, 1], (256, 192)),  # d = 78: heads of 39 dims
+]
+
+
 def probe(t, key):
     t = t.detach().float().reshape(-1)
     idx = (synth.uniform01(99, "probe." + key, 32) * t.numel()).astype(np.int64)
@@ -66,19 +77,23 @@ def main():
     os.makedirs(OUT, exist_ok=True)
     nets = {}
     only = set(sys.argv[1:])  # optional: regenerate just these tags
-    for tag, cname, length, (H, W), full in CASES:
+    for tag, cname, opts, length, (H, W), full in [(t, c, None, l, hw, f) for t, c, l, hw, f in CASES] + [(t, c, o, l, hw, True) for t, c, o, l, hw in VARIANTS]:
         if only and tag not in only:
             continue
-        cfg = config.load_config(cname)
-        if cname not in nets:
+        cfg = config.load_config(cname, opts)
+        nkey = cname if opts is None else tag
+        if nkey not in nets:
             net = ref_shim.build_reference_model(cfg)
             spec = synth.spec_of(net)
             sd = synth.make_state_dict(spec)
             net.load_state_dict(sd, strict=True)
-            nets[cname] = (net, sd)
-            with open(os.path.join(OUT, cname + "_keys.json"), "w") as f:
-                json.dump({k: [list(s), d] for k, s, d in spec}, f, indent=0, sort_keys=True)
-        net, sd = nets[cname]
+            nets[nkey] = (net, sd)
+            base = os.path.join(OUT, cname + "_keys.json")
+            man = {k: [list(s), d] for k, s, d in spec}
+            if opts is None or not os.path.exists(base) or json.load(open(base)) != man:  # (a variant with the base inventory re-uses its manifest)
+                with open(os.path.join(OUT, nkey + "_keys.json"), "w") as f:
+                    json.dump(man, f, indent=0, sort_keys=True)
+        net, sd = nets[nkey]
         x, m, length = synth.make_inputs(length, H, W)
         with torch.no_grad():
             y = net(x, m, length)

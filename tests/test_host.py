@@ -216,9 +216,49 @@ def test_every_shipped_yaml_builds(name):
 
 def test_validate_config_refuses_unshipped_combinations():
     from i2r_amd import engine
-    for opts in (["MODEL.N_HEAD", "8"], ["MODEL.MULTI_POS_EMBEDDING", "cat_vec"], ["MODEL.NORMALIZE_BEFORE", "True"]):
+    for opts in (["MODEL.MULTI_POS_EMBEDDING", "cat_vec"], ["MODEL.MULTI_POS_EMBEDDING", "sine"]):
         with pytest.raises(NotImplementedError):
             engine.validate_config(config.load_config("w48_pure_en6", opts))
+
+
+def test_validate_config_accepts_the_encoder_variants():
+    """MODEL.N_HEAD (yacs default 8, lib/config/default.py:63) and MODEL.NORMALIZE_BEFORE are served by the general encoder layer
+    (engine.Packer.encoder_layer_mh + i2r_mh_attention); a head count that does not divide DIM_MODEL fails like nn.MultiheadAttention"""
+    from i2r_amd import engine
+    from _golden import VARIANTS
+    for cname, opts in VARIANTS.values():
+        engine.validate_config(config.load_config(cname, opts))
+    with pytest.raises(ValueError):
+        engine.validate_config(config.load_config("hrt_192_p4_b4", ["MODEL.N_HEAD", 8]))  # DIM_MODEL 78
+    assert engine.Packer.mh_width(8, 12) == (16, 128) and engine.Packer.mh_width(2, 39) == (48, 96) and engine.Packer.mh_width(1, 96) == (96, 96)
+    assert engine.Packer.mh_width(7, 16) == (16, 128)  # 7 fragments -> 8: a count the conv kernels split
+
+
+def test_general_encoder_layer_packing_reproduces_the_layer():
+    """Packer.encoder_layer_mh on CPU tensors: the 1x1-conv weight images, unpacked, give back q / k / v / out-proj of nn.MultiheadAttention
+    in the head-padded channel order (head h's dim j at h*hp + j, scale folded into q)"""
+    from i2r_amd import engine
+    d, dff, heads = 96, 192, 8
+    spec = arch.Spec()
+    spec.encoder_layer("L", d, dff)
+    sd = synth.make_state_dict(spec)
+    pk = engine.Packer(sd, "cpu", "fp32")
+    L = pk.encoder_layer_mh("L", d, dff, heads)
+    hp, hs, hd = L["hp"], L["hs"], d // heads
+    assert (hp, hs) == (16, 128) and L["qk"].cout == 2 * hs and L["v"].cout == hs and L["o"].cin == hs
+
+    def unpack(pc):  # k4 [1, cin_pad/4, cout_pad, 4] -> [cout, cin]
+        w = pc.w.view(1, -1, pc.cout_pad, 4).permute(0, 1, 3, 2).reshape(-1, pc.cout_pad)
+        return w[:pc.cin, :pc.cout].t()
+    wi, bi = sd["L.self_attn.in_proj_weight"], sd["L.self_attn.in_proj_bias"]
+    wqk, wv, wo = unpack(L["qk"]), unpack(L["v"]), unpack(L["o"])
+    for h in range(heads):
+        rows = slice(h * hp, h * hp + hd)
+        src = slice(h * hd, (h + 1) * hd)
+        assert torch.allclose(wqk[rows], wi[:d][src] * hd ** -0.5, atol=1e-7) and torch.allclose(L["qk"].bias[rows], bi[:d][src] * hd ** -0.5, atol=1e-7)
+        assert torch.equal(wqk[hs:][rows], wi[d:2 * d][src]) and torch.equal(wv[rows], wi[2 * d:][src])
+        assert torch.equal(wo[:, rows], sd["L.self_attn.out_proj.weight"][:, src])
+        assert wqk[h * hp + hd:(h + 1) * hp].abs().max() == 0 and wo[:, h * hp + hd:(h + 1) * hp].abs().max() == 0
 
 
 def test_conv_cat_folds_the_downsample_into_conv3():

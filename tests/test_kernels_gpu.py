@@ -664,6 +664,78 @@ def test_encoder_layer_matches_oracle(d, length, hw, use_pos):
         assert out.t.view(-1, out.cs)[:, 78:].abs().max().item() == 0.0
 
 
+@pytest.mark.parametrize("d,heads,pre_norm,length,hw,use_pos,n_layers", [
+    (96, 8, False, [3, 1, 2], (16, 12), True, 2),    # yacs default N_HEAD: heads of 12 dims padded to 16
+    (96, 2, False, [2, 1], (6, 6), True, 1),          # heads of 48 dims; 36 tokens per person: partial query / key tiles
+    (96, 1, True, [1, 2], (16, 12), True, 2),         # forward_pre with one head of 96 dims
+    (96, 4, True, [3], (5, 4), False, 1),             # heads of 24 dims (-> 32), 60 tokens, pre-norm without position embedding
+    (78, 2, False, [2, 3], (16, 12), False, 1),       # HRFormer inter-human width: heads of 39 dims (-> 48), rows padded to 80
+    (78, 6, True, [1], (16, 12), True, 1),            # heads of 13 dims (-> 16): 6 x 16 = 96 wide parts
+    (96, 3, False, [5], (24, 18), True, 1),           # 2160 keys in one group, heads of 32 dims
+])
+def test_general_encoder_layer_matches_oracle(d, heads, pre_norm, length, hw, use_pos, n_layers):
+    """Packer.encoder_layer_mh + Program.encoder_mh (1x1 convs, i2r_layernorm, i2r_mh_attention) against the oracle's encoder_layer with
+    n_head / pre_norm (reference attention.py:61-103)"""
+    h, w = hw
+    S = sum(length)
+    sd2, layers = {}, []
+    for i in range(n_layers):
+        one = _encoder_sd(d, 192, "mh%d_%d_%d_%d" % (i, d, heads, S))
+        sd2.update({k.replace("L.", "E.layers.%d." % i): v for k, v in one.items()})
+        layers.append(engine.Packer(one, torch.device(DEV)).encoder_layer_mh("L", d, 192, heads))
+    feat = _rand((S, d, h, w), "mf%d%d%d" % (d, heads, S))
+    pos = _rand((S, d, h, w), "mp%d%d%d" % (d, heads, S), 0.5) if use_pos else None
+    ref = i2r_cpu.inter_human_encoder(sd2, "E", n_layers, feat, pos, length, n_head=heads, pre_norm=pre_norm)
+    P = engine.Program(torch.device(DEV))
+    fa = to_act(P, feat)
+    pa = to_act(P, pos) if use_pos else None
+    offs = [0]
+    for n in length:
+        offs.append(offs[-1] + n * h * w)
+    out = P.encoder(fa, layers, offs, pos=pa.ptr if pa is not None else 0, pre_norm=pre_norm)
+    assert sum(1 for k, _, _ in P.ops if k == engine.cabi.OP_MH_ATTN) == n_layers
+    run(P)
+    run(P)  # replay on recycled activation buffers
+    got = from_act(out)
+    err = (got - ref).abs().max().item()
+    assert err < 2e-4 * max(1.0, ref.abs().max().item() / 4), "general encoder d=%d heads=%d pre=%s max-abs %.3e" % (d, heads, pre_norm, err)
+    if d == 78:
+        assert out.t.view(-1, out.cs)[:S * h * w, 78:].abs().max().item() == 0.0
+
+
+def test_general_encoder_regroups_without_rebuilding():
+    """Program.set_groups on a general stack: the same program under another persons-per-image grouping equals a program built for it"""
+    d, heads, h, w = 96, 8, 16, 12
+    one = _encoder_sd(d, 192, "mhrg")
+    sd2 = {k.replace("L.", "E.layers.0."): v for k, v in one.items()}
+    L = engine.Packer(one, torch.device(DEV)).encoder_layer_mh("L", d, 192, heads)
+    feat = _rand((4, d, h, w), "mhrgf")
+    P = engine.Program(torch.device(DEV))
+    fa = to_act(P, feat)
+    out = P.encoder(fa, [L], [0, 2 * h * w, 4 * h * w], regroupable=True)
+    run(P)
+    a = from_act(out).clone()
+    grouping, tok = P.groupings[-1]
+    P.set_groups(grouping, [0, 3 * tok, 4 * tok])
+    run(P)
+    b = from_act(out)
+    for length, got in (([2, 2], a), ([3, 1], b)):
+        ref = i2r_cpu.inter_human_encoder(sd2, "E", 1, feat, None, length, n_head=heads)
+        assert (got - ref).abs().max().item() < 2e-4
+
+
+def test_mh_attention_rejects_bad_arguments():
+    import ctypes as C
+    from i2r_amd import cabi
+    L = cabi.lib()
+    t = torch.zeros(64 * 64, device=DEV)
+    g = torch.tensor([0, 16], dtype=torch.int32, device=DEV)
+    ok = dict(qk=t.data_ptr(), v=t.data_ptr(), out=t.data_ptr(), grp_off=g.data_ptr(), n_grp=1, heads=2, hp=16, k_off=32, qk_cs=64, v_cs=32, out_cs=32, n_qtiles16=1)
+    for bad in (dict(hp=12), dict(hp=272), dict(k_off=16), dict(qk_cs=48), dict(v_cs=16), dict(out_cs=30), dict(n_qtiles16=0), dict(heads=0), dict(qk=None)):
+        a = cabi.MhAttnArgs(**dict(ok, **bad))
+        assert L.i2r_mh_attention(C.byref(a), None) != 0 and b"i2r_mh_attention" in L.i2r_last_error()
+
+
 def _encoder_stack_case(n_layers, length, hw, d=96, want_out=False):
     """multi-layer stack: layers > 0 take K / V from the fused tail of the previous layer (ping-pong fragment buffers)"""
     h, w = hw

@@ -6,7 +6,7 @@ import pytest
 import torch
 
 import i2r_cpu
-from _golden import CASES, setup
+from _golden import CASES, VARIANTS, setup
 from i2r_amd import cabi, models
 
 pytestmark = pytest.mark.gpu
@@ -46,6 +46,31 @@ def test_heatmaps_match_reference_golden(tag):
         if "out_" + k in g:
             err_ref = np.abs(t.numpy() - g["out_" + k]).max()
             assert err_ref < TOL, "%s/%s vs reference golden max-abs %.3e" % (tag, k, err_ref)
+
+
+@pytest.mark.parametrize("tag", sorted(VARIANTS))
+def test_variant_heatmaps_match_reference_golden(tag):
+    """Reference-expressible settings no shipped yaml uses (MODEL.N_HEAD > 1, MODEL.NORMALIZE_BEFORE, ...): golden heat maps produced by
+    the reference itself under the same KEY VALUE overrides (oracle/make_golden.py VARIANTS)"""
+    cfg, sd, x, m, length, g = setup(tag)
+    net = eval("models." + cfg.MODEL.NAME + ".get_pose_net")(cfg, is_train=False)
+    net.load_state_dict(sd, strict=True)
+    net = net.cuda()
+    y = net(x.cuda(), m.cuda(), length)
+    torch.cuda.synchronize()
+    outs = y if isinstance(y, dict) else {"multi": y}
+    for k, t in outs.items():
+        ref = g["out_" + k]
+        t = t.cpu().numpy()
+        assert t.shape == ref.shape and np.isfinite(t).all()
+        err = np.abs(t - ref).max()
+        assert err < TOL * max(1.0, np.abs(ref).max() / 8), "%s/%s vs reference golden max-abs %.3e (max|ref| %.1f)" % (tag, k, err, np.abs(ref).max())
+    progs = [P for P, _ in net.engine().programs.values()]
+    if cfg.MODEL.N_HEAD > 1 or cfg.MODEL.NORMALIZE_BEFORE:
+        assert sum(1 for P in progs for k, _, _ in P.ops if k == cabi.OP_MH_ATTN) > 0
+    y2 = net(x.cuda(), m.cuda(), length)  # replay of the cached program
+    for k, t in (y2 if isinstance(y2, dict) else {"multi": y2}).items():
+        assert torch.equal(t, outs[k])
 
 
 def test_direct_conv_path_still_matches_reference():

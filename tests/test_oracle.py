@@ -4,7 +4,7 @@ import pytest
 import torch
 
 import i2r_cpu
-from _golden import CASES, probe_of, setup
+from _golden import CASES, VARIANTS, probe_of, setup
 
 
 def _flatten(collect):
@@ -18,7 +18,7 @@ def _flatten(collect):
     return out
 
 
-@pytest.mark.parametrize("tag", sorted(CASES))
+@pytest.mark.parametrize("tag", sorted(CASES) + sorted(VARIANTS))
 def test_oracle_matches_reference_golden(tag):
     torch.set_num_threads(8)
     cfg, sd, x, m, length, g = setup(tag)
