@@ -135,6 +135,16 @@ def multi_position_embedding(spec, p, mode, d_model, trans_size, vec_dim):
         raise ValueError("MULTI_POS_EMBEDDING=%r" % mode)
 
 
+def upconv(spec, p, d):
+    """UpConv (interformer.py:25-64, interformer_2stage.py:174-206): fuse_layers = conv1x1 + BN (+ nearest Upsample), double_conv =
+    (conv3x3 + BN + ReLU) x 2"""
+    spec.conv(p + ".fuse_layers.0", d, d, 1)
+    spec.bn(p + ".fuse_layers.1", d)
+    for i in (0, 3):
+        spec.conv(p + ".double_conv.%d" % i, d, d, 3)
+        spec.bn(p + ".double_conv.%d" % (i + 1), d)
+
+
 def vanilla_spec(cfg):
     """interformer_pureMulti.TransPoseH (:421-494)."""
     M = cfg["MODEL"]
@@ -226,6 +236,8 @@ def interformer_spec(cfg):
         if extra["DECONV_WITH_BIAS"]:
             spec.append(("deconv_layers.0.bias", (planes,), F32))
         spec.bn("deconv_layers.1", planes)
+    elif up == "upconv":
+        upconv(spec, "upsample_layer", d)
     else:
         raise NotImplementedError("UPSAMPLE_TYPE=%r" % up)
     spec.conv("final_layer", M["NUM_JOINTS"], d, extra["FINAL_CONV_KERNEL"], bias=True)
@@ -248,9 +260,11 @@ def interformer_2stage_spec(cfg):
         spec.encoder_layer("multi_global_encoder.layers.%d" % l, d, M["DIM_FEEDFORWARD"])
     planes = extra["NUM_DECONV_FILTERS"][0]
     up = M["UPSAMPLE_TYPE"]
-    names = {"multiplex": ["deconv_layers"], "deconv": ["deconv_layers1", "deconv_layers2", "deconv_layers3"]}
+    names = {"multiplex": ["deconv_layers"], "deconv": ["deconv_layers1", "deconv_layers2", "deconv_layers3"], "upconv": []}
     if up not in names:
         raise NotImplementedError("UPSAMPLE_TYPE=%r" % up)
+    if up == "upconv":
+        upconv(spec, "upsample_conv", d)
     for n in names[up]:
         spec.append((n + ".0.weight", (planes, planes, 4, 4), F32))
         if extra["DECONV_WITH_BIAS"]:

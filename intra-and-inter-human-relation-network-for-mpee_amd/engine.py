@@ -295,9 +295,28 @@ class Packer:
                     blocks=blocks, conv_end=self.conv(p + ".conv_end"))
 
     def head(self, key):
+        """final_layer (with bias) for i2r_head.  EXTRA.FINAL_CONV_KERNEL = 3 (padding 1; interformer.py:176-182, interformer_pureMulti.py:486-492,
+        transpose_h.py:472-478): the 3x3 conv runs on the conv kernel with its outputs padded to 48 channels (zero weights: a width the kernel
+        splits), and i2r_head -- the kernel that writes the boundary NCHW layout -- follows with an identity matrix and no bias (exact in fp32)."""
         w = self.sd[key + ".weight"]
         cout, cin, kh, kw = w.shape
-        assert kh == 1 and kw == 1, "FINAL_CONV_KERNEL=3 heads are not used by the shipped configs"
+        assert kh == kw and kh in (1, 3), "final_layer kernel %dx%d" % (kh, kw)
+        if kh == 3:
+            cp = 48
+            assert cout <= 32
+            w_taps = torch.zeros(9, cin, cp, dtype=torch.float64)
+            w_taps[:, :, :cout] = w.double().permute(2, 3, 1, 0).reshape(9, cin, cout)
+            bias = torch.zeros(cp, dtype=torch.float64)
+            bias[:cout] = self.sd[key + ".bias"].double()
+            taps = [(dy, dx) for dy in range(3) for dx in range(3)]
+            pc = self._pc(w_taps, self._dev(bias.float()), cin, cp, taps, -1, -1, 1, 3)
+            if self.dtype == 0:
+                wf = torch.zeros(cp, cin, 3, 3, dtype=torch.float64)
+                wf[:cout] = w.double()
+                pc.w_wino = self._dev(pack_k4(winograd_weights(wf), _r16(cin), cp))
+            eye = torch.zeros(cout, cp)
+            eye[torch.arange(cout), torch.arange(cout)] = 1.0
+            return dict(w=self._dev(eye), bias=self._dev(torch.zeros(cout)), cin=cp, cout=cout, conv3=pc)
         cin_pad = _r16(cin)
         wp = torch.zeros(cout, cin_pad)
         wp[:, :cin] = w.view(cout, cin)
@@ -1077,8 +1096,13 @@ class Program:
     def head(self, x, hd, out_ptr=0, lane=0):
         assert x.dt == 0, "fp32 kernel: the producer must store fp32 (conv(..., out_dt=0))"
         self.keep.append(hd)
+        tmp = None
+        if hd.get("conv3") is not None:  # FINAL_CONV_KERNEL 3: the conv kernel does the 3x3 (+ bias), i2r_head only transposes to NCHW
+            x = tmp = self.conv(x, hd["conv3"], out_dt=0, lane=lane)
         a = cabi.HeadArgs(x.ptr, hd["w"].data_ptr(), hd["bias"].data_ptr(), out_ptr, x.n, x.h, x.w, hd["cin"], x.cs, hd["cout"])
         self.ops.append((cabi.OP_HEAD, lane, a))
+        if tmp is not None:
+            self.release(tmp)
         return a
 
     def encoder(self, x, layers, grp_off_host, pos=None, pos_period=0, lane=0, regroupable=False, pre_norm=False, pos_table=None):
@@ -1669,12 +1693,12 @@ def validate_config(cfg, name=None):
             raise NotImplementedError("interformer_2stage always has a first stage")
         if sf == "hrformer" and M["DIM_MODEL"] != 78:
             raise NotImplementedError("HRFormer-B emits 78 channels (hrformer.py:2527), DIM_MODEL=%r" % (M["DIM_MODEL"],))
-        if M["UPSAMPLE_TYPE"] not in ("deconv", "multiplex"):
+        if M["UPSAMPLE_TYPE"] not in ("deconv", "multiplex", "upconv"):
             raise NotImplementedError("UPSAMPLE_TYPE=%r" % (M["UPSAMPLE_TYPE"],))
         if M["ATTENTION_TYPE"] != "default":
             raise NotImplementedError("ATTENTION_TYPE=%r" % (M["ATTENTION_TYPE"],))
-    if M["EXTRA"]["FINAL_CONV_KERNEL"] != 1:
-        raise NotImplementedError("FINAL_CONV_KERNEL=%r (shipped configs: 1)" % (M["EXTRA"]["FINAL_CONV_KERNEL"],))
+    if M["EXTRA"]["FINAL_CONV_KERNEL"] not in (1, 3):  # (the reference pads only the 3x3 case: any other size changes the map size)
+        raise NotImplementedError("FINAL_CONV_KERNEL=%r (1 or 3)" % (M["EXTRA"]["FINAL_CONV_KERNEL"],))
 
 
 _LANE_STREAMS = {}  # device -> side streams shared by every Engine of the process
@@ -1804,6 +1828,13 @@ class Engine:
                                 for i in range(n)]
             elif up == "multiplex":
                 self.deconvs = [pk.deconv("deconv_layers.0", "deconv_layers.1")] * 2
+            elif up == "upconv":
+                # UpConv (interformer.py:25-64 as upsample_layer; interformer_2stage.py:174-206,244 as upsample_conv): 1x1 conv + BN, nearest
+                # upsampling by HEATMAP_SIZE[0] // TRANS_SIZE[1] (the conv kernel replicates its outputs), then (3x3 conv + BN + ReLU) twice
+                q = "upsample_layer" if self.name == "interformer" else "upsample_conv"
+                self.deconvs = []
+                self.upconv = dict(scale=M["HEATMAP_SIZE"][0] // M["TRANS_SIZE"][1], fuse=pk.conv(q + ".fuse_layers.0", q + ".fuse_layers.1"),
+                                   c1=pk.conv(q + ".double_conv.0", q + ".double_conv.1"), c2=pk.conv(q + ".double_conv.3", q + ".double_conv.4"))
             else:
                 raise NotImplementedError("UPSAMPLE_TYPE=%r" % up)
             self.head = pk.head("final_layer")
@@ -1940,6 +1971,14 @@ class Engine:
         for n in length:
             offs.append(offs[-1] + n * tok)
         e = P.encoder(f, self.layers, offs, pos=pos_ptr, regroupable=True, pre_norm=self.pre_norm)
+        uc = getattr(self, "upconv", None)
+        if uc is not None:
+            u = P.conv(e, uc["fuse"], up=uc["scale"])
+            P.release(e)
+            t = P.conv(u, uc["c1"], relu=True)
+            P.release(u)
+            e = P.conv(t, uc["c2"], relu=True, res_post=single_feat)  # (2-stage models: x = single_res + x behind the ReLU, interformer.py:315)
+            P.release(t)
         for i, dc in enumerate(self.deconvs):
             last = i == len(self.deconvs) - 1
             # 2-stage models add the first-stage features AFTER the deconv's ReLU (x = single_res + x, interformer.py:315)

@@ -56,6 +56,20 @@ def _deconv_bn_relu(sd, p_deconv, p_bn, x):
 # HRNet-W48-S backbone (interformer_pureMulti.py:37-107, 246-410, 543-633, 675-704; same code in
 # transpose_h.py:621-647)
 # --------------------------------------------------------------------------------------------------
+def _final_layer(sd, p, x):
+    """final_layer: Conv2d(d, J, FINAL_CONV_KERNEL, padding = 1 if the kernel is 3 else 0) with bias (interformer.py:176-182)"""
+    w = sd[p + ".weight"]
+    return F.conv2d(x, w, sd[p + ".bias"], padding=1 if w.shape[-1] == 3 else 0)
+
+
+def _upconv(sd, p, x, scale):
+    """UpConv.forward (interformer.py:25-64 / interformer_2stage.py:174-206): conv1x1 + BN, nearest Upsample(scale), (conv3x3 + BN + ReLU) x 2"""
+    x = _bn(sd, p + ".fuse_layers.1", _conv(sd, p + ".fuse_layers.0", x, pad=0))
+    x = F.interpolate(x, scale_factor=scale, mode="nearest")
+    x = F.relu(_bn(sd, p + ".double_conv.1", _conv(sd, p + ".double_conv.0", x)))
+    return F.relu(_bn(sd, p + ".double_conv.4", _conv(sd, p + ".double_conv.3", x)))
+
+
 def _basic_block(sd, p, x):
     """interformer_pureMulti.py:50-66"""
     o = F.relu(_bn(sd, p + ".bn1", _conv(sd, p + ".conv1", x)))
@@ -262,7 +276,7 @@ def forward_vanilla(sd, cfg, x, pos_mask, length, collect=None):
     f = _deconv_bn_relu(sd, "deconv_layers.0", "deconv_layers.1", f)
     if collect is not None:
         collect["deconv"] = f
-    return F.conv2d(f, sd["final_layer.weight"], sd["final_layer.bias"])
+    return _final_layer(sd, "final_layer", f)
 
 
 # --------------------------------------------------------------------------------------------------
@@ -300,7 +314,7 @@ def forward_transpose_h(sd, p, cfg, x, collect=None):
         if collect is not None:
             collect["single.layers.%d" % l] = tok
     f = tok.transpose(1, 2).reshape(S, d, h, w)
-    return f, F.conv2d(f, sd[p + "final_layer.weight"], sd[p + "final_layer.bias"])
+    return f, _final_layer(sd, p + "final_layer", f)
 
 
 # --------------------------------------------------------------------------------------------------
@@ -340,7 +354,9 @@ def forward_two_stage(sd, cfg, x, pos_mask, length, collect=None):
     if collect is not None:
         collect["encoder"] = f
     up = M["UPSAMPLE_TYPE"]
-    if M["NAME"] == "interformer_2stage":  # interformer_2stage.py:366-379: as many layers as pooling steps were taken
+    if up == "upconv":  # interformer.py:311-312 (upsample_layer) / interformer_2stage.py:379-380 (upsample_conv)
+        f = _upconv(sd, "upsample_layer" if M["NAME"] == "interformer" else "upsample_conv", f, M["HEATMAP_SIZE"][0] // M["TRANS_SIZE"][1])
+    elif M["NAME"] == "interformer_2stage":  # interformer_2stage.py:366-379: as many layers as pooling steps were taken
         n = int(math.log(feat.shape[-1] // f.shape[-1], 2))
         for i in range(n):
             key = "deconv_layers" if up == "multiplex" else "deconv_layers%d" % (i + 1)
@@ -358,7 +374,7 @@ def forward_two_stage(sd, cfg, x, pos_mask, length, collect=None):
         raise NotImplementedError("UPSAMPLE_TYPE=%r" % up)
     if feat is not None:
         f = feat + f  # residual (:315)
-    multi = F.conv2d(f, sd["final_layer.weight"], sd["final_layer.bias"])
+    multi = _final_layer(sd, "final_layer", f)
     if M["INTER_SUPERVISION"] and not M["SINGLEFORMER_FIX"] and feat is not None:
         return {"single": single, "multi": multi}
     return multi

@@ -52,6 +52,9 @@ VARIANTS = [
     ("tph_nh4_l11", "tph_192_p6_b4", ["MODEL.N_HEAD", 4], [1, 1], (256, 192)),                # both encoder stacks multi-head (sine table in stage 1)
     ("bare_pre_l21", "w48_bare_p6", ["MODEL.NORMALIZE_BEFORE", True], [2, 1], (256, 192)),    # forward_pre, one head of 96 dims
     ("hrt_pre_nh2_l21", "hrt_192_p4_b4", ["MODEL.NORMALIZE_BEFORE", True, "MODEL.N_HEAD", 2], [2, 1], (256, 192)),  # d = 78: heads of 39 dims
+    ("w48_fk3_l21", "w48_pure_en6", ["MODEL.EXTRA.FINAL_CONV_KERNEL", 3], [2, 1], (256, 192)),            # 3x3 final_layer (padding 1)
+    ("tph_up_l21", "tph_192_p6_b4", ["MODEL.UPSAMPLE_TYPE", "upconv"], [2, 1], (256, 192)),               # interformer.UpConv (upsample_layer.*)
+    ("tph2s_up_fk3_l12", "coco_tph_192_p4_b4", ["MODEL.UPSAMPLE_TYPE", "upconv", "MODEL.EXTRA.FINAL_CONV_KERNEL", 3], [1, 2], (256, 192)),  # interformer_2stage.UpConv (upsample_conv.*), both heads 3x3
 ]
 
 

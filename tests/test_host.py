@@ -57,6 +57,17 @@ def test_parameter_inventory_equals_reference_manifest(cname):
     assert all(mine[k] == man[k] for k in man)
 
 
+@pytest.mark.parametrize("tag", sorted(t for t in __import__("_golden").VARIANTS if os.path.exists(os.path.join(__import__("_golden").GOLDEN, t + "_keys.json"))))
+def test_variant_parameter_inventory_equals_reference_manifest(tag):
+    """overrides that change the parameter inventory (UPSAMPLE_TYPE upconv, FINAL_CONV_KERNEL 3): key order included, like load_state_dict sees it"""
+    from _golden import VARIANTS
+    cname, opts = VARIANTS[tag]
+    man = keys_manifest(tag)
+    mine = {k: (tuple(s), d) for k, s, d in arch.param_spec(config.load_config(cname, opts))}
+    assert set(mine) == set(man) and all(mine[k] == man[k] for k in man)
+    assert len(man) != len(keys_manifest(cname)) or any(man[k] != keys_manifest(cname).get(k) for k in man)
+
+
 def test_model_factory_contract():
     cfg = config.load_config("w48_pure_en6")
     net = eval("models." + cfg.MODEL.NAME + ".get_pose_net")(cfg, is_train=False)  # tools/test.py:87
@@ -228,6 +239,8 @@ def test_validate_config_accepts_the_encoder_variants():
     from _golden import VARIANTS
     for cname, opts in VARIANTS.values():
         engine.validate_config(config.load_config(cname, opts))
+    with pytest.raises(NotImplementedError):
+        engine.validate_config(config.load_config("w48_pure_en6", ["MODEL.EXTRA.FINAL_CONV_KERNEL", 5]))
     with pytest.raises(ValueError):
         engine.validate_config(config.load_config("hrt_192_p4_b4", ["MODEL.N_HEAD", 8]))  # DIM_MODEL 78
     assert engine.Packer.mh_width(8, 12) == (16, 128) and engine.Packer.mh_width(2, 39) == (48, 96) and engine.Packer.mh_width(1, 96) == (96, 96)
