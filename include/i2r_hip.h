@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define I2R_ABI_VERSION 10
+#define I2R_ABI_VERSION 11
 
 /* The library is built with -fvisibility=hidden: the entry points declared in this header (marked I2R_API) are its ONLY exported
  * symbols (tests/test_host.py holds the header, the dynamic symbol table and cabi.EXPORTS equal). */
@@ -158,6 +158,19 @@ I2R_API int i2r_stem_conv(const float* in_nchw, const float* w, const float* bia
  * folded in, bias[64].  n_src / n_valid as in i2r_stem_conv (mirrored copies for the flip test, capacity padding). */
 I2R_API int i2r_pe_res_stem(const float* mask_nchw, const float* w_pre, const float* w7, const float* bias, float* out_nhwc,
                     int32_t n_img, int32_t in_h, int32_t in_w, int32_t cout, int32_t out_cs, int32_t n_src, int32_t n_valid, void* stream);
+
+/* i2r_pe_cat_vec -- PositionEmbeddingImage mode 'cat_vec' (position_embedding.py:19-23,69-87): per person, the boundary NCHW bbox mask
+ * [n_src, 1, in_h, in_w] max-pooled `rate` times (MaxPool2d(3, 2, 1)) down to th x tw, flattened, through nn.Linear(th*tw, vec)
+ * (w: float[vec][th*tw] as the reference stores it, bias[vec]), the resulting vector repeated over the th*tw tokens of the person:
+ * written into channels [c0, c0 + vec) of the NHWC token rows out [n_img, th, tw, out_cs]; channels [c0 + vec, c_end) get zeros.
+ * c0 = 0: the additive embedding of interformer_pureMulti.py:757,770 / interformer_2stage.py:398-406 (vec = DIM_MODEL there);
+ * c0 = DIM_MODEL: the second half of torch.cat([x, multi_pos], dim=2) in interformer.py:296-298 (the first half is written by
+ * the launch that produces x).  n_src / n_valid as in i2r_stem_conv (mirrored copies for the flip test, capacity padding). */
+typedef struct i2r_pe_cat_vec_args {
+    const float* in; const float* w; const float* bias; float* out;
+    int32_t n_img, in_h, in_w, th, tw, rate, vec, out_cs, c0, c_end, n_src, n_valid;
+} i2r_pe_cat_vec_args;
+I2R_API int i2r_pe_cat_vec(const i2r_pe_cat_vec_args* a, void* stream);
 
 /* i2r_maxpool3x3s2 -- nn.MaxPool2d(kernel_size=3, stride=2, padding=1) on NHWC
  * (interformer.py:162,260-264; position_embedding.py:9,106-109).  c % 4 == 0. */
@@ -458,7 +471,7 @@ enum {
     I2R_OP_ENC_KV = 5, I2R_OP_ENC_LAYER = 6, I2R_OP_FORK = 7, I2R_OP_JOIN = 8, I2R_OP_CONV_GROUP = 9,
     I2R_OP_LAYERNORM = 10, I2R_OP_WINATTN = 11, I2R_OP_DWCONV = 12, I2R_OP_UPSAMPLE = 13, I2R_OP_CONV_CHAIN = 14,
     I2R_OP_PE_RES_STEM = 15, I2R_OP_HRT_ATTN = 16, I2R_OP_HRT_MLP = 17, I2R_OP_XSYNC = 18, I2R_OP_FUSE_UP = 19,
-    I2R_OP_CONV1X1_PAIR = 20, I2R_OP_CONV1X1_LP = 21, I2R_OP_MH_ATTN = 22
+    I2R_OP_CONV1X1_PAIR = 20, I2R_OP_CONV1X1_LP = 21, I2R_OP_MH_ATTN = 22, I2R_OP_PE_CAT_VEC = 23
 };
 
 typedef struct i2r_stem_args {

@@ -218,10 +218,13 @@ def interformer_spec(cfg):
         raise NotImplementedError("MODEL.SINGLEFORMER=%r" % (sf,))
     multi_position_embedding(spec, "multi_position_embedding", M["MULTI_POS_EMBEDDING"], d, M["TRANS_SIZE"],
                              M["MULTI_POS_EMBEDDING_DIM"])
-    assert not (M["MULTI_POS_EMBEDDING"] == "cat_vec" and M["USE_MULTI_POS"]), "cat_vec fusion not supported"
+    wide = d
+    if M["MULTI_POS_EMBEDDING"] == "cat_vec" and M["USE_MULTI_POS"]:  # interformer.py:157-158, attention.py:1035-1040: concatenated, wider encoder
+        wide = d + M["MULTI_POS_EMBEDDING_DIM"]
+        spec.conv("fc", d, wide, 1, bias=True)
     assert M["ATTENTION_TYPE"] == "default", "only ATTENTION_TYPE 'default' is reachable from the shipped configs"
     for l in range(M["ENCODER_MULTI_LAYERS"]):
-        spec.encoder_layer("multi_global_encoder.layers.%d" % l, d, M["DIM_FEEDFORWARD"])
+        spec.encoder_layer("multi_global_encoder.layers.%d" % l, wide, M["DIM_FEEDFORWARD"])
     planes = extra["NUM_DECONV_FILTERS"][0]
     up = M["UPSAMPLE_TYPE"]
     if up == "deconv":

@@ -14,7 +14,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libi2r_hip.so")
 
 MAX_TAPS = 9
-ABI_VERSION = 10  # I2R_ABI_VERSION of include/i2r_hip.h
+ABI_VERSION = 11  # I2R_ABI_VERSION of include/i2r_hip.h
 OP_CONV, OP_STEM, OP_MAXPOOL, OP_HEAD, OP_ENC_KV, OP_ENC_LAYER, OP_FORK, OP_JOIN, OP_CONV_GROUP = 1, 2, 3, 4, 5, 6, 7, 8, 9
 MAX_GROUP = 4
 OP_LAYERNORM, OP_WINATTN, OP_DWCONV, OP_UPSAMPLE = 10, 11, 12, 13
@@ -27,6 +27,7 @@ OP_FUSE_UP = 19
 OP_CONV1X1_PAIR = 20
 OP_CONV1X1_LP = 21
 OP_MH_ATTN = 22
+OP_PE_CAT_VEC = 23
 SYNC_OPS = (OP_FORK, OP_JOIN, OP_XSYNC)  # ops whose `lane` field is a lane mask and that launch nothing
 
 _fp = C.c_void_p  # device pointers travel as integers
@@ -68,6 +69,12 @@ class StemArgs(C.Structure):
 class PeResArgs(C.Structure):
     _fields_ = [("in_", _fp), ("w_pre", _fp), ("w7", _fp), ("bias", _fp), ("out", _fp),
                 ("n_img", _i32), ("in_h", _i32), ("in_w", _i32), ("cout", _i32), ("out_cs", _i32), ("n_src", _i32), ("n_valid", _i32)]
+
+
+class PeCatVecArgs(C.Structure):
+    _fields_ = [("in_", _fp), ("w", _fp), ("bias", _fp), ("out", _fp),
+                ("n_img", _i32), ("in_h", _i32), ("in_w", _i32), ("th", _i32), ("tw", _i32), ("rate", _i32), ("vec", _i32), ("out_cs", _i32),
+                ("c0", _i32), ("c_end", _i32), ("n_src", _i32), ("n_valid", _i32)]
 
 
 class PoolArgs(C.Structure):
@@ -161,7 +168,7 @@ class Op(C.Structure):
 
 # every symbol include/i2r_hip.h declares (tests/test_host.py::test_cabi_library_exports_every_declared_symbol checks the built library exports them all)
 EXPORTS = ("i2r_conv", "i2r_conv_grouped", "i2r_conv_kernel_name", "i2r_stem_conv", "i2r_pe_res_stem", "i2r_maxpool3x3s2", "i2r_head", "i2r_layernorm", "i2r_window_attn", "i2r_hrt_attn_block", "i2r_hrt_mlp_block", "i2r_dwconv3x3",
-           "i2r_upsample_bilinear_add", "i2r_upsample_bilinear_add_multi", "i2r_fuse_up_add", "i2r_conv1x1_pair", "i2r_conv1x1_lp", "i2r_flip_merge", "i2r_decode", "i2r_crop_affine", "i2r_box_mask", "i2r_crop_affine_cv2", "i2r_box_mask_cv2", "i2r_person_inputs_cv2", "i2r_conv_chain_pack", "i2r_conv_chain", "i2r_encoder_kv", "i2r_encoder_layer", "i2r_mh_attention",
+           "i2r_upsample_bilinear_add", "i2r_upsample_bilinear_add_multi", "i2r_fuse_up_add", "i2r_conv1x1_pair", "i2r_conv1x1_lp", "i2r_flip_merge", "i2r_decode", "i2r_crop_affine", "i2r_box_mask", "i2r_crop_affine_cv2", "i2r_box_mask_cv2", "i2r_person_inputs_cv2", "i2r_conv_chain_pack", "i2r_conv_chain", "i2r_encoder_kv", "i2r_encoder_layer", "i2r_mh_attention", "i2r_pe_cat_vec",
            "i2r_run_program", "i2r_abi_version", "i2r_last_error", "i2r_device_check")
 
 _LIB = None
@@ -206,6 +213,7 @@ def load_library(path=LIB_PATH):
     L.i2r_upsample_bilinear_add.argtypes = [_fp, _fp, _fp, _i32, _i32, _i32, _i32, _i32, _i32, _i32, C.c_void_p]
     L.i2r_encoder_kv.argtypes = [C.POINTER(EncoderDesc), C.c_void_p]
     L.i2r_encoder_layer.argtypes = [C.POINTER(EncoderDesc), C.c_void_p]
+    L.i2r_pe_cat_vec.argtypes = [C.POINTER(PeCatVecArgs), C.c_void_p]
     L.i2r_mh_attention.argtypes = [C.POINTER(MhAttnArgs), C.c_void_p]
     L.i2r_run_program.argtypes = [C.POINTER(Op), _i32, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p)]
     L.i2r_device_check.argtypes = [_i32, C.POINTER(_i32), C.POINTER(_i32)]

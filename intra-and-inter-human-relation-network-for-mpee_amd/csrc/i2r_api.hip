@@ -152,6 +152,7 @@ extern "C" int i2r_run_program(const i2r_op* ops, int32_t n_ops, void* const* st
             }
             case I2R_OP_CONV1X1_PAIR: rc = i2r_conv1x1_pair((const i2r_conv1x1_pair_args*)op.args, st); break;
             case I2R_OP_CONV1X1_LP: rc = i2r_conv1x1_lp((const i2r_conv1x1_lp_args*)op.args, st); break;
+            case I2R_OP_PE_CAT_VEC: rc = i2r_pe_cat_vec((const i2r_pe_cat_vec_args*)op.args, st); break;
             case I2R_OP_MH_ATTN: rc = i2r_mh_attention((const i2r_mh_attn_args*)op.args, st); break;
             case I2R_OP_ENC_KV: rc = i2r_encoder_kv((const i2r_encoder_desc*)op.args, st); break;
             case I2R_OP_ENC_LAYER: rc = i2r_encoder_layer((const i2r_encoder_desc*)op.args, st); break;

@@ -496,6 +496,67 @@ extern "C" int i2r_pe_res_stem(const float* mask_nchw, const float* w_pre, const
     return I2R_OK;
 }
 
+namespace {
+// PositionEmbeddingImage mode 'cat_vec' (position_embedding.py:19-23, 69-87): the bbox mask of a person max-pooled `rate` times
+// (MaxPool2d(3, 2, 1): r cascaded pools = one max over the window [i 2^r - (2^r - 1), i 2^r + (2^r - 1)] clipped to the image, the
+// padding being -inf), flattened, through nn.Linear(th*tw, vec) -- one vector per person, repeated over all th*tw tokens of the person.
+// One workgroup per person crop: pooled map and vector in LDS, then the broadcast store into channels [c0, c0 + vec) of the token rows
+// (zeros up to c_end: the row padding, when this is the last part of the row).
+__global__ __launch_bounds__(256) void pe_cat_vec_k(const float* __restrict__ mask, const float* __restrict__ wfc, const float* __restrict__ bfc,
+                                                    float* __restrict__ out, int in_h, int in_w, int th, int tw, int rate, int vec, int out_cs, int c0,
+                                                    int c_end, int n_src, int n_valid) {
+    extern __shared__ float sm[];  // pooled[th*tw] | v[c_end - c0]
+    const int img = blockIdx.x, tid = threadIdx.x;
+    const bool mirror = img >= n_src;
+    const int src = min(mirror ? img - n_src : img, n_valid - 1);
+    const float* m = mask + (size_t)src * in_h * in_w;
+    const int P = th * tw, R = (1 << rate) - 1;
+    float* pooled = sm;
+    float* v = sm + P;
+    for (int p = tid; p < P; p += 256) {
+        const int iy = p / tw, ix = p - iy * tw;
+        const int y0 = max((iy << rate) - R, 0), y1 = min((iy << rate) + R, in_h - 1);
+        const int x0 = max((ix << rate) - R, 0), x1 = min((ix << rate) + R, in_w - 1);
+        float mx = -INFINITY;
+        for (int y = y0; y <= y1; ++y)
+            for (int x = x0; x <= x1; ++x) mx = fmaxf(mx, m[y * in_w + (mirror ? in_w - 1 - x : x)]);
+        pooled[p] = mx;
+    }
+    __syncthreads();
+    for (int c = tid; c < c_end - c0; c += 256) {
+        float a = 0.f;
+        if (c < vec) {
+            a = bfc[c];
+            for (int p = 0; p < P; ++p) a = fmaf(wfc[(size_t)c * P + p], pooled[p], a);
+        }
+        v[c] = a;
+    }
+    __syncthreads();
+    const int nc = c_end - c0;
+    float* o = out + (size_t)img * P * out_cs + c0;
+    for (int i = tid; i < P * nc; i += 256) {
+        const int t = i / nc, c = i - t * nc;
+        o[(size_t)t * out_cs + c] = v[c];
+    }
+}
+}  // namespace
+
+extern "C" int i2r_pe_cat_vec(const i2r_pe_cat_vec_args* a, void* stream) {
+    I2R_CHECK_ARG(a && a->in && a->w && a->bias && a->out, "i2r_pe_cat_vec: null pointer");
+    I2R_CHECK_ARG(a->n_src >= 1 && (a->n_img == a->n_src || a->n_img == 2 * a->n_src) && a->n_valid >= 1 && a->n_valid <= a->n_src,
+                  "i2r_pe_cat_vec: n_img=%d n_src=%d n_valid=%d", a->n_img, a->n_src, a->n_valid);
+    I2R_CHECK_ARG(a->rate >= 0 && a->rate <= 8 && a->th >= 1 && a->tw >= 1 && ((a->in_h - 1) >> a->rate) + 1 == a->th && ((a->in_w - 1) >> a->rate) + 1 == a->tw,
+                  "i2r_pe_cat_vec: %dx%d pooled %d times is not %dx%d", a->in_h, a->in_w, a->rate, a->th, a->tw);
+    I2R_CHECK_ARG(a->vec >= 1 && a->c0 >= 0 && a->c_end >= a->c0 + a->vec && a->c_end <= a->out_cs, "i2r_pe_cat_vec: channels [%d, %d + %d) .. %d of %d",
+                  a->c0, a->c0, a->vec, a->c_end, a->out_cs);
+    const size_t lds = (size_t)(a->th * a->tw + a->c_end - a->c0) * sizeof(float);
+    I2R_CHECK_ARG(lds <= 64 * 1024, "i2r_pe_cat_vec: %zu bytes of LDS", lds);
+    hipLaunchKernelGGL(pe_cat_vec_k, dim3((unsigned)a->n_img), dim3(256), lds, (hipStream_t)stream, a->in, a->w, a->bias, a->out, a->in_h, a->in_w,
+                       a->th, a->tw, a->rate, a->vec, a->out_cs, a->c0, a->c_end, a->n_src, a->n_valid);
+    I2R_CHECK_LAUNCH("i2r_pe_cat_vec");
+    return I2R_OK;
+}
+
 extern "C" int i2r_maxpool3x3s2(const float* in, float* out, int32_t n_img, int32_t in_h, int32_t in_w, int32_t c,
                                 int32_t in_cs, int32_t out_cs, void* stream) {
     I2R_CHECK_ARG(in && out && in != out, "i2r_maxpool3x3s2: bad pointers");

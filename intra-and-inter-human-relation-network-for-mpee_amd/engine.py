@@ -980,9 +980,23 @@ class Program:
         self.flush_group(grp, lane=lane)
         return out
 
-    def maxpool(self, x, lane=0):
+    def pe_cat_vec(self, fc, n, h, w, th, tw, out, c0, lane=0, n_src=None):
+        """PositionEmbeddingImage 'cat_vec': one vector per person from the boundary mask [n_src, 1, h, w], written into channels [c0, c0 + vec)
+        of every token row of `out` (zeros behind, up to the row stride)"""
+        rate = int(math.log(w // tw, 2))
+        assert (out.n, out.h, out.w) == (n, th, tw) and out.dt == 0 and c0 + fc["vec"] <= out.cs
+        self.keep.append(fc)
+        ns = n if n_src is None else n_src
+        a = cabi.PeCatVecArgs(0, fc["w"].data_ptr(), fc["b"].data_ptr(), out.ptr, n, h, w, th, tw, rate, fc["vec"], out.cs, c0, out.cs, ns, ns)
+        self.ops.append((cabi.OP_PE_CAT_VEC, lane, a))
+        return a
+
+    def maxpool(self, x, lane=0, out=None):
+        """out: a (wider) destination whose first x.cs channels receive the pooled map (the x half of a channel concatenation)"""
         assert x.dt == 0, "fp32 kernel: the producer must store fp32 (conv(..., out_dt=0))"
-        out = self.alloc(x.n, (x.h - 1) // 2 + 1, (x.w - 1) // 2 + 1, x.c)
+        if out is None:
+            out = self.alloc(x.n, (x.h - 1) // 2 + 1, (x.w - 1) // 2 + 1, x.c)
+        assert (out.n, out.h, out.w) == (x.n, (x.h - 1) // 2 + 1, (x.w - 1) // 2 + 1) and out.cs >= x.cs and out.dt == 0
         a = cabi.PoolArgs(x.ptr, out.ptr, x.n, x.h, x.w, x.cs, x.cs, out.cs)  # pool all cs channels (pads stay 0)
         self.ops.append((cabi.OP_MAXPOOL, lane, a))
         return out
@@ -1683,8 +1697,14 @@ def validate_config(cfg, name=None):
         raise NotImplementedError("MODEL.NAME=%r" % (name,))
     if name in ("hrnet", "transpose_h", "hrformer"):
         return
-    if M["USE_MULTI_POS"] and M["MULTI_POS_EMBEDDING"] not in ("conv", "res"):
-        raise NotImplementedError("MULTI_POS_EMBEDDING=%r with USE_MULTI_POS (shipped configs use 'conv' or 'res')" % (M["MULTI_POS_EMBEDDING"],))
+    if M["USE_MULTI_POS"] and M["MULTI_POS_EMBEDDING"] not in ("conv", "res", "cat_vec"):
+        # 'sine': PositionEmbeddingImage.forward returns a 3-D table there (position_embedding.py:88-91) and every caller then fails in
+        # padding / flatten_input (permute of 5 dims) -- the reference itself cannot run it
+        raise NotImplementedError("MULTI_POS_EMBEDDING=%r with USE_MULTI_POS (the reference's own forward raises for 'sine')" % (M["MULTI_POS_EMBEDDING"],))
+    if M["USE_MULTI_POS"] and M["MULTI_POS_EMBEDDING"] == "cat_vec" and name == "interformer":
+        wide = M["DIM_MODEL"] + M["MULTI_POS_EMBEDDING_DIM"]
+        if wide % M["N_HEAD"]:
+            raise ValueError("cat_vec: DIM_MODEL + MULTI_POS_EMBEDDING_DIM = %d must be divisible by N_HEAD=%r" % (wide, M["N_HEAD"]))
     if name != "interformer_pureMulti":
         sf = M["SINGLEFORMER"]
         if sf not in ("transpose_h", "hrformer") and sf:
@@ -1788,6 +1808,9 @@ class Engine:
         # forward_pre exists in every copy of the layer class, but only attention.py:1040 (get_default_encoder: the inter-human stack of
         # MODEL.NAME interformer) passes cfg.MODEL.NORMALIZE_BEFORE on; the other constructors leave the default False
         self.pre_norm = bool(M["NORMALIZE_BEFORE"]) and self.name == "interformer"
+        # interformer.py:296-303 (and only there): 'cat_vec' CONCATENATES the per-person vector to the token channels, the inter-human
+        # encoder is DIM_MODEL + MULTI_POS_EMBEDDING_DIM wide (attention.py:1035-1040) and a 1x1 conv `fc` brings the width back
+        self.cat_concat = self.name == "interformer" and M["MULTI_POS_EMBEDDING"] == "cat_vec" and bool(M["USE_MULTI_POS"])
         self.singleformer = None
         if self.name == "hrnet":  # stand-alone backbone (models/hrnet.py): tower + reduce, see forward_backbone()
             self.tower = HRNetW48(pk, "", M["EXTRA"])
@@ -1816,7 +1839,10 @@ class Engine:
             self.use_pos = bool(M["USE_MULTI_POS"])
             if self.use_pos:
                 self._pack_pos(pk, "multi_position_embedding", M["MULTI_POS_EMBEDDING"])
-            self.layers = [self._enc_layer("multi_global_encoder.layers.%d" % l, self.pre_norm) for l in range(M["ENCODER_MULTI_LAYERS"])]
+            wide = d + (M["MULTI_POS_EMBEDDING_DIM"] if self.cat_concat else 0)
+            self.layers = [self._enc_layer("multi_global_encoder.layers.%d" % l, self.pre_norm, d=wide) for l in range(M["ENCODER_MULTI_LAYERS"])]
+            if self.cat_concat:
+                self.cat_fc = pk.conv("fc")
             up = M["UPSAMPLE_TYPE"]
             if up == "deconv" and self.name == "interformer_2stage":  # deconv_layers1..3, as many as pooling steps (:366-379)
                 w4 = M["IMAGE_SIZE"][0] // 4
@@ -1842,11 +1868,11 @@ class Engine:
         else:
             raise NotImplementedError("MODEL.NAME=%r" % self.name)
 
-    def _enc_layer(self, p, pre_norm=False):
+    def _enc_layer(self, p, pre_norm=False, d=None):
         """One encoder layer under state-dict prefix p: the fused single-head post-norm kernels (i2r_encoder_layer) for what every shipped
         yaml asks for, else the general layer around i2r_mh_attention (any N_HEAD, pre-norm, other widths), always in fp32."""
         M = self.cfg["MODEL"]
-        d, dff, heads = M["DIM_MODEL"], M["DIM_FEEDFORWARD"], M["N_HEAD"]
+        d, dff, heads = d or M["DIM_MODEL"], M["DIM_FEEDFORWARD"], M["N_HEAD"]
         if heads == 1 and not pre_norm and _r16(d) in (96, 80) and _r16(dff) == 192:
             return self._pk.encoder_layer(p, d, dff)
         if getattr(self, "_pk32", None) is None:
@@ -1894,11 +1920,24 @@ class Engine:
             self.pe_conv2 = pk.conv(p + ".conv2", p + ".bn2", stride=2)
         elif mode == "res":
             self.pe_res = pk.pe_res(p)
+        elif mode == "cat_vec":
+            # nn.Linear(TRANS_SIZE[0] * TRANS_SIZE[1], vec_dim) on the pooled mask (position_embedding.py:19-23): vec_dim = DIM_MODEL in
+            # interformer_pureMulti.py:465, MULTI_POS_EMBEDDING_DIM in interformer.py:155 / interformer_2stage.py
+            w, b = pk.sd[p + ".fc.weight"], pk.sd[p + ".fc.bias"]
+            self.pe_fc = dict(w=pk._dev(w.float()), b=pk._dev(b.float()), vec=int(w.shape[0]))
+            if not self.cat_concat and self.pe_fc["vec"] != self.cfg["MODEL"]["DIM_MODEL"]:  # (the reference fails on src + pos the same way)
+                raise ValueError("MULTI_POS_EMBEDDING cat_vec as an additive embedding needs MULTI_POS_EMBEDDING_DIM == DIM_MODEL (%d vs %d)"
+                                 % (self.pe_fc["vec"], self.cfg["MODEL"]["DIM_MODEL"]))
         else:
-            raise NotImplementedError("MULTI_POS_EMBEDDING=%r with USE_MULTI_POS (shipped configs use 'conv' or 'res')" % (mode,))
+            raise NotImplementedError("MULTI_POS_EMBEDDING=%r with USE_MULTI_POS" % (mode,))
 
     # ---- program construction ----
-    def _pos_branch(self, P, n, h, w, trans_w, n_src=None):
+    def _pos_branch(self, P, n, h, w, trans_w, n_src=None, cat=None):
+        """cat (mode cat_vec of MODEL.NAME interformer): the token buffer whose channels behind DIM_MODEL receive the embedding"""
+        if self.pe_mode == "cat_vec":
+            th = h // (w // trans_w)
+            out = cat if cat is not None else P.alloc(n, th, trans_w, self.pe_fc["vec"])
+            return out, P.pe_cat_vec(self.pe_fc, n, h, w, th, trans_w, out, self.cfg["MODEL"]["DIM_MODEL"] if cat is not None else 0, n_src=n_src)
         if self.pe_mode == "res":  # conv_pre -> resnet18[:5] -> conv_end (position_embedding.py:93-97), then the pooling loop (:106-109)
             r = self.pe_res
             a, pe_args = P.pe_res_stem(r, n, h, w, n_src=n_src)
@@ -1937,6 +1976,11 @@ class Engine:
             S, length = 2 * S, list(length) + list(length)
         bare = self.name == "interformer_pureMulti" or not self.singleformer
         assert part is None or bare
+        cat, d = None, M["DIM_MODEL"]
+        if self.cat_concat:  # torch.cat([x, multi_pos], dim=2): both producers write their channel range of ONE token buffer
+            assert part is None
+            tw = M["TRANS_SIZE"][-1]
+            cat = P.alloc(S, H // (W // tw), tw, d + self.pe_fc["vec"])
         if bare and part == "tail":
             down = 4 * 2 ** (M["EXTRA"]["STAGE3"]["NUM_BRANCHES"] - 1)  # the lowest branch of the tower (interformer_pureMulti.py:702)
             f = patch["feat"] = P.alloc(S, H // down, W // down, self.reduce.cout)
@@ -1944,7 +1988,9 @@ class Engine:
             single_feat = None
         elif bare:
             xs, patch["x"] = self.tower.emit(P, S, H, W, n_src=n_src)
-            f = P.conv(xs[-1], self.reduce, out_dt=0)
+            if cat is not None:
+                assert (xs[-1].h, xs[-1].w) == (cat.h, cat.w), "cat_vec: the backbone output is not TRANS_SIZE"
+            f = P.conv(xs[-1], self.reduce, out_dt=0, out=cat)
             P.release(*xs)
             single_feat = None
             if part == "tower":
@@ -1956,21 +2002,28 @@ class Engine:
             if self.return_dict:
                 patch["single"] = P.head(g, self.single_head)
             f = g
-            for _ in range(int(math.log(f.w // M["TRANS_SIZE"][-1], 2))):
-                c = P.maxpool(f)
+            steps = int(math.log(f.w // M["TRANS_SIZE"][-1], 2))
+            if cat is not None and steps == 0:
+                raise NotImplementedError("cat_vec with a first stage whose maps already are TRANS_SIZE")
+            for i in range(steps):
+                c = P.maxpool(f, out=cat if i == steps - 1 else None)
                 if f is not single_feat:
                     P.release(f)
                 f = c
         pos_ptr = 0
         if self.use_pos:
-            pos, patch["pos_mask"] = self._pos_branch(P, S, H, W, M["TRANS_SIZE"][-1], n_src=n_src)
+            pos, patch["pos_mask"] = self._pos_branch(P, S, H, W, M["TRANS_SIZE"][-1], n_src=n_src, cat=cat)
             assert (pos.h, pos.w, pos.cs) == (f.h, f.w, f.cs)
-            pos_ptr = pos.ptr
+            pos_ptr = pos.ptr if cat is None else 0  # (concatenated: the encoder gets no additive embedding, interformer.py:299)
         tok = f.h * f.w
         offs = [0]
         for n in length:
             offs.append(offs[-1] + n * tok)
         e = P.encoder(f, self.layers, offs, pos=pos_ptr, regroupable=True, pre_norm=self.pre_norm)
+        if cat is not None:  # self.fc: Conv2d(DIM_MODEL + MULTI_POS_EMBEDDING_DIM, DIM_MODEL, 1) with bias (interformer.py:157-158,302-303)
+            t = P.conv(e, self.cat_fc, out_dt=0)
+            P.release(e)
+            e = t
         uc = getattr(self, "upconv", None)
         if uc is not None:
             u = P.conv(e, uc["fuse"], up=uc["scale"])
@@ -2085,6 +2138,8 @@ class Engine:
         if not isinstance(getattr(self, "tower", None), HRNetW48) and _tune("I2R_SPLIT_BATCH", "1") != "2":  # (2: A/B, any tower)
             return None
         if H is not None and (H % 16 or W % 16):
+            return None
+        if self.cat_concat:  # (the tower / tail hand-over buffer is DIM_MODEL wide)
             return None
         bounds = shard_bounds(list(length), parts)
         if not all(bounds[i + 1] > bounds[i] for i in range(parts)):

@@ -248,8 +248,16 @@ def multi_position_embedding(sd, p, pos_mask, trans_w, mode="conv"):
     elif mode == "conv":
         x = F.relu(_bn(sd, p + ".bn1", _conv(sd, p + ".conv1", pos_mask, stride=2)))
         x = F.relu(_bn(sd, p + ".bn2", _conv(sd, p + ".conv2", x, stride=2)))
+    elif mode == "cat_vec":
+        # position_embedding.py:69-87: pool the MASK down to TRANS_SIZE, Linear(h*w, vec) per person, the vector repeated over the person's tokens
+        x = pos_mask
+        for _ in range(int(math.log(x.shape[-1] // trans_w, 2))):
+            x = _maxpool(x)
+        S, _, h, w = x.shape
+        v = F.linear(x.reshape(S, h * w), sd[p + ".fc.weight"], sd[p + ".fc.bias"])
+        return v[:, :, None, None].expand(S, v.shape[1], h, w).contiguous()
     else:
-        raise NotImplementedError("MULTI_POS_EMBEDDING=%r is not restated (no shipped yaml enables it with USE_MULTI_POS)" % (mode,))
+        raise NotImplementedError("MULTI_POS_EMBEDDING=%r: the reference's own forward fails for 'sine' (a 3-D table meets a 5-D permute)" % (mode,))
     for _ in range(int(math.log(x.shape[-1] // trans_w, 2))):
         x = _maxpool(x)
     return x
@@ -348,9 +356,14 @@ def forward_two_stage(sd, cfg, x, pos_mask, length, collect=None):
         pos = multi_position_embedding(sd, "multi_position_embedding", pos_mask, M["TRANS_SIZE"][-1], M["MULTI_POS_EMBEDDING"])
         if collect is not None:
             collect["pos"] = pos
+    cat = pos is not None and M["MULTI_POS_EMBEDDING"] == "cat_vec" and M["NAME"] == "interformer"
+    if cat:  # interformer.py:296-303: concatenated instead of added, no additive embedding, `fc` back to DIM_MODEL behind the encoder
+        f, pos = torch.cat([f, pos], dim=1), None
     # (only attention.py:1040 -- the inter-human stack of MODEL.NAME interformer -- hands NORMALIZE_BEFORE to its layers)
     f = inter_human_encoder(sd, "multi_global_encoder", M["ENCODER_MULTI_LAYERS"], f, pos, length,
                             M["N_HEAD"], collect, pre_norm=bool(M["NORMALIZE_BEFORE"]) and M["NAME"] == "interformer")
+    if cat:
+        f = F.conv2d(f, sd["fc.weight"], sd["fc.bias"])
     if collect is not None:
         collect["encoder"] = f
     up = M["UPSAMPLE_TYPE"]

@@ -54,6 +54,10 @@ VARIANTS = [
     ("hrt_pre_nh2_l21", "hrt_192_p4_b4", ["MODEL.NORMALIZE_BEFORE", True, "MODEL.N_HEAD", 2], [2, 1], (256, 192)),  # d = 78: heads of 39 dims
     ("w48_fk3_l21", "w48_pure_en6", ["MODEL.EXTRA.FINAL_CONV_KERNEL", 3], [2, 1], (256, 192)),            # 3x3 final_layer (padding 1)
     ("tph_up_l21", "tph_192_p6_b4", ["MODEL.UPSAMPLE_TYPE", "upconv"], [2, 1], (256, 192)),               # interformer.UpConv (upsample_layer.*)
+    ("w48_cv_l21", "w48_pure_en6", ["MODEL.MULTI_POS_EMBEDDING", "cat_vec"], [2, 1], (256, 192)),           # per-person vector ADDED (interformer_pureMulti.py:770)
+    ("bare_cv_l21", "w48_bare_p6", ["MODEL.MULTI_POS_EMBEDDING", "cat_vec"], [2, 1], (256, 192)),            # CONCATENATED: 192-wide encoder + fc (interformer.py:296-303)
+    ("ochtph_cv_nh2_l21", "ochuman_tph_192_p3_b8", ["MODEL.MULTI_POS_EMBEDDING", "cat_vec", "MODEL.N_HEAD", 2], [2, 1], (256, 192)),  # the same behind a TransPose-H first stage
+    ("tph2s_cv_l12", "coco_tph_192_p4_b4", ["MODEL.MULTI_POS_EMBEDDING", "cat_vec", "MODEL.USE_MULTI_POS", True], [1, 2], (256, 192)),  # interformer_2stage: added
     ("tph2s_up_fk3_l12", "coco_tph_192_p4_b4", ["MODEL.UPSAMPLE_TYPE", "upconv", "MODEL.EXTRA.FINAL_CONV_KERNEL", 3], [1, 2], (256, 192)),  # interformer_2stage.UpConv (upsample_conv.*), both heads 3x3
 ]
 

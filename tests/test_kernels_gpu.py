@@ -724,6 +724,45 @@ def test_general_encoder_regroups_without_rebuilding():
         assert (got - ref).abs().max().item() < 2e-4
 
 
+@pytest.mark.parametrize("S,h,w,th,tw,vec,c0,cs,flip", [
+    (3, 256, 192, 16, 12, 96, 0, 96, False),     # additive embedding of the vanilla model
+    (2, 256, 192, 16, 12, 96, 96, 192, True),    # second half of the concatenated token rows, mirrored copies for the flip test
+    (2, 384, 288, 24, 18, 96, 78, 176, False),   # HRFormer width: starts at channel 78, zeros behind channel 174
+    (2, 50, 44, 13, 11, 40, 0, 48, True),        # 50 -> 25 -> 13, 44 -> 22 -> 11: odd intermediate sizes (clipped windows)
+])
+def test_pe_cat_vec_matches_torch(S, h, w, th, tw, vec, c0, cs, flip):
+    """i2r_pe_cat_vec against the reference's own steps (position_embedding.py:69-87): MaxPool2d(3, 2, 1) cascade, Linear, repeat"""
+    import ctypes as C
+    import math
+    from i2r_amd import cabi
+    rate = int(math.log2(w // tw))
+    mask = (_rand((S, 1, h, w), "cvm%d%d" % (h, c0)) > 0.2).float()
+    mask[0, 0, : h // 3] = 0
+    W, b = _rand((vec, th * tw), "cvw%d" % c0, 0.2), _rand((vec,), "cvb%d" % c0, 0.3)
+    srcs = [mask] + ([torch.flip(mask, dims=[3])] if flip else [])
+    refs = []
+    for m in srcs:
+        x = m
+        for _ in range(rate):
+            x = F.max_pool2d(x, 3, 2, 1)
+        assert x.shape[-2:] == (th, tw)
+        refs.append(F.linear(x.reshape(S, th * tw), W, b))
+    ref = torch.cat(refs, 0)
+    n = S * len(srcs)
+    out = torch.full((n, th, tw, cs), 7.0, device=DEV)
+    md, Wd, bd = mask.to(DEV), W.to(DEV), b.to(DEV)
+    a = cabi.PeCatVecArgs(md.data_ptr(), Wd.data_ptr(), bd.data_ptr(), out.data_ptr(), n, h, w, th, tw, rate, vec, cs, c0, cs, S, S)
+    cabi.check(cabi.lib().i2r_pe_cat_vec(C.byref(a), None), "pe_cat_vec")
+    torch.cuda.synchronize()
+    got = out.cpu()
+    assert (got[..., :c0] == 7.0).all()                      # the x half belongs to another launch
+    assert (got[..., c0 + vec:] == 0.0).all()                # row padding
+    err = (got[..., c0:c0 + vec] - ref[:, None, None, :]).abs().max().item()
+    assert err < 1e-5 * max(1.0, ref.abs().max().item()), err
+    bad = cabi.PeCatVecArgs(md.data_ptr(), Wd.data_ptr(), bd.data_ptr(), out.data_ptr(), n, h, w, th + 1, tw, rate, vec, cs, c0, cs, S, S)
+    assert cabi.lib().i2r_pe_cat_vec(C.byref(bad), None) != 0
+
+
 def test_mh_attention_rejects_bad_arguments():
     import ctypes as C
     from i2r_amd import cabi
