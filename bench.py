@@ -178,6 +178,10 @@ def op_model(kind, st, precision, enc_lens=None):
         oh, ow = (st.in_h - 1) // 2 + 1, (st.in_w - 1) // 2 + 1
         return ("pe_res_stem_k", st.n_img * (st.in_h * st.in_w * 54.0 + oh * ow * 2.0 * 147 * st.cout),
                 float(st.n_src * st.in_h * st.in_w * 4 + st.n_img * oh * ow * st.out_cs * 4), None)
+    if kind == cabi.OP_PE_CAT_VEC:  # window maxima of the mask, one th*tw-long dot product per vector element, the broadcast store
+        P = st.th * st.tw
+        return ("pe_cat_vec_k", float(st.n_img * (st.in_h * st.in_w + 2.0 * P * st.vec)),
+                float(st.n_valid * st.in_h * st.in_w * 4 + st.n_img * P * (st.c_end - st.c0) * 4 + st.vec * (P + 1) * 4), None)
     if kind == cabi.OP_HEAD:
         npix = st.n_img * st.h * st.w_
         return ("head_mfma_k" if st.cin <= 128 else "head_k", 2.0 * npix * st.cin * st.cout, float(npix * (st.in_cs + st.cout) * 4), "fp32")
