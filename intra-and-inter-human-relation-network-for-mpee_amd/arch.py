@@ -254,7 +254,6 @@ def interformer_2stage_spec(cfg):
     extra = M["EXTRA"]
     d = M["DIM_MODEL"]
     assert M["SINGLEFORMER"] == "transpose_h", "interformer_2stage is shipped with the TransPose-H first stage only"
-    assert not M["DOMAIN_TRANS"], "DOMAIN_TRANS is false in every shipped config"
     spec = Spec()
     spec.extend(transpose_h_spec(cfg, "singleformer."))
     multi_position_embedding(spec, "multi_position_embedding", M["MULTI_POS_EMBEDDING"], d, M["TRANS_SIZE"],
@@ -274,6 +273,9 @@ def interformer_2stage_spec(cfg):
             spec.append((n + ".0.bias", (planes,), F32))
         spec.bn(n + ".1", planes)
     spec.conv("final_layer", M["NUM_JOINTS"], d, extra["FINAL_CONV_KERNEL"], bias=True)
+    if M["DOMAIN_TRANS"]:  # interformer_2stage.py:277-279
+        spec.conv("domain_trans_1", d, d, 1, bias=True)
+        spec.conv("domain_trans_2", d, d, 1, bias=True)
     return spec
 
 

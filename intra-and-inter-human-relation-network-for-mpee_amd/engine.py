@@ -1864,6 +1864,9 @@ class Engine:
             else:
                 raise NotImplementedError("UPSAMPLE_TYPE=%r" % up)
             self.head = pk.head("final_layer")
+            # interformer_2stage.py:277-279,413-414: x = domain_trans_1(single_res) + domain_trans_2(x) (two 1x1 convs with bias) instead of the sum
+            self.domain_trans = ((pk.conv("domain_trans_1"), pk.conv("domain_trans_2"))
+                                 if self.name == "interformer_2stage" and M["DOMAIN_TRANS"] else None)
             self.return_dict = bool(M["INTER_SUPERVISION"]) and not M["SINGLEFORMER_FIX"] and bool(sf)
         else:
             raise NotImplementedError("MODEL.NAME=%r" % self.name)
@@ -2024,19 +2027,26 @@ class Engine:
             t = P.conv(e, self.cat_fc, out_dt=0)
             P.release(e)
             e = t
+        dtr = getattr(self, "domain_trans", None)
+        res_feat = single_feat if dtr is None else None
         uc = getattr(self, "upconv", None)
         if uc is not None:
             u = P.conv(e, uc["fuse"], up=uc["scale"])
             P.release(e)
             t = P.conv(u, uc["c1"], relu=True)
             P.release(u)
-            e = P.conv(t, uc["c2"], relu=True, res_post=single_feat)  # (2-stage models: x = single_res + x behind the ReLU, interformer.py:315)
+            e = P.conv(t, uc["c2"], relu=True, res_post=res_feat)  # (2-stage models: x = single_res + x behind the ReLU, interformer.py:315)
             P.release(t)
         for i, dc in enumerate(self.deconvs):
             last = i == len(self.deconvs) - 1
             # 2-stage models add the first-stage features AFTER the deconv's ReLU (x = single_res + x, interformer.py:315)
-            u = P.deconv(e, dc, relu=True, res_post=single_feat if (last and single_feat is not None) else None)
+            u = P.deconv(e, dc, relu=True, res_post=res_feat if (last and res_feat is not None) else None)
             P.release(e)
+            e = u
+        if dtr is not None:
+            t = P.conv(single_feat, dtr[0], out_dt=0)
+            u = P.conv(e, dtr[1], res1=t, out_dt=0)
+            P.release(e, t)
             e = u
         patch["multi"] = P.head(e, self.head)
         P.finalize()

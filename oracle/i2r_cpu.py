@@ -316,7 +316,8 @@ def forward_transpose_h(sd, p, cfg, x, collect=None):
     f = F.conv2d(ys[M["HRNET_RES_LAYER"]], sd[p + "reduce.weight"])
     S, d, h, w = f.shape
     tok = f.flatten(2).transpose(1, 2)  # [S, hw, d]
-    pos = sd[p + "pos_embedding"].reshape(1, h * w, d)  # a (non-trainable) parameter -> read from weights
+    # a parameter (sine table or learnable) -> read from the weights; POS_EMBEDDING 'none': no parameter, no embedding (transpose_h.py:485-488)
+    pos = sd[p + "pos_embedding"].reshape(1, h * w, d) if M["POS_EMBEDDING"] != "none" else None
     for l in range(M["ENCODER_LAYERS"]):
         tok = encoder_layer(sd, "%sglobal_encoder.layers.%d" % (p, l), tok, pos, None, M["N_HEAD"])
         if collect is not None:
@@ -385,7 +386,9 @@ def forward_two_stage(sd, cfg, x, pos_mask, length, collect=None):
         f = _deconv_bn_relu(sd, "deconv_layers.0", "deconv_layers.1", f)
     else:
         raise NotImplementedError("UPSAMPLE_TYPE=%r" % up)
-    if feat is not None:
+    if feat is not None and M["NAME"] == "interformer_2stage" and M["DOMAIN_TRANS"]:  # interformer_2stage.py:413-414
+        f = (F.conv2d(feat, sd["domain_trans_1.weight"], sd["domain_trans_1.bias"]) + F.conv2d(f, sd["domain_trans_2.weight"], sd["domain_trans_2.bias"]))
+    elif feat is not None:
         f = feat + f  # residual (:315)
     multi = _final_layer(sd, "final_layer", f)
     if M["INTER_SUPERVISION"] and not M["SINGLEFORMER_FIX"] and feat is not None:

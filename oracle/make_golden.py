@@ -58,6 +58,9 @@ VARIANTS = [
     ("bare_cv_l21", "w48_bare_p6", ["MODEL.MULTI_POS_EMBEDDING", "cat_vec"], [2, 1], (256, 192)),            # CONCATENATED: 192-wide encoder + fc (interformer.py:296-303)
     ("ochtph_cv_nh2_l21", "ochuman_tph_192_p3_b8", ["MODEL.MULTI_POS_EMBEDDING", "cat_vec", "MODEL.N_HEAD", 2], [2, 1], (256, 192)),  # the same behind a TransPose-H first stage
     ("tph2s_cv_l12", "coco_tph_192_p4_b4", ["MODEL.MULTI_POS_EMBEDDING", "cat_vec", "MODEL.USE_MULTI_POS", True], [1, 2], (256, 192)),  # interformer_2stage: added
+    ("tph2s_dt_l12", "coco_tph_192_p4_b4", ["MODEL.DOMAIN_TRANS", True], [1, 2], (256, 192)),               # interformer_2stage.py:413-414
+    ("w48_d64_l21", "w48_pure_en6", ["MODEL.DIM_MODEL", 64, "MODEL.DIM_FEEDFORWARD", 128, "MODEL.EXTRA.NUM_DECONV_FILTERS", [64]], [2, 1], (256, 192)),  # other widths
+    ("tph_pnone_l11", "tph_192_p6_b4", ["MODEL.POS_EMBEDDING", "none"], [1, 1], (256, 192)),                  # TransPose-H without its position table
     ("tph2s_up_fk3_l12", "coco_tph_192_p4_b4", ["MODEL.UPSAMPLE_TYPE", "upconv", "MODEL.EXTRA.FINAL_CONV_KERNEL", 3], [1, 2], (256, 192)),  # interformer_2stage.UpConv (upsample_conv.*), both heads 3x3
 ]
 
