@@ -278,6 +278,42 @@ def test_low_precision_modes_within_stated_tolerance(tag, precision):
         assert d.abs().max().item() > 1e-4  # it really is the 16-bit path
 
 
+@pytest.mark.parametrize("tag,precision", [("w48_nh8_l21", "bf16"), ("bare_cv_l21", "fp16"), ("tph2s_up_fk3_l12", "bf16"), ("hrt_pre_nh2_l21", "fp16")])
+def test_variant_configs_in_16bit_modes(tag, precision):
+    """set_precision on the variant configs: the towers and the conv tails switch to 16-bit operands / storage, the general encoder layer
+    stays fp32 (engine.Engine._enc_layer) -- same tolerances as the shipped configs"""
+    cfg, sd, x, m, length, g = setup(tag)
+    net = eval("models." + cfg.MODEL.NAME + ".get_pose_net")(cfg, is_train=False)
+    net.load_state_dict(sd, strict=True)
+    net = net.cuda()
+    y = net.set_precision(precision)(x.cuda(), m.cuda(), length)
+    torch.cuda.synchronize()
+    outs = y if isinstance(y, dict) else {"multi": y}
+    for k, t in outs.items():
+        ref = torch.from_numpy(g["out_" + k])
+        tol_max, tol_rms = (LP_TOL_SINGLE if k == "single" else LP_TOL)[precision]
+        d = t.cpu() - ref
+        assert torch.isfinite(t).all()
+        assert d.abs().max().item() <= tol_max * ref.abs().max().item(), (tag, k, d.abs().max().item(), ref.abs().max().item())
+        assert d.pow(2).mean().sqrt().item() <= tol_rms * ref.pow(2).mean().sqrt().item()
+        assert d.abs().max().item() > 1e-5  # it really is the 16-bit path
+
+
+def test_variant_config_ragged_batches_share_one_program():
+    """the general encoder regroups like the fused one: two batches of the same crop count but other persons-per-image lists run on ONE
+    cached program (Program.set_groups patches the attention launches), each equal to the oracle"""
+    from i2r_amd import synth
+    cfg, sd, _, _, _, _ = setup("w48_nh8_l21")
+    net = models.interformer_pureMulti.get_pose_net(cfg, is_train=False)
+    net.load_state_dict(sd, strict=True)
+    net = net.cuda()
+    for length, seed in (([3, 1, 2], 5), ([1, 4, 1], 6), ([6], 7)):
+        x, m, length = synth.make_inputs(length, 256, 192, seed=seed)
+        y = net(x.cuda(), m.cuda(), length).cpu()
+        assert (y - i2r_cpu.forward(sd, cfg, x, m, length)).abs().max().item() < TOL
+    assert net.engine().n_builds == 1
+
+
 def _variants(net):
     """which kernel variant each encoder layer of the cached programs resolved to: (d, dtype) per layer descriptor"""
     out = []

@@ -58,6 +58,25 @@ def test_flip_test_single_batched_forward_matches_two_oracle_forwards():
     assert (plain - i2r_cpu.forward(sd, cfg, x, m, length)).abs().max().item() < 1e-3
 
 
+@pytest.mark.parametrize("tag", ["bare_cv_l21", "w48_nh8_l21", "tph2s_up_fk3_l12"])
+def test_flip_test_of_variant_configs(tag):
+    """the batched flip test on settings no shipped yaml uses: the concatenated cat_vec embedding (its kernel mirrors the mask itself),
+    the multi-head general encoder (token groups doubled), UpConv + 3x3 heads"""
+    cfg, sd, x, m, length, g = setup(tag)
+    net = eval("models." + cfg.MODEL.NAME + ".get_pose_net")(cfg, is_train=False)
+    net.load_state_dict(sd, strict=True)
+    net = net.cuda()
+    pairs = caller.FLIP_PAIRS["crowdpose" if cfg.MODEL.NUM_JOINTS == 14 else "coco"]
+    got = net.forward_flip(x.cuda(), m.cuda(), length, pairs).cpu()
+
+    def multi(a, b, c):
+        z = i2r_cpu.forward(sd, cfg, a, b, c)
+        return z["multi"] if isinstance(z, dict) else z
+    ref = post_cpu.flip_test(multi, x, m, length, pairs)
+    assert got.shape == ref.shape
+    assert (got - ref).abs().max().item() < 1e-3 * max(1.0, ref.abs().max().item() / 8)
+
+
 def test_flip_test_two_stage_dict_model():
     cfg, sd, x, m, length, g = setup("tph_l21")
     net = models.interformer.get_pose_net(cfg, is_train=False)
