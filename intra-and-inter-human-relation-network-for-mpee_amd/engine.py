@@ -23,8 +23,19 @@ import torch
 from . import cabi
 
 
-def _r16(c):
+def _m16(c):
     return (c + 15) // 16 * 16
+
+
+def _r16(c):
+    """Channel count -> row width of an activation / padded width of a weight matrix: the next multiple of 16 whose number of
+    16-channel fragments the conv kernels can split (a multiple of 3, 4 or 5: conv_split, csrc/i2r_conv.hip).  Every width of the shipped
+    models is its own image (48, 64, 80 = 78 padded, 96, 160, 192, 256, 320, 384, 624, ...); 16 and 32 (HRNet-W32's first branch, W18)
+    become 48 with zero weights and zero activations in the pad channels."""
+    n = (c + 15) // 16
+    while not any(n % k == 0 for k in (3, 4, 5)):
+        n += 1
+    return 16 * n
 
 
 # ------------------------------------------------------------------------------------------------
@@ -380,7 +391,7 @@ class Packer:
     def mh_width(heads, hd):
         """(hp, hs): head dim padded to a multiple of 16 (csrc/i2r_encoder_mh.hip) and the width of a q / k / v / attention-output part,
         heads*hp rounded up to a fragment count the conv kernels split (conv_split: a multiple of 3, 4 or 5 sixteen-channel blocks)"""
-        hp = _r16(hd)
+        hp = _m16(hd)
         f = heads * hp // 16
         while not any(f % k == 0 for k in (3, 4, 5)):
             f += 1
@@ -733,6 +744,9 @@ class Program:
             out = self.alloc(x.n, oh, ow, pc.cout, x.dt if out_dt is None else out_dt)
         assert out.cs >= pc.cout_pad or out.cs >= pc.cout
         assert out.dt in (0, pc.dtype) and all(r is None or r.dt == out.dt for r in (res1, res2, res_post)), "residuals share the output's storage type"
+        self._check_like(out, res1, res2, res_post)
+        if in2 is not None and (in2.n, in2.h, in2.w, in2.cs) != (x.n, x.h, x.w, x.cs):
+            raise ValueError("conv second input is [%d, %d, %d, cs %d], the first [%d, %d, %d, cs %d]" % (in2.n, in2.h, in2.w, in2.cs, x.n, x.h, x.w, x.cs))
         self.keep.append(pc)  # the descriptor holds raw pointers: keep the packed weights alive with the program
         d = cabi.ConvDesc()
         d.in_, d.in2, d.w, d.bias = x.ptr, (in2.ptr if in2 is not None else None), pc.w.data_ptr(), pc.bias.data_ptr()
@@ -1069,12 +1083,21 @@ class Program:
         self.ops.append((cabi.OP_UPSAMPLE, lane, a))
         return out
 
+    @staticmethod
+    def _check_like(out, *residuals):
+        """the kernels index a residual like the output: a smaller map would be read out of bounds (e.g. a 2-stage config whose up-sampled
+        map is not the first stage's size -- the reference fails on that sum too)"""
+        for r in residuals:
+            if r is not None and (r.n, r.h, r.w, r.cs) != (out.n, out.h, out.w, out.cs):
+                raise ValueError("conv residual is [%d, %d, %d, row %d], the output [%d, %d, %d, row %d]" % (r.n, r.h, r.w, r.cs, out.n, out.h, out.w, out.cs))
+
     def conv1x1_lp(self, x, pc, relu=False, res1=None, res_post=None, out=None, lane=0, act=None, out_dt=None):
         """single 1x1 conv over few pixels in the 16-bit modes (i2r_conv1x1_lp: operands straight from global memory, K split over the
         workgroup's waves); same semantics as conv(): out = act(W x + b + res1) + res_post"""
         if out is None:
             out = self.alloc(x.n, x.h, x.w, pc.cout, x.dt if out_dt is None else out_dt)
         assert out.cs >= pc.cout_pad and out.dt in (0, pc.dtype) and all(r is None or (r.dt == out.dt and r.cs == out.cs) for r in (res1, res_post))
+        self._check_like(out, res1, res_post)
         self.keep.append(pc)
         a = cabi.Conv1x1LpArgs(x.ptr, pc.w_lp1.data_ptr(), pc.bias.data_ptr(), res1.ptr if res1 is not None else None,
                                res_post.ptr if res_post is not None else None, out.ptr, x.n * x.h * x.w, pc.cin_pad, pc.cout_pad, x.cs, out.cs,
@@ -1691,7 +1714,7 @@ def validate_config(cfg, name=None):
         heads, d = M["N_HEAD"], M["DIM_MODEL"]
         if heads < 1 or d % heads:  # (nn.MultiheadAttention asserts the same)
             raise ValueError("MODEL.DIM_MODEL=%r must be divisible by MODEL.N_HEAD=%r" % (d, heads))
-        if _r16(d // heads) > 256:
+        if _m16(d // heads) > 256:
             raise NotImplementedError("head dim %d > 256 (i2r_mh_attention)" % (d // heads,))
     if name not in ("hrnet", "transpose_h", "hrformer", "interformer_pureMulti", "interformer", "interformer_2stage"):
         raise NotImplementedError("MODEL.NAME=%r" % (name,))

@@ -299,6 +299,19 @@ def test_variant_configs_in_16bit_modes(tag, precision):
         assert d.abs().max().item() > 1e-5  # it really is the 16-bit path
 
 
+def test_mismatched_two_stage_geometry_raises_instead_of_reading_out_of_bounds():
+    """HRNET_RES_LAYER 1 makes the first stage emit 32x24 maps while the up-sampling path still ends at HEATMAP_SIZE 64x48: the reference
+    fails on `single_res + x` (interformer.py:315); here the residual of the last deconv must be refused at program build (it used to be
+    handed to the kernel, which read it like a 64x48 map)"""
+    from i2r_amd import arch, config, synth
+    cfg = config.load_config("tph_192_p6_b4", ["MODEL.HRNET_RES_LAYER", 1, "MODEL.TRANS_SIZE", [8, 6]])
+    net = models.interformer.get_pose_net(cfg, is_train=False)
+    net.load_state_dict(synth.make_state_dict(arch.param_spec(cfg)), strict=True)
+    x, m, length = synth.make_inputs([2, 1], 256, 192)
+    with pytest.raises(ValueError, match="residual"):
+        net.cuda()(x.cuda(), m.cuda(), length)
+
+
 def test_variant_config_ragged_batches_share_one_program():
     """the general encoder regroups like the fused one: two batches of the same crop count but other persons-per-image lists run on ONE
     cached program (Program.set_groups patches the attention launches), each equal to the oracle"""
