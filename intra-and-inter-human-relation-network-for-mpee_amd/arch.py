@@ -145,6 +145,13 @@ def upconv(spec, p, d):
         spec.bn(p + ".double_conv.%d" % (i + 1), d)
 
 
+def deconv_geometry(extra):
+    """(planes, kernel) of the up-sampling ConvTranspose2d layers: one layer per Sequential, kernel 4, 3 or 2 (_get_deconv_cfg,
+    interformer_pureMulti.py:635-646); more layers per Sequential would change the heat-map size and are not expressible usefully"""
+    assert extra["NUM_DECONV_LAYERS"] == 1 and len(extra["NUM_DECONV_KERNELS"]) == 1 and extra["NUM_DECONV_KERNELS"][0] in (2, 3, 4)
+    return extra["NUM_DECONV_FILTERS"][0], extra["NUM_DECONV_KERNELS"][0]
+
+
 def vanilla_spec(cfg):
     """interformer_pureMulti.TransPoseH (:421-494)."""
     M = cfg["MODEL"]
@@ -159,9 +166,8 @@ def vanilla_spec(cfg):
     spec.conv("reduce", d, ch[-1], 1)
     for l in range(M["ENCODER_LAYERS"]):
         spec.encoder_layer("global_encoder.layers.%d" % l, d, dff)
-    assert extra["NUM_DECONV_LAYERS"] == 1 and list(extra["NUM_DECONV_KERNELS"]) == [4]
-    planes = extra["NUM_DECONV_FILTERS"][0]
-    spec.append(("deconv_layers.0.weight", (planes, planes, 4, 4), F32))
+    planes, dk = deconv_geometry(extra)
+    spec.append(("deconv_layers.0.weight", (planes, planes, dk, dk), F32))
     if extra["DECONV_WITH_BIAS"]:
         spec.append(("deconv_layers.0.bias", (planes,), F32))
     spec.bn("deconv_layers.1", planes)
@@ -225,17 +231,17 @@ def interformer_spec(cfg):
     assert M["ATTENTION_TYPE"] == "default", "only ATTENTION_TYPE 'default' is reachable from the shipped configs"
     for l in range(M["ENCODER_MULTI_LAYERS"]):
         spec.encoder_layer("multi_global_encoder.layers.%d" % l, wide, M["DIM_FEEDFORWARD"])
-    planes = extra["NUM_DECONV_FILTERS"][0]
+    planes, dk = deconv_geometry(extra)
     up = M["UPSAMPLE_TYPE"]
     if up == "deconv":
         n = int(math.log(M["HEATMAP_SIZE"][0] // M["TRANS_SIZE"][1], 2))
         for i in range(n):
-            spec.append(("upsample_layer.deconv_layers.%d.0.weight" % i, (planes, planes, 4, 4), F32))
+            spec.append(("upsample_layer.deconv_layers.%d.0.weight" % i, (planes, planes, dk, dk), F32))
             if extra["DECONV_WITH_BIAS"]:
                 spec.append(("upsample_layer.deconv_layers.%d.0.bias" % i, (planes,), F32))
             spec.bn("upsample_layer.deconv_layers.%d.1" % i, planes)
     elif up == "multiplex":
-        spec.append(("deconv_layers.0.weight", (planes, planes, 4, 4), F32))
+        spec.append(("deconv_layers.0.weight", (planes, planes, dk, dk), F32))
         if extra["DECONV_WITH_BIAS"]:
             spec.append(("deconv_layers.0.bias", (planes,), F32))
         spec.bn("deconv_layers.1", planes)
@@ -260,7 +266,7 @@ def interformer_2stage_spec(cfg):
                              M["MULTI_POS_EMBEDDING_DIM"])
     for l in range(M["ENCODER_MULTI_LAYERS"]):
         spec.encoder_layer("multi_global_encoder.layers.%d" % l, d, M["DIM_FEEDFORWARD"])
-    planes = extra["NUM_DECONV_FILTERS"][0]
+    planes, dk = deconv_geometry(extra)
     up = M["UPSAMPLE_TYPE"]
     names = {"multiplex": ["deconv_layers"], "deconv": ["deconv_layers1", "deconv_layers2", "deconv_layers3"], "upconv": []}
     if up not in names:
@@ -268,7 +274,7 @@ def interformer_2stage_spec(cfg):
     if up == "upconv":
         upconv(spec, "upsample_conv", d)
     for n in names[up]:
-        spec.append((n + ".0.weight", (planes, planes, 4, 4), F32))
+        spec.append((n + ".0.weight", (planes, planes, dk, dk), F32))
         if extra["DECONV_WITH_BIAS"]:
             spec.append((n + ".0.bias", (planes,), F32))
         spec.bn(n + ".1", planes)

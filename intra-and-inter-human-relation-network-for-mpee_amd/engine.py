@@ -256,14 +256,14 @@ class Packer:
         return self._pc(w.double().t().reshape(1, cin, cout), self._dev(bias.float()), cin, cout, [(0, 0)], 0, 0, 1, 1)
 
     def deconv(self, deconv_key, bn_key, eps=1e-5):
-        """ConvTranspose2d(k=4, s=2, p=1) [Cin, Cout, 4, 4] (+BN) -> {(py,px): PackedConv with 2x2 taps}.
+        """ConvTranspose2d(k=4, s=2, p=1) [Cin, Cout, 4, 4] (+BN) -> {(py,px): PackedConv with 2x2 taps} (k = 3, 2: fewer taps, DECONV_TAPS).
 
         out[2q+py] gathers in[q+iy0+dy]:  py=0: iy0=-1, ky = 3-2dy ;  py=1: iy0=0, ky = 2-2dy  (oy = 2*iy - 1 + ky).
         """
         w = self.sd[deconv_key + ".weight"]
         cin, cout, kh, kw = w.shape
-        assert kh == 4 and kw == 4
-        wf, bf = fold_bn(w.permute(1, 0, 2, 3), self._bn(bn_key), self.sd.get(deconv_key + ".bias"), eps)  # [Cout,Cin,4,4]
+        assert kh == kw and kh in self.DECONV_TAPS, "ConvTranspose2d kernel %dx%d (the reference's _get_deconv_cfg knows 2, 3, 4)" % (kh, kw)
+        wf, bf = fold_bn(w.permute(1, 0, 2, 3), self._bn(bn_key), self.sd.get(deconv_key + ".bias"), eps)  # [Cout,Cin,k,k]
         cout_pad = _r16(cout)
         bias = torch.zeros(cout_pad, dtype=torch.float64)
         bias[:cout] = bf
@@ -271,16 +271,18 @@ class Packer:
         out = {}
         for py in (0, 1):
             for px in (0, 1):
-                taps, mats = [], []
-                for dy in (0, 1):
-                    for dx in (0, 1):
-                        ky = 3 - 2 * dy if py == 0 else 2 - 2 * dy
-                        kx = 3 - 2 * dx if px == 0 else 2 - 2 * dx
-                        taps.append((dy, dx))
-                        mats.append(wf[:, :, ky, kx].t())  # [Cin, Cout]
-                w_taps = torch.stack(mats, 0)
-                out[(py, px)] = self._pc(w_taps, bias, cin, cout, taps, -1 if py == 0 else 0, -1 if px == 0 else 0, 1, 2)
+                (iy0, kys), (ix0, kxs) = self.DECONV_TAPS[kh][py], self.DECONV_TAPS[kh][px]
+                taps = [(dy, dx) for dy in range(len(kys)) for dx in range(len(kxs))]
+                w_taps = torch.stack([wf[:, :, kys[dy], kxs[dx]].t() for dy, dx in taps], 0)  # [taps, Cin, Cout]
+                out[(py, px)] = self._pc(w_taps, bias, cin, cout, taps, iy0, ix0, 1, max(len(kys), len(kxs)))
         return out
+
+    # ConvTranspose2d(k, stride 2, padding p, output_padding op) with the reference's (k, p, op) in {(4, 1, 0), (3, 1, 1), (2, 0, 0)}
+    # (_get_deconv_cfg, interformer_pureMulti.py:635-646): out[o] = sum in[i] w[o + p - 2i].  Per output parity o = 2q + par, along one
+    # axis: (first input offset i0 relative to q, kernel index of every tap d, i = q + i0 + d)
+    DECONV_TAPS = {4: {0: (-1, (3, 1)), 1: (0, (2, 0))},
+                   3: {0: (0, (1,)), 1: (0, (2, 0))},
+                   2: {0: (0, (0,)), 1: (0, (1,))}}
 
     def stem(self, conv_key, bn_key, eps=1e-5):
         w = self.sd[conv_key + ".weight"]  # [cout, cin, 3, 3]

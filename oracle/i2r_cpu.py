@@ -47,8 +47,11 @@ def _maxpool(x):
 
 
 def _deconv_bn_relu(sd, p_deconv, p_bn, x):
-    """ConvTranspose2d(k=4, s=2, p=1, output_padding=0, bias=False) + BN + ReLU (interformer.py:84-122)."""
-    y = F.conv_transpose2d(x, sd[p_deconv + ".weight"], sd.get(p_deconv + ".bias"), stride=2, padding=1)
+    """ConvTranspose2d(k, s=2, padding, output_padding) + BN + ReLU with (k, padding, output_padding) = (4, 1, 0) | (3, 1, 1) | (2, 0, 0)
+    (_get_deconv_cfg, interformer.py:84-95; every shipped yaml: 4)."""
+    w = sd[p_deconv + ".weight"]
+    pad, opad = {4: (1, 0), 3: (1, 1), 2: (0, 0)}[w.shape[-1]]
+    y = F.conv_transpose2d(x, w, sd.get(p_deconv + ".bias"), stride=2, padding=pad, output_padding=opad)
     return F.relu(_bn(sd, p_bn, y))
 
 
