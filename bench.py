@@ -156,7 +156,7 @@ def op_model(kind, st, precision, enc_lens=None):
         nbytes = n * cs * 4 * (3 if st.pos else 2) + 2 * n * cs * kv_e * (2 if st.next_w_in else 1) + (4 * d * d + 2 * d * dff) * kv_e
         name = ("enc_layer_lp4_k" if (st.n_qtiles192 > 0 and st.n_qtiles64 >= 512) else "enc_layer_lp_k") if islp else "enc_layer4_k"
         return name, flop, float(nbytes), lp if islp else "fp32"
-    if kind == cabi.OP_MH_ATTN:  # QK^T + PV over the token's group at the real model width (the head pads are not counted)
+    if kind == cabi.OP_MH_ATTN:  # QK^T + PV over the token's group as executed (heads of hp = head dim padded to 16)
         lens = enc_lens or []
         n = sum(lens)
         return "enc_mh_attn_k", sum(4.0 * st.heads * st.hp * L * L for L in lens), float(n * (st.qk_cs + st.v_cs + st.out_cs) * 4), "fp32"
