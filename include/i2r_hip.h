@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define I2R_ABI_VERSION 11
+#define I2R_ABI_VERSION 12
 
 /* The library is built with -fvisibility=hidden: the entry points declared in this header (marked I2R_API) are its ONLY exported
  * symbols (tests/test_host.py holds the header, the dynamic symbol table and cabi.EXPORTS equal). */
@@ -450,11 +450,11 @@ I2R_API int i2r_encoder_layer(const i2r_encoder_desc* d, void* stream);
  *   v   [n_tok, v_cs], out [n_tok, out_cs]: head h at channels [h*hp, h*hp + hp); out's channels behind heads*hp are written as zeros
  *   grp_off device int32 [n_grp + 1]: group g owns token rows [grp_off[g], grp_off[g+1]) (keys of other groups are never seen: the
  *       reference's pad + key_padding_mask, interformer_pureMulti.py:706-750)
- *   n_qtiles16 = sum over groups of ceil(len / 16) (the host knows the lengths)
- * fp32 matrix pipe, one wave per (16-query tile, head), no workspace. */
+ *   n_qtiles16 / 32 / 64 = sum over groups of ceil(len / 16 | 32 | 64) (the host knows the lengths; the kernel picks its query tile by hp)
+ * fp32 matrix pipe, one wave per (query tile, head), no workspace. */
 typedef struct i2r_mh_attn_args {
     const float* qk; const float* v; float* out; const int32_t* grp_off;
-    int32_t n_grp, heads, hp, k_off, qk_cs, v_cs, out_cs, n_qtiles16;
+    int32_t n_grp, heads, hp, k_off, qk_cs, v_cs, out_cs, n_qtiles16, n_qtiles32, n_qtiles64;
 } i2r_mh_attn_args;
 I2R_API int i2r_mh_attention(const i2r_mh_attn_args* a, void* stream);
 

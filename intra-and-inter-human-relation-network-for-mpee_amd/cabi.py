@@ -14,7 +14,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libi2r_hip.so")
 
 MAX_TAPS = 9
-ABI_VERSION = 11  # I2R_ABI_VERSION of include/i2r_hip.h
+ABI_VERSION = 12  # I2R_ABI_VERSION of include/i2r_hip.h
 OP_CONV, OP_STEM, OP_MAXPOOL, OP_HEAD, OP_ENC_KV, OP_ENC_LAYER, OP_FORK, OP_JOIN, OP_CONV_GROUP = 1, 2, 3, 4, 5, 6, 7, 8, 9
 MAX_GROUP = 4
 OP_LAYERNORM, OP_WINATTN, OP_DWCONV, OP_UPSAMPLE = 10, 11, 12, 13
@@ -95,7 +95,7 @@ class LnArgs(C.Structure):
 class MhAttnArgs(C.Structure):
     _fields_ = [("qk", _fp), ("v", _fp), ("out", _fp), ("grp_off", _fp),
                 ("n_grp", _i32), ("heads", _i32), ("hp", _i32), ("k_off", _i32), ("qk_cs", _i32), ("v_cs", _i32), ("out_cs", _i32),
-                ("n_qtiles16", _i32)]
+                ("n_qtiles16", _i32), ("n_qtiles32", _i32), ("n_qtiles64", _i32)]
 
 
 class WinAttnArgs(C.Structure):

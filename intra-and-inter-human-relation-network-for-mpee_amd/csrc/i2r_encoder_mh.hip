@@ -4,7 +4,8 @@
 // the general form behind the same config keys: the host composes a layer from 1x1 i2r_conv launches (q|k, v, out-proj, FFN),
 // i2r_layernorm and this launch.
 //
-// One wave per (16-query tile of a group, head), flash-style over the group's keys in tiles of 16, everything on the fp32 matrix pipe
+// One wave per (tile of 16 NQ queries of a group, head), flash-style over the group's keys in tiles of 16 (the next tile's operands
+// fetched under the current one's arithmetic), everything on the fp32 matrix pipe
 // (v_mfma_f32_16x16x4_f32) without LDS:
 //   S^T = K Q^T     A = K rows (lane (li, g) holds key li, dims 16u + 4g + c as one 16-byte load), B = Q^T (same dims of query li):
 //                   the contraction index of step (u, c) runs over g, i.e. over the four dims 16u + 4g + c -- any enumeration of the
@@ -28,7 +29,7 @@ struct MhK {
 
 constexpr float kLog2e = 1.4426950408889634f;
 
-template <int HB>  // hp / 16
+template <int HB, int NQ>  // hp / 16, 16-query tiles per wave (they share every K / V fragment the wave loads)
 __global__ __launch_bounds__(256) void enc_mh_attn_k(const MhK p) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int li = lane & 15, g = lane >> 4;
@@ -38,74 +39,97 @@ __global__ __launch_bounds__(256) void enc_mh_attn_k(const MhK p) {
     for (; gi < p.n_grp; ++gi) {
         g0 = p.grp_off[gi];
         g1 = p.grp_off[gi + 1];
-        const int nt = (g1 - g0 + 15) >> 4;
+        const int nt = (g1 - g0 + 16 * NQ - 1) / (16 * NQ);
         if (t < nt) break;
         t -= nt;
     }
     if (gi >= p.n_grp) return;
-    const int q0 = g0 + t * 16;
+    const int q0 = g0 + t * 16 * NQ;
     const int hc = head * p.hp + 4 * g;
-    const int qrow = min(q0 + li, g1 - 1);
-    f32x4 q[HB], o[HB];
+    f32x4 q[NQ][HB], o[NQ][HB];
+    float m[NQ], l[NQ];
 #pragma unroll
-    for (int u = 0; u < HB; ++u) {
-        q[u] = *reinterpret_cast<const f32x4*>(p.qk + (size_t)qrow * p.qk_cs + hc + 16 * u) * kLog2e;  // (exp2 below)
-        o[u] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    }
-    float m = -INFINITY, l = 0.f;
-    for (int k0 = g0; k0 < g1; k0 += 16) {
-        const int krow = min(k0 + li, g1 - 1);
-        const float* kp = p.qk + (size_t)krow * p.qk_cs + p.k_off + hc;
-        f32x4 s = {0.f, 0.f, 0.f, 0.f};
+    for (int n = 0; n < NQ; ++n) {
+        const int qrow = min(q0 + 16 * n + li, g1 - 1);
 #pragma unroll
         for (int u = 0; u < HB; ++u) {
-            const f32x4 kk = *reinterpret_cast<const f32x4*>(kp + 16 * u);
-#pragma unroll
-            for (int c = 0; c < 4; ++c) s = mfma16(kk[c], q[u][c], s);
+            q[n][u] = *reinterpret_cast<const f32x4*>(p.qk + (size_t)qrow * p.qk_cs + hc + 16 * u) * kLog2e;  // (exp2 below)
+            o[n][u] = (f32x4){0.f, 0.f, 0.f, 0.f};
         }
-        // the V operands of this key tile (rows clamped: their probabilities are zero)
-        float vv[4][HB];
+        m[n] = -INFINITY;
+        l[n] = 0.f;
+    }
+    // the operands of one key tile: K rows as float4 (lane: key li, dims 16u + 4g ..), V as the A operand of the PV steps (lane: dim li of
+    // block db, key 4g + r); rows clamped to the group (their probabilities are zero)
+    auto load_tile = [&](int k0, f32x4(&kk)[HB], float(&vv)[4][HB]) {
+        const float* kp = p.qk + (size_t)min(k0 + li, g1 - 1) * p.qk_cs + p.k_off + hc;
+#pragma unroll
+        for (int u = 0; u < HB; ++u) kk[u] = *reinterpret_cast<const f32x4*>(kp + 16 * u);
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             const float* vp = p.v + (size_t)min(k0 + 4 * g + r, g1 - 1) * p.v_cs + head * p.hp + li;
 #pragma unroll
             for (int db = 0; db < HB; ++db) vv[r][db] = vp[16 * db];
         }
-        float mx = -INFINITY;
+    };
+    f32x4 kk[HB], kn[HB];
+    float vv[4][HB], vn[4][HB];
+    load_tile(g0, kk, vv);
+    for (int k0 = g0; k0 < g1; k0 += 16) {
+        load_tile(min(k0 + 16, g1 - 1), kn, vn);  // (the next tile flies under this one's arithmetic; past the end: a harmless re-read)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            if (k0 + 4 * g + r >= g1) s[r] = -INFINITY;
-            mx = fmaxf(mx, s[r]);
+        for (int n = 0; n < NQ; ++n) {
+            f32x4 s = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int u = 0; u < HB; ++u)
+#pragma unroll
+                for (int c = 0; c < 4; ++c) s = mfma16(kk[u][c], q[n][u][c], s);
+            float mx = -INFINITY;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                if (k0 + 4 * g + r >= g1) s[r] = -INFINITY;
+                mx = fmaxf(mx, s[r]);
+            }
+            mx = fmaxf(mx, __shfl_xor(mx, 16));
+            mx = fmaxf(mx, __shfl_xor(mx, 32));
+            const float m_new = fmaxf(m[n], mx);  // (finite: key k0 of every tile exists)
+            const float alpha = __builtin_amdgcn_exp2f(m[n] - m_new);
+            float pr[4], ps = 0.f;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                pr[r] = __builtin_amdgcn_exp2f(s[r] - m_new);
+                ps += pr[r];
+            }
+            l[n] = l[n] * alpha + ps;
+            m[n] = m_new;
+#pragma unroll
+            for (int db = 0; db < HB; ++db) o[n][db] *= alpha;
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+#pragma unroll
+                for (int db = 0; db < HB; ++db) o[n][db] = mfma16(vv[r][db], pr[r], o[n][db]);
         }
-        mx = fmaxf(mx, __shfl_xor(mx, 16));
-        mx = fmaxf(mx, __shfl_xor(mx, 32));
-        const float m_new = fmaxf(m, mx);  // (finite: key k0 of every tile exists)
-        const float alpha = __builtin_amdgcn_exp2f(m - m_new);
-        float pr[4], ps = 0.f;
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            pr[r] = __builtin_amdgcn_exp2f(s[r] - m_new);
-            ps += pr[r];
-        }
-        l = l * alpha + ps;
-        m = m_new;
-#pragma unroll
-        for (int db = 0; db < HB; ++db) o[db] *= alpha;
+        for (int u = 0; u < HB; ++u) kk[u] = kn[u];
 #pragma unroll
         for (int r = 0; r < 4; ++r)
 #pragma unroll
-            for (int db = 0; db < HB; ++db) o[db] = mfma16(vv[r][db], pr[r], o[db]);
+            for (int db = 0; db < HB; ++db) vv[r][db] = vn[r][db];
     }
-    l += __shfl_xor(l, 16);
-    l += __shfl_xor(l, 32);
-    const float inv = 1.f / l;
-    if (q0 + li < g1) {
-        float* op = p.out + (size_t)(q0 + li) * p.out_cs;
 #pragma unroll
-        for (int db = 0; db < HB; ++db) *reinterpret_cast<f32x4*>(op + hc + 16 * db) = o[db] * inv;
-        // the columns behind the last head are the zero-weight pad columns of the out-proj: keep them finite
-        if (head == 0)
-            for (int c = p.heads * p.hp + 4 * g; c < p.out_cs; c += 16) *reinterpret_cast<f32x4*>(op + c) = (f32x4){0.f, 0.f, 0.f, 0.f};
+    for (int n = 0; n < NQ; ++n) {
+        float ls = l[n];
+        ls += __shfl_xor(ls, 16);
+        ls += __shfl_xor(ls, 32);
+        const float inv = 1.f / ls;
+        if (q0 + 16 * n + li < g1) {
+            float* op = p.out + (size_t)(q0 + 16 * n + li) * p.out_cs;
+#pragma unroll
+            for (int db = 0; db < HB; ++db) *reinterpret_cast<f32x4*>(op + hc + 16 * db) = o[n][db] * inv;
+            // the columns behind the last head are the zero-weight pad columns of the out-proj: keep them finite
+            if (head == 0)
+                for (int c = p.heads * p.hp + 4 * g; c < p.out_cs; c += 16) *reinterpret_cast<f32x4*>(op + c) = (f32x4){0.f, 0.f, 0.f, 0.f};
+        }
     }
 }
 
@@ -118,14 +142,31 @@ extern "C" int i2r_mh_attention(const i2r_mh_attn_args* a, void* stream) {
     I2R_CHECK_ARG(a->k_off >= hs && a->k_off % 4 == 0 && a->qk_cs >= a->k_off + hs && a->v_cs >= hs && a->out_cs >= hs && a->qk_cs % 4 == 0 &&
                       a->v_cs % 4 == 0 && a->out_cs % 4 == 0,
                   "i2r_mh_attention: row strides qk=%d (k at %d) v=%d out=%d for %d heads x %d", a->qk_cs, a->k_off, a->v_cs, a->out_cs, a->heads, a->hp);
-    I2R_CHECK_ARG(a->n_grp > 0 && a->n_qtiles16 > 0 && a->n_qtiles16 < (1 << 30), "i2r_mh_attention: n_grp=%d n_qtiles16=%d", a->n_grp, a->n_qtiles16);
+    I2R_CHECK_ARG(a->n_grp > 0 && a->n_qtiles64 > 0 && a->n_qtiles64 <= a->n_qtiles32 && a->n_qtiles32 <= a->n_qtiles16 && a->n_qtiles16 < (1 << 30),
+                  "i2r_mh_attention: n_grp=%d n_qtiles16/32/64=%d/%d/%d", a->n_grp, a->n_qtiles16, a->n_qtiles32, a->n_qtiles64);
     MhK k{a->qk, a->v, a->out, a->grp_off, a->n_grp, a->heads, a->hp, a->k_off, a->qk_cs, a->v_cs, a->out_cs};
     typedef void (*fn_t)(const MhK);
-    static const fn_t fns[16] = {enc_mh_attn_k<1>,  enc_mh_attn_k<2>,  enc_mh_attn_k<3>,  enc_mh_attn_k<4>,  enc_mh_attn_k<5>,  enc_mh_attn_k<6>,
-                                 enc_mh_attn_k<7>,  enc_mh_attn_k<8>,  enc_mh_attn_k<9>,  enc_mh_attn_k<10>, enc_mh_attn_k<11>, enc_mh_attn_k<12>,
-                                 enc_mh_attn_k<13>, enc_mh_attn_k<14>, enc_mh_attn_k<15>, enc_mh_attn_k<16>};
+    // query tiles per wave (they share the K / V fragments a wave loads; registers: q and o are NQ x HB fragments): up to 64 queries for
+    // heads of <= 32 dims, 32 up to 96 dims, 16 beyond -- but never so few waves that the chip's 1024 SIMDs go unfilled (an inter-human
+    // stack over a few hundred tokens per image keeps 16-query tiles)
+    static const fn_t fn1[16] = {enc_mh_attn_k<1, 1>,  enc_mh_attn_k<2, 1>,  enc_mh_attn_k<3, 1>,  enc_mh_attn_k<4, 1>,  enc_mh_attn_k<5, 1>,  enc_mh_attn_k<6, 1>,
+                                 enc_mh_attn_k<7, 1>,  enc_mh_attn_k<8, 1>,  enc_mh_attn_k<9, 1>,  enc_mh_attn_k<10, 1>, enc_mh_attn_k<11, 1>, enc_mh_attn_k<12, 1>,
+                                 enc_mh_attn_k<13, 1>, enc_mh_attn_k<14, 1>, enc_mh_attn_k<15, 1>, enc_mh_attn_k<16, 1>};
+    static const fn_t fn2[6] = {enc_mh_attn_k<1, 2>, enc_mh_attn_k<2, 2>, enc_mh_attn_k<3, 2>, enc_mh_attn_k<4, 2>, enc_mh_attn_k<5, 2>, enc_mh_attn_k<6, 2>};
+    static const fn_t fn4[2] = {enc_mh_attn_k<1, 4>, enc_mh_attn_k<2, 4>};
+    const int hb = a->hp / 16;
+    constexpr long long kMinWaves = 4096;
+    fn_t fn = fn1[hb - 1];
+    int n_tiles = a->n_qtiles16;
+    if (hb <= 2 && (long long)a->n_qtiles64 * a->heads >= kMinWaves) {
+        fn = fn4[hb - 1];
+        n_tiles = a->n_qtiles64;
+    } else if (hb <= 6 && (long long)a->n_qtiles32 * a->heads >= kMinWaves) {
+        fn = fn2[hb - 1];
+        n_tiles = a->n_qtiles32;
+    }
     const int wpb = a->heads >= 4 ? 4 : a->heads;  // waves (= heads) per workgroup
-    hipLaunchKernelGGL(fns[a->hp / 16 - 1], dim3((unsigned)a->n_qtiles16, (unsigned)((a->heads + wpb - 1) / wpb)), dim3(64 * wpb), 0, (hipStream_t)stream, k);
+    hipLaunchKernelGGL(fn, dim3((unsigned)n_tiles, (unsigned)((a->heads + wpb - 1) / wpb)), dim3(64 * wpb), 0, (hipStream_t)stream, k);
     I2R_CHECK_LAUNCH("i2r_mh_attention");
     return I2R_OK;
 }

@@ -1233,7 +1233,7 @@ class Program:
             if pre_norm:
                 self.release(qk_in)
             att = self.alloc(x.n, x.h, x.w, L["hs"])
-            a = cabi.MhAttnArgs(qk.ptr, v.ptr, att.ptr, goff.data_ptr(), 0, L["heads"], L["hp"], L["hs"], qk.cs, v.cs, att.cs, 0)
+            a = cabi.MhAttnArgs(qk.ptr, v.ptr, att.ptr, goff.data_ptr(), 0, L["heads"], L["hp"], L["hs"], qk.cs, v.cs, att.cs, 0, 0, 0)
             self.ops.append((cabi.OP_MH_ATTN, lane, a))
             mh_args.append(a)
             self.release(qk, v)
@@ -1279,7 +1279,7 @@ class Program:
             d.n_qtiles192 = nq192 if _ENC_LP4 else 0
             d.dtype = dt  # (both kernel families take any group offsets: K / V blocks are numbered group by group)
         for a in grouping.get("mh", ()):
-            a.n_grp, a.n_qtiles16 = len(offs) - 1, nq16
+            a.n_grp, a.n_qtiles16, a.n_qtiles32, a.n_qtiles64 = len(offs) - 1, nq16, nq, nq64
         grouping["current"] = offs
 
     def fork(self, mask):

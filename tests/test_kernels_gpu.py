@@ -763,14 +763,55 @@ def test_pe_cat_vec_matches_torch(S, h, w, th, tw, vec, c0, cs, flip):
     assert cabi.lib().i2r_pe_cat_vec(C.byref(bad), None) != 0
 
 
+@pytest.mark.parametrize("heads,hd,n_grp,nq_expect", [(8, 12, 40, 64), (2, 39, 70, 32), (1, 100, 6, 16)])
+def test_mh_attention_large_launches_use_wider_query_tiles(heads, hd, n_grp, nq_expect):
+    """i2r_mh_attention through the raw C-ABI on launches big enough for the 64- / 32-query tiles (>= 4096 waves; the model-level cases
+    stay on 16-query tiles), ragged groups of 800-1100 tokens, against torch per group and head"""
+    import ctypes as C
+    from i2r_amd import cabi
+    hp = (hd + 15) // 16 * 16
+    hs = heads * hp
+    g = torch.Generator().manual_seed(heads * 100 + hd)
+    lens = [int(v) for v in torch.randint(800, 1100, (n_grp,), generator=g)]
+    offs = [0]
+    for n in lens:
+        offs.append(offs[-1] + n)
+    n_tok = offs[-1]
+    nq16, nq32, nq64 = (sum(-(-n // t) for n in lens) for t in (16, 32, 64))
+    assert {64: nq64 * heads >= 4096, 32: nq64 * heads < 4096 <= nq32 * heads or hp > 32, 16: True}[nq_expect]
+    q = torch.zeros(n_tok, heads, hp)
+    k = torch.zeros(n_tok, heads, hp)
+    v = torch.zeros(n_tok, heads, hp)
+    q[..., :hd] = torch.randn(n_tok, heads, hd, generator=g) * (3.0 * hd ** -0.5)  # (the host folds head_dim^-0.5 into q: logits of a few units)
+    k[..., :hd] = torch.randn(n_tok, heads, hd, generator=g)
+    v[..., :hd] = torch.randn(n_tok, heads, hd, generator=g)
+    qk = torch.cat([q.reshape(n_tok, hs), k.reshape(n_tok, hs)], 1).contiguous().to(DEV)
+    vd = v.reshape(n_tok, hs).contiguous().to(DEV)
+    out = torch.full((n_tok, hs), float("nan"), device=DEV)
+    goff = torch.tensor(offs, dtype=torch.int32, device=DEV)
+    a = cabi.MhAttnArgs(qk.data_ptr(), vd.data_ptr(), out.data_ptr(), goff.data_ptr(), n_grp, heads, hp, hs, 2 * hs, hs, hs, nq16, nq32, nq64)
+    cabi.check(cabi.lib().i2r_mh_attention(C.byref(a), None), "mh_attention")
+    torch.cuda.synchronize()
+    got = out.cpu().view(n_tok, heads, hp)
+    err = 0.0
+    for i in range(n_grp):
+        sl = slice(offs[i], offs[i + 1])
+        s_ = torch.einsum("qhd,khd->hqk", q[sl], k[sl])
+        ref = torch.einsum("hqk,khd->qhd", torch.softmax(s_, -1), v[sl])
+        err = max(err, (got[sl] - ref).abs().max().item())
+    assert err < 2e-5, err
+    assert torch.isfinite(got).all()
+
+
 def test_mh_attention_rejects_bad_arguments():
     import ctypes as C
     from i2r_amd import cabi
     L = cabi.lib()
     t = torch.zeros(64 * 64, device=DEV)
     g = torch.tensor([0, 16], dtype=torch.int32, device=DEV)
-    ok = dict(qk=t.data_ptr(), v=t.data_ptr(), out=t.data_ptr(), grp_off=g.data_ptr(), n_grp=1, heads=2, hp=16, k_off=32, qk_cs=64, v_cs=32, out_cs=32, n_qtiles16=1)
-    for bad in (dict(hp=12), dict(hp=272), dict(k_off=16), dict(qk_cs=48), dict(v_cs=16), dict(out_cs=30), dict(n_qtiles16=0), dict(heads=0), dict(qk=None)):
+    ok = dict(qk=t.data_ptr(), v=t.data_ptr(), out=t.data_ptr(), grp_off=g.data_ptr(), n_grp=1, heads=2, hp=16, k_off=32, qk_cs=64, v_cs=32, out_cs=32, n_qtiles16=1, n_qtiles32=1,
+              n_qtiles64=1)
+    for bad in (dict(hp=12), dict(hp=272), dict(k_off=16), dict(qk_cs=48), dict(v_cs=16), dict(out_cs=30), dict(n_qtiles16=0), dict(n_qtiles64=0), dict(n_qtiles32=2), dict(heads=0), dict(qk=None)):
         a = cabi.MhAttnArgs(**dict(ok, **bad))
         assert L.i2r_mh_attention(C.byref(a), None) != 0 and b"i2r_mh_attention" in L.i2r_last_error()
 
