@@ -1722,10 +1722,14 @@ def validate_config(cfg, name=None):
         raise NotImplementedError("MODEL.NAME=%r" % (name,))
     if name in ("hrnet", "transpose_h", "hrformer"):
         return
-    if M["USE_MULTI_POS"] and M["MULTI_POS_EMBEDDING"] not in ("conv", "res", "cat_vec"):
-        # 'sine': PositionEmbeddingImage.forward returns a 3-D table there (position_embedding.py:88-91) and every caller then fails in
-        # padding / flatten_input (permute of 5 dims) -- the reference itself cannot run it
-        raise NotImplementedError("MULTI_POS_EMBEDDING=%r with USE_MULTI_POS (the reference's own forward raises for 'sine')" % (M["MULTI_POS_EMBEDDING"],))
+    if M["USE_MULTI_POS"] and M["MULTI_POS_EMBEDDING"] not in ("conv", "res", "cat_vec", "sine"):
+        raise NotImplementedError("MULTI_POS_EMBEDDING=%r" % (M["MULTI_POS_EMBEDDING"],))
+    if M["USE_MULTI_POS"] and M["MULTI_POS_EMBEDDING"] == "sine" and (name != "interformer" or M["DIM_MODEL"] % 4):
+        # PositionEmbeddingImage.forward returns a 3-D table for 'sine' (position_embedding.py:88-91): interformer_pureMulti.flatten_input
+        # and interformer_2stage.flatten_input permute it as five dimensions and raise; interformer's encoder passes it through
+        # (attention.py:131-137).  The sin / cos halves only stack when DIM_MODEL / 2 is even (:53-56).
+        raise NotImplementedError("MULTI_POS_EMBEDDING sine with USE_MULTI_POS: the reference's own forward raises for MODEL.NAME %s / DIM_MODEL %d"
+                                  % (name, M["DIM_MODEL"]))
     if M["USE_MULTI_POS"] and M["MULTI_POS_EMBEDDING"] == "cat_vec" and name == "interformer":
         wide = M["DIM_MODEL"] + M["MULTI_POS_EMBEDDING_DIM"]
         if wide % M["N_HEAD"]:
@@ -1948,6 +1952,8 @@ class Engine:
             self.pe_conv2 = pk.conv(p + ".conv2", p + ".bn2", stride=2)
         elif mode == "res":
             self.pe_res = pk.pe_res(p)
+        elif mode == "sine":
+            pass  # (no parameters: rows of a canvas table computed on the host exactly as the reference does, _sine_table)
         elif mode == "cat_vec":
             # nn.Linear(TRANS_SIZE[0] * TRANS_SIZE[1], vec_dim) on the pooled mask (position_embedding.py:19-23): vec_dim = DIM_MODEL in
             # interformer_pureMulti.py:465, MULTI_POS_EMBEDDING_DIM in interformer.py:155 / interformer_2stage.py
@@ -1960,6 +1966,50 @@ class Engine:
             raise NotImplementedError("MULTI_POS_EMBEDDING=%r with USE_MULTI_POS" % (mode,))
 
     # ---- program construction ----
+    def _sine_table(self, n, h, w, d, cs):
+        """PositionEmbeddingImage.make_sine_position_embedding (position_embedding.py:34-61) for n = max(length) persons: a sine embedding
+        over a canvas of h x (n w) cells, flattened row-major; the reference adds row l to token l of the (person, y, x)-ordered sequence
+        of an image (a 3-D pos is not permuted, attention.py:131-137), so person q owns rows [q h w, (q + 1) h w).  Computed on the
+        host with the reference's own sequence of torch CPU ops (it builds the table on the CPU in every forward) -> [n, h w, cs] on the device."""
+        key = (n, h, w, d)
+        cache = self.__dict__.setdefault("_sine_tables", {})
+        if key not in cache:
+            W = n * w
+            area = torch.ones(1, h, W)
+            y_embed = area.cumsum(1, dtype=torch.float32)
+            x_embed = area.cumsum(2, dtype=torch.float32)
+            half = d // 2
+            y_embed = y_embed / (y_embed[:, -1:, :] + 1e-6) * (2 * math.pi)
+            x_embed = x_embed / (x_embed[:, :, -1:] + 1e-6) * (2 * math.pi)
+            dim_t = torch.arange(half, dtype=torch.float32)
+            dim_t = 10000 ** (2 * torch.div(dim_t, 2, rounding_mode="floor") / half)
+            pos_x = x_embed[:, :, :, None] / dim_t
+            pos_y = y_embed[:, :, :, None] / dim_t
+            pos_x = torch.stack((pos_x[:, :, :, 0::2].sin(), pos_x[:, :, :, 1::2].cos()), dim=4).flatten(3)
+            pos_y = torch.stack((pos_y[:, :, :, 0::2].sin(), pos_y[:, :, :, 1::2].cos()), dim=4).flatten(3)
+            tab = torch.cat((pos_y, pos_x), dim=3).reshape(h * W, d)  # (row-major canvas)
+            out = torch.zeros(n, h * w, cs)
+            out[:, :, :d] = tab.view(n, h * w, d)
+            if len(cache) > 16:
+                cache.clear()
+            cache[key] = out.to(self.device)
+        return cache[key]
+
+    def _fill_sine(self, patch, glen):
+        """rows of the 'sine' multi-position embedding for the crops of this forward (glen: persons per token group, capacity groups included)"""
+        pos = patch.get("pos_sine")
+        if pos is None:
+            return
+        n = max(self._sine_n, 1)
+        key = (n, tuple(glen))
+        if patch.get("_sine_key") == key:
+            return
+        tab = self._sine_table(n, pos.h, pos.w, pos.c, pos.cs)
+        idx = torch.tensor([q for g in glen for q in range(g)], dtype=torch.long).to(self.device, non_blocking=True)
+        assert idx.numel() == pos.n
+        pos.view().view(pos.n, pos.h * pos.w, pos.cs).copy_(tab[idx])
+        patch["_sine_key"] = key
+
     def _pos_branch(self, P, n, h, w, trans_w, n_src=None, cat=None):
         """cat (mode cat_vec of MODEL.NAME interformer): the token buffer whose channels behind DIM_MODEL receive the embedding"""
         if self.pe_mode == "cat_vec":
@@ -2039,7 +2089,12 @@ class Engine:
                     P.release(f)
                 f = c
         pos_ptr = 0
-        if self.use_pos:
+        if self.use_pos and self.pe_mode == "sine":
+            # the mask is ignored (position_embedding.py:88-91); the rows are filled per forward (_fill_sine: they depend on max(length))
+            pos = patch["pos_sine"] = P.alloc(S, f.h, f.w, f.c)
+            pos.t.zero_()
+            pos_ptr = pos.ptr
+        elif self.use_pos:
             pos, patch["pos_mask"] = self._pos_branch(P, S, H, W, M["TRANS_SIZE"][-1], n_src=n_src, cat=cat)
             assert (pos.h, pos.w, pos.cs) == (f.h, f.w, f.cs)
             pos_ptr = pos.ptr if cat is None else 0  # (concatenated: the encoder gets no additive embedding, interformer.py:299)
@@ -2149,6 +2204,7 @@ class Engine:
         S, _, H, W = x.shape
         assert S == sum(length), "sum(length)=%d != number of crops %d" % (sum(length), S)
         assert all(n >= 1 for n in length), "every image needs at least one person"
+        self._sine_n = max(length)  # (MULTI_POS_EMBEDDING sine: the canvas is max(length) persons wide, for every part of this batch)
         with torch.cuda.device(self.device):  # kernels and events go to the CURRENT device: make it this engine's
             return self._forward(x, pos_mask, list(length), flip_joint_map, S, H, W)
 
@@ -2289,6 +2345,7 @@ class Engine:
             for n in glen:
                 go.append(go[-1] + n * tok)
             Pt.set_groups(grouping, go)
+        self._fill_sine(patch, glen)
         J = M["NUM_JOINTS"]
         keep = [x]
         if "pos_mask" in patch:
@@ -2329,6 +2386,7 @@ class Engine:
             for n in glen:
                 offs.append(offs[-1] + n * tok)
             P.set_groups(grouping, offs)
+        self._fill_sine(patch, glen)
         J = M["NUM_JOINTS"]
         patch["x"].in_ = x.data_ptr()
         patch["x"].n_valid = S

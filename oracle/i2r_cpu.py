@@ -226,7 +226,30 @@ def inter_human_encoder(sd, p, n_layers, feat, pos, length, n_head=1, collect=No
     return _unpad_persons(out, length)
 
 
-def multi_position_embedding(sd, p, pos_mask, trans_w, mode="conv"):
+def sine_canvas_embedding(d_model, h, w, n, temperature=10000, scale=2 * math.pi):
+    """PositionEmbeddingImage.make_sine_position_embedding (position_embedding.py:34-61) for one batch entry: a 2-D sine embedding over a
+    canvas of h x (n w) cells -- n = max(length) persons side by side -- flattened row-major to [h * n * w, d_model].  The reference adds
+    row l of this table to token l of the image's (person, y, x)-ordered sequence (attention.py:131-137: a 3-D pos is not permuted), i.e.
+    the canvas position of a token is NOT its own (y, x): restated as is."""
+    W = n * w
+    area = torch.ones(1, h, W)
+    y_embed = area.cumsum(1, dtype=torch.float32)
+    x_embed = area.cumsum(2, dtype=torch.float32)
+    half = d_model // 2
+    eps = 1e-6
+    y_embed = y_embed / (y_embed[:, -1:, :] + eps) * scale
+    x_embed = x_embed / (x_embed[:, :, -1:] + eps) * scale
+    dim_t = torch.arange(half, dtype=torch.float32)
+    dim_t = temperature ** (2 * torch.div(dim_t, 2, rounding_mode="floor") / half)
+    pos_x = x_embed[:, :, :, None] / dim_t
+    pos_y = y_embed[:, :, :, None] / dim_t
+    pos_x = torch.stack((pos_x[:, :, :, 0::2].sin(), pos_x[:, :, :, 1::2].cos()), dim=4).flatten(3)
+    pos_y = torch.stack((pos_y[:, :, :, 0::2].sin(), pos_y[:, :, :, 1::2].cos()), dim=4).flatten(3)
+    pos = torch.cat((pos_y, pos_x), dim=3).permute(0, 3, 1, 2)  # [1, d, h, W]
+    return pos.flatten(2).permute(2, 0, 1)[:, 0, :]             # [h * W, d]
+
+
+def multi_position_embedding(sd, p, pos_mask, trans_w, mode="conv", length=None, d_model=None):
     """PositionEmbeddingImage modes 'conv' (position_embedding.py:99-104) and 'res' (:93-97), then the pooling loop
     (:106-109): [S,1,H,W] -> [S,d,h,w].
 
@@ -259,8 +282,15 @@ def multi_position_embedding(sd, p, pos_mask, trans_w, mode="conv"):
         S, _, h, w = x.shape
         v = F.linear(x.reshape(S, h * w), sd[p + ".fc.weight"], sd[p + ".fc.bias"])
         return v[:, :, None, None].expand(S, v.shape[1], h, w).contiguous()
+    elif mode == "sine":
+        # position_embedding.py:88-91 (MODEL.NAME interformer only: the other two model classes permute the 3-D result as if it were 5-D
+        # and raise): the mask is ignored; person q of an image owns rows [q h w, (q + 1) h w) of the canvas table of its batch
+        h = pos_mask.shape[-2] // (pos_mask.shape[-1] // trans_w)
+        tab = sine_canvas_embedding(d_model, h, trans_w, max(length))
+        rows = [tab[q * h * trans_w:(q + 1) * h * trans_w] for n in length for q in range(n)]
+        return torch.stack(rows, 0).view(len(rows), h, trans_w, d_model).permute(0, 3, 1, 2).contiguous()
     else:
-        raise NotImplementedError("MULTI_POS_EMBEDDING=%r: the reference's own forward fails for 'sine' (a 3-D table meets a 5-D permute)" % (mode,))
+        raise NotImplementedError("MULTI_POS_EMBEDDING=%r" % (mode,))
     for _ in range(int(math.log(x.shape[-1] // trans_w, 2))):
         x = _maxpool(x)
     return x
@@ -357,7 +387,9 @@ def forward_two_stage(sd, cfg, x, pos_mask, length, collect=None):
             f = _maxpool(f)
     pos = None
     if M["USE_MULTI_POS"]:
-        pos = multi_position_embedding(sd, "multi_position_embedding", pos_mask, M["TRANS_SIZE"][-1], M["MULTI_POS_EMBEDDING"])
+        if M["MULTI_POS_EMBEDDING"] == "sine" and M["NAME"] != "interformer":
+            raise NotImplementedError("MULTI_POS_EMBEDDING sine: interformer_2stage permutes the 3-D table as if it were 5-D and raises")
+        pos = multi_position_embedding(sd, "multi_position_embedding", pos_mask, M["TRANS_SIZE"][-1], M["MULTI_POS_EMBEDDING"], length, M["DIM_MODEL"])
         if collect is not None:
             collect["pos"] = pos
     cat = pos is not None and M["MULTI_POS_EMBEDDING"] == "cat_vec" and M["NAME"] == "interformer"

@@ -227,9 +227,12 @@ def test_every_shipped_yaml_builds(name):
 
 def test_validate_config_refuses_unshipped_combinations():
     from i2r_amd import engine
-    for opts in (["MODEL.MULTI_POS_EMBEDDING", "sine"], ["MODEL.UPSAMPLE_TYPE", "bilinear"], ["MODEL.ATTENTION_TYPE", "window"]):
-        with pytest.raises(NotImplementedError):  # ('sine': the reference's own forward raises, see engine.validate_config)
+    for opts in (["MODEL.UPSAMPLE_TYPE", "bilinear"], ["MODEL.ATTENTION_TYPE", "window"]):
+        with pytest.raises(NotImplementedError):
             engine.validate_config(config.load_config("w48_bare_p6", opts))
+    for cname in ("w48_pure_en6", "coco_tph_192_p4_b4"):  # 'sine' outside MODEL.NAME interformer: the reference's own forward raises
+        with pytest.raises(NotImplementedError):
+            engine.validate_config(config.load_config(cname, ["MODEL.MULTI_POS_EMBEDDING", "sine", "MODEL.USE_MULTI_POS", True]))
     with pytest.raises(ValueError):  # 96 + 96 = 192 channels do not split into 5 heads
         engine.validate_config(config.load_config("w48_bare_p6", ["MODEL.MULTI_POS_EMBEDDING", "cat_vec", "MODEL.N_HEAD", 5]))
 

@@ -299,6 +299,27 @@ def test_variant_configs_in_16bit_modes(tag, precision):
         assert d.abs().max().item() > 1e-5  # it really is the 16-bit path
 
 
+def test_sine_multi_position_embedding_follows_the_batch():
+    """MULTI_POS_EMBEDDING sine (MODEL.NAME interformer): the canvas table is max(length) persons wide, so the rows a crop gets depend on the
+    batch it is in -- two groupings of six crops on ONE cached program, each against the oracle; the flip test doubles the groups"""
+    from i2r_amd import caller, synth
+    import post_cpu
+    cfg, sd, _, _, _, _ = setup("bare_sine_l213")
+    net = models.interformer.get_pose_net(cfg, is_train=False)
+    net.load_state_dict(sd, strict=True)
+    net = net.cuda()
+    for length, seed in (([2, 1, 3], 0), ([3, 3], 4), ([1, 1, 1, 1, 1, 1], 5), ([2, 1, 3], 0)):
+        x, m, length = synth.make_inputs(length, 256, 192, seed=seed)
+        y = net(x.cuda(), m.cuda(), length).cpu()
+        assert (y - i2r_cpu.forward(sd, cfg, x, m, length)).abs().max().item() < TOL, length
+    assert net.engine().n_builds == 1
+    x, m, length = synth.make_inputs([2, 1, 3], 256, 192, seed=0)
+    pairs = caller.FLIP_PAIRS["crowdpose"]
+    got = net.forward_flip(x.cuda(), m.cuda(), length, pairs).cpu()
+    ref = post_cpu.flip_test(lambda a, b, c: i2r_cpu.forward(sd, cfg, a, b, c), x, m, length, pairs)
+    assert (got - ref).abs().max().item() < TOL
+
+
 def test_mismatched_two_stage_geometry_raises_instead_of_reading_out_of_bounds():
     """HRNET_RES_LAYER 1 makes the first stage emit 32x24 maps while the up-sampling path still ends at HEATMAP_SIZE 64x48: the reference
     fails on `single_res + x` (interformer.py:315); here the residual of the last deconv must be refused at program build (it used to be
