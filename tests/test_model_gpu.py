@@ -299,6 +299,34 @@ def test_variant_configs_in_16bit_modes(tag, precision):
         assert d.abs().max().item() > 1e-5  # it really is the 16-bit path
 
 
+@pytest.mark.parametrize("cname,opts", [
+    ("w48_bare_p6", ["MODEL.N_HEAD", 4, "MODEL.NORMALIZE_BEFORE", True, "MODEL.MULTI_POS_EMBEDDING", "cat_vec", "MODEL.UPSAMPLE_TYPE", "upconv",
+                     "MODEL.EXTRA.FINAL_CONV_KERNEL", 3]),
+    ("coco_tph_192_p4_b4", ["MODEL.N_HEAD", 2, "MODEL.DOMAIN_TRANS", True, "MODEL.EXTRA.NUM_DECONV_KERNELS", [3], "MODEL.EXTRA.FINAL_CONV_KERNEL", 3,
+                            "MODEL.MULTI_POS_EMBEDDING", "cat_vec", "MODEL.USE_MULTI_POS", True]),
+    ("w48_pure_en6", ["MODEL.EXTRA.STAGE2.NUM_CHANNELS", [32, 64], "MODEL.EXTRA.STAGE3.NUM_CHANNELS", [32, 64, 128], "MODEL.N_HEAD", 8,
+                      "MODEL.MULTI_POS_EMBEDDING", "cat_vec", "MODEL.EXTRA.NUM_DECONV_KERNELS", [2]]),
+    ("ochuman_tph_192_p3_b8", ["MODEL.MULTI_POS_EMBEDDING", "sine", "MODEL.N_HEAD", 3, "MODEL.UPSAMPLE_TYPE", "upconv", "MODEL.POS_EMBEDDING", "none",
+                               "MODEL.NORMALIZE_BEFORE", True]),
+])
+def test_combined_variants_match_oracle(cname, opts):
+    """several non-shipped settings at once (each one alone is pinned by a reference-made golden, tests/test_oracle.py): interactions of the
+    general encoder with cat_vec / sine, UpConv, 3x3 heads, other deconv kernels, narrow towers -- against the oracle, ragged batch"""
+    from i2r_amd import arch, config, synth
+    cfg = config.load_config(cname, opts)
+    sd = synth.make_state_dict(arch.param_spec(cfg))
+    net = eval("models." + cfg.MODEL.NAME + ".get_pose_net")(cfg, is_train=False)
+    net.load_state_dict(sd, strict=True)
+    x, m, length = synth.make_inputs([1, 3, 2], 256, 192, seed=11)
+    y = net.cuda()(x.cuda(), m.cuda(), length)
+    z = i2r_cpu.forward(sd, cfg, x, m, length)
+    outs, refs = (y if isinstance(y, dict) else {"multi": y}), (z if isinstance(z, dict) else {"multi": z})
+    for k, t in outs.items():
+        assert torch.isfinite(t).all()
+        err = (t.cpu() - refs[k]).abs().max().item()
+        assert err < TOL * max(1.0, refs[k].abs().max().item() / 8), (cname, k, err, refs[k].abs().max().item())
+
+
 def test_sine_multi_position_embedding_follows_the_batch():
     """MULTI_POS_EMBEDDING sine (MODEL.NAME interformer): the canvas table is max(length) persons wide, so the rows a crop gets depend on the
     batch it is in -- two groupings of six crops on ONE cached program, each against the oracle; the flip test doubles the groups"""
