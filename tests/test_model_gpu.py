@@ -327,6 +327,40 @@ def test_combined_variants_match_oracle(cname, opts):
         assert err < TOL * max(1.0, refs[k].abs().max().item() / 8), (cname, k, err, refs[k].abs().max().item())
 
 
+@pytest.mark.parametrize("opts", [["MODEL.HRNET_RES_LAYER", 1], ["MODEL.POS_EMBEDDING", "learnable", "MODEL.N_HEAD", 2], ["MODEL.HRNET_RES_LAYER", 2, "MODEL.POS_EMBEDDING", "none"]])
+def test_standalone_transpose_h_variants(opts):
+    """models.transpose_h alone (transpose_h.py:418-480,649-655) on another branch of the tower (HRNET_RES_LAYER: 32x24 / 16x12 token maps and
+    heat maps), with a learnable / no position table, two heads: (features, heat maps) against the oracle's first-stage restatement"""
+    from i2r_amd import arch, config, synth
+    cfg = config.load_config("tph_192_p6_b4", opts)
+    spec = arch.transpose_h_spec(cfg)
+    sd = synth.make_state_dict(spec)
+    net = models.transpose_h.get_pose_net(cfg, is_train=False)
+    net.load_state_dict(sd, strict=True)
+    x, _, _ = synth.make_inputs([2, 1], 256, 192, seed=2)
+    feat, hm = net.cuda()(x.cuda())
+    rf, rh = i2r_cpu.forward_transpose_h(sd, "", cfg, x)
+    r = cfg.MODEL.HRNET_RES_LAYER
+    assert feat.shape == rf.shape == (3, 96, 64 >> r, 48 >> r) and hm.shape == rh.shape
+    assert (feat.cpu() - rf).abs().max().item() < TOL and (hm.cpu() - rh).abs().max().item() < TOL
+
+
+@pytest.mark.parametrize("opts,is_dict", [(["MODEL.INTER_SUPERVISION", False], False), (["MODEL.SINGLEFORMER_FIX", True], False), ([], True)])
+def test_two_stage_return_type_follows_the_config(opts, is_dict):
+    """interformer.py:319-323: {'single', 'multi'} only with INTER_SUPERVISION and a first stage that is not frozen, else the 'multi' tensor"""
+    from i2r_amd import arch, config, synth
+    cfg = config.load_config("tph_192_p6_b4", opts)
+    sd = synth.make_state_dict(arch.param_spec(cfg))
+    net = models.interformer.get_pose_net(cfg, is_train=False)
+    net.load_state_dict(sd, strict=True)
+    x, m, length = synth.make_inputs([1, 1], 256, 192, seed=3)
+    y = net.cuda()(x.cuda(), m.cuda(), length)
+    z = i2r_cpu.forward(sd, cfg, x, m, length)
+    assert isinstance(y, dict) == isinstance(z, dict) == is_dict
+    ym, zm = (y["multi"], z["multi"]) if is_dict else (y, z)
+    assert (ym.cpu() - zm).abs().max().item() < TOL
+
+
 def test_sine_multi_position_embedding_follows_the_batch():
     """MULTI_POS_EMBEDDING sine (MODEL.NAME interformer): the canvas table is max(length) persons wide, so the rows a crop gets depend on the
     batch it is in -- two groupings of six crops on ONE cached program, each against the oracle; the flip test doubles the groups"""
