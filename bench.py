@@ -178,6 +178,10 @@ def op_model(kind, st, precision, enc_lens=None):
         oh, ow = (st.in_h - 1) // 2 + 1, (st.in_w - 1) // 2 + 1
         return ("pe_res_stem_k", st.n_img * (st.in_h * st.in_w * 54.0 + oh * ow * 2.0 * 147 * st.cout),
                 float(st.n_src * st.in_h * st.in_w * 4 + st.n_img * oh * ow * st.out_cs * 4), None)
+    if kind == cabi.OP_ROWS_GATHER:
+        return "rows_gather_k", 0.0, float(2 * st.n_out * st.floats_per_crop * 4), None
+    if kind == cabi.OP_VIEW_SCRAMBLE:
+        return "view_scramble_k", 0.0, float(st.n_out * st.hw * st.cs * 4 + st.n_images * st.max_persons * st.hw * st.cs * 4), None
     if kind == cabi.OP_PE_CAT_VEC:  # window maxima of the mask, one th*tw-long dot product per vector element, the broadcast store
         P = st.th * st.tw
         return ("pe_cat_vec_k", float(st.n_img * (st.in_h * st.in_w + 2.0 * P * st.vec)),

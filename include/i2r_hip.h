@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define I2R_ABI_VERSION 12
+#define I2R_ABI_VERSION 13
 
 /* The library is built with -fvisibility=hidden: the entry points declared in this header (marked I2R_API) are its ONLY exported
  * symbols (tests/test_host.py holds the header, the dynamic symbol table and cabi.EXPORTS equal). */
@@ -455,8 +455,26 @@ I2R_API int i2r_encoder_layer(const i2r_encoder_desc* d, void* stream);
 typedef struct i2r_mh_attn_args {
     const float* qk; const float* v; float* out; const int32_t* grp_off;
     int32_t n_grp, heads, hp, k_off, qk_cs, v_cs, out_cs, n_qtiles16, n_qtiles32, n_qtiles64;
+    const int32_t* key_len;   /* optional device int32 [n_grp]: group g attends to its FIRST key_len[g] rows only; all its rows stay queries
+                                 (padded persons under a key_padding_mask, ATTENTION_TYPE window) */
 } i2r_mh_attn_args;
 I2R_API int i2r_mh_attention(const i2r_mh_attn_args* a, void* stream);
+
+/* MODEL.ATTENTION_TYPE != 'default' (MODEL.NAME interformer: attention.py:991-1031,1046-1062) -- the inter-human "encoder" is ONE
+ * GeneralTransformerBlock: a multi-head attention (q / k / v / out projections with bias, MHA_ :494-835; the relative position bias is
+ * gathered but its addition is commented out, :780-786) over the (person, y, x) tokens of an image INCLUDING the padded persons' rows
+ * (zero features, keys masked), no residual / FFN / norm, whose [L, B, C] output is then RE-VIEWED: permute(0, 2, 1).contiguous()
+ * .view(B, C, P, H, W) (:1025-1029).  The two helpers below restate the padding and that view; the projections are i2r_conv launches, the
+ * attention i2r_mh_attention with key_len.
+ * i2r_rows_gather: out crop i = src crop map[i] (device int32 [n_out]), zeros where map[i] < 0 (padding_tensor, interformer.py:230-249).
+ * i2r_view_scramble: o = attention output rows [n_images][max_persons * hw][cs]; out crop s (NHWC [hw, cs], c real channels) = element
+ *   (b', p') = (person_map[s] / max_persons, person_map[s] % max_persons) of the re-viewed tensor:
+ *   out[s][yx][c'] = o[b][l][cc] with f = ((b' c + c') max_persons + p') hw + yx, b = f % n_images, cc = (f / n_images) % c, l = f / (c n_images). */
+I2R_API int i2r_rows_gather(const float* src, float* out, const int32_t* map, int32_t n_out, int32_t floats_per_crop, void* stream);
+I2R_API int i2r_view_scramble(const float* o, float* out, const int32_t* person_map, int32_t n_out, int32_t n_images, int32_t max_persons, int32_t c,
+                              int32_t cs, int32_t hw, void* stream);
+typedef struct i2r_gather_args { const float* src; float* out; const int32_t* map; int32_t n_out, floats_per_crop; } i2r_gather_args;
+typedef struct i2r_scramble_args { const float* o; float* out; const int32_t* person_map; int32_t n_out, n_images, max_persons, c, cs, hw; } i2r_scramble_args;
 
 /* ------------------------------------------------------------------------------------------------
  * Program runner: replay a pre-built list of launches from one C call (no per-op host overhead, and
@@ -471,7 +489,7 @@ enum {
     I2R_OP_ENC_KV = 5, I2R_OP_ENC_LAYER = 6, I2R_OP_FORK = 7, I2R_OP_JOIN = 8, I2R_OP_CONV_GROUP = 9,
     I2R_OP_LAYERNORM = 10, I2R_OP_WINATTN = 11, I2R_OP_DWCONV = 12, I2R_OP_UPSAMPLE = 13, I2R_OP_CONV_CHAIN = 14,
     I2R_OP_PE_RES_STEM = 15, I2R_OP_HRT_ATTN = 16, I2R_OP_HRT_MLP = 17, I2R_OP_XSYNC = 18, I2R_OP_FUSE_UP = 19,
-    I2R_OP_CONV1X1_PAIR = 20, I2R_OP_CONV1X1_LP = 21, I2R_OP_MH_ATTN = 22, I2R_OP_PE_CAT_VEC = 23
+    I2R_OP_CONV1X1_PAIR = 20, I2R_OP_CONV1X1_LP = 21, I2R_OP_MH_ATTN = 22, I2R_OP_PE_CAT_VEC = 23, I2R_OP_ROWS_GATHER = 24, I2R_OP_VIEW_SCRAMBLE = 25
 };
 
 typedef struct i2r_stem_args {

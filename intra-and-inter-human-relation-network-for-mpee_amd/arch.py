@@ -228,9 +228,16 @@ def interformer_spec(cfg):
     if M["MULTI_POS_EMBEDDING"] == "cat_vec" and M["USE_MULTI_POS"]:  # interformer.py:157-158, attention.py:1035-1040: concatenated, wider encoder
         wide = d + M["MULTI_POS_EMBEDDING_DIM"]
         spec.conv("fc", d, wide, 1, bias=True)
-    assert M["ATTENTION_TYPE"] == "default", "only ATTENTION_TYPE 'default' is reachable from the shipped configs"
-    for l in range(M["ENCODER_MULTI_LAYERS"]):
-        spec.encoder_layer("multi_global_encoder.layers.%d" % l, wide, M["DIM_FEEDFORWARD"])
+    if M["ATTENTION_TYPE"] == "default":
+        for l in range(M["ENCODER_MULTI_LAYERS"]):
+            spec.encoder_layer("multi_global_encoder.layers.%d" % l, wide, M["DIM_FEEDFORWARD"])
+    else:  # attention.get_hrformer_encoder (:1046-1051): ONE GeneralTransformerBlock = MHA_ with a relative position table + an unused norm1
+        ws, a = M["WINDOW_SIZE"], "multi_global_encoder.attn.attn"
+        spec.append((a + ".relative_position_bias_table", ((2 * ws - 1) ** 2, M["N_HEAD"]), F32))
+        spec.append((a + ".relative_position_index", (ws * ws, ws * ws), I64))
+        for n in ("k_proj", "v_proj", "q_proj", "out_proj"):
+            spec.linear(a + "." + n, wide, wide)
+        spec.layer_norm("multi_global_encoder.norm1", wide)
     planes, dk = deconv_geometry(extra)
     up = M["UPSAMPLE_TYPE"]
     if up == "deconv":

@@ -14,7 +14,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libi2r_hip.so")
 
 MAX_TAPS = 9
-ABI_VERSION = 12  # I2R_ABI_VERSION of include/i2r_hip.h
+ABI_VERSION = 13  # I2R_ABI_VERSION of include/i2r_hip.h
 OP_CONV, OP_STEM, OP_MAXPOOL, OP_HEAD, OP_ENC_KV, OP_ENC_LAYER, OP_FORK, OP_JOIN, OP_CONV_GROUP = 1, 2, 3, 4, 5, 6, 7, 8, 9
 MAX_GROUP = 4
 OP_LAYERNORM, OP_WINATTN, OP_DWCONV, OP_UPSAMPLE = 10, 11, 12, 13
@@ -28,6 +28,7 @@ OP_CONV1X1_PAIR = 20
 OP_CONV1X1_LP = 21
 OP_MH_ATTN = 22
 OP_PE_CAT_VEC = 23
+OP_ROWS_GATHER, OP_VIEW_SCRAMBLE = 24, 25
 SYNC_OPS = (OP_FORK, OP_JOIN, OP_XSYNC)  # ops whose `lane` field is a lane mask and that launch nothing
 
 _fp = C.c_void_p  # device pointers travel as integers
@@ -95,7 +96,16 @@ class LnArgs(C.Structure):
 class MhAttnArgs(C.Structure):
     _fields_ = [("qk", _fp), ("v", _fp), ("out", _fp), ("grp_off", _fp),
                 ("n_grp", _i32), ("heads", _i32), ("hp", _i32), ("k_off", _i32), ("qk_cs", _i32), ("v_cs", _i32), ("out_cs", _i32),
-                ("n_qtiles16", _i32), ("n_qtiles32", _i32), ("n_qtiles64", _i32)]
+                ("n_qtiles16", _i32), ("n_qtiles32", _i32), ("n_qtiles64", _i32), ("key_len", _fp)]
+
+
+class GatherArgs(C.Structure):
+    _fields_ = [("src", _fp), ("out", _fp), ("map", _fp), ("n_out", _i32), ("floats_per_crop", _i32)]
+
+
+class ScrambleArgs(C.Structure):
+    _fields_ = [("o", _fp), ("out", _fp), ("person_map", _fp), ("n_out", _i32), ("n_images", _i32), ("max_persons", _i32), ("c", _i32), ("cs", _i32),
+                ("hw", _i32)]
 
 
 class WinAttnArgs(C.Structure):
@@ -168,7 +178,7 @@ class Op(C.Structure):
 
 # every symbol include/i2r_hip.h declares (tests/test_host.py::test_cabi_library_exports_every_declared_symbol checks the built library exports them all)
 EXPORTS = ("i2r_conv", "i2r_conv_grouped", "i2r_conv_kernel_name", "i2r_stem_conv", "i2r_pe_res_stem", "i2r_maxpool3x3s2", "i2r_head", "i2r_layernorm", "i2r_window_attn", "i2r_hrt_attn_block", "i2r_hrt_mlp_block", "i2r_dwconv3x3",
-           "i2r_upsample_bilinear_add", "i2r_upsample_bilinear_add_multi", "i2r_fuse_up_add", "i2r_conv1x1_pair", "i2r_conv1x1_lp", "i2r_flip_merge", "i2r_decode", "i2r_crop_affine", "i2r_box_mask", "i2r_crop_affine_cv2", "i2r_box_mask_cv2", "i2r_person_inputs_cv2", "i2r_conv_chain_pack", "i2r_conv_chain", "i2r_encoder_kv", "i2r_encoder_layer", "i2r_mh_attention", "i2r_pe_cat_vec",
+           "i2r_upsample_bilinear_add", "i2r_upsample_bilinear_add_multi", "i2r_fuse_up_add", "i2r_conv1x1_pair", "i2r_conv1x1_lp", "i2r_flip_merge", "i2r_decode", "i2r_crop_affine", "i2r_box_mask", "i2r_crop_affine_cv2", "i2r_box_mask_cv2", "i2r_person_inputs_cv2", "i2r_conv_chain_pack", "i2r_conv_chain", "i2r_encoder_kv", "i2r_encoder_layer", "i2r_mh_attention", "i2r_pe_cat_vec", "i2r_rows_gather", "i2r_view_scramble",
            "i2r_run_program", "i2r_abi_version", "i2r_last_error", "i2r_device_check")
 
 _LIB = None
@@ -213,6 +223,8 @@ def load_library(path=LIB_PATH):
     L.i2r_upsample_bilinear_add.argtypes = [_fp, _fp, _fp, _i32, _i32, _i32, _i32, _i32, _i32, _i32, C.c_void_p]
     L.i2r_encoder_kv.argtypes = [C.POINTER(EncoderDesc), C.c_void_p]
     L.i2r_encoder_layer.argtypes = [C.POINTER(EncoderDesc), C.c_void_p]
+    L.i2r_rows_gather.argtypes = [_fp, _fp, _fp, _i32, _i32, C.c_void_p]
+    L.i2r_view_scramble.argtypes = [_fp, _fp, _fp, _i32, _i32, _i32, _i32, _i32, _i32, C.c_void_p]
     L.i2r_pe_cat_vec.argtypes = [C.POINTER(PeCatVecArgs), C.c_void_p]
     L.i2r_mh_attention.argtypes = [C.POINTER(MhAttnArgs), C.c_void_p]
     L.i2r_run_program.argtypes = [C.POINTER(Op), _i32, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p)]

@@ -152,6 +152,16 @@ extern "C" int i2r_run_program(const i2r_op* ops, int32_t n_ops, void* const* st
             }
             case I2R_OP_CONV1X1_PAIR: rc = i2r_conv1x1_pair((const i2r_conv1x1_pair_args*)op.args, st); break;
             case I2R_OP_CONV1X1_LP: rc = i2r_conv1x1_lp((const i2r_conv1x1_lp_args*)op.args, st); break;
+            case I2R_OP_ROWS_GATHER: {
+                const i2r_gather_args* a = (const i2r_gather_args*)op.args;
+                rc = i2r_rows_gather(a->src, a->out, a->map, a->n_out, a->floats_per_crop, st);
+                break;
+            }
+            case I2R_OP_VIEW_SCRAMBLE: {
+                const i2r_scramble_args* a = (const i2r_scramble_args*)op.args;
+                rc = i2r_view_scramble(a->o, a->out, a->person_map, a->n_out, a->n_images, a->max_persons, a->c, a->cs, a->hw, st);
+                break;
+            }
             case I2R_OP_PE_CAT_VEC: rc = i2r_pe_cat_vec((const i2r_pe_cat_vec_args*)op.args, st); break;
             case I2R_OP_MH_ATTN: rc = i2r_mh_attention((const i2r_mh_attn_args*)op.args, st); break;
             case I2R_OP_ENC_KV: rc = i2r_encoder_kv((const i2r_encoder_desc*)op.args, st); break;

@@ -24,6 +24,7 @@ struct MhK {
     const float* v;    // [n_tok, v_cs]
     float* out;        // [n_tok, out_cs]
     const int* grp_off;
+    const int* key_len;  // optional: group g attends to its first key_len[g] rows only (the others are queries without being keys)
     int n_grp, heads, hp, k_off, qk_cs, v_cs, out_cs;
 };
 
@@ -45,12 +46,14 @@ __global__ __launch_bounds__(256) void enc_mh_attn_k(const MhK p) {
     }
     if (gi >= p.n_grp) return;
     const int q0 = g0 + t * 16 * NQ;
+    const int q1 = g1;                           // queries: the whole group
+    if (p.key_len) g1 = g0 + p.key_len[gi];      // keys: its first key_len rows (key_padding_mask of the padded persons)
     const int hc = head * p.hp + 4 * g;
     f32x4 q[NQ][HB], o[NQ][HB];
     float m[NQ], l[NQ];
 #pragma unroll
     for (int n = 0; n < NQ; ++n) {
-        const int qrow = min(q0 + 16 * n + li, g1 - 1);
+        const int qrow = min(q0 + 16 * n + li, q1 - 1);
 #pragma unroll
         for (int u = 0; u < HB; ++u) {
             q[n][u] = *reinterpret_cast<const f32x4*>(p.qk + (size_t)qrow * p.qk_cs + hc + 16 * u) * kLog2e;  // (exp2 below)
@@ -122,7 +125,7 @@ __global__ __launch_bounds__(256) void enc_mh_attn_k(const MhK p) {
         ls += __shfl_xor(ls, 16);
         ls += __shfl_xor(ls, 32);
         const float inv = 1.f / ls;
-        if (q0 + 16 * n + li < g1) {
+        if (q0 + 16 * n + li < q1) {
             float* op = p.out + (size_t)(q0 + 16 * n + li) * p.out_cs;
 #pragma unroll
             for (int db = 0; db < HB; ++db) *reinterpret_cast<f32x4*>(op + hc + 16 * db) = o[n][db] * inv;
@@ -133,7 +136,64 @@ __global__ __launch_bounds__(256) void enc_mh_attn_k(const MhK p) {
     }
 }
 
+// crop i of out = crop map[i] of src, or zeros (map[i] < 0): the reference's padding_tensor (interformer.py:230-249) for the consumers that
+// need the padded persons as ROWS (ATTENTION_TYPE window: their tokens are queries whose outputs the final view() redistributes)
+__global__ __launch_bounds__(256) void rows_gather_k(const f32x4* __restrict__ src, f32x4* __restrict__ out, const int* __restrict__ map, int n_out, int per_crop4) {
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= (long long)n_out * per_crop4) return;
+    const int crop = (int)(i / per_crop4), r = (int)(i - (long long)crop * per_crop4);
+    const int m = map[crop];
+    out[i] = m >= 0 ? src[(size_t)m * per_crop4 + r] : (f32x4){0.f, 0.f, 0.f, 0.f};
+}
+
+// GeneralTransformerBlock.forward of attention.py (:1025-1029): the attention output [L, B, C] (L = P H W tokens of an image, B images) goes
+// through permute(0, 2, 1).contiguous().view(B, C, P, H, W) -- a REINTERPRETATION of the [L, C, B] memory, not a transpose -- and
+// permute(0, 2, 1, 3, 4).view(B P, C, H, W); get_valid_output then keeps the real persons.  Element (b', p', c', y, x) of the result is flat
+// element f = (((b' C + c') P + p') H + y) W + x of [L, C, B], i.e. o[l = f / (C B)][b = f % B][c = (f / B) % C].  Restated as is.
+// o: [B][L][cs] rows (image-major, as the attention launch writes them); out: NHWC crops of the real persons, crop s = (b', p') = pm[s].
+__global__ __launch_bounds__(256) void view_scramble_k(const float* __restrict__ o, float* __restrict__ out, const int* __restrict__ pm, int n_out, int B, int P,
+                                                        int C, int cs, int HW) {
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= (long long)n_out * HW * cs) return;
+    const int c = (int)(i % cs);
+    const long long t = i / cs;
+    const int yx = (int)(t % HW), s = (int)(t / HW);
+    float v = 0.f;
+    if (c < C) {
+        const int bp = pm[s], b1 = bp / P, p1 = bp - b1 * P;
+        const long long f = (((long long)b1 * C + c) * P + p1) * HW + yx;
+        const int b = (int)(f % B);
+        const long long r = f / B;
+        const int cc = (int)(r % C);
+        const long long l = r / C;
+        v = o[((long long)b * P * HW + l) * cs + cc];
+    }
+    out[i] = v;
+}
+
 }  // namespace
+
+extern "C" int i2r_rows_gather(const float* src, float* out, const int32_t* map, int32_t n_out, int32_t floats_per_crop, void* stream) {
+    I2R_CHECK_ARG(src && out && map && src != out, "i2r_rows_gather: bad pointers");
+    I2R_CHECK_ARG(n_out > 0 && floats_per_crop > 0 && floats_per_crop % 4 == 0, "i2r_rows_gather: n_out=%d floats_per_crop=%d", n_out, floats_per_crop);
+    const long long n4 = (long long)n_out * (floats_per_crop / 4);
+    I2R_CHECK_ARG((n4 + 255) / 256 < (1ll << 31), "i2r_rows_gather: grid");
+    hipLaunchKernelGGL(rows_gather_k, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, (hipStream_t)stream, reinterpret_cast<const f32x4*>(src),
+                       reinterpret_cast<f32x4*>(out), map, n_out, floats_per_crop / 4);
+    I2R_CHECK_LAUNCH("i2r_rows_gather");
+    return I2R_OK;
+}
+
+extern "C" int i2r_view_scramble(const float* o, float* out, const int32_t* person_map, int32_t n_out, int32_t n_images, int32_t max_persons, int32_t c,
+                                 int32_t cs, int32_t hw, void* stream) {
+    I2R_CHECK_ARG(o && out && person_map && o != out, "i2r_view_scramble: bad pointers");
+    I2R_CHECK_ARG(n_out > 0 && n_images > 0 && max_persons > 0 && c > 0 && c <= cs && hw > 0, "i2r_view_scramble: sizes");
+    const long long n = (long long)n_out * hw * cs;
+    I2R_CHECK_ARG((n + 255) / 256 < (1ll << 31) && (long long)n_images * max_persons * hw * cs < (1ll << 40), "i2r_view_scramble: grid");
+    hipLaunchKernelGGL(view_scramble_k, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, o, out, person_map, n_out, n_images, max_persons, c, cs, hw);
+    I2R_CHECK_LAUNCH("i2r_view_scramble");
+    return I2R_OK;
+}
 
 extern "C" int i2r_mh_attention(const i2r_mh_attn_args* a, void* stream) {
     I2R_CHECK_ARG(a && a->qk && a->v && a->out && a->grp_off, "i2r_mh_attention: null pointer");
@@ -144,7 +204,7 @@ extern "C" int i2r_mh_attention(const i2r_mh_attn_args* a, void* stream) {
                   "i2r_mh_attention: row strides qk=%d (k at %d) v=%d out=%d for %d heads x %d", a->qk_cs, a->k_off, a->v_cs, a->out_cs, a->heads, a->hp);
     I2R_CHECK_ARG(a->n_grp > 0 && a->n_qtiles64 > 0 && a->n_qtiles64 <= a->n_qtiles32 && a->n_qtiles32 <= a->n_qtiles16 && a->n_qtiles16 < (1 << 30),
                   "i2r_mh_attention: n_grp=%d n_qtiles16/32/64=%d/%d/%d", a->n_grp, a->n_qtiles16, a->n_qtiles32, a->n_qtiles64);
-    MhK k{a->qk, a->v, a->out, a->grp_off, a->n_grp, a->heads, a->hp, a->k_off, a->qk_cs, a->v_cs, a->out_cs};
+    MhK k{a->qk, a->v, a->out, a->grp_off, a->key_len, a->n_grp, a->heads, a->hp, a->k_off, a->qk_cs, a->v_cs, a->out_cs};
     typedef void (*fn_t)(const MhK);
     // query tiles per wave (they share the K / V fragments a wave loads; registers: q and o are NQ x HB fragments): up to 64 queries for
     // heads of <= 32 dims, 32 up to 96 dims, 16 beyond -- but never so few waves that the chip's 1024 SIMDs go unfilled (an inter-human

@@ -423,6 +423,25 @@ class Packer:
                     w2=self.linear_as_conv(s[p + ".linear2.weight"], s[p + ".linear2.bias"]),
                     ln1=self.ln(p + ".norm1", d), ln2=self.ln(p + ".norm2", d))
 
+    def window_block(self, a, d, heads):
+        """MHA_ of attention.py (:494-835) under key prefix a: separate q / k / v / out projections with bias, in the head-padded channel
+        order of encoder_layer_mh (head_dim^-0.5 folded into q); the relative position table is a parameter nobody reads (:780-786)"""
+        assert self.dtype == 0
+        s = self.sd
+        hd = d // heads
+        assert hd * heads == d
+        hp, hs = self.mh_width(heads, hd)
+        rows = torch.tensor([hh * hp + j for hh in range(heads) for j in range(hd)])
+        wqk, bqk = torch.zeros(2 * hs, d, dtype=torch.float64), torch.zeros(2 * hs, dtype=torch.float64)
+        wqk[rows], bqk[rows] = s[a + ".q_proj.weight"].double() * float(hd) ** -0.5, s[a + ".q_proj.bias"].double() * float(hd) ** -0.5
+        wqk[hs + rows], bqk[hs + rows] = s[a + ".k_proj.weight"].double(), s[a + ".k_proj.bias"].double()
+        wv, bv = torch.zeros(hs, d, dtype=torch.float64), torch.zeros(hs, dtype=torch.float64)
+        wv[rows], bv[rows] = s[a + ".v_proj.weight"].double(), s[a + ".v_proj.bias"].double()
+        wo = torch.zeros(d, hs, dtype=torch.float64)
+        wo[:, rows] = s[a + ".out_proj.weight"].double()
+        return dict(heads=heads, hp=hp, hs=hs, d=d, cs=_r16(d), qk=self.linear_as_conv(wqk, bqk), v=self.linear_as_conv(wv, bv),
+                    o=self.linear_as_conv(wo, s[a + ".out_proj.bias"]))
+
     def dw(self, conv_key, bn_key, eps=1e-5):
         """depth-wise 3x3 [C,1,3,3] (+bias) + BN -> tap-major [9][cs] weights + [cs] bias."""
         w = self.sd[conv_key + ".weight"]
@@ -994,6 +1013,25 @@ class Program:
         for (py, px), pc in pcs.items():
             self.conv(x, pc, relu=relu, res_post=res_post, out=out, out_step=2, out_off=(py, px), lane=lane, group=grp)
         self.flush_group(grp, lane=lane)
+        return out
+
+    def rows_gather(self, src, crop_map, lane=0):
+        """[len(crop_map), h, w, c] whose crop i is crop crop_map[i] of src, zeros for -1 (padding_tensor: the padded persons as rows)"""
+        out = self.alloc(len(crop_map), src.h, src.w, src.c)
+        m = torch.tensor(list(crop_map), dtype=torch.int32).to(self.device)
+        self.keep.append(m)
+        a = cabi.GatherArgs(src.ptr, out.ptr, m.data_ptr(), len(crop_map), src.h * src.w * src.cs)
+        self.ops.append((cabi.OP_ROWS_GATHER, lane, a))
+        return out
+
+    def view_scramble(self, o, person_map, n_images, max_persons, c, lane=0):
+        """GeneralTransformerBlock's re-viewing of the attention output (attention.py:1025-1029, i2r_view_scramble) + get_valid_output"""
+        out = self.alloc(len(person_map), o.h, o.w, c)
+        m = torch.tensor(list(person_map), dtype=torch.int32).to(self.device)
+        self.keep.append(m)
+        a = cabi.ScrambleArgs(o.ptr, out.ptr, m.data_ptr(), len(person_map), n_images, max_persons, c, out.cs, o.h * o.w)
+        assert o.cs == out.cs and o.n == n_images * max_persons
+        self.ops.append((cabi.OP_VIEW_SCRAMBLE, lane, a))
         return out
 
     def pe_cat_vec(self, fc, n, h, w, th, tw, out, c0, lane=0, n_src=None):
@@ -1744,8 +1782,9 @@ def validate_config(cfg, name=None):
             raise NotImplementedError("HRFormer-B emits 78 channels (hrformer.py:2527), DIM_MODEL=%r" % (M["DIM_MODEL"],))
         if M["UPSAMPLE_TYPE"] not in ("deconv", "multiplex", "upconv"):
             raise NotImplementedError("UPSAMPLE_TYPE=%r" % (M["UPSAMPLE_TYPE"],))
-        if M["ATTENTION_TYPE"] != "default":
-            raise NotImplementedError("ATTENTION_TYPE=%r" % (M["ATTENTION_TYPE"],))
+        # (only interformer.py:160 reads ATTENTION_TYPE, through attention.get_encoder; interformer_2stage builds its own encoder classes)
+        if name == "interformer" and M["ATTENTION_TYPE"] != "default" and M["USE_MULTI_POS"] and M["MULTI_POS_EMBEDDING"] not in ("conv", "res"):
+            raise NotImplementedError("ATTENTION_TYPE=%r with MULTI_POS_EMBEDDING=%r" % (M["ATTENTION_TYPE"], M["MULTI_POS_EMBEDDING"]))
     if M["EXTRA"]["FINAL_CONV_KERNEL"] not in (1, 3):  # (the reference pads only the 3x3 case: any other size changes the map size)
         raise NotImplementedError("FINAL_CONV_KERNEL=%r (1 or 3)" % (M["EXTRA"]["FINAL_CONV_KERNEL"],))
 
@@ -1840,6 +1879,9 @@ class Engine:
         # interformer.py:296-303 (and only there): 'cat_vec' CONCATENATES the per-person vector to the token channels, the inter-human
         # encoder is DIM_MODEL + MULTI_POS_EMBEDDING_DIM wide (attention.py:1035-1040) and a 1x1 conv `fc` brings the width back
         self.cat_concat = self.name == "interformer" and M["MULTI_POS_EMBEDDING"] == "cat_vec" and bool(M["USE_MULTI_POS"])
+        # interformer.py:160 -> attention.get_encoder: any ATTENTION_TYPE but 'default' swaps the encoder stack for ONE GeneralTransformerBlock
+        # (attention.py:991-1031): a multi-head attention over the padded person sequence whose output is re-viewed, see _build
+        self.window_attn = self.name == "interformer" and M["ATTENTION_TYPE"] != "default"
         self.singleformer = None
         if self.name == "hrnet":  # stand-alone backbone (models/hrnet.py): tower + reduce, see forward_backbone()
             self.tower = HRNetW48(pk, "", M["EXTRA"])
@@ -1869,7 +1911,12 @@ class Engine:
             if self.use_pos:
                 self._pack_pos(pk, "multi_position_embedding", M["MULTI_POS_EMBEDDING"])
             wide = d + (M["MULTI_POS_EMBEDDING_DIM"] if self.cat_concat else 0)
-            self.layers = [self._enc_layer("multi_global_encoder.layers.%d" % l, self.pre_norm, d=wide) for l in range(M["ENCODER_MULTI_LAYERS"])]
+            if self.window_attn:
+                self.layers = []
+                pk32 = pk if pk.dtype == 0 else Packer(pk.sd, self.device, "fp32")
+                self.win_block = pk32.window_block("multi_global_encoder.attn.attn", d, M["N_HEAD"])
+            else:
+                self.layers = [self._enc_layer("multi_global_encoder.layers.%d" % l, self.pre_norm, d=wide) for l in range(M["ENCODER_MULTI_LAYERS"])]
             if self.cat_concat:
                 self.cat_fc = pk.conv("fc")
             up = M["UPSAMPLE_TYPE"]
@@ -2088,6 +2135,9 @@ class Engine:
                 if f is not single_feat:
                     P.release(f)
                 f = c
+        if self.window_attn:
+            e = self._emit_window_block(P, patch, f, single_feat, S, H, W, length)
+            return self._emit_tail(P, patch, e, single_feat)
         pos_ptr = 0
         if self.use_pos and self.pe_mode == "sine":
             # the mask is ignored (position_embedding.py:88-91); the rows are filled per forward (_fill_sine: they depend on max(length))
@@ -2107,6 +2157,49 @@ class Engine:
             t = P.conv(e, self.cat_fc, out_dt=0)
             P.release(e)
             e = t
+        return self._emit_tail(P, patch, e, single_feat)
+
+    def _emit_window_block(self, P, patch, f, single_feat, S, H, W, length):
+        """ATTENTION_TYPE != 'default' (attention.py:991-1031): the persons of every image padded to max(length) ROWS (zero features; the
+        position branch of a zero mask), q|k = (x + pos) W, v = x W, multi-head attention of all P h w rows of an image over the keys of its
+        real persons, out-proj (no residual, no FFN, no norm), then the re-viewing of the [L, B, C] output and get_valid_output.
+        The padded layout, hence the program, belongs to this `length` (no capacity padding, no regrouping)."""
+        M, L = self.cfg["MODEL"], self.win_block
+        assert sum(length) == S and f.n == S
+        B, Pm, hw = len(length), max(length), f.h * f.w
+        starts = [sum(length[:b]) for b in range(B)]
+        pad_map = [starts[b] + q if q < length[b] else -1 for b in range(B) for q in range(Pm)]
+        xp = P.rows_gather(f, pad_map)
+        if f is not single_feat:
+            P.release(f)
+        pos_p = None
+        if self.use_pos:  # crops 0..S-1: the persons' masks; crop S: the zero mask every padded person gets (interformer.py:275)
+            pos, patch["pos_mask"] = self._pos_branch(P, S + 1, H, W, M["TRANS_SIZE"][-1], n_src=S + 1)
+            assert (pos.h, pos.w, pos.cs) == (xp.h, xp.w, xp.cs)
+            pos_p = P.rows_gather(pos, [m if m >= 0 else S for m in pad_map])
+            P.release(pos)
+        qk = P.conv(xp, L["qk"], in2=pos_p)
+        v = P.conv(xp, L["v"])
+        P.release(xp)
+        if pos_p is not None:
+            P.release(pos_p)
+        att = P.alloc(B * Pm, f.h, f.w, L["hs"])
+        goff = torch.tensor([b * Pm * hw for b in range(B + 1)], dtype=torch.int32).to(self.device)
+        klen = torch.tensor([n * hw for n in length], dtype=torch.int32).to(self.device)
+        P.keep += [goff, klen, L]
+        nq16, nq32, nq64 = (B * (-(-(Pm * hw) // t)) for t in (16, 32, 64))
+        a = cabi.MhAttnArgs(qk.ptr, v.ptr, att.ptr, goff.data_ptr(), B, L["heads"], L["hp"], L["hs"], qk.cs, v.cs, att.cs, nq16, nq32, nq64, klen.data_ptr())
+        P.ops.append((cabi.OP_MH_ATTN, 0, a))
+        P.enc_stacks.append(dict(descs=[], mh=[a], goff=goff, current=tuple(b * Pm * hw for b in range(B + 1))))
+        P.release(qk, v)
+        o = P.conv(att, L["o"])
+        P.release(att)
+        e = P.view_scramble(o, [b * Pm + q for b in range(B) for q in range(length[b])], B, Pm, M["DIM_MODEL"])
+        P.release(o)
+        return e
+
+    def _emit_tail(self, P, patch, e, single_feat):
+        """up-sampling layers (+ the 2-stage residual / DOMAIN_TRANS) and final_layer behind the inter-human encoder output e"""
         dtr = getattr(self, "domain_trans", None)
         res_feat = single_feat if dtr is None else None
         uc = getattr(self, "upconv", None)
@@ -2205,6 +2298,20 @@ class Engine:
         assert S == sum(length), "sum(length)=%d != number of crops %d" % (sum(length), S)
         assert all(n >= 1 for n in length), "every image needs at least one person"
         self._sine_n = max(length)  # (MULTI_POS_EMBEDDING sine: the canvas is max(length) persons wide, for every part of this batch)
+        if self.window_attn and flip_joint_map is not None:
+            # the window type mixes the rows of ALL images of a call (attention.py:1025-1029): the mirrored batch must be a call of its
+            # own, as in validate() (function.py:142-162), not extra token groups of this one
+            with torch.cuda.device(self.device):
+                x = x.to(self.device)
+                pm = pos_mask.to(self.device) if pos_mask is not None else None
+                a = self._forward(x, pm, list(length), None, S, H, W)
+                b = self._forward(torch.flip(x, dims=[3]), torch.flip(pm, dims=[3]) if pm is not None else None, list(length), None, S, H, W)
+                a, b = (a["multi"], b["multi"]) if isinstance(a, dict) else (a, b)
+                J = M["NUM_JOINTS"]
+                merged = torch.empty(S, J, H // 4, W // 4, dtype=torch.float32, device=self.device)
+                cabi.check(cabi.lib().i2r_flip_merge(a.contiguous().data_ptr(), b.contiguous().data_ptr(), flip_joint_map.data_ptr(), merged.data_ptr(),
+                                                     S, J, H // 4, W // 4, torch.cuda.current_stream(self.device).cuda_stream), "i2r_flip_merge")
+                return merged
         with torch.cuda.device(self.device):  # kernels and events go to the CURRENT device: make it this engine's
             return self._forward(x, pos_mask, list(length), flip_joint_map, S, H, W)
 
@@ -2230,7 +2337,7 @@ class Engine:
             return None
         if H is not None and (H % 16 or W % 16):
             return None
-        if self.cat_concat:  # (the tower / tail hand-over buffer is DIM_MODEL wide)
+        if self.cat_concat or self.window_attn:  # (the hand-over buffer is DIM_MODEL wide; the window type re-views the WHOLE batch's output)
             return None
         bounds = shard_bounds(list(length), parts)
         if not all(bounds[i + 1] > bounds[i] for i in range(parts)):
@@ -2375,6 +2482,8 @@ class Engine:
         # persons-per-image grouping enters through the encoder's offset table, the real crop count through the stem kernels
         cap = self.capacity(S)
         key = (cap, H, W, flip) if slot == 0 else (cap, H, W, flip, slot)  # (a Program owns its arena: the concurrent half needs its own)
+        if self.window_attn:  # the padded person layout IS the program: no capacity slots, one program per `length`
+            cap, key = S, (S, H, W, flip, "window", tuple(length))
         P, patch = self._program(key, lambda: self._build(cap, H, W, list(length) + [1] * (cap - S), flip))
         self.last_concurrent = []
         self.last_programs = [P]  # the program(s) of the most recent forward (bench.py's per-launch timing pass replays them; _forward merges the parts')
@@ -2394,8 +2503,11 @@ class Engine:
         if "pos_mask" in patch:
             pm = pos_mask.to(self.device, torch.float32).contiguous()
             assert pm.shape == (S, 1, H, W)
+            n_pm = S
+            if self.window_attn:  # one more crop: the zero mask of the padded persons (_emit_window_block)
+                pm, n_pm = torch.cat([pm, pm.new_zeros(1, 1, H, W)], 0), S + 1
             patch["pos_mask"].in_ = pm.data_ptr()
-            patch["pos_mask"].n_valid = S
+            patch["pos_mask"].n_valid = n_pm
             keep.append(pm)
         n_out = 2 * cap if flip else cap
         out = torch.empty(n_out, J, H // 4, W // 4, dtype=torch.float32, device=self.device)

@@ -392,14 +392,20 @@ def forward_two_stage(sd, cfg, x, pos_mask, length, collect=None):
         pos = multi_position_embedding(sd, "multi_position_embedding", pos_mask, M["TRANS_SIZE"][-1], M["MULTI_POS_EMBEDDING"], length, M["DIM_MODEL"])
         if collect is not None:
             collect["pos"] = pos
+    window = M["NAME"] == "interformer" and M["ATTENTION_TYPE"] != "default"
     cat = pos is not None and M["MULTI_POS_EMBEDDING"] == "cat_vec" and M["NAME"] == "interformer"
-    if cat:  # interformer.py:296-303: concatenated instead of added, no additive embedding, `fc` back to DIM_MODEL behind the encoder
-        f, pos = torch.cat([f, pos], dim=1), None
-    # (only attention.py:1040 -- the inter-human stack of MODEL.NAME interformer -- hands NORMALIZE_BEFORE to its layers)
-    f = inter_human_encoder(sd, "multi_global_encoder", M["ENCODER_MULTI_LAYERS"], f, pos, length,
-                            M["N_HEAD"], collect, pre_norm=bool(M["NORMALIZE_BEFORE"]) and M["NAME"] == "interformer")
-    if cat:
-        f = F.conv2d(f, sd["fc.weight"], sd["fc.bias"])
+    if window:
+        if M["USE_MULTI_POS"] and M["MULTI_POS_EMBEDDING"] not in ("conv", "res"):
+            raise NotImplementedError("ATTENTION_TYPE window with MULTI_POS_EMBEDDING %r" % (M["MULTI_POS_EMBEDDING"],))
+        f = _window_type_encoder(sd, cfg, f, pos_mask, length)
+    else:
+        if cat:  # interformer.py:296-303: concatenated instead of added, no additive embedding, `fc` back to DIM_MODEL behind the encoder
+            f, pos = torch.cat([f, pos], dim=1), None
+        # (only attention.py:1040 -- the inter-human stack of MODEL.NAME interformer -- hands NORMALIZE_BEFORE to its layers)
+        f = inter_human_encoder(sd, "multi_global_encoder", M["ENCODER_MULTI_LAYERS"], f, pos, length,
+                                M["N_HEAD"], collect, pre_norm=bool(M["NORMALIZE_BEFORE"]) and M["NAME"] == "interformer")
+        if cat:
+            f = F.conv2d(f, sd["fc.weight"], sd["fc.bias"])
     if collect is not None:
         collect["encoder"] = f
     up = M["UPSAMPLE_TYPE"]
@@ -429,6 +435,45 @@ def forward_two_stage(sd, cfg, x, pos_mask, length, collect=None):
     if M["INTER_SUPERVISION"] and not M["SINGLEFORMER_FIX"] and feat is not None:
         return {"single": single, "multi": multi}
     return multi
+
+
+def _window_type_encoder(sd, cfg, f, pos_mask, length):
+    """MODEL.ATTENTION_TYPE != 'default' (interformer.py:160 -> attention.get_hrformer_encoder :1046-1051): ONE GeneralTransformerBlock
+    (:991-1031) instead of the encoder stack -- MHA_ (:494-835: q / k / v / out projections, head_dim^-0.5 on q, key_padding_mask, softmax;
+    the relative position bias is gathered but never added, :780-786) over the PADDED person sequence of every image, no residual, no FFN,
+    no norm (norm1 exists, unused); then x.permute(0, 2, 1).contiguous().view(B, C, P, H, W) on the [L, B, C] output (:1025-1029), which
+    re-interprets the memory instead of transposing it.  Restated literally, padded persons included (their rows are queries)."""
+    M = cfg["MODEL"]
+    S, d, h, w = f.shape
+    B, P = len(length), max(length)
+    heads = M["N_HEAD"]
+    hd = d // heads
+    x = _pad_persons(f, length)                                   # [B, P, d, h, w], zeros for the padded persons
+    pos = None
+    if M["USE_MULTI_POS"]:
+        pm = _pad_persons(pos_mask, length)                       # zero masks for the padded persons (interformer.py:275)
+        pos = multi_position_embedding(sd, "multi_position_embedding", pm.reshape(B * P, *pos_mask.shape[1:]), M["TRANS_SIZE"][-1],
+                                       M["MULTI_POS_EMBEDDING"]).view(B, P, d, h, w)
+    mask = torch.zeros(B, P, h, w, dtype=torch.bool)
+    for b, n in enumerate(length):
+        mask[b, n:] = True
+    tok = x.permute(0, 2, 1, 3, 4).flatten(2).permute(2, 0, 1)    # [L, B, C]
+    L = tok.shape[0]
+    qk_in = tok if pos is None else tok + pos.permute(0, 2, 1, 3, 4).flatten(2).permute(2, 0, 1)
+    a = "multi_global_encoder.attn.attn."
+    q = F.linear(qk_in, sd[a + "q_proj.weight"], sd[a + "q_proj.bias"]) * (hd ** -0.5)
+    k = F.linear(qk_in, sd[a + "k_proj.weight"], sd[a + "k_proj.bias"])
+    v = F.linear(tok, sd[a + "v_proj.weight"], sd[a + "v_proj.bias"])
+    q = q.contiguous().view(L, B * heads, hd).transpose(0, 1)
+    k = k.contiguous().view(L, B * heads, hd).transpose(0, 1)
+    v = v.contiguous().view(L, B * heads, hd).transpose(0, 1)
+    s = torch.bmm(q, k.transpose(1, 2)).view(B, heads, L, L)
+    s = s.masked_fill(mask.flatten(1)[:, None, None, :], float("-inf")).view(B * heads, L, L)
+    o = torch.bmm(torch.softmax(s, dim=-1), v).transpose(0, 1).contiguous().view(L, B, d)
+    o = F.linear(o, sd[a + "out_proj.weight"], sd[a + "out_proj.bias"])
+    y = o.permute(0, 2, 1).contiguous().view(B, d, P, h, w)       # (:1026 -- a view of [L, C, B] memory)
+    y = y.permute(0, 2, 1, 3, 4).contiguous().view(B * P, d, h, w)
+    return _unpad_persons(y.view(B, P, d, h, w), length)
 
 
 def forward(sd, cfg, x, pos_mask, length, collect=None):

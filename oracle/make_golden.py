@@ -67,6 +67,8 @@ VARIANTS = [
     ("tph_dk2_l21", "tph_192_p6_b4", ["MODEL.EXTRA.NUM_DECONV_KERNELS", [2]], [2, 1], (256, 192)),           # ConvTranspose2d(2, 2, 0): one tap per parity
     ("bare_sine_l213", "w48_bare_p6", ["MODEL.MULTI_POS_EMBEDDING", "sine"], [2, 1, 3], (256, 192)),          # canvas table, 3 persons wide (position_embedding.py:34-61,88-91)
     ("ochtph_sine_l12", "ochuman_tph_192_p3_b8", ["MODEL.MULTI_POS_EMBEDDING", "sine"], [1, 2], (256, 192)),  # the same behind a TransPose-H first stage
+    ("bare_win_l213", "w48_bare_p6", ["MODEL.ATTENTION_TYPE", "window", "MODEL.N_HEAD", 2], [2, 1, 3], (256, 192)),    # ONE MHA_ block + the re-viewing of its output (attention.py:991-1031)
+    ("tph_win_l12", "tph_192_p6_b4", ["MODEL.ATTENTION_TYPE", "window", "MODEL.N_HEAD", 4], [1, 2], (256, 192)),       # the same without a position embedding, behind TransPose-H
     ("tph2s_up_fk3_l12", "coco_tph_192_p4_b4", ["MODEL.UPSAMPLE_TYPE", "upconv", "MODEL.EXTRA.FINAL_CONV_KERNEL", 3], [1, 2], (256, 192)),  # interformer_2stage.UpConv (upsample_conv.*), both heads 3x3
 ]
 

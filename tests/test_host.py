@@ -227,9 +227,11 @@ def test_every_shipped_yaml_builds(name):
 
 def test_validate_config_refuses_unshipped_combinations():
     from i2r_amd import engine
-    for opts in (["MODEL.UPSAMPLE_TYPE", "bilinear"], ["MODEL.ATTENTION_TYPE", "window"]):
+    for opts in (["MODEL.UPSAMPLE_TYPE", "bilinear"], ["MODEL.ATTENTION_TYPE", "window", "MODEL.MULTI_POS_EMBEDDING", "cat_vec"]):
         with pytest.raises(NotImplementedError):
             engine.validate_config(config.load_config("w48_bare_p6", opts))
+    # (ATTENTION_TYPE is read by interformer.py:160 only: the other model classes ignore it, and so does the engine)
+    engine.validate_config(config.load_config("coco_tph_192_p4_b4", ["MODEL.ATTENTION_TYPE", "window"]))
     for cname in ("w48_pure_en6", "coco_tph_192_p4_b4"):  # 'sine' outside MODEL.NAME interformer: the reference's own forward raises
         with pytest.raises(NotImplementedError):
             engine.validate_config(config.load_config(cname, ["MODEL.MULTI_POS_EMBEDDING", "sine", "MODEL.USE_MULTI_POS", True]))

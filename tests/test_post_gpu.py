@@ -58,7 +58,7 @@ def test_flip_test_single_batched_forward_matches_two_oracle_forwards():
     assert (plain - i2r_cpu.forward(sd, cfg, x, m, length)).abs().max().item() < 1e-3
 
 
-@pytest.mark.parametrize("tag", ["bare_cv_l21", "w48_nh8_l21", "tph2s_up_fk3_l12"])
+@pytest.mark.parametrize("tag", ["bare_cv_l21", "w48_nh8_l21", "tph2s_up_fk3_l12", "bare_win_l213"])
 def test_flip_test_of_variant_configs(tag):
     """the batched flip test on settings no shipped yaml uses: the concatenated cat_vec embedding (its kernel mirrors the mask itself),
     the multi-head general encoder (token groups doubled), UpConv + 3x3 heads"""
