@@ -803,6 +803,68 @@ def test_mh_attention_large_launches_use_wider_query_tiles(heads, hd, n_grp, nq_
     assert torch.isfinite(got).all()
 
 
+def test_rows_gather_and_view_scramble_match_torch():
+    """the two helpers of ATTENTION_TYPE window through the raw C-ABI: padding_tensor as rows, and the reference's
+    permute(0, 2, 1).contiguous().view(B, C, P, H, W) of the [L, B, C] attention output (attention.py:1025-1029) + get_valid_output"""
+    import ctypes as C
+    from i2r_amd import cabi
+    L = cabi.lib()
+    B, P, Cc, cs, H, W = 3, 4, 78, 80, 5, 3
+    lengths = [2, 4, 1]
+    S, HW = sum(lengths), H * W
+    src = torch.zeros(S, HW, cs)
+    src[..., :Cc] = _rand((S, HW, Cc), "rgsrc")
+    starts = [0, 2, 6]
+    pad_map = [starts[b] + q if q < lengths[b] else -1 for b in range(B) for q in range(P)]
+    md = torch.tensor(pad_map, dtype=torch.int32, device=DEV)
+    sd_, out = src.to(DEV), torch.full((B * P, HW, cs), 9.0, device=DEV)
+    cabi.check(L.i2r_rows_gather(sd_.data_ptr(), out.data_ptr(), md.data_ptr(), B * P, HW * cs, None), "gather")
+    torch.cuda.synchronize()
+    ref = torch.stack([src[m] if m >= 0 else torch.zeros(HW, cs) for m in pad_map])
+    assert torch.equal(out.cpu(), ref)
+    # the re-viewing: o rows [B][L = P HW][cs]  ->  reference tensor [L, B, C] -> permute(0, 2, 1).view(B, C, P, H, W) -> real persons
+    o = torch.zeros(B, P * HW, cs)
+    o[..., :Cc] = _rand((B, P * HW, Cc), "vso")
+    lbc = o[..., :Cc].permute(1, 0, 2).contiguous()                      # [L, B, C] as MHA_ returns it
+    y = lbc.permute(0, 2, 1).contiguous().view(B, Cc, P, H, W).permute(0, 2, 1, 3, 4).contiguous()   # [B, P, C, H, W]
+    person_map = [b * P + q for b in range(B) for q in range(lengths[b])]
+    want = torch.stack([y[m // P, m % P] for m in person_map]).permute(0, 2, 3, 1).reshape(S, HW, Cc)   # NHWC rows
+    pm = torch.tensor(person_map, dtype=torch.int32, device=DEV)
+    got = torch.full((S, HW, cs), 9.0, device=DEV)
+    cabi.check(L.i2r_view_scramble(o.to(DEV).data_ptr(), got.data_ptr(), pm.data_ptr(), S, B, P, Cc, cs, HW, None), "scramble")
+    torch.cuda.synchronize()
+    assert torch.equal(got.cpu()[..., :Cc], want) and got.cpu()[..., Cc:].abs().max().item() == 0.0
+    assert L.i2r_rows_gather(sd_.data_ptr(), out.data_ptr(), md.data_ptr(), B * P, HW * cs + 2, None) != 0
+    assert L.i2r_view_scramble(got.data_ptr(), got.data_ptr(), pm.data_ptr(), S, B, P, Cc, cs, HW, None) != 0
+
+
+def test_mh_attention_key_len_limits_the_keys_not_the_queries():
+    """key_len (padded persons under a key_padding_mask): every row of a group is a query, its first key_len rows are the keys"""
+    import ctypes as C
+    from i2r_amd import cabi
+    heads, hd, hp = 2, 12, 16
+    hs = heads * hp
+    lens, klens = [70, 33, 48], [35, 33, 16]
+    offs = [0, 70, 103, 151]
+    n_tok = offs[-1]
+    g = torch.Generator().manual_seed(5)
+    q, k, v = (torch.zeros(n_tok, heads, hp) for _ in range(3))
+    for t in (q, k, v):
+        t[..., :hd] = torch.randn(n_tok, heads, hd, generator=g)
+    qk = torch.cat([q.reshape(n_tok, hs), k.reshape(n_tok, hs)], 1).contiguous().to(DEV)
+    vd, out = v.reshape(n_tok, hs).contiguous().to(DEV), torch.full((n_tok, hs), float("nan"), device=DEV)
+    goff, kl = torch.tensor(offs, dtype=torch.int32, device=DEV), torch.tensor(klens, dtype=torch.int32, device=DEV)
+    nq = [sum(-(-n // t) for n in lens) for t in (16, 32, 64)]
+    a = cabi.MhAttnArgs(qk.data_ptr(), vd.data_ptr(), out.data_ptr(), goff.data_ptr(), 3, heads, hp, hs, 2 * hs, hs, hs, nq[0], nq[1], nq[2], kl.data_ptr())
+    cabi.check(cabi.lib().i2r_mh_attention(C.byref(a), None), "mh_attention")
+    torch.cuda.synchronize()
+    got = out.cpu().view(n_tok, heads, hp)
+    for i in range(3):
+        sl, ks = slice(offs[i], offs[i + 1]), slice(offs[i], offs[i] + klens[i])
+        ref = torch.einsum("hqk,khd->qhd", torch.softmax(torch.einsum("qhd,khd->hqk", q[sl], k[ks]), -1), v[ks])
+        assert (got[sl] - ref).abs().max().item() < 2e-5
+
+
 def test_mh_attention_rejects_bad_arguments():
     import ctypes as C
     from i2r_amd import cabi
