@@ -567,6 +567,20 @@ typedef struct i2r_op {
 /* streams: array of 4 hipStream_t (lane 0 = the caller's stream); events: array of >= 8 hipEvent_t
  * created by the caller with hipEventDisableTiming.  Both may be NULL when every op uses lane 0. */
 I2R_API int i2r_run_program(const i2r_op* ops, int32_t n_ops, void* const* streams, void* const* events);
+/* The same replay with every LAUNCH timed through caller-owned events (hipEventCreate with timing enabled; entries of sync ops -- FORK /
+ * JOIN / XSYNC -- are ignored): the launch of op i goes out through hipExtLaunchKernelGGL with t1[i] BOUND to the dispatch (its completion
+ * signal carries the kernel's end time; no extra packet, the replay is not slowed down) and, where t0[i] is non-NULL, t0[i] as a marker in
+ * front of it (~5 us of stream time).  hipEventElapsedTime(t0[i], t1[i]) is the kernel's own duration IN SITU -- with the program's other
+ * lanes and any sibling program in flight; for a launch without a start marker the start is the completion of whatever it waited for (its
+ * predecessor on the stream, or the lanes a sync op named), i.e. the t1 of those ops.  tools/probe/event_timing.hip on MI355X, kernels of
+ * 20 / 50 us: start + stop 20.9 / 50.9 us at 26.3 / 56.5 us per launch of stream time; stop only 21.4 / 51.4 us between consecutive stops
+ * at 21.5 / 51.5 us per launch (= the untimed rate); plain hipEventRecord pairs 23.7 / 53.6 us at 29.0 / 58.8.  A rocprofv3 kernel trace
+ * of the same forward is NOT comparable where streams overlap: its host-side interception serialises the part-batch programs
+ * (DESIGN.md section 5).  This is the measurement hook of bench.py (per-kernel durations from HIP events on the stream the
+ * kernel is launched on); the reference has no counterpart (tools/compute_flops.py:21-32 times whole forwards).
+ * t0, t1: n_ops entries each; t1[i] NULL = op i is not timed. */
+I2R_API int i2r_run_program_timed(const i2r_op* ops, int32_t n_ops, void* const* streams, void* const* events, void* const* t0,
+                                  void* const* t1);
 
 I2R_API int i2r_abi_version(void);
 I2R_API const char* i2r_last_error(void);

@@ -179,7 +179,7 @@ class Op(C.Structure):
 # every symbol include/i2r_hip.h declares (tests/test_host.py::test_cabi_library_exports_every_declared_symbol checks the built library exports them all)
 EXPORTS = ("i2r_conv", "i2r_conv_grouped", "i2r_conv_kernel_name", "i2r_stem_conv", "i2r_pe_res_stem", "i2r_maxpool3x3s2", "i2r_head", "i2r_layernorm", "i2r_window_attn", "i2r_hrt_attn_block", "i2r_hrt_mlp_block", "i2r_dwconv3x3",
            "i2r_upsample_bilinear_add", "i2r_upsample_bilinear_add_multi", "i2r_fuse_up_add", "i2r_conv1x1_pair", "i2r_conv1x1_lp", "i2r_flip_merge", "i2r_decode", "i2r_crop_affine", "i2r_box_mask", "i2r_crop_affine_cv2", "i2r_box_mask_cv2", "i2r_person_inputs_cv2", "i2r_conv_chain_pack", "i2r_conv_chain", "i2r_encoder_kv", "i2r_encoder_layer", "i2r_mh_attention", "i2r_pe_cat_vec", "i2r_rows_gather", "i2r_view_scramble",
-           "i2r_run_program", "i2r_abi_version", "i2r_last_error", "i2r_device_check")
+           "i2r_run_program", "i2r_run_program_timed", "i2r_abi_version", "i2r_last_error", "i2r_device_check")
 
 _LIB = None
 
@@ -228,6 +228,7 @@ def load_library(path=LIB_PATH):
     L.i2r_pe_cat_vec.argtypes = [C.POINTER(PeCatVecArgs), C.c_void_p]
     L.i2r_mh_attention.argtypes = [C.POINTER(MhAttnArgs), C.c_void_p]
     L.i2r_run_program.argtypes = [C.POINTER(Op), _i32, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p)]
+    L.i2r_run_program_timed.argtypes = [C.POINTER(Op), _i32] + [C.POINTER(C.c_void_p)] * 4
     L.i2r_device_check.argtypes = [_i32, C.POINTER(_i32), C.POINTER(_i32)]
     L.i2r_last_error.restype = C.c_char_p
     for name in EXPORTS:

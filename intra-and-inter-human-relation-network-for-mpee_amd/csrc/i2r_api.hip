@@ -5,6 +5,7 @@
 #include "i2r_common.h"
 
 static thread_local char g_err[512] = "";
+thread_local hipEvent_t i2r_tls_t0 = nullptr, i2r_tls_t1 = nullptr;  // timing pair of the op being replayed (i2r_common.h: i2r_launch)
 
 void i2r_set_error(const char* fmt, ...) {
     va_list ap;
@@ -31,7 +32,8 @@ extern "C" int i2r_device_check(int32_t dev, int32_t* cu_count, int32_t* lds_byt
     return I2R_OK;
 }
 
-extern "C" int i2r_run_program(const i2r_op* ops, int32_t n_ops, void* const* streams, void* const* events) {
+// t0 / t1 (both or neither): per-op timing events of i2r_run_program_timed, recorded on the op's own stream around its launch
+static int run_program(const i2r_op* ops, int32_t n_ops, void* const* streams, void* const* events, void* const* t0, void* const* t1) {
     I2R_CHECK_ARG(ops && n_ops >= 0, "i2r_run_program: null program");
     int next_event = 0;
     for (int i = 0; i < n_ops; ++i) {
@@ -87,6 +89,10 @@ extern "C" int i2r_run_program(const i2r_op* ops, int32_t n_ops, void* const* st
         I2R_CHECK_ARG(op.lane >= 0 && op.lane < 4 && op.args, "i2r_run_program: op %d bad lane/args", i);
         void* st = streams ? streams[op.lane] : nullptr;
         I2R_CHECK_ARG(streams || op.lane == 0, "i2r_run_program: op %d uses lane %d without streams", i, op.lane);
+        if (t0 && t1 && t1[i]) {
+            i2r_tls_t0 = (hipEvent_t)t0[i];
+            i2r_tls_t1 = (hipEvent_t)t1[i];
+        }
         switch (op.kind) {
             case I2R_OP_CONV: rc = i2r_conv((const i2r_conv_desc*)op.args, st); break;
             case I2R_OP_CONV_GROUP: {
@@ -168,7 +174,18 @@ extern "C" int i2r_run_program(const i2r_op* ops, int32_t n_ops, void* const* st
             case I2R_OP_ENC_LAYER: rc = i2r_encoder_layer((const i2r_encoder_desc*)op.args, st); break;
             default: i2r_set_error("i2r_run_program: op %d unknown kind %d", i, op.kind); return I2R_E_ARG;
         }
+        i2r_tls_t0 = i2r_tls_t1 = nullptr;
         if (rc != I2R_OK) return rc;
     }
     return I2R_OK;
+}
+
+extern "C" int i2r_run_program(const i2r_op* ops, int32_t n_ops, void* const* streams, void* const* events) {
+    return run_program(ops, n_ops, streams, events, nullptr, nullptr);
+}
+
+extern "C" int i2r_run_program_timed(const i2r_op* ops, int32_t n_ops, void* const* streams, void* const* events, void* const* t0,
+                                     void* const* t1) {
+    I2R_CHECK_ARG(t0 && t1, "i2r_run_program_timed: null timing event arrays");
+    return run_program(ops, n_ops, streams, events, t0, t1);
 }

@@ -1,6 +1,7 @@
 // Shared helpers for the gfx950 kernels of libi2r_hip.so (internal; the public boundary is include/i2r_hip.h).
 #pragma once
 #include <hip/hip_runtime.h>
+#include <hip/hip_ext.h>
 #include <stdint.h>
 #include <stdio.h>
 
@@ -70,6 +71,22 @@ __device__ __forceinline__ int xcd_band_item(int b, int total) {
 }
 
 void i2r_set_error(const char* fmt, ...);
+
+// Every kernel launch of the library goes through i2r_launch.  Normally it IS kernel<<<grid, block, shmem, stream>>>(args...).  While
+// i2r_run_program_timed replays an op, the calling thread's timing pair is set: the launch then goes through hipExtLaunchKernelGGL with
+// the STOP event bound to the dispatch itself (its completion signal carries the kernel's end time: no extra packet) and, if given, the
+// START event as a marker in front of it (include/i2r_hip.h: i2r_run_program_timed).  An op that launches several kernels keeps the
+// first start and the last stop.
+extern thread_local hipEvent_t i2r_tls_t0, i2r_tls_t1;
+template <typename... KArgs, typename... Args>
+inline void i2r_launch(void (*kernel)(KArgs...), dim3 grid, dim3 block, size_t shmem, hipStream_t stream, Args&&... args) {
+    if (i2r_tls_t1) {
+        hipExtLaunchKernelGGL(kernel, grid, block, (uint32_t)shmem, stream, i2r_tls_t0, i2r_tls_t1, 0, static_cast<KArgs>(args)...);
+        i2r_tls_t0 = nullptr;
+    } else {
+        kernel<<<grid, block, shmem, stream>>>(static_cast<KArgs>(args)...);
+    }
+}
 
 #define I2R_CHECK_ARG(cond, ...)            \
     do {                                    \

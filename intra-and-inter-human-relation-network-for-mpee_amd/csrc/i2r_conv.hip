@@ -693,7 +693,7 @@ extern "C" int i2r_conv_grouped(const i2r_conv_desc* const* descs, int32_t n, co
     if (lds_max > 64 * 1024)
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_max);
     const unsigned grid = (unsigned)total;
-    hipLaunchKernelGGL(fn, dim3(grid), dim3(256), lds_max, (hipStream_t)stream, grp);
+    i2r_launch(fn, dim3(grid), dim3(256), lds_max, (hipStream_t)stream, grp);
     I2R_CHECK_LAUNCH("i2r_conv");
     return I2R_OK;
 }
@@ -787,7 +787,7 @@ extern "C" int i2r_conv_chain(const i2r_conv_chain_args* a, void* stream) {
         i2r_set_error("i2r_conv_chain: hipMemsetAsync failed");
         return I2R_E_LAUNCH;
     }
-    hipLaunchKernelGGL(fn, dim3((unsigned)a->n_blocks), dim3(256), (size_t)a->lds_bytes, (hipStream_t)stream, c);
+    i2r_launch(fn, dim3((unsigned)a->n_blocks), dim3(256), (size_t)a->lds_bytes, (hipStream_t)stream, c);
     I2R_CHECK_LAUNCH("i2r_conv_chain");
     return I2R_OK;
 }

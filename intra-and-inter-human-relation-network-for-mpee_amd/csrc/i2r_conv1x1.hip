@@ -157,7 +157,7 @@ extern "C" int i2r_conv1x1_pair(const i2r_conv1x1_pair_args* a, void* stream) {
     else fn = a->cb_out ? pick_res<8, 4>(mt, a->res != nullptr) : pick_res<8, 0>(mt, a->res != nullptr);
     I2R_CHECK_ARG(fn != nullptr, "i2r_conv1x1_pair: mt=%d (1, 2, 4)", mt);
     const int waves = (k.n_tiles + mt - 1) / mt;
-    hipLaunchKernelGGL(fn, dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, (hipStream_t)stream, k);
+    i2r_launch(fn, dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, (hipStream_t)stream, k);
     I2R_CHECK_LAUNCH("i2r_conv1x1_pair");
     return I2R_OK;
 }

@@ -176,7 +176,7 @@ extern "C" int i2r_conv1x1_lp(const i2r_conv1x1_lp_args* a, void* stream) {
     I2R_CHECK_ARG(fn != nullptr, "i2r_conv1x1_lp: mt=%d (1, 2, 4)", mt);
     const long long nblk = (long long)((k.n_tiles + mt - 1) / mt) * k.n_groups;
     I2R_CHECK_ARG(nblk < (1ll << 31), "i2r_conv1x1_lp: grid");
-    hipLaunchKernelGGL(fn, dim3((unsigned)nblk), dim3(256), 0, (hipStream_t)stream, k);
+    i2r_launch(fn, dim3((unsigned)nblk), dim3(256), 0, (hipStream_t)stream, k);
     I2R_CHECK_LAUNCH("i2r_conv1x1_lp");
     return I2R_OK;
 }

@@ -1349,18 +1349,18 @@ extern "C" int i2r_encoder_kv(const i2r_encoder_desc* d, void* stream) {
         I2R_CHECK_ARG(nblk > 0, "i2r_encoder_kv: n_qtiles%d", TB == 2 ? 64 : 32);
         const bool c6 = d->cs == 96;
         if (d->dtype == 1) {
-            if (c6) hipLaunchKernelGGL((enc_kv_lp_k<6, 6, 1, TB>), dim3(nblk), dim3(64), 0, (hipStream_t)stream, k);
-            else hipLaunchKernelGGL((enc_kv_lp_k<6, 5, 1, TB>), dim3(nblk), dim3(64), 0, (hipStream_t)stream, k);
+            if (c6) i2r_launch((enc_kv_lp_k<6, 6, 1, TB>), dim3(nblk), dim3(64), 0, (hipStream_t)stream, k);
+            else i2r_launch((enc_kv_lp_k<6, 5, 1, TB>), dim3(nblk), dim3(64), 0, (hipStream_t)stream, k);
         } else {
-            if (c6) hipLaunchKernelGGL((enc_kv_lp_k<6, 6, 2, TB>), dim3(nblk), dim3(64), 0, (hipStream_t)stream, k);
-            else hipLaunchKernelGGL((enc_kv_lp_k<6, 5, 2, TB>), dim3(nblk), dim3(64), 0, (hipStream_t)stream, k);
+            if (c6) i2r_launch((enc_kv_lp_k<6, 6, 2, TB>), dim3(nblk), dim3(64), 0, (hipStream_t)stream, k);
+            else i2r_launch((enc_kv_lp_k<6, 5, 2, TB>), dim3(nblk), dim3(64), 0, (hipStream_t)stream, k);
         }
     } else {
         I2R_CHECK_ARG(d->n_qtiles16 > 0, "i2r_encoder_kv: n_qtiles16");
         if (d->cs == 96)
-            hipLaunchKernelGGL(enc_kv_k<6>, dim3((unsigned)d->n_qtiles16), dim3(256), 0, (hipStream_t)stream, k);
+            i2r_launch(enc_kv_k<6>, dim3((unsigned)d->n_qtiles16), dim3(256), 0, (hipStream_t)stream, k);
         else
-            hipLaunchKernelGGL(enc_kv_k<5>, dim3((unsigned)d->n_qtiles16), dim3(256), 0, (hipStream_t)stream, k);
+            i2r_launch(enc_kv_k<5>, dim3((unsigned)d->n_qtiles16), dim3(256), 0, (hipStream_t)stream, k);
     }
     I2R_CHECK_LAUNCH("i2r_encoder_kv");
     return I2R_OK;
@@ -1369,8 +1369,8 @@ extern "C" int i2r_encoder_kv(const i2r_encoder_desc* d, void* stream) {
 namespace {
 template <int QF, int DT>
 void launch_lp(const EncK& k, bool c6, unsigned grid, hipStream_t st) {
-    if (c6) hipLaunchKernelGGL((enc_layer_lp_k<6, 12, QF, DT, 6>), dim3(grid), dim3(64), 0, st, k);
-    else hipLaunchKernelGGL((enc_layer_lp_k<6, 12, QF, DT, 5>), dim3(grid), dim3(64), 0, st, k);
+    if (c6) i2r_launch((enc_layer_lp_k<6, 12, QF, DT, 6>), dim3(grid), dim3(64), 0, st, k);
+    else i2r_launch((enc_layer_lp_k<6, 12, QF, DT, 5>), dim3(grid), dim3(64), 0, st, k);
 }
 }  // namespace
 
@@ -1398,11 +1398,11 @@ extern "C" int i2r_encoder_layer(const i2r_encoder_desc* d, void* stream) {
             k.n_qblk = d->n_qtiles192;
             const unsigned g4 = (unsigned)((d->n_qtiles192 + 7) / 8 * 8);
             if (d->dtype == 1) {
-                if (c6) hipLaunchKernelGGL((enc_layer_lp4_k<6, 12, 1, 6>), dim3(g4), dim3(256), 0, (hipStream_t)stream, k);
-                else hipLaunchKernelGGL((enc_layer_lp4_k<6, 12, 1, 5>), dim3(g4), dim3(256), 0, (hipStream_t)stream, k);
+                if (c6) i2r_launch((enc_layer_lp4_k<6, 12, 1, 6>), dim3(g4), dim3(256), 0, (hipStream_t)stream, k);
+                else i2r_launch((enc_layer_lp4_k<6, 12, 1, 5>), dim3(g4), dim3(256), 0, (hipStream_t)stream, k);
             } else {
-                if (c6) hipLaunchKernelGGL((enc_layer_lp4_k<6, 12, 2, 6>), dim3(g4), dim3(256), 0, (hipStream_t)stream, k);
-                else hipLaunchKernelGGL((enc_layer_lp4_k<6, 12, 2, 5>), dim3(g4), dim3(256), 0, (hipStream_t)stream, k);
+                if (c6) i2r_launch((enc_layer_lp4_k<6, 12, 2, 6>), dim3(g4), dim3(256), 0, (hipStream_t)stream, k);
+                else i2r_launch((enc_layer_lp4_k<6, 12, 2, 5>), dim3(g4), dim3(256), 0, (hipStream_t)stream, k);
             }
         } else if (d->dtype == 1) {
             if (big) launch_lp<4, 1>(k, c6, grid, (hipStream_t)stream); else launch_lp<1, 1>(k, c6, grid, (hipStream_t)stream);
@@ -1431,13 +1431,13 @@ extern "C" int i2r_encoder_layer(const i2r_encoder_desc* d, void* stream) {
         grid = 512;
     }
     if (d->cs == 96) {
-        if (qt == 2) hipLaunchKernelGGL((enc_layer4_k<6, 12, 2>), dim3(grid), dim3(256), 0, (hipStream_t)stream, k);
-        else if (split) hipLaunchKernelGGL((enc_layer4_k<6, 12, 1, 2>), dim3(grid), dim3(256), 0, (hipStream_t)stream, k);
-        else hipLaunchKernelGGL((enc_layer4_k<6, 12, 1>), dim3(grid), dim3(256), 0, (hipStream_t)stream, k);
+        if (qt == 2) i2r_launch((enc_layer4_k<6, 12, 2>), dim3(grid), dim3(256), 0, (hipStream_t)stream, k);
+        else if (split) i2r_launch((enc_layer4_k<6, 12, 1, 2>), dim3(grid), dim3(256), 0, (hipStream_t)stream, k);
+        else i2r_launch((enc_layer4_k<6, 12, 1>), dim3(grid), dim3(256), 0, (hipStream_t)stream, k);
     } else {
-        if (qt == 2) hipLaunchKernelGGL((enc_layer4_k<5, 12, 2>), dim3(grid), dim3(256), 0, (hipStream_t)stream, k);
-        else if (split) hipLaunchKernelGGL((enc_layer4_k<5, 12, 1, 2>), dim3(grid), dim3(256), 0, (hipStream_t)stream, k);
-        else hipLaunchKernelGGL((enc_layer4_k<5, 12, 1>), dim3(grid), dim3(256), 0, (hipStream_t)stream, k);
+        if (qt == 2) i2r_launch((enc_layer4_k<5, 12, 2>), dim3(grid), dim3(256), 0, (hipStream_t)stream, k);
+        else if (split) i2r_launch((enc_layer4_k<5, 12, 1, 2>), dim3(grid), dim3(256), 0, (hipStream_t)stream, k);
+        else i2r_launch((enc_layer4_k<5, 12, 1>), dim3(grid), dim3(256), 0, (hipStream_t)stream, k);
     }
     I2R_CHECK_LAUNCH("i2r_encoder_layer");
     return I2R_OK;

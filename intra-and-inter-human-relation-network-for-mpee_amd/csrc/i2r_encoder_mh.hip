@@ -178,7 +178,7 @@ extern "C" int i2r_rows_gather(const float* src, float* out, const int32_t* map,
     I2R_CHECK_ARG(n_out > 0 && floats_per_crop > 0 && floats_per_crop % 4 == 0, "i2r_rows_gather: n_out=%d floats_per_crop=%d", n_out, floats_per_crop);
     const long long n4 = (long long)n_out * (floats_per_crop / 4);
     I2R_CHECK_ARG((n4 + 255) / 256 < (1ll << 31), "i2r_rows_gather: grid");
-    hipLaunchKernelGGL(rows_gather_k, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, (hipStream_t)stream, reinterpret_cast<const f32x4*>(src),
+    i2r_launch(rows_gather_k, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, (hipStream_t)stream, reinterpret_cast<const f32x4*>(src),
                        reinterpret_cast<f32x4*>(out), map, n_out, floats_per_crop / 4);
     I2R_CHECK_LAUNCH("i2r_rows_gather");
     return I2R_OK;
@@ -190,7 +190,7 @@ extern "C" int i2r_view_scramble(const float* o, float* out, const int32_t* pers
     I2R_CHECK_ARG(n_out > 0 && n_images > 0 && max_persons > 0 && c > 0 && c <= cs && hw > 0, "i2r_view_scramble: sizes");
     const long long n = (long long)n_out * hw * cs;
     I2R_CHECK_ARG((n + 255) / 256 < (1ll << 31) && (long long)n_images * max_persons * hw * cs < (1ll << 40), "i2r_view_scramble: grid");
-    hipLaunchKernelGGL(view_scramble_k, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, o, out, person_map, n_out, n_images, max_persons, c, cs, hw);
+    i2r_launch(view_scramble_k, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, o, out, person_map, n_out, n_images, max_persons, c, cs, hw);
     I2R_CHECK_LAUNCH("i2r_view_scramble");
     return I2R_OK;
 }
@@ -226,7 +226,7 @@ extern "C" int i2r_mh_attention(const i2r_mh_attn_args* a, void* stream) {
         n_tiles = a->n_qtiles32;
     }
     const int wpb = a->heads >= 4 ? 4 : a->heads;  // waves (= heads) per workgroup
-    hipLaunchKernelGGL(fn, dim3((unsigned)n_tiles, (unsigned)((a->heads + wpb - 1) / wpb)), dim3(64 * wpb), 0, (hipStream_t)stream, k);
+    i2r_launch(fn, dim3((unsigned)n_tiles, (unsigned)((a->heads + wpb - 1) / wpb)), dim3(64 * wpb), 0, (hipStream_t)stream, k);
     I2R_CHECK_LAUNCH("i2r_mh_attention");
     return I2R_OK;
 }

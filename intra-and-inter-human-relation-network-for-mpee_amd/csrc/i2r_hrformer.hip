@@ -297,7 +297,7 @@ extern "C" int i2r_layernorm(const float* in, const float* w, const float* b, fl
     const long long nthr = (long long)npix * 16;
     typedef void (*ln_fn)(const float*, const float*, const float*, float*, int, int, int, float);
     static const ln_fn fns[3] = {layernorm_k<0>, layernorm_k<1>, layernorm_k<2>};
-    hipLaunchKernelGGL(fns[out_dt], dim3((unsigned)((nthr + 255) / 256)), dim3(256), 0, (hipStream_t)stream, in, w, b, out, npix, c, cs, eps);
+    i2r_launch(fns[out_dt], dim3((unsigned)((nthr + 255) / 256)), dim3(256), 0, (hipStream_t)stream, in, w, b, out, npix, c, cs, eps);
     I2R_CHECK_LAUNCH("i2r_layernorm");
     return I2R_OK;
 }
@@ -312,7 +312,7 @@ extern "C" int i2r_window_attn(const float* qkv, const float* bias_qkv, float* o
     const int pad_top = (nwy * 7 - h) / 2, pad_left = (nwx * 7 - w) / 2;
     const long long nblk = (long long)n_img * nwy * nwx * heads;
     I2R_CHECK_ARG(nblk < (1ll << 31), "i2r_window_attn: grid");
-    hipLaunchKernelGGL(window_attn_k<40>, dim3((unsigned)nblk), dim3(256), 0, (hipStream_t)stream, qkv, bias_qkv, out, n_img, h, w,
+    i2r_launch(window_attn_k<40>, dim3((unsigned)nblk), dim3(256), 0, (hipStream_t)stream, qkv, bias_qkv, out, n_img, h, w,
                        hs, heads, hd, nwy, nwx, pad_top, pad_left);
     I2R_CHECK_LAUNCH("i2r_window_attn");
     return I2R_OK;
@@ -328,11 +328,11 @@ extern "C" int i2r_dwconv3x3(const float* in, const float* w, const float* bias,
         const long long nthr = (long long)n_img * ((in_h + 3) / 4) * in_w * (cs / 4);
         typedef void (*dw_fn)(const float*, const float*, const float*, float*, int, int, int, int, int, int);
         static const dw_fn fns[3] = {dwconv3x3_s1_k<0>, dwconv3x3_s1_k<1>, dwconv3x3_s1_k<2>};
-        hipLaunchKernelGGL(fns[dt], dim3((unsigned)((nthr + 255) / 256)), dim3(256), 0, (hipStream_t)stream, in, w, bias, out, n_img, in_h, in_w,
+        i2r_launch(fns[dt], dim3((unsigned)((nthr + 255) / 256)), dim3(256), 0, (hipStream_t)stream, in, w, bias, out, n_img, in_h, in_w,
                            cs / 4, cs, act);
     } else {
         const long long nthr = (long long)n_img * out_h * out_w * (cs / 4);
-        hipLaunchKernelGGL(dwconv3x3_k, dim3((unsigned)((nthr + 255) / 256)), dim3(256), 0, (hipStream_t)stream, in, w, bias, out, n_img,
+        i2r_launch(dwconv3x3_k, dim3((unsigned)((nthr + 255) / 256)), dim3(256), 0, (hipStream_t)stream, in, w, bias, out, n_img,
                            in_h, in_w, out_h, out_w, cs / 4, cs, stride, act);
     }
     I2R_CHECK_LAUNCH("i2r_dwconv3x3");
@@ -351,9 +351,9 @@ extern "C" int i2r_upsample_bilinear_add_multi(const i2r_up_args* a, void* strea
         I2R_CHECK_ARG(k.scale[t] >= 1 && k.H % k.scale[t] == 0 && k.W % k.scale[t] == 0, "i2r_upsample_bilinear_add: term %d: scale %d does not divide %dx%d", t, k.scale[t], k.H, k.W);
     const long long nthr = (long long)k.n_img * k.H * k.W * k.c4;
     const dim3 grid((unsigned)((nthr + 255) / 256));
-    if (nt == 1) hipLaunchKernelGGL(upsample_add_k<1>, grid, dim3(256), 0, (hipStream_t)stream, k);
-    else if (nt == 2) hipLaunchKernelGGL(upsample_add_k<2>, grid, dim3(256), 0, (hipStream_t)stream, k);
-    else hipLaunchKernelGGL(upsample_add_k<3>, grid, dim3(256), 0, (hipStream_t)stream, k);
+    if (nt == 1) i2r_launch(upsample_add_k<1>, grid, dim3(256), 0, (hipStream_t)stream, k);
+    else if (nt == 2) i2r_launch(upsample_add_k<2>, grid, dim3(256), 0, (hipStream_t)stream, k);
+    else i2r_launch(upsample_add_k<3>, grid, dim3(256), 0, (hipStream_t)stream, k);
     I2R_CHECK_LAUNCH("i2r_upsample_bilinear_add");
     return I2R_OK;
 }

@@ -397,10 +397,10 @@ __global__ __launch_bounds__(64 * (HEADS / HPW), OCC) void hrt_attn_head_k(const
 template <int DT>
 bool launch(const I2rAttnK& k, int cs, int heads, long long nblk, hipStream_t stream) {
     const dim3 grid((unsigned)((nblk + 7) / 8 * 8));
-    if (cs == 80 && heads == 2) hipLaunchKernelGGL((hrt_attn_head_k<DT, 5, 2, 1, 3>), grid, dim3(128), 0, stream, k);
-    else if (cs == 160 && heads == 4) hipLaunchKernelGGL((hrt_attn_head_k<DT, 10, 4, 1, 3>), grid, dim3(256), 0, stream, k);
-    else if (cs == 320 && heads == 8) hipLaunchKernelGGL((hrt_attn_head_k<DT, 20, 8, 1, 2>), grid, dim3(512), 0, stream, k);
-    else if (cs == 624 && heads == 16) hipLaunchKernelGGL((hrt_attn_head_k<DT, 39, 16, 2, 2>), grid, dim3(512), 0, stream, k);
+    if (cs == 80 && heads == 2) i2r_launch((hrt_attn_head_k<DT, 5, 2, 1, 3>), grid, dim3(128), 0, stream, k);
+    else if (cs == 160 && heads == 4) i2r_launch((hrt_attn_head_k<DT, 10, 4, 1, 3>), grid, dim3(256), 0, stream, k);
+    else if (cs == 320 && heads == 8) i2r_launch((hrt_attn_head_k<DT, 20, 8, 1, 2>), grid, dim3(512), 0, stream, k);
+    else if (cs == 624 && heads == 16) i2r_launch((hrt_attn_head_k<DT, 39, 16, 2, 2>), grid, dim3(512), 0, stream, k);
     else return false;
     return true;
 }

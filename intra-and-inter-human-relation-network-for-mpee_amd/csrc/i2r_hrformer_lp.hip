@@ -304,8 +304,8 @@ __global__ __launch_bounds__(256 * HG, HG == 1 ? I2R_ATT_OCC78 : I2R_ATT_OCC156)
 template <int DT>
 int launch(const AttnK& k, int heads, long long nblk, hipStream_t stream) {
     const dim3 grid((unsigned)((nblk + 7) / 8 * 8));
-    if (heads == 2) hipLaunchKernelGGL((hrt_attn_block_k<DT, 5, 2, 1, I2R_ATT_RB78>), grid, dim3(256), 0, stream, k);
-    else hipLaunchKernelGGL((hrt_attn_block_k<DT, 10, 4, 2, I2R_ATT_RB156>), grid, dim3(512), 0, stream, k);
+    if (heads == 2) i2r_launch((hrt_attn_block_k<DT, 5, 2, 1, I2R_ATT_RB78>), grid, dim3(256), 0, stream, k);
+    else i2r_launch((hrt_attn_block_k<DT, 10, 4, 2, I2R_ATT_RB156>), grid, dim3(512), 0, stream, k);
     return 0;
 }
 

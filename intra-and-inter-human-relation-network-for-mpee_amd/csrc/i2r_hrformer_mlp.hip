@@ -333,11 +333,11 @@ extern "C" int i2r_hrt_mlp_block(const float* x, float* out, const float* ln_w, 
         const bool ok = i2r_mlp_wide_launch(k, dtype, cs, nblk, (hipStream_t)stream);
         I2R_CHECK_ARG(ok, "i2r_hrt_mlp_block: no output-block-ownership kernel for cs=%d", cs);
     } else if (dtype == 1) {
-        if (cs == 80) hipLaunchKernelGGL((hrt_mlp_block_k<1, 5, 2>), grid, dim3(128), 0, (hipStream_t)stream, k);
-        else hipLaunchKernelGGL((hrt_mlp_block_k<1, 10, 4>), grid, dim3(256), 0, (hipStream_t)stream, k);
+        if (cs == 80) i2r_launch((hrt_mlp_block_k<1, 5, 2>), grid, dim3(128), 0, (hipStream_t)stream, k);
+        else i2r_launch((hrt_mlp_block_k<1, 10, 4>), grid, dim3(256), 0, (hipStream_t)stream, k);
     } else {
-        if (cs == 80) hipLaunchKernelGGL((hrt_mlp_block_k<2, 5, 2>), grid, dim3(128), 0, (hipStream_t)stream, k);
-        else hipLaunchKernelGGL((hrt_mlp_block_k<2, 10, 4>), grid, dim3(256), 0, (hipStream_t)stream, k);
+        if (cs == 80) i2r_launch((hrt_mlp_block_k<2, 5, 2>), grid, dim3(128), 0, (hipStream_t)stream, k);
+        else i2r_launch((hrt_mlp_block_k<2, 10, 4>), grid, dim3(256), 0, (hipStream_t)stream, k);
     }
     I2R_CHECK_LAUNCH("i2r_hrt_mlp_block");
     return I2R_OK;

@@ -184,7 +184,7 @@ extern "C" int i2r_person_inputs_cv2(const i2r_image_ref* images, int32_t n_imag
     Norm3 nm;
     for (int c = 0; c < 3; ++c) { nm.mean[c] = mean[c]; nm.inv_std[c] = inv_std[c]; }  // (HOST arrays: they travel as kernel arguments)
     const long long nthr = (long long)n_crops * oh * ow;
-    hipLaunchKernelGGL(person_inputs_cv2_k, dim3((unsigned)((nthr + 255) / 256)), dim3(256), 0, (hipStream_t)stream, images, crops, n_images, swap_rb,
+    i2r_launch(person_inputs_cv2_k, dim3((unsigned)((nthr + 255) / 256)), dim3(256), 0, (hipStream_t)stream, images, crops, n_images, swap_rb,
                        nm, x_out, mask_out, n_crops, oh, ow);
     I2R_CHECK_LAUNCH("i2r_person_inputs_cv2");
     return I2R_OK;
@@ -195,7 +195,7 @@ extern "C" int i2r_crop_affine_cv2(const unsigned char* img, int32_t ih, int32_t
     I2R_CHECK_ARG(img && inv_m && mean && inv_std && out, "i2r_crop_affine_cv2: null pointer");
     I2R_CHECK_ARG(ih > 0 && iw > 0 && row_bytes >= 3 * iw && n > 0 && oh > 0 && ow > 0, "i2r_crop_affine_cv2: sizes");
     const long long nthr = (long long)n * oh * ow;
-    hipLaunchKernelGGL(crop_affine_cv2_k, dim3((unsigned)((nthr + 255) / 256)), dim3(256), 0, (hipStream_t)stream, img, ih, iw, row_bytes,
+    i2r_launch(crop_affine_cv2_k, dim3((unsigned)((nthr + 255) / 256)), dim3(256), 0, (hipStream_t)stream, img, ih, iw, row_bytes,
                        swap_rb, inv_m, mean, inv_std, out, n, oh, ow);
     I2R_CHECK_LAUNCH("i2r_crop_affine_cv2");
     return I2R_OK;
@@ -205,7 +205,7 @@ extern "C" int i2r_box_mask_cv2(const int32_t* boxes, int32_t ih, int32_t iw, fl
     I2R_CHECK_ARG(boxes && out, "i2r_box_mask_cv2: null pointer");
     I2R_CHECK_ARG(ih > 0 && iw > 0 && n > 0 && oh > 0 && ow > 0, "i2r_box_mask_cv2: sizes");
     const long long nthr = (long long)n * oh * ow;
-    hipLaunchKernelGGL(box_mask_cv2_k, dim3((unsigned)((nthr + 255) / 256)), dim3(256), 0, (hipStream_t)stream, boxes, ih, iw, out, n, oh, ow);
+    i2r_launch(box_mask_cv2_k, dim3((unsigned)((nthr + 255) / 256)), dim3(256), 0, (hipStream_t)stream, boxes, ih, iw, out, n, oh, ow);
     I2R_CHECK_LAUNCH("i2r_box_mask_cv2");
     return I2R_OK;
 }
@@ -216,7 +216,7 @@ extern "C" int i2r_crop_affine(const unsigned char* img, int32_t ih, int32_t iw,
     I2R_CHECK_ARG(img && inv_trans && mean && inv_std && out, "i2r_crop_affine: null pointer");
     I2R_CHECK_ARG(ih > 0 && iw > 0 && row_bytes >= 3 * iw && n > 0 && oh > 0 && ow > 0, "i2r_crop_affine: sizes");
     const long long nthr = (long long)n * oh * ow;
-    hipLaunchKernelGGL(crop_affine_k, dim3((unsigned)((nthr + 255) / 256)), dim3(256), 0, (hipStream_t)stream, img, ih, iw, row_bytes,
+    i2r_launch(crop_affine_k, dim3((unsigned)((nthr + 255) / 256)), dim3(256), 0, (hipStream_t)stream, img, ih, iw, row_bytes,
                        swap_rb, inv_trans, mean, inv_std, out, n, oh, ow);
     I2R_CHECK_LAUNCH("i2r_crop_affine");
     return I2R_OK;
@@ -226,7 +226,7 @@ extern "C" int i2r_box_mask(const int32_t* boxes, int32_t ih, int32_t iw, float*
     I2R_CHECK_ARG(boxes && out, "i2r_box_mask: null pointer");
     I2R_CHECK_ARG(ih > 0 && iw > 0 && n > 0 && oh > 0 && ow > 0, "i2r_box_mask: sizes");
     const long long nthr = (long long)n * oh * ow;
-    hipLaunchKernelGGL(box_mask_k, dim3((unsigned)((nthr + 255) / 256)), dim3(256), 0, (hipStream_t)stream, boxes, ih, iw, out, n, oh, ow);
+    i2r_launch(box_mask_k, dim3((unsigned)((nthr + 255) / 256)), dim3(256), 0, (hipStream_t)stream, boxes, ih, iw, out, n, oh, ow);
     I2R_CHECK_LAUNCH("i2r_box_mask");
     return I2R_OK;
 }

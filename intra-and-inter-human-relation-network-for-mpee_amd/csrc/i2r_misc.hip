@@ -443,7 +443,7 @@ extern "C" int i2r_fuse_up_add(const float* base, const float* t1, int32_t s1, c
     const unsigned nblk = (unsigned)((nq + 255) / 256);
     typedef void (*fn_t)(const float*, const float*, int, const float*, int, float*, long long, int, int, int, int);
     static const fn_t fns[3] = {fuse_up_add_k<0>, fuse_up_add_k<1>, fuse_up_add_k<2>};
-    hipLaunchKernelGGL(fns[dt], dim3(nblk), dim3(256), 0, (hipStream_t)stream, base, t1, sh1, t2, sh2, out, nq, h, w, cs / 4, act);
+    i2r_launch(fns[dt], dim3(nblk), dim3(256), 0, (hipStream_t)stream, base, t1, sh1, t2, sh2, out, nq, h, w, cs / 4, act);
     I2R_CHECK_LAUNCH("i2r_fuse_up_add");
     return I2R_OK;
 }
@@ -468,14 +468,14 @@ extern "C" int i2r_stem_conv(const float* in_nchw, const float* w, const float* 
         const long long frags = ((long long)n_img * out_h * out_w + 15) / 16;
         const long long nb = (frags + 4 * FR - 1) / (4 * FR);
         I2R_CHECK_ARG(nb > 0 && frags * 16 + 64 * FR < (1ll << 31), "i2r_stem_conv: grid");
-        hipLaunchKernelGGL(mf[cin == 3][out_dt], dim3((unsigned)nb), dim3(256), 0, (hipStream_t)stream, in_nchw, w, bias, out_nhwc, n_img,
+        i2r_launch(mf[cin == 3][out_dt], dim3((unsigned)nb), dim3(256), 0, (hipStream_t)stream, in_nchw, w, bias, out_nhwc, n_img,
                            in_h, in_w, out_h, out_w, out_cs, n_src, n_valid);
         I2R_CHECK_LAUNCH("i2r_stem_conv");
         return I2R_OK;
     }
     typedef void (*stem_fn)(const float*, const float*, const float*, float*, int, int, int, int, int, int, int, int, int);
     static const stem_fn fns[2][3] = {{stem_conv_k<1, 0>, stem_conv_k<1, 1>, stem_conv_k<1, 2>}, {stem_conv_k<3, 0>, stem_conv_k<3, 1>, stem_conv_k<3, 2>}};
-    hipLaunchKernelGGL(fns[cin == 3][out_dt], dim3(nblk), dim3(256), (size_t)(9 * cin + 1) * cout * sizeof(float), (hipStream_t)stream, in_nchw, w,
+    i2r_launch(fns[cin == 3][out_dt], dim3(nblk), dim3(256), (size_t)(9 * cin + 1) * cout * sizeof(float), (hipStream_t)stream, in_nchw, w,
                        bias, out_nhwc, n_img, in_h, in_w, out_h, out_w, cout, out_cs, n_src, n_valid);
     I2R_CHECK_LAUNCH("i2r_stem_conv");
     return I2R_OK;
@@ -490,7 +490,7 @@ extern "C" int i2r_pe_res_stem(const float* mask_nchw, const float* w_pre, const
     I2R_CHECK_ARG(cout == 64 && out_cs >= cout && out_cs % 4 == 0, "i2r_pe_res_stem: cout=%d (resnet18 conv1 has 64) out_cs=%d", cout, out_cs);
     const int out_h = (in_h - 1) / 2 + 1, out_w = (in_w - 1) / 2 + 1;
     const int tiles_y = (out_h + 7) / 8, tiles_x = (out_w + 7) / 8;
-    hipLaunchKernelGGL(pe_res_stem_k, dim3((unsigned)(n_img * tiles_y * tiles_x)), dim3(256), 0, (hipStream_t)stream, mask_nchw, w_pre, w7,
+    i2r_launch(pe_res_stem_k, dim3((unsigned)(n_img * tiles_y * tiles_x)), dim3(256), 0, (hipStream_t)stream, mask_nchw, w_pre, w7,
                        bias, out_nhwc, n_img, in_h, in_w, out_h, out_w, out_cs, n_src, n_valid, tiles_x, tiles_y);
     I2R_CHECK_LAUNCH("i2r_pe_res_stem");
     return I2R_OK;
@@ -551,7 +551,7 @@ extern "C" int i2r_pe_cat_vec(const i2r_pe_cat_vec_args* a, void* stream) {
                   a->c0, a->c0, a->vec, a->c_end, a->out_cs);
     const size_t lds = (size_t)(a->th * a->tw + a->c_end - a->c0) * sizeof(float);
     I2R_CHECK_ARG(lds <= 64 * 1024, "i2r_pe_cat_vec: %zu bytes of LDS", lds);
-    hipLaunchKernelGGL(pe_cat_vec_k, dim3((unsigned)a->n_img), dim3(256), lds, (hipStream_t)stream, a->in, a->w, a->bias, a->out, a->in_h, a->in_w,
+    i2r_launch(pe_cat_vec_k, dim3((unsigned)a->n_img), dim3(256), lds, (hipStream_t)stream, a->in, a->w, a->bias, a->out, a->in_h, a->in_w,
                        a->th, a->tw, a->rate, a->vec, a->out_cs, a->c0, a->c_end, a->n_src, a->n_valid);
     I2R_CHECK_LAUNCH("i2r_pe_cat_vec");
     return I2R_OK;
@@ -564,7 +564,7 @@ extern "C" int i2r_maxpool3x3s2(const float* in, float* out, int32_t n_img, int3
                   "i2r_maxpool3x3s2: c=%d in_cs=%d out_cs=%d", c, in_cs, out_cs);
     const int out_h = (in_h - 1) / 2 + 1, out_w = (in_w - 1) / 2 + 1;
     const long long nthr = (long long)n_img * out_h * out_w * (c / 4);
-    hipLaunchKernelGGL(maxpool_k, dim3((unsigned)((nthr + 255) / 256)), dim3(256), 0, (hipStream_t)stream, in, out, n_img,
+    i2r_launch(maxpool_k, dim3((unsigned)((nthr + 255) / 256)), dim3(256), 0, (hipStream_t)stream, in, out, n_img,
                        in_h, in_w, out_h, out_w, c / 4, in_cs, out_cs);
     I2R_CHECK_LAUNCH("i2r_maxpool3x3s2");
     return I2R_OK;
@@ -580,7 +580,7 @@ extern "C" int i2r_head(const float* in, const float* w, const float* bias, floa
         typedef void (*mfma_fn)(const float*, const float*, const float*, float*, int, int, int, int, int);
         const mfma_fn mf = cout <= 16 ? head_mfma_k<1, FR> : head_mfma_k<2, FR>;
         const long long waves = (npix + 16 * FR - 1) / (16 * FR);
-        hipLaunchKernelGGL(mf, dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, (hipStream_t)stream, in, w, bias, out_nchw, (int)npix, h * w_, cin,
+        i2r_launch(mf, dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, (hipStream_t)stream, in, w, bias, out_nchw, (int)npix, h * w_, cin,
                            in_cs, cout);
         I2R_CHECK_LAUNCH("i2r_head");
         return I2R_OK;
@@ -589,7 +589,7 @@ extern "C" int i2r_head(const float* in, const float* w, const float* bias, floa
     typedef void (*head_fn)(const float*, const float*, const float*, float*, int, int, int, int, int);
     const int jp = cout <= 16 ? 16 : cout <= 20 ? 20 : 32;
     const head_fn fn = jp == 16 ? head_k<16> : jp == 20 ? head_k<20> : head_k<32>;
-    hipLaunchKernelGGL(fn, dim3(nblk), dim3(256), (size_t)(cin / 4) * jp * sizeof(f32x4), (hipStream_t)stream, in, w, bias, out_nchw, n_img, h * w_,
+    i2r_launch(fn, dim3(nblk), dim3(256), (size_t)(cin / 4) * jp * sizeof(f32x4), (hipStream_t)stream, in, w, bias, out_nchw, n_img, h * w_,
                        cin, in_cs, cout);
     I2R_CHECK_LAUNCH("i2r_head");
     return I2R_OK;

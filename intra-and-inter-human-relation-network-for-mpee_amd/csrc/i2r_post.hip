@@ -123,7 +123,7 @@ extern "C" int i2r_flip_merge(const float* y, const float* y_flipped, const int3
                               int32_t h, int32_t w, void* stream) {
     I2R_CHECK_ARG(y && y_flipped && joint_map && out, "i2r_flip_merge: null pointer");
     const long long tot = (long long)n * joints * h * w;
-    hipLaunchKernelGGL(flip_merge_k, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, (hipStream_t)stream, y, y_flipped, joint_map,
+    i2r_launch(flip_merge_k, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, (hipStream_t)stream, y, y_flipped, joint_map,
                        out, n, joints, h, w);
     I2R_CHECK_LAUNCH("i2r_flip_merge");
     return I2R_OK;
@@ -137,7 +137,7 @@ extern "C" int i2r_decode(const float* heatmaps, const float* center, const floa
     I2R_CHECK_ARG(lds <= 150 * 1024 && w > 1, "i2r_decode: heatmap %dx%d too large", h, w);
     if (lds > 64 * 1024)
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(decode_k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    hipLaunchKernelGGL(decode_k, dim3((unsigned)(n * joints)), dim3(256), lds, (hipStream_t)stream, heatmaps, center, scale, preds,
+    i2r_launch(decode_k, dim3((unsigned)(n * joints)), dim3(256), lds, (hipStream_t)stream, heatmaps, center, scale, preds,
                        maxvals, joints, h, w, blur_kernel, transform_back);
     I2R_CHECK_LAUNCH("i2r_decode");
     return I2R_OK;

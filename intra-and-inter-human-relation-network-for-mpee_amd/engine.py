@@ -1371,13 +1371,50 @@ class Program:
                 events = self._own_events()
             evs = (C.c_void_p * 8)(*[e.cuda_event for e in events])
         try:
-            cabi.check(L.i2r_run_program(self._c_ops, len(self.ops), streams, evs), "i2r_run_program")
+            if Program.timing_log is not None:  # bench.py's in-situ pass: every launch of this run bracketed by two timing events
+                self._run_timed(L, streams, evs)
+            else:
+                cabi.check(L.i2r_run_program(self._c_ops, len(self.ops), streams, evs), "i2r_run_program")
         except Exception:
             # a launch list that stopped half-way may leave hand-off counters of the encoder's partial key split non-zero; the
             # kernels rely on finding them zero (include/i2r_hip.h: split_cnt)
             for t in self.split_counters:
                 t.zero_()
             raise
+
+    # In-situ per-launch timing (bench.py `roofline`): while `Program.timing_log` is a list, every run() of every program
+    # goes through i2r_run_program_timed and appends (program, t0 events, t1 events, the four lanes' stream handles); the forward itself --
+    # streams, lanes, sibling part-batch programs, fork / join / xsync -- is exactly the product's.  Every launch gets a STOP event bound
+    # to its dispatch and (timing_markers) a START marker in front of it: elapsed(start, stop) is the kernel's own duration, whatever the
+    # host or the other lanes do; the marker costs its stream ~5 us per launch (tools/probe/event_timing.hip), so the timed forward is
+    # 10-20 % slower than the real one.  Without markers (only the first launch on each stream of a program has one) a launch's start is
+    # the completion of what it waited for -- its predecessor on the stream, or the lanes a fork / join / xsync named -- which
+    # bench.in_situ_timing reconstructs from the stop events; measured on MI355X that form counts every moment a stream waits for the
+    # HOST as kernel time (w48: 52.4 us per Winograd launch against 46.9 with markers) and still slows the forward by 12 %.
+    # The caller synchronises, then reads the events (before the next timed run of the same program re-binds them).
+    timing_log = None
+    timing_markers = True  # True: a start marker in front of EVERY launch (durations = the kernels' own); False: only at stream heads
+
+    def _run_timed(self, L, streams, evs):
+        n = len(self.ops)
+        key = tuple(streams)
+        if getattr(self, "_tev", (None,))[0] != key:  # events are created once per program (and lane layout)
+            t0, t1, seen = [None] * n, [None] * n, set()
+            for i, (kind, lane, st) in enumerate(self.ops):
+                if kind in cabi.SYNC_OPS:
+                    continue
+                t1[i] = torch.cuda.Event(enable_timing=True)
+                t1[i].record()  # (creates the underlying hipEvent_t; the library re-binds it to the launch)
+                if Program.timing_markers or streams[lane] not in seen:
+                    seen.add(streams[lane])
+                    t0[i] = torch.cuda.Event(enable_timing=True)
+                    t0[i].record()
+            torch.cuda.synchronize(self.device)
+            self._tev = (key, t0, t1, (C.c_void_p * n)(*[e.cuda_event if e is not None else None for e in t0]),
+                         (C.c_void_p * n)(*[e.cuda_event if e is not None else None for e in t1]))
+        _, t0, t1, a0, a1 = self._tev
+        cabi.check(L.i2r_run_program_timed(self._c_ops, n, streams, evs, a0, a1), "i2r_run_program_timed")
+        Program.timing_log.append((self, t0, t1, key))
 
     def _own_events(self):
         if not hasattr(self, "_events"):
@@ -1790,29 +1827,35 @@ def validate_config(cfg, name=None):
 
 
 _LANE_STREAMS = {}  # device -> side streams shared by every Engine of the process
+_LANE_SPARE = {}    # device -> probed streams that share a hardware queue with the caller's stream or with a lane (kept alive, unused)
+_LANE_PROBE = {}    # device -> [one record per candidate stream: what the probe measured and what became of it] (bench.py prints it as `lanes`)
 
 
-def _streams_overlap(a, b, cycles=400000):
-    """True if work queued on streams a and b runs side by side (different hardware queues): a spin kernel on each, timed together.
-    HIP maps streams onto a handful of hardware queues in creation order; two streams on one queue serialise."""
-    def once(both):
-        e0, e1, e2 = (torch.cuda.Event(enable_timing=True) for _ in range(3))
-        e0.record(a)
-        b.wait_event(e0)
-        with torch.cuda.stream(a):
+def _spin_pair_ms(a, b, both, cycles):
+    """ms from the start of a spin kernel on stream a to the end of it and (both) of a second one on stream b"""
+    e0, e1, e2 = (torch.cuda.Event(enable_timing=True) for _ in range(3))
+    e0.record(a)
+    b.wait_event(e0)
+    with torch.cuda.stream(a):
+        torch.cuda._sleep(cycles)
+    if both:
+        with torch.cuda.stream(b):
             torch.cuda._sleep(cycles)
-        if both:
-            with torch.cuda.stream(b):
-                torch.cuda._sleep(cycles)
-        e1.record(b)
-        a.wait_event(e1)
-        e2.record(a)
-        e2.synchronize()
-        return e0.elapsed_time(e2)
-    once(True)  # (first use of a stream binds its queue)
-    t1 = min(once(False) for _ in range(2))
-    t2 = min(once(True) for _ in range(2))
-    return t2 < 1.5 * t1
+    e1.record(b)
+    a.wait_event(e1)
+    e2.record(a)
+    e2.synchronize()
+    return e0.elapsed_time(e2)
+
+
+def _streams_overlap(a, b, cycles=100000, runs=3):
+    """(overlap?, ms alone, ms together): work queued on streams a and b runs side by side (different hardware queues) if a spin kernel
+    on each, started together, takes about as long as one alone (median of `runs`; ~1 ms per spin on the 100 MHz ROCm clock).
+    HIP maps streams onto a handful of hardware queues in creation order; two streams on one queue serialise."""
+    _spin_pair_ms(a, b, True, cycles)  # (first use of a stream binds its queue)
+    t1 = sorted(_spin_pair_ms(a, b, False, cycles) for _ in range(runs))[runs // 2]
+    t2 = sorted(_spin_pair_ms(a, b, True, cycles) for _ in range(runs))[runs // 2]
+    return t2 < 1.5 * t1, t1, t2
 
 
 def lane_streams(device, n):
@@ -1822,32 +1865,49 @@ def lane_streams(device, n):
     four-lane HRFormer forward 7-16 % slower, and a process that had created an RCCL communicator first (its streams shift the order)
     lost the whole part-batch overlap (w48 fp32 3.75 -> 5.09 ms per step, tools/gather_cost.py).  So every candidate stream is PROBED:
     it becomes a lane only if a spin kernel on it runs side by side with one on the current stream and on every lane chosen so far
-    (_streams_overlap); candidates that share a queue are kept aside.  Engines of one process issue their forwards one after the
-    other, so sharing the streams costs nothing; it only adds ordering if they ever did not."""
+    (_streams_overlap); candidates that share a queue are kept aside.  At most 12 candidates; every probe is recorded in _LANE_PROBE
+    (bench.py: `lanes`); I2R_LANE_PROBE=0 takes the streams as they come.  A process that is going to create an RCCL communicator calls
+    this BEFORE init_process_group (bench.py does), so the lanes' queues do not depend on what RCCL creates.  Engines of one process
+    issue their forwards one after the other, so sharing the streams costs nothing; it only adds ordering if they ever did not."""
     key = str(device)
     lst = _LANE_STREAMS.setdefault(key, [])
     if len(lst) < n:
+        probe = os.environ.get("I2R_LANE_PROBE", "1") != "0" and hasattr(torch.cuda, "_sleep")
+        log = _LANE_PROBE.setdefault(key, [])
         with torch.cuda.device(device):
             cur = torch.cuda.current_stream(device)
             spare = _LANE_SPARE.setdefault(key, [])
             for _ in range(int(_tune("I2R_STREAM_SKIP", "0"))):  # (A/B: shift the creation order)
                 spare.append(torch.cuda.Stream(device=device))
             tries = 0
-            while len(lst) < n and tries < 24:
+            while len(lst) < n and tries < 12:
                 tries += 1
                 st = torch.cuda.Stream(device=device)
-                try:
-                    ok = _streams_overlap(cur, st) and all(_streams_overlap(o, st) for o in lst)
-                except Exception:  # (no spin kernel on this build: take the stream as it comes)
-                    ok = True
+                rec = {"stream": hex(st.cuda_stream), "candidate": tries}
+                ok = True
+                if probe:
+                    for who, other in [("caller", cur)] + [("lane%d" % (i + 1), o) for i, o in enumerate(lst)]:
+                        ok, t1, t2 = _streams_overlap(other, st)
+                        rec["vs_" + who] = {"alone_ms": round(t1, 3), "together_ms": round(t2, 3), "overlap": ok}
+                        if not ok:
+                            break
+                else:
+                    rec["probe"] = "off"
+                rec["role"] = ("lane%d" % (len(lst) + 1)) if ok else "spare (shares a hardware queue)"
+                log.append(rec)
                 (lst if ok else spare).append(st)
             while len(lst) < n:  # (fewer independent queues than lanes: the remaining lanes share)
-                lst.append(spare.pop() if spare else torch.cuda.Stream(device=device))
+                st = spare.pop() if spare else torch.cuda.Stream(device=device)
+                log.append({"stream": hex(st.cuda_stream), "role": "lane%d (no independent queue left: shares)" % (len(lst) + 1)})
+                lst.append(st)
             torch.cuda.synchronize(device)
     return lst[:n]
 
 
-_LANE_SPARE = {}  # device -> probed streams that share a hardware queue with the caller's stream or with a lane (kept alive, unused)
+def lane_report(device):
+    """what lane_streams found on this device, for the bench line"""
+    key = str(torch.device(device)) if not isinstance(device, str) else device
+    return {"lanes": [hex(s.cuda_stream) for s in _LANE_STREAMS.get(key, [])], "candidates": list(_LANE_PROBE.get(key, []))}
 
 
 class Engine:

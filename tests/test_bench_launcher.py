@@ -26,8 +26,8 @@ def test_gpus2_self_launch_gloo_stub():
     assert len(lines) == 1, p.stdout  # ONE line, from rank 0 only
     out = json.loads(lines[0])
     assert out["n_gpus"] == 2 and out["steps"] == 3 and out["scaling"] == "weak"
-    assert out["config"]["crops_per_gpu_step"] == 16 and "dp2" in out["config"]["parallelism"] and "heat maps" in out["config"]["parallelism"]
-    assert out["gather_alt"]["payload"] == "keypoints" and out["gather_alt"]["ms_per_step"] > 0
+    assert out["config"]["crops_per_gpu_step"] == 16 and "dp2" in out["config"]["parallelism"] and "key points" in out["config"]["parallelism"]
+    assert out["gather_alt"]["payload"] == "heatmaps" and out["gather_alt"]["ms_per_step"] > 0
     assert "STUB" in out["data"] and out["value"] == 0.0  # a stub run can never be mistaken for a measurement
 
 
@@ -43,7 +43,7 @@ def test_gpus1_world1_collective_strong_gloo_stub():
     assert out["n_gpus"] == 1 and out["scaling"] == "strong" and "dp1" in out["config"]["parallelism"]
     sh = out["shards"]
     assert sh["images_total"] == 64 and sh["crops_per_rank"] == [sh["crops_total"]] and sh["forwards_per_rank_step"] == [4]
-    assert out["gather_alt"]["payload"] == "keypoints"
+    assert out["gather_alt"]["payload"] == "heatmaps"
     bad = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--world1-collective", "--backend", "gloo", "--selftest-stub"],
                          cwd=ROOT, env=_env(), capture_output=True, text=True, timeout=600)
     assert bad.returncode != 0 and "world1-collective" in (bad.stdout + bad.stderr)
