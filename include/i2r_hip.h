@@ -456,7 +456,8 @@ typedef struct i2r_mh_attn_args {
     const float* qk; const float* v; float* out; const int32_t* grp_off;
     int32_t n_grp, heads, hp, k_off, qk_cs, v_cs, out_cs, n_qtiles16, n_qtiles32, n_qtiles64;
     const int32_t* key_len;   /* optional device int32 [n_grp]: group g attends to its FIRST key_len[g] rows only; all its rows stay queries
-                                 (padded persons under a key_padding_mask, ATTENTION_TYPE window) */
+                                 (padded persons under a key_padding_mask, ATTENTION_TYPE window).  Precondition 1 <= key_len[g] <= length of
+                                 group g; the kernel clamps to that range (a device array cannot be validated by the host entry point) */
 } i2r_mh_attn_args;
 I2R_API int i2r_mh_attention(const i2r_mh_attn_args* a, void* stream);
 

@@ -47,7 +47,8 @@ __global__ __launch_bounds__(256) void enc_mh_attn_k(const MhK p) {
     if (gi >= p.n_grp) return;
     const int q0 = g0 + t * 16 * NQ;
     const int q1 = g1;                           // queries: the whole group
-    if (p.key_len) g1 = g0 + p.key_len[gi];      // keys: its first key_len rows (key_padding_mask of the padded persons)
+    if (p.key_len) g1 = g0 + min(max(p.key_len[gi], 1), g1 - g0);  // keys: its first key_len rows (key_padding_mask of the padded persons),
+                                                                  // clamped to [1, group length]: no row of another group is ever read
     const int hc = head * p.hp + 4 * g;
     f32x4 q[NQ][HB], o[NQ][HB];
     float m[NQ], l[NQ];

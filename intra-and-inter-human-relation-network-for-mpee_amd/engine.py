@@ -1018,6 +1018,7 @@ class Program:
     def rows_gather(self, src, crop_map, lane=0):
         """[len(crop_map), h, w, c] whose crop i is crop crop_map[i] of src, zeros for -1 (padding_tensor: the padded persons as rows)"""
         out = self.alloc(len(crop_map), src.h, src.w, src.c)
+        assert out.cs == src.cs, "rows_gather copies whole rows: source and output need the same row stride (%d vs %d)" % (src.cs, out.cs)
         m = torch.tensor(list(crop_map), dtype=torch.int32).to(self.device)
         self.keep.append(m)
         a = cabi.GatherArgs(src.ptr, out.ptr, m.data_ptr(), len(crop_map), src.h * src.w * src.cs)

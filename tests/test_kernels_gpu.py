@@ -1297,3 +1297,64 @@ def test_encoder_layer_low_precision(precision, d, length, hw, period):
     assert err.max().item() < tol_max and err.mean().item() < tol_mean, (err.max().item(), err.mean().item())
     if d == 78:
         assert out.t.view(-1, out.cs)[:, 78:].abs().max().item() == 0.0  # pad channels stay exactly zero
+
+
+def test_run_program_timed_same_results_and_positive_durations():
+    """i2r_run_program_timed (include/i2r_hip.h): the replay whose launches carry timing events -- bench.py's in-situ measurement hook --
+    writes exactly what i2r_run_program writes, every launch's elapsed(start, stop) is positive and below the replay's wall time, and the
+    forward of a whole model through Program.timing_log equals the untimed one bit for bit."""
+    import ctypes as C
+    from i2r_amd import cabi
+    sd = {"c.weight": _rand((48, 48, 3, 3), "wt", (6.0 / (48 * 9)) ** 0.5), "d.weight": _rand((96, 48, 1, 1), "wt2", (6.0 / 48) ** 0.5)}
+    x = _rand((2, 48, 64, 48), "xt")
+    P = engine.Program(torch.device(DEV))
+    pk = engine.Packer(sd, torch.device(DEV))
+    xa = to_act(P, x)
+    y1 = P.conv(xa, pk.conv("c", None), relu=True)
+    y2 = P.conv(y1, pk.conv("d", None), relu=False)
+    run(P)
+    ref = from_act(y2).clone()
+    y2.t.zero_()
+    n = len(P.ops)
+    launches = [i for i, (kind, lane, st) in enumerate(P.ops) if kind not in cabi.SYNC_OPS]
+    assert len(launches) == 2
+    ev0 = [torch.cuda.Event(enable_timing=True) for _ in range(n)]
+    ev1 = [torch.cuda.Event(enable_timing=True) for _ in range(n)]
+    for e in ev0 + ev1:
+        e.record()
+    cur = torch.cuda.current_stream().cuda_stream
+    streams = (C.c_void_p * 4)(cur, cur, cur, cur)
+    a0 = (C.c_void_p * n)(*[e.cuda_event for e in ev0])
+    a1 = (C.c_void_p * n)(*[e.cuda_event for e in ev1])
+    L = cabi.lib()
+    w0, w1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    w0.record()
+    cabi.check(L.i2r_run_program_timed(P._c_ops, n, streams, None, a0, a1), "timed")
+    w1.record()
+    torch.cuda.synchronize()
+    assert torch.equal(from_act(y2), ref)
+    wall = w0.elapsed_time(w1)
+    for i in launches:
+        d = ev0[i].elapsed_time(ev1[i])
+        assert 0.0 < d <= wall, (i, d, wall)
+    assert L.i2r_run_program_timed(P._c_ops, n, streams, None, None, None) != 0   # both event arrays are required
+    # a whole model: the armed forward logs every program and changes nothing
+    from _golden import setup
+    from i2r_amd import models
+    cfg, sd2, x2, m2, length, g = setup("w48_l213")
+    net = models.interformer_pureMulti.get_pose_net(cfg, is_train=False)
+    net.load_state_dict(sd2, strict=True)
+    net = net.cuda()
+    y_plain = net(x2.cuda(), m2.cuda(), length)
+    engine.Program.timing_log = []
+    try:
+        y_timed = net(x2.cuda(), m2.cuda(), length)
+        torch.cuda.synchronize()
+        log = engine.Program.timing_log
+    finally:
+        engine.Program.timing_log = None
+    assert torch.equal(y_plain, y_timed) and len(log) >= 1
+    for Pm, t0, t1, lanes in log:
+        for i, (kind, lane, st) in enumerate(Pm.ops):
+            if kind not in cabi.SYNC_OPS:
+                assert t0[i].elapsed_time(t1[i]) > 0.0

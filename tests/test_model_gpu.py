@@ -48,10 +48,18 @@ def test_heatmaps_match_reference_golden(tag):
             assert err_ref < TOL, "%s/%s vs reference golden max-abs %.3e" % (tag, k, err_ref)
 
 
+def variant_bar(ref):
+    """The bar of the VARIANT goldens is RELATIVE above |y| = 8: max-abs < 1e-3 * max(1, max|ref| / 8).  The ten shipped-yaml tags
+    (test_heatmaps_match_reference_golden) keep north_star's absolute 1e-3; some variant configs with synthetic weights produce outputs of
+    |y| up to ~20 (a 3x3 final layer, the window block's re-viewed output), where fp32 summation order alone moves the result by 1e-4 .. 1e-3
+    -- the same relative accuracy (1.25e-4 of the output range) is what is held there.  DESIGN.md section 3 states this bar."""
+    return TOL * max(1.0, float(np.abs(ref).max()) / 8)
+
+
 @pytest.mark.parametrize("tag", sorted(VARIANTS))
-def test_variant_heatmaps_match_reference_golden(tag):
+def test_variant_heatmaps_match_reference_golden_relative_bar_above_8(tag):
     """Reference-expressible settings no shipped yaml uses (MODEL.N_HEAD > 1, MODEL.NORMALIZE_BEFORE, ...): golden heat maps produced by
-    the reference itself under the same KEY VALUE overrides (oracle/make_golden.py VARIANTS)"""
+    the reference itself under the same KEY VALUE overrides (oracle/make_golden.py VARIANTS); bar = variant_bar (relative above |y| = 8)"""
     cfg, sd, x, m, length, g = setup(tag)
     net = eval("models." + cfg.MODEL.NAME + ".get_pose_net")(cfg, is_train=False)
     net.load_state_dict(sd, strict=True)
@@ -64,7 +72,7 @@ def test_variant_heatmaps_match_reference_golden(tag):
         t = t.cpu().numpy()
         assert t.shape == ref.shape and np.isfinite(t).all()
         err = np.abs(t - ref).max()
-        assert err < TOL * max(1.0, np.abs(ref).max() / 8), "%s/%s vs reference golden max-abs %.3e (max|ref| %.1f)" % (tag, k, err, np.abs(ref).max())
+        assert err < variant_bar(ref), "%s/%s vs reference golden max-abs %.3e (max|ref| %.1f)" % (tag, k, err, np.abs(ref).max())
     progs = [P for P, _ in net.engine().programs.values()]
     if cfg.MODEL.N_HEAD > 1 or cfg.MODEL.NORMALIZE_BEFORE:
         assert sum(1 for P in progs for k, _, _ in P.ops if k == cabi.OP_MH_ATTN) > 0
