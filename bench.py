@@ -212,7 +212,7 @@ def op_model(kind, st, precision, enc_lens=None):
     if kind == cabi.OP_CONV1X1_LP:
         n = st.n_pix
         return ("conv1x1_lp_k", 2.0 * n * st.cin_pad * st.cout_pad,
-                float(n * (st.x_cs * _esz(st.in_16) + st.out_cs * _esz(st.out_16) * (1 + bool(st.res1) + bool(st.res_post))) + st.cin_pad * st.cout_pad * 2), precision)
+                float(n * (st.x_cs * _esz(st.in_16) + st.out_cs * _esz(st.out_16) * (1 + bool(st.res1) + bool(st.res2) + bool(st.res_post))) + st.cin_pad * st.cout_pad * 2), precision)
     return "op%d" % kind, 0.0, 0.0, None
 
 
@@ -295,11 +295,21 @@ def in_situ_timing(fwd, precision, reps=5):
         for P, t0, t1, lane_streams in log:
             models = {i: (name, flop, nbytes, pipe) for i, name, flop, nbytes, pipe in _op_models(P, precision)}
             ready = {}  # stream handle -> time (ms after e0) at which everything this stream has to wait for is complete
+            slot_t = {}  # record slot -> `ready` of the recording stream at the record
 
             def mx(*v):
                 v = [x for x in v if x is not None]
                 return max(v) if v else None
             for i, (kind, lane, st) in enumerate(P.ops):
+                if kind == cabi.OP_LANE_FLAGS:
+                    continue
+                if kind in (cabi.OP_RECORD, cabi.OP_WAIT):
+                    sk, slot = lane_streams[lane & 3], (lane >> 8) & 7
+                    if kind == cabi.OP_RECORD:
+                        slot_t[slot] = ready.get(sk)
+                    else:
+                        ready[sk] = mx(ready.get(sk), slot_t.get(slot))
+                    continue
                 if kind in cabi.SYNC_OPS:  # what the sync op makes each stream wait for (csrc/i2r_api.hip: run_program)
                     ls = [lane_streams[l] for l in range(4) if lane & (1 << l)]
                     s0 = lane_streams[0]

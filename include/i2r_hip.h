@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define I2R_ABI_VERSION 13
+#define I2R_ABI_VERSION 14
 
 /* The library is built with -fvisibility=hidden: the entry points declared in this header (marked I2R_API) are its ONLY exported
  * symbols (tests/test_host.py holds the header, the dynamic symbol table and cabi.EXPORTS equal). */
@@ -349,7 +349,7 @@ I2R_API int i2r_conv1x1_pair(const i2r_conv1x1_pair_args* a, void* stream);
 
 /* i2r_conv1x1_lp -- 1x1 convolution (+ folded BN) over a small number of NHWC pixel rows on the 16-bit matrix pipe, operands straight
  * from global memory, K split over the four waves of a workgroup:
- *     out = act(W x + bias [+ res1]) [+ res_post]          act: 0 none, 1 ReLU, 2 exact-erf GELU
+ *     out = act(W x + bias [+ res1] [+ res2]) [+ res_post]          act: 0 none, 1 ReLU, 2 exact-erf GELU
  * Replaces the single 1x1 convs of the unfused HRFormer-B transformer blocks -- q|k|v and out projections (hrformer.py:1164-1180),
  * MlpDWBN fc1 / fc2 (:1094-1119) -- and of the fuse layers (:1629-1704) where the pixel count is a few thousand and i2r_conv is bound
  * by its per-chunk staging latency.  w: fragment-packed 16-bit [cout_pad / 16][ceil(cin_pad / 32)][64 lanes][8] (engine.pack_frag32:
@@ -359,6 +359,8 @@ I2R_API int i2r_conv1x1_pair(const i2r_conv1x1_pair_args* a, void* stream);
 typedef struct i2r_conv1x1_lp_args {
     const void* x; const void* w; const float* bias; const void* res1; const void* res_post; void* out;
     int32_t n_pix, cin_pad, cout_pad, x_cs, out_cs, act, dtype, in_16, out_16, mt;
+    const void* res2;   /* ABI 14: second pre-activation residual, out = act((W x + bias + res1) + res2) [+ res_post]: the last 1x1 conv of an
+                           HRFormer down path that closes a fuse sum (running sum + the branch's own map, hrformer.py:1716-1731) */
 } i2r_conv1x1_lp_args;
 I2R_API int i2r_conv1x1_lp(const i2r_conv1x1_lp_args* a, void* stream);
 
@@ -484,13 +486,26 @@ typedef struct i2r_scramble_args { const float* o; float* out; const int32_t* pe
  * I2R_OP_XSYNC (op.lane = mask of lanes, bit 0 = lane 0): every lane of the mask continues only after everything issued so far on
  * every OTHER lane of the mask (one event per lane, all-to-all waits) -- the barrier between the branch blocks and the fuse
  * layers of an HRFormer module when branch i and fuse output i both live on lane i, so that no lane idles behind lane 0.
+ * I2R_OP_RECORD / I2R_OP_WAIT (round 6; op.lane = lane | slot << 8, slot 0..7): RECORD puts event 8 + slot on the lane's stream behind
+ * everything issued on it so far; WAIT makes the lane's stream wait for the LAST record of that slot (nothing if it was recorded on the
+ * same stream).  Point-to-point, so a lane waits only for what its next launch reads, in the order the producers finish: on MI355X
+ * a cross-stream wait costs the waiter ~10 us after the producer ends and the all-to-all form ~20 us for three lanes
+ * (tools/probe/xstream_latency*.hip) -- the HRFormer fuse layers now start the terms of the early lanes under the last lane's blocks.
+ * A program with these ops needs an `events` array of 16 entries; RECORD's op.lane also carries the consumer lanes (mask << 16).
+ * DEVICE-SIDE FORM: behind an I2R_OP_LANE_FLAGS op (op.args = device int32[64], zeroed once by the caller; NULL = stay with events)
+ * FORK / JOIN / RECORD / WAIT become one-wave kernels -- the producer's stream sets flags behind its work, the consumer's stream spins
+ * on its flag, clears it and ends (~6 us instead of ~20 us per cross-lane hop).  The caller hands the buffer over ONLY when every lane
+ * stream is its own hardware queue (a spinning kernel in front of the kernel that signals it would never end; engine.lane_streams
+ * probes this) and never replays two programs that share a buffer at the same time; a wait gives up after 50 ms and sets entry 63 of
+ * the buffer instead of hanging the GPU.  XSYNC keeps the event form.
  * ------------------------------------------------------------------------------------------------ */
 enum {
     I2R_OP_CONV = 1, I2R_OP_STEM = 2, I2R_OP_MAXPOOL = 3, I2R_OP_HEAD = 4,
     I2R_OP_ENC_KV = 5, I2R_OP_ENC_LAYER = 6, I2R_OP_FORK = 7, I2R_OP_JOIN = 8, I2R_OP_CONV_GROUP = 9,
     I2R_OP_LAYERNORM = 10, I2R_OP_WINATTN = 11, I2R_OP_DWCONV = 12, I2R_OP_UPSAMPLE = 13, I2R_OP_CONV_CHAIN = 14,
     I2R_OP_PE_RES_STEM = 15, I2R_OP_HRT_ATTN = 16, I2R_OP_HRT_MLP = 17, I2R_OP_XSYNC = 18, I2R_OP_FUSE_UP = 19,
-    I2R_OP_CONV1X1_PAIR = 20, I2R_OP_CONV1X1_LP = 21, I2R_OP_MH_ATTN = 22, I2R_OP_PE_CAT_VEC = 23, I2R_OP_ROWS_GATHER = 24, I2R_OP_VIEW_SCRAMBLE = 25
+    I2R_OP_CONV1X1_PAIR = 20, I2R_OP_CONV1X1_LP = 21, I2R_OP_MH_ATTN = 22, I2R_OP_PE_CAT_VEC = 23, I2R_OP_ROWS_GATHER = 24, I2R_OP_VIEW_SCRAMBLE = 25,
+    I2R_OP_RECORD = 26, I2R_OP_WAIT = 27, I2R_OP_LANE_FLAGS = 28
 };
 
 typedef struct i2r_stem_args {
@@ -565,8 +580,8 @@ typedef struct i2r_op {
     const void* args;      /* host pointer to the matching *_desc / *_args struct */
 } i2r_op;
 
-/* streams: array of 4 hipStream_t (lane 0 = the caller's stream); events: array of >= 8 hipEvent_t
- * created by the caller with hipEventDisableTiming.  Both may be NULL when every op uses lane 0. */
+/* streams: array of 4 hipStream_t (lane 0 = the caller's stream); events: array of >= 8 hipEvent_t (16 when the program holds
+ * RECORD / WAIT ops) created by the caller with hipEventDisableTiming.  Both may be NULL when every op uses lane 0. */
 I2R_API int i2r_run_program(const i2r_op* ops, int32_t n_ops, void* const* streams, void* const* events);
 /* The same replay with every LAUNCH timed through caller-owned events (hipEventCreate with timing enabled; entries of sync ops -- FORK /
  * JOIN / XSYNC -- are ignored): the launch of op i goes out through hipExtLaunchKernelGGL with t1[i] BOUND to the dispatch (its completion

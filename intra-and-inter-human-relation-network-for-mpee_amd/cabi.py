@@ -14,7 +14,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libi2r_hip.so")
 
 MAX_TAPS = 9
-ABI_VERSION = 13  # I2R_ABI_VERSION of include/i2r_hip.h
+ABI_VERSION = 14  # I2R_ABI_VERSION of include/i2r_hip.h
 OP_CONV, OP_STEM, OP_MAXPOOL, OP_HEAD, OP_ENC_KV, OP_ENC_LAYER, OP_FORK, OP_JOIN, OP_CONV_GROUP = 1, 2, 3, 4, 5, 6, 7, 8, 9
 MAX_GROUP = 4
 OP_LAYERNORM, OP_WINATTN, OP_DWCONV, OP_UPSAMPLE = 10, 11, 12, 13
@@ -29,7 +29,9 @@ OP_CONV1X1_LP = 21
 OP_MH_ATTN = 22
 OP_PE_CAT_VEC = 23
 OP_ROWS_GATHER, OP_VIEW_SCRAMBLE = 24, 25
-SYNC_OPS = (OP_FORK, OP_JOIN, OP_XSYNC)  # ops whose `lane` field is a lane mask and that launch nothing
+OP_RECORD, OP_WAIT = 26, 27  # point-to-point: lane field = lane | slot << 8 (| consumer lanes << 16 for RECORD)
+OP_LANE_FLAGS = 28          # args = device int32[64] flag buffer: the sync ops behind it run as device-side signal / wait kernels
+SYNC_OPS = (OP_FORK, OP_JOIN, OP_XSYNC, OP_RECORD, OP_WAIT, OP_LANE_FLAGS)  # ops that launch nothing (FORK / JOIN / XSYNC: `lane` is a lane mask)
 
 _fp = C.c_void_p  # device pointers travel as integers
 _i32 = C.c_int32
@@ -150,7 +152,7 @@ class Conv1x1PairArgs(C.Structure):
 class Conv1x1LpArgs(C.Structure):
     _fields_ = [("x", _fp), ("w", _fp), ("bias", _fp), ("res1", _fp), ("res_post", _fp), ("out", _fp),
                 ("n_pix", _i32), ("cin_pad", _i32), ("cout_pad", _i32), ("x_cs", _i32), ("out_cs", _i32), ("act", _i32), ("dtype", _i32),
-                ("in_16", _i32), ("out_16", _i32), ("mt", _i32)]
+                ("in_16", _i32), ("out_16", _i32), ("mt", _i32), ("res2", _fp)]
 
 
 class ConvGroupArgs(C.Structure):

@@ -32,13 +32,54 @@ extern "C" int i2r_device_check(int32_t dev, int32_t* cu_count, int32_t* lds_byt
     return I2R_OK;
 }
 
+// ---- device-side lane synchronisation (round 6) -------------------------------------------------------------------------------------
+// A cross-stream dependency through events (hipEventRecord -> hipStreamWaitEvent) costs the WAITING stream ~10 us after the producer
+// ends, ~20 us inside a forward (marker packet + cross-queue barrier packet; tools/probe/xstream_latency*.hip), and an HRFormer forward
+// crosses lanes on its critical path 13 times.  Behind an I2R_OP_LANE_FLAGS op (a flag buffer) the same ops are two one-wave kernels: the
+// producer's stream sets flags behind its work (lane_signal_k), the consumer's stream runs lane_wait_k, which spins (with s_sleep)
+// until its flag is set, clears it and ends -- the consumer's next kernel follows in stream order.  Kernel boundaries give the same
+// release / acquire as with events.  Preconditions (the CALLER checks them, engine.Program.run): every lane is its own hardware queue
+// (a waiting kernel must never sit in front of the kernel that signals it) and the program issues every signal before the waits for it
+// (launch-list order = host enqueue order).  A wait gives up after ~50 ms and raises flags[I2R_FLAG_TIMEOUT] instead of hanging the GPU.
+constexpr int I2R_FLAG_TIMEOUT = 63;
+__global__ void lane_signal_k(int* flags, int row, int mask) {
+    const int l = threadIdx.x;
+    if (l < 4 && (mask & (1 << l))) __hip_atomic_store(flags + row * 4 + l, 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+}
+__global__ void lane_wait_k(int* flags, int idx) {
+    if (threadIdx.x != 0) return;
+    long long t0 = wall_clock64();
+    while (__hip_atomic_load(flags + idx, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) == 0) {
+        __builtin_amdgcn_s_sleep(8);
+        if (wall_clock64() - t0 > 5000000LL) {  // 50 ms at 100 MHz
+            __hip_atomic_store(flags + I2R_FLAG_TIMEOUT, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            break;
+        }
+    }
+    __hip_atomic_store(flags + idx, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+static inline void lane_signal(int* flags, int row, int mask, void* stream) {
+    lane_signal_k<<<dim3(1), dim3(64), 0, (hipStream_t)stream>>>(flags, row, mask);
+}
+static inline void lane_wait(int* flags, int row, int lane, void* stream) {
+    lane_wait_k<<<dim3(1), dim3(64), 0, (hipStream_t)stream>>>(flags, row * 4 + lane);
+}
+
 // t0 / t1 (both or neither): per-op timing events of i2r_run_program_timed, recorded on the op's own stream around its launch
 static int run_program(const i2r_op* ops, int32_t n_ops, void* const* streams, void* const* events, void* const* t0, void* const* t1) {
     I2R_CHECK_ARG(ops && n_ops >= 0, "i2r_run_program: null program");
     int next_event = 0;
+    void* slot_stream[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};  // stream of the last RECORD per slot
+    bool slot_set[8] = {false, false, false, false, false, false, false, false};                      // (the null stream is a valid stream)
+    // flag rows: 0..7 = record slots, 8 = fork, 8 + l = join from lane l (l >= 1): [row][consumer lane]
+    int* flags = nullptr;  // set by I2R_OP_LANE_FLAGS: the device-side form of the sync ops behind it
     for (int i = 0; i < n_ops; ++i) {
         const i2r_op& op = ops[i];
         int rc = I2R_OK;
+        if (op.kind == I2R_OP_LANE_FLAGS) {
+            flags = streams ? (int*)op.args : nullptr;
+            continue;
+        }
         if (op.kind == I2R_OP_XSYNC) {  // all-to-all among the lanes of the mask: one event per lane, every other lane waits for it
             if (!streams) continue;  // single-stream replay: program order already is the order
             bool distinct = false;
@@ -63,8 +104,48 @@ static int run_program(const i2r_op* ops, int32_t n_ops, void* const* streams, v
             }
             continue;
         }
+        if (op.kind == I2R_OP_RECORD || op.kind == I2R_OP_WAIT) {  // point-to-point: lane = op.lane & 3, event 8 + slot
+            if (!streams) continue;
+            const int l = op.lane & 3, slot = (op.lane >> 8) & 7, consumers = (op.lane >> 16) & 15;
+            I2R_CHECK_ARG(events, "i2r_run_program: record / wait needs events");
+            hipEvent_t ev = (hipEvent_t)events[8 + slot];
+            if (op.kind == I2R_OP_RECORD) {
+                slot_stream[slot] = streams[l];
+                slot_set[slot] = true;
+                if (flags) lane_signal(flags, slot, consumers & ~(1 << l), streams[l]);
+                else if (hipEventRecord(ev, (hipStream_t)streams[l]) != hipSuccess) rc = I2R_E_LAUNCH;
+            } else {
+                I2R_CHECK_ARG(slot_set[slot], "i2r_run_program: op %d waits for slot %d before any record", i, slot);
+                if (flags) lane_wait(flags, slot, l, streams[l]);
+                else if (slot_stream[slot] != streams[l] && hipStreamWaitEvent((hipStream_t)streams[l], ev, 0) != hipSuccess) rc = I2R_E_LAUNCH;
+            }
+            if (flags && hipGetLastError() != hipSuccess) rc = I2R_E_LAUNCH;
+            if (rc != I2R_OK) {
+                i2r_set_error("i2r_run_program: record / wait failed at op %d", i);
+                return rc;
+            }
+            continue;
+        }
         if (op.kind == I2R_OP_FORK || op.kind == I2R_OP_JOIN) {
             I2R_CHECK_ARG(streams && events, "i2r_run_program: fork/join needs streams and events");
+            if (flags) {  // (device-side form, see lane_signal_k)
+                if (op.kind == I2R_OP_FORK) {
+                    lane_signal(flags, 8, op.lane & 14, streams[0]);
+                    for (int l = 1; l < 4; ++l)
+                        if (op.lane & (1 << l)) lane_wait(flags, 8, l, streams[l]);
+                } else {
+                    for (int l = 1; l < 4; ++l)
+                        if (op.lane & (1 << l)) {
+                            lane_signal(flags, 8 + l, 1, streams[l]);
+                            lane_wait(flags, 8 + l, 0, streams[0]);
+                        }
+                }
+                if (hipGetLastError() != hipSuccess) {
+                    i2r_set_error("i2r_run_program: device-side fork/join failed at op %d", i);
+                    return I2R_E_LAUNCH;
+                }
+                continue;
+            }
             if (op.kind == I2R_OP_FORK) {  // lanes in the mask wait for everything issued on lane 0 so far
                 hipEvent_t ev = (hipEvent_t)events[next_event++ & 7];
                 if (hipEventRecord(ev, (hipStream_t)streams[0]) != hipSuccess) rc = I2R_E_LAUNCH;

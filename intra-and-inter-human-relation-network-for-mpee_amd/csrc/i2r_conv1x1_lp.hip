@@ -1,6 +1,6 @@
 // 1x1 convolution over a SMALL number of NHWC pixel rows with 16-bit MFMA operands, straight from global memory (gfx950).
 //
-//   out = act(W x + b [+ res1]) [+ res_post]          x: [n_pix, x_cs] fp32 or 16 bit, out / res: [n_pix, out_cs] fp32 or 16 bit
+//   out = act(W x + b [+ res1] [+ res2]) [+ res_post]          x: [n_pix, x_cs] fp32 or 16 bit, out / res: [n_pix, out_cs] fp32 or 16 bit
 //
 // The low-resolution branches of HRFormer-B (C = 312 @ 16x12, C = 624 @ 8x6: 3072 / 768 pixels at 16 crops) run their transformer blocks
 // as single launches of LayerNorm, q|k|v projection, window attention, out projection, fc1, depth-wise conv and fc2 on the critical
@@ -32,7 +32,7 @@ __device__ __forceinline__ f32x4 pack8_lp(f32x4 lo, f32x4 hi) {  // 8 fp32 -> 8 
 }
 
 struct Lp1K {
-    const void* x; const void* w; const float* bias; const void* res1; const void* res_post; void* out;
+    const void* x; const void* w; const float* bias; const void* res1; const void* res2; const void* res_post; void* out;
     int n_pix, n_tiles, kc, k_tail, x_cs, out_cs, n_groups, act, out16;  // kc: 32-channel steps (the last one half-filled when k_tail)
 };
 
@@ -108,7 +108,7 @@ __global__ __launch_bounds__(256) void conv1x1_lp_k(const Lp1K p) {
     const bool o16 = p.out16 != 0;
     const unsigned oe = o16 ? 2u : 4u;
     const unsigned out_bytes = (unsigned)p.n_pix * p.out_cs * oe;
-    const __amdgpu_buffer_rsrc_t rs_out = make_rsrc(p.out, out_bytes), rs_r1 = make_rsrc(p.res1, out_bytes), rs_rp = make_rsrc(p.res_post, out_bytes);
+    const __amdgpu_buffer_rsrc_t rs_out = make_rsrc(p.out, out_bytes), rs_r1 = make_rsrc(p.res1, out_bytes), rs_r2 = make_rsrc(p.res2, out_bytes), rs_rp = make_rsrc(p.res_post, out_bytes);
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt) {
         const int q = (tile0 + mt) * 16 + li;
@@ -122,6 +122,7 @@ __global__ __launch_bounds__(256) void conv1x1_lp_k(const Lp1K p) {
             for (int w = 0; w < 4; ++w) v += (w == wave) ? acc[mt][nf] : part[idx][w == wave ? 0 : (w - wave + 3) & 3][slot];  // fixed order 0 .. 3: bit-identical replays
             const int soff = 16 * (f0 + nf) * (int)oe;
             if (p.res1) v += buf_ld_act4<DT>(rs_r1, orow + soff, o16);
+            if (p.res2) v += buf_ld_act4<DT>(rs_r2, orow + soff, o16);  // ((conv + res1) + res2: the order of the implicit-GEMM epilogue)
             if (p.act == 1) {
                 v[0] = fmaxf(v[0], 0.f); v[1] = fmaxf(v[1], 0.f); v[2] = fmaxf(v[2], 0.f); v[3] = fmaxf(v[3], 0.f);
             } else if (p.act == 2) {  // exact-erf GELU, as the implicit-GEMM kernel's epilogue (hrformer.py:1197)
@@ -166,7 +167,7 @@ extern "C" int i2r_conv1x1_lp(const i2r_conv1x1_lp_args* a, void* stream) {
     const int nf = n_frag % 5 == 0 ? 5 : n_frag % 6 == 0 ? 6 : n_frag % 4 == 0 ? 4 : n_frag % 3 == 0 ? 3 : 0;
     I2R_CHECK_ARG(nf != 0, "i2r_conv1x1_lp: cout_pad / 16 = %d is no multiple of 3, 4, 5 or 6 (use i2r_conv)", n_frag);
     Lp1K k;
-    k.x = a->x; k.w = a->w; k.bias = a->bias; k.res1 = a->res1; k.res_post = a->res_post; k.out = a->out;
+    k.x = a->x; k.w = a->w; k.bias = a->bias; k.res1 = a->res1; k.res2 = a->res2; k.res_post = a->res_post; k.out = a->out;
     k.n_pix = a->n_pix; k.n_tiles = (a->n_pix + 15) / 16; k.kc = (a->cin_pad + 31) / 32; k.k_tail = (a->cin_pad & 16) != 0; k.x_cs = a->x_cs; k.out_cs = a->out_cs;
     k.n_groups = n_frag / nf; k.act = a->act; k.out16 = a->out_16;
     // two pixel tiles per workgroup (each weight fragment feeds two MFMAs) when that still leaves a workgroup per CU

@@ -271,8 +271,14 @@ __global__ __launch_bounds__(64 * W, (W + 3) / 4) void hrt_mlp_wide_k(const I2rM
 template <int DT>
 bool launch(const I2rMlpK& k, int cs, long long nblk, hipStream_t stream) {
     const dim3 grid((unsigned)((nblk + 7) / 8 * 8));
-    if (cs == 320) i2r_launch((hrt_mlp_wide_k<DT, 20, 10>), grid, dim3(640), 0, stream, k);
-    else if (cs == 160) i2r_launch((hrt_mlp_wide_k<DT, 10, 10>), grid, dim3(640), 0, stream, k);
+#ifndef I2R_MLPW_W312
+#define I2R_MLPW_W312 10
+#endif
+#ifndef I2R_MLPW_W156
+#define I2R_MLPW_W156 10
+#endif
+    if (cs == 320) i2r_launch((hrt_mlp_wide_k<DT, 20, I2R_MLPW_W312>), grid, dim3(64 * I2R_MLPW_W312), 0, stream, k);
+    else if (cs == 160) i2r_launch((hrt_mlp_wide_k<DT, 10, I2R_MLPW_W156>), grid, dim3(64 * I2R_MLPW_W156), 0, stream, k);
     else if (cs == 80) i2r_launch((hrt_mlp_wide_k<DT, 5, 5>), grid, dim3(320), 0, stream, k);
     else return false;
     return true;

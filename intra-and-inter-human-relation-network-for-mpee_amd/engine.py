@@ -136,6 +136,8 @@ _PAIR_MT = int(_tune("I2R_PAIR_MT", "0"))  # 16-pixel tiles per wave of that ker
 WINOGRAD = _tune("I2R_WINOGRAD", "1") != "0"  # fp32 3x3 stride-1 convs on the Winograd F(2x2, 3x3) kernels
 _S2_MT = int(_tune("I2R_S2_MT", "1"))  # pixel fragments per wave of the stride-2 convs of the direct kernels (A/B: 0 = cost model's choice)
 _FUSE_PRE = int(_tune("I2R_FUSE_PRE", "1"))  # A/B: 0 = the fuse layers' down paths run entirely on the output's lane, after the xsync
+DEVICE_SYNC = _tune("I2R_DEVICE_SYNC", "1") != "0"  # fork / join / record / wait as device-side signal / wait kernels (csrc/i2r_api.hip) when the lanes are independent queues
+_FUSE_P2P = int(_tune("I2R_FUSE_P2P", "1"))  # A/B: 0 = one all-to-all xsync between a module's blocks and its fuse layers (rounds 3-5)
 _LANE_CAP = int(_tune("I2R_LANE_CAP", "4"))  # HRFormer-B: branches i >= cap - 1 share stream lane cap - 1 (A/B: fewer, longer lanes)
 
 
@@ -747,12 +749,12 @@ class Program:
         consumer is an fp32 kernel: encoder, max-pool, head, ...)"""
         assert x.cs >= pc.cin_pad and x.c == pc.cin, "conv input channels %d/%d vs weight %d" % (x.c, x.cs, pc.cin)
         assert x.dt in (0, pc.dtype), "16-bit stored input needs the matching 16-bit conv (input %d, conv %d)" % (x.dt, pc.dtype)
-        if (LP1X1 and pc.w_lp1 is not None and group is None and in2 is None and res2 is None and up == 1 and out_step == 1 and tuple(out_off) == (0, 0)
+        if (LP1X1 and pc.w_lp1 is not None and group is None and in2 is None and up == 1 and out_step == 1 and tuple(out_off) == (0, 0)
                 and out_hw is None and x.n * x.h * x.w <= LP1X1_MAX_PIX and (out is None or (out.n, out.h, out.w) == (x.n, x.h, x.w))
                 # (the kernel's own limits, i2r_conv1x1_lp: whole output rows of cout_pad channels, residual rows laid out like the output)
-                and (out is None or out.cs >= pc.cout_pad) and all(r is None or out is None or r.cs == out.cs for r in (res1, res_post))
-                and all(r is None or r.cs >= pc.cout_pad for r in (res1, res_post))):
-            return self.conv1x1_lp(x, pc, relu=relu, res1=res1, res_post=res_post, out=out, lane=lane, act=act, out_dt=out_dt)
+                and (out is None or out.cs >= pc.cout_pad) and all(r is None or out is None or r.cs == out.cs for r in (res1, res2, res_post))
+                and all(r is None or r.cs >= pc.cout_pad for r in (res1, res2, res_post))):
+            return self.conv1x1_lp(x, pc, relu=relu, res1=res1, res2=res2, res_post=res_post, out=out, lane=lane, act=act, out_dt=out_dt)
         k = pc.ksize
         if pc.stride == 1:
             conv_h, conv_w = x.h, x.w  # 'same' geometry for 1x1 / 3x3 pad 1 / deconv parity 2x2
@@ -1132,17 +1134,18 @@ class Program:
             if r is not None and (r.n, r.h, r.w, r.cs) != (out.n, out.h, out.w, out.cs):
                 raise ValueError("conv residual is [%d, %d, %d, row %d], the output [%d, %d, %d, row %d]" % (r.n, r.h, r.w, r.cs, out.n, out.h, out.w, out.cs))
 
-    def conv1x1_lp(self, x, pc, relu=False, res1=None, res_post=None, out=None, lane=0, act=None, out_dt=None):
+    def conv1x1_lp(self, x, pc, relu=False, res1=None, res_post=None, out=None, lane=0, act=None, out_dt=None, res2=None):
         """single 1x1 conv over few pixels in the 16-bit modes (i2r_conv1x1_lp: operands straight from global memory, K split over the
         workgroup's waves); same semantics as conv(): out = act(W x + b + res1) + res_post"""
         if out is None:
             out = self.alloc(x.n, x.h, x.w, pc.cout, x.dt if out_dt is None else out_dt)
-        assert out.cs >= pc.cout_pad and out.dt in (0, pc.dtype) and all(r is None or (r.dt == out.dt and r.cs == out.cs) for r in (res1, res_post))
-        self._check_like(out, res1, res_post)
+        assert out.cs >= pc.cout_pad and out.dt in (0, pc.dtype) and all(r is None or (r.dt == out.dt and r.cs == out.cs) for r in (res1, res2, res_post))
+        self._check_like(out, res1, res2, res_post)
         self.keep.append(pc)
         a = cabi.Conv1x1LpArgs(x.ptr, pc.w_lp1.data_ptr(), pc.bias.data_ptr(), res1.ptr if res1 is not None else None,
                                res_post.ptr if res_post is not None else None, out.ptr, x.n * x.h * x.w, pc.cin_pad, pc.cout_pad, x.cs, out.cs,
-                               (int(relu) if act is None else act), pc.dtype, int(x.dt != 0), int(out.dt != 0), _LP1X1_MT)
+                               (int(relu) if act is None else act), pc.dtype, int(x.dt != 0), int(out.dt != 0), _LP1X1_MT,
+                               res2.ptr if res2 is not None else None)
         self.ops.append((cabi.OP_CONV1X1_LP, lane, a))
         return out
 
@@ -1323,6 +1326,8 @@ class Program:
 
     def fork(self, mask):
         """lanes in `mask` (bits 1..3) start after everything issued so far on lane 0"""
+        if not any(k == cabi.OP_LANE_FLAGS for k, _, _ in self.ops):
+            self.ops.append((cabi.OP_LANE_FLAGS, 0, None))  # (run() points it at the flag buffer when the device-side sync form may be used)
         self.ops.append((cabi.OP_FORK, mask, None))
         self.in_fork = True
 
@@ -1341,8 +1346,39 @@ class Program:
         self.ops.append((cabi.OP_XSYNC, mask, None))
         self._flush_lane_pools()
 
+    # Point-to-point synchronisation inside a fork region (round 6).  `records(lanes)`: every lane puts an event behind what it has issued so
+    # far; `wait(lane, slot)`: that lane's stream waits for one of them -- emitted right before the first launch that reads the other
+    # lane's data, so a lane starts the terms of the lanes that are done while the last one is still busy (an all-to-all xsync costs
+    # every lane ~20 us after the LAST lane ends, tools/probe/xstream_latency2.hip).  Buffers: what the lanes had released when they
+    # recorded becomes reusable by every lane at `all_waited()` -- the point of the launch list behind which every lane has waited for
+    # every record; what is released after the records waits for the next round.  tests/test_lanes.py replays the happens-before relation.
+    def records(self, lanes):
+        assert self.in_fork and not getattr(self, "_snap", None)
+        slots, region = {}, 0
+        for l in lanes:
+            region |= 1 << l
+        for l in lanes:  # (every lane of the region waits for every record of the round -- _emit_module makes sure -- so every flag is consumed)
+            slot = self._next_slot = (getattr(self, "_next_slot", -1) + 1) % 8
+            self.ops.append((cabi.OP_RECORD, l | slot << 8 | region << 16, None))
+            slots[l] = slot
+        self._snap = (self.pending, self.lane_pool)
+        self.pending, self.lane_pool = [], {}
+        return slots
+
+    def wait(self, lane, slot):
+        self.ops.append((cabi.OP_WAIT, lane | slot << 8, None))
+
+    def all_waited(self):
+        pend, lp = self._snap
+        self._snap = None
+        for t in pend:
+            self.pool.setdefault(t.numel(), []).append(t)
+        for (_, numel), lst in lp.items():
+            self.pool.setdefault(numel, []).extend(lst)
+
     def join(self, mask):
         """lane 0 continues after the lanes in `mask`; buffers freed inside the region become reusable"""
+        assert not getattr(self, "_snap", None)
         self.ops.append((cabi.OP_JOIN, mask, None))
         self.in_fork = False
         self._flush_lane_pools()
@@ -1355,6 +1391,7 @@ class Program:
             arr[i].kind, arr[i].lane = kind, lane
             arr[i].args = C.cast(C.pointer(st), C.c_void_p) if st is not None else None
         self._c_ops = arr
+        self._flags_op = next((i for i, (kind, _, _) in enumerate(self.ops) if kind == cabi.OP_LANE_FLAGS), None)
         self.uses_lanes = any(lane != 0 or kind in cabi.SYNC_OPS for kind, lane, _ in self.ops)
 
     def run(self, side_streams=None, events=None):
@@ -1367,10 +1404,16 @@ class Program:
         else:
             streams = (C.c_void_p * 4)(cur, *[s.cuda_stream for s in side_streams])
         evs = None
+        if self._flags_op is not None:
+            # device-side fork / join / record / wait only when every lane stream was PROBED to run beside the caller's stream and beside
+            # every other lane (its own hardware queue): a spinning wait kernel must never sit in front of the kernel that signals it
+            spin = side_streams is not None and DEVICE_SYNC and lanes_independent(self.device, side_streams, cur)
+            self._c_ops[self._flags_op].args = self._lane_flags().data_ptr() if spin else None
+            self.device_sync = spin
         if self.uses_lanes:
             if events is None:
                 events = self._own_events()
-            evs = (C.c_void_p * 8)(*[e.cuda_event for e in events])
+            evs = (C.c_void_p * len(events))(*[e.cuda_event for e in events])
         try:
             if Program.timing_log is not None:  # bench.py's in-situ pass: every launch of this run bracketed by two timing events
                 self._run_timed(L, streams, evs)
@@ -1417,9 +1460,18 @@ class Program:
         cabi.check(L.i2r_run_program_timed(self._c_ops, n, streams, evs, a0, a1), "i2r_run_program_timed")
         Program.timing_log.append((self, t0, t1, key))
 
+    def _lane_flags(self):
+        if not hasattr(self, "_flags"):
+            self._flags = torch.zeros(64, dtype=torch.int32, device=self.device)
+        return self._flags
+
+    def sync_timed_out(self):
+        """True if a device-side wait of this program ever gave up (50 ms): its results are then not ordered and must not be used"""
+        return hasattr(self, "_flags") and bool(self._flags[63].item())
+
     def _own_events(self):
         if not hasattr(self, "_events"):
-            self._events = [torch.cuda.Event(enable_timing=False) for _ in range(8)]
+            self._events = [torch.cuda.Event(enable_timing=False) for _ in range(16)]  # 0..7: fork / join / xsync (rotating), 8..15: record slots
             for e in self._events:
                 e.record()  # forces creation of the underlying hipEvent_t
         return self._events
@@ -1685,7 +1737,7 @@ class HRFormerB:
         # all-to-all xsync: the high-resolution lanes finish their blocks early (fused kernels) while the low-resolution lanes, with
         # eight small launches per block, are the longest of every region (tools/op_list.py) -- and would otherwise also run the
         # down paths' dw convs over the big maps.
-        pre = {}
+        pre, pre_y = {}, {}
         if lanes and _FUSE_PRE:
             for i in range(mod["n_out"]):
                 for j in range(min(i, nb)):
@@ -1701,8 +1753,32 @@ class HRFormerB:
                             cur = P.conv(d, pc, relu=True, lane=lj)
                             P.release(d)
                     pre[(i, j)] = d
-        if lanes:
+                    if _FUSE_P2P and j == 0 and i >= 2 and i < nb:
+                        # the FIRST term of output i >= 2 adds nothing (y = fuse[i][0](x_0), hrformer.py:1718): its last 1x1 conv runs here
+                        # too, on the source lane -- the low-resolution lane i, the last to finish its blocks, then has one launch less
+                        # between its blocks and the next module's
+                        y0 = P.alloc(xs[i].n, xs[i].h, xs[i].w, xs[i].c)
+                        P.conv(d, hops[-1][1], relu=False, out=y0, lane=lj)
+                        P.release(d)
+                        pre_y[i] = y0
+        # Round 6: point-to-point waits instead of one all-to-all xsync.  Every lane records behind its blocks (and the down-path
+        # prologues); a fuse lane waits for lane j right before its first launch that reads lane j's data.  The low-resolution lane is
+        # the last to finish its blocks, and the terms that do not read it -- the 1x1 convs over the other branches, the last convs of the
+        # down paths -- now run under it instead of ~20 us after it (I2R_FUSE_P2P=0: the all-to-all form).
+        p2p = lanes and _FUSE_P2P
+        slots, waited = {}, {}
+        if p2p:
+            region = sorted({min(i, _LANE_CAP - 1) for i in range(nb)})
+            slots = P.records(region)
+            waited = {l: {l} for l in region}
+        elif lanes:
             P.xsync((1 << nb) - 1)
+
+        def need(ln, j):  # lane ln is about to read what branch j's lane wrote before the records
+            lj = min(j, _LANE_CAP - 1)
+            if p2p and lj not in waited[ln]:
+                P.wait(ln, slots[lj])
+                waited[ln].add(lj)
         outs = []
         for i in range(mod["n_out"]):
             ln = min(i, _LANE_CAP - 1) if lanes else 0
@@ -1715,11 +1791,18 @@ class HRFormerB:
                     acc = xs[i]
                     j += 1
                     continue
+                if j == 0 and i in pre_y:  # (the whole first term ran on lane 0 ahead of the records)
+                    need(ln, 0)
+                    acc, y, j = pre_y[i], pre_y[i], 1
+                    continue
                 if y is None:
                     y = P.alloc(xs[i].n, xs[i].h, xs[i].w, xs[i].c)
                 if j > i:  # 1x1 conv + BN at low resolution of EVERY lower branch (they are the trailing terms of the sum), then
                     # ONE pass that up-samples and adds them in order, + ReLU (bit-identical to a pass per term)
-                    ts = [P.conv(xs[jj], mod["fuse"][(i, jj)], lane=ln) for jj in range(j, nb)]
+                    ts = []
+                    for jj in range(j, nb):
+                        need(ln, jj)
+                        ts.append(P.conv(xs[jj], mod["fuse"][(i, jj)], lane=ln))
                     for k0 in range(0, len(ts), 3):
                         P.upsample_add(ts[k0:k0 + 3], acc if k0 == 0 else y, y, act=1 if k0 + 3 >= len(ts) else 0, lane=ln)
                     P.release(*ts)
@@ -1727,6 +1810,7 @@ class HRFormerB:
                 else:
                     cur = xs[j]
                     hops = mod["fuse"][(i, j)]
+                    need(ln, j)
                     for k, (dw, pc) in enumerate(hops):
                         if (i, j) in pre:  # (everything up to the last dw conv ran on lane j before the xsync)
                             if k < len(hops) - 1:
@@ -1749,7 +1833,13 @@ class HRFormerB:
                             P.release(d)
                 acc, j = y, jn
             outs.append(y)
-        P.release_deferred(*xs)  # (read by every fuse lane: reusable after the next xsync / the stage's join)
+        if p2p:  # every lane behind every record before anything released ahead of the records changes hands
+            for ln in waited:
+                for lj in waited:
+                    if lj not in waited[ln]:
+                        P.wait(ln, slots[lj])
+            P.all_waited()
+        P.release_deferred(*xs)  # (read by every fuse lane: reusable after the next xsync / round of waits / the stage's join)
         return outs
 
     def emit(self, P, n, h, w, n_src=None):
@@ -1877,6 +1967,7 @@ def lane_streams(device, n):
         log = _LANE_PROBE.setdefault(key, [])
         with torch.cuda.device(device):
             cur = torch.cuda.current_stream(device)
+            _LANE_CALLER.setdefault(key, cur.cuda_stream)
             spare = _LANE_SPARE.setdefault(key, [])
             for _ in range(int(_tune("I2R_STREAM_SKIP", "0"))):  # (A/B: shift the creation order)
                 spare.append(torch.cuda.Stream(device=device))
@@ -1903,6 +1994,21 @@ def lane_streams(device, n):
                 lst.append(st)
             torch.cuda.synchronize(device)
     return lst[:n]
+
+
+_LANE_CALLER = {}   # device -> handle of the caller's stream the lanes were probed against
+
+
+def lanes_independent(device, streams, caller=None):
+    """True if every one of `streams` is a PROBED lane of the device that ran beside the caller's stream and beside every lane chosen
+    before it (lane_streams recorded `overlap: true` for all its pairs) -- i.e. each has a hardware queue of its own.  Streams that were
+    taken without a probe (I2R_LANE_PROBE=0, no spin kernel) or that had to share a queue do not qualify."""
+    key = str(device)
+    ok = {int(r["stream"], 16) for r in _LANE_PROBE.get(key, []) if str(r.get("role", "")).startswith("lane") and "shares" not in r["role"]
+          and any(k.startswith("vs_") for k in r) and all(v["overlap"] for k, v in r.items() if k.startswith("vs_"))}
+    if caller is not None and _LANE_CALLER.get(key) != caller:  # (probed against another caller stream: nothing is known about this one)
+        return False
+    return all(s.cuda_stream in ok for s in streams)
 
 
 def lane_report(device):

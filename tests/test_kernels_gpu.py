@@ -272,6 +272,8 @@ def test_conv1x1_pair_through_the_c_abi(k_a, cb, res, relu_a, relu_b, n_pix, mt)
     ("fp16", 1248, 312, 2, 16, 12, 2, 0, 2, 0, 1),   # fc2 + GELU + post-activation residual, K = 78 steps
     ("bf16", 624, 78, 5, 8, 6, 1, 1, 1, 1, 0),       # fuse 1x1 from the lowest branch, ReLU, 240 pixels (tile tail), cout 78 -> 5 fragments
     ("bf16", 160, 156, 2, 5, 7, 1, 1, 0, 0, 0),      # 70 pixels: partial last tile; cin 156 padded to 160 (10 steps over 4 waves)
+    ("bf16", 156, 312, 3, 16, 12, 0, 0, 1, 2, 0),    # last 1x1 of a down path closing a fuse sum: (conv + running sum) + the branch's own map, ReLU (res1 + res2, ABI 14)
+    ("fp16", 312, 624, 2, 8, 6, 0, 0, 1, 2, 0),
 ])
 def test_conv1x1_lp_matches_torch_and_the_igemm_path(precision, cin, cout, n, h, w, in_dt, out_dt, act, nres1, npost):
     """Program.conv routes single 1x1 convs over few pixels of the 16-bit modes to i2r_conv1x1_lp: against torch (float64 on the
@@ -286,8 +288,11 @@ def test_conv1x1_lp_matches_torch_and_the_igemm_path(precision, cin, cout, n, h,
     r1 = _rand(tuple(ref.shape), "r1" + tag) if nres1 else None
     rp = _rand(tuple(ref.shape), "rp" + tag) if npost else None
     rq = (lambda t: q(t)) if out_dt else (lambda t: t.double())
+    r2 = _rand(tuple(ref.shape), "r2" + tag) if nres1 > 1 else None
     if r1 is not None:
         ref = ref + rq(r1)
+    if r2 is not None:
+        ref = ref + rq(r2)
     if act == 1:
         ref = F.relu(ref)
     elif act == 2:
@@ -303,7 +308,7 @@ def test_conv1x1_lp_matches_torch_and_the_igemm_path(precision, cin, cout, n, h,
             pc = engine.Packer(sd, torch.device(DEV), precision).conv("c")
             assert pc.w_lp1 is not None
             xa = to_act(P, x, in_dt)
-            out = P.conv(xa, pc, act=act, res1=to_act(P, r1, out_dt) if r1 is not None else None,
+            out = P.conv(xa, pc, act=act, res1=to_act(P, r1, out_dt) if r1 is not None else None, res2=to_act(P, r2, out_dt) if r2 is not None else None,
                          res_post=to_act(P, rp, out_dt) if rp is not None else None, out_dt=out_dt)
             kinds = [k for k, _, _ in P.ops]
             run(P)

@@ -46,7 +46,7 @@ def _accesses(kind, st):
     if kind == cabi.OP_MAXPOOL:
         return [g("in_")], [g("out")]
     if kind == cabi.OP_CONV1X1_LP:
-        return [p for p in (g("x"), g("res1"), g("res_post")) if p], [g("out")]
+        return [p for p in (g("x"), g("res1"), g("res2"), g("res_post")) if p], [g("out")]
     if kind == cabi.OP_CONV1X1_PAIR:
         return [p for p in (g("x"), g("res")) if p], [p for p in (g("y"), g("z")) if p]
     raise AssertionError("op kind %d not modelled" % kind)
@@ -67,6 +67,7 @@ def check_program(program):
         return i if i >= 0 and ptr < rs[i][1] else None  # weights / tables are read-only: not arena buffers
 
     clock = [[0, 0, 0, 0] for _ in range(4)]   # vector clock of each lane
+    slot_clock = {}                            # record slot -> clock snapshot of the recording lane (I2R_OP_RECORD / I2R_OP_WAIT)
     last_w = {}   # buffer -> (lane, clock snapshot) of the last write
     reads = {}    # buffer -> list of (lane, snapshot) since the last write
     checked = 0
@@ -84,6 +85,14 @@ def check_program(program):
             for l in range(1, 4):
                 if lane & (1 << l):
                     clock[0] = [max(a, b) for a, b in zip(clock[0], clock[l])]
+            continue
+        if kind == cabi.OP_LANE_FLAGS:
+            continue
+        if kind == cabi.OP_RECORD:  # point-to-point: the slot remembers what the recording lane has seen and done
+            slot_clock[(lane >> 8) & 7] = list(clock[lane & 3])
+            continue
+        if kind == cabi.OP_WAIT:    # the waiting lane sees everything the slot's last record saw
+            clock[lane & 3] = [max(a, b) for a, b in zip(clock[lane & 3], slot_clock[(lane >> 8) & 7])]
             continue
         if kind == cabi.OP_XSYNC:  # all-to-all among the lanes of the mask
             ls = [l for l in range(4) if lane & (1 << l)]
@@ -130,13 +139,15 @@ def test_hrformer_lane_schedule_has_no_race(cname, precision, n, h, w):
     P.store_dt = pk.dtype
     ys, _ = tower.emit(P, n, h, w)
     kinds = [k for k, _, _ in P.ops]
-    assert kinds.count(cabi.OP_XSYNC) == 7 and kinds.count(cabi.OP_FORK) == 3 and kinds.count(cabi.OP_JOIN) == 3  # 7 modules, 3 stages
+    # 7 modules in 3 stages: one round of records per module (2 + 4 x 3 + 2 x 4 lanes), every lane waits for every other lane's record
+    assert kinds.count(cabi.OP_XSYNC) == 0 and kinds.count(cabi.OP_FORK) == 3 and kinds.count(cabi.OP_JOIN) == 3
+    assert kinds.count(cabi.OP_RECORD) == 2 + 4 * 3 + 2 * 4 and kinds.count(cabi.OP_WAIT) == 2 * 1 + 4 * 3 * 2 + 2 * 4 * 3
     assert {lane for k, lane, _ in P.ops if k not in cabi.SYNC_OPS} == {0, 1, 2, 3}
-    assert check_program(P) > 100
+    assert check_program(P) > 50
 
 
 def test_checker_catches_a_missing_sync():
-    """the same program with its xsyncs removed must be reported as racy (the checker is not vacuous)"""
+    """the same program with its point-to-point waits removed must be reported as racy (the checker is not vacuous)"""
     cfg = config.load_config("hrt_192_p4_b4")
     sd = synth.make_state_dict(arch.param_spec(cfg))
     dev = torch.device("cpu")
@@ -144,6 +155,6 @@ def test_checker_catches_a_missing_sync():
     P = engine.Program(dev)
     P.store_dt = pk.dtype
     engine.HRFormerB(pk, "singleformer.").emit(P, 2, 256, 192)
-    P.ops = [op for op in P.ops if op[0] != cabi.OP_XSYNC]
+    P.ops = [op for op in P.ops if op[0] != cabi.OP_WAIT]
     with pytest.raises(AssertionError, match="races"):
         check_program(P)

@@ -7,5 +7,5 @@ S=$R/intra-and-inter-human-relation-network-for-mpee_amd/csrc
 B=$S/build
 name=$1; stem=$2; shift 2
 mkdir -p /tmp/abv
-/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wno-unused-result -mllvm -amdgpu-mfma-vgpr-form -I $R/include -I $S "$@" -c $S/$stem.hip -o /tmp/abv/$name.o || exit 1
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -fvisibility=hidden -Wno-unused-result -mllvm -amdgpu-mfma-vgpr-form -I $R/include -I $S "$@" -c $S/$stem.hip -o /tmp/abv/$name.o || exit 1
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC $(ls $B/*.o | grep -v "/$stem.o") /tmp/abv/$name.o -o $R/tools/ab/lib_$name.so
