@@ -805,6 +805,8 @@ def quick_workload(cname, dev, steps=30, warmup=5):
            "kernel_time_sum_ms_per_step": r["kernel_time_sum_ms_per_step"],
            "kernel_time_overlap": round(r["kernel_time_sum_ms_per_step"] / (dt / steps * 1e3), 3),
            "per_kernel_avg_launch_us": r["per_kernel_avg_launch_us"], "forward_ms_with_timing_events": r["forward_ms_with_timing_events"]}
+    if any(getattr(P, "uses_lanes", False) for P in eng.last_programs):
+        out["device_side_lane_sync"] = any(getattr(P, "device_sync", False) for P in eng.last_programs)
     if "attention_blocks" in r:
         out["attention_blocks"] = {k: r["attention_blocks"][k] for k in ("kernels", "ms_per_step", "achieved", "peak", "frac", "standalone") if k in r["attention_blocks"]}
     out["parity"] = oracle_parity(cfg, sd, x, m, length, fwd(), precision)
@@ -873,33 +875,31 @@ def collective_overhead(dev, cname="hrt_192_p4_b4", rounds=5, steps=20):
         x, m, _ = synth.make_inputs(length, H_, W_, seed=0)
         x, m = x.to(dev), m.to(dev)
         counts = [sum(length)]
-        pending = [None]
-
         def plain():
             y = net(x, m, length)
             return y["multi"] if isinstance(y, dict) else y
 
+        posts = {"keypoints": i2r_dist.PostStep(dev, counts, decode=lambda t: caller.decode(t, None, None, cfg.TEST.BLUR_KERNEL, transform_back=False)),
+                 "heatmaps": i2r_dist.PostStep(dev, counts)}
+
         def make(payload):
             def step():
                 y = plain()
-                if payload == "keypoints":
-                    preds, maxv = caller.decode(y, None, None, cfg.TEST.BLUR_KERNEL, transform_back=False)
-                    h = i2r_dist.gather_keypoints(preds, maxv, counts, async_op=True)
-                else:
-                    h = i2r_dist.gather_heatmaps_async(y, counts)
-                if pending[0] is not None:
-                    pending[0].wait()
-                pending[0] = h
+                posts[payload](y)
                 return y
             return step
 
         def run(fn):
-            dt, _ = _time_steps(fn, steps, 3)
-            if pending[0] is not None:
-                pending[0].wait()
-                pending[0] = None
+            for _ in range(3):
+                fn()
             torch.cuda.synchronize()
-            return dt / steps * 1e3
+            t0 = time.perf_counter()
+            for _ in range(steps):
+                fn()
+            for ps in posts.values():  # (the last step's decode + gather belong to the timed region)
+                ps.result()
+            torch.cuda.synchronize()
+            return (time.perf_counter() - t0) / steps * 1e3
         kp, hm = make("keypoints"), make("heatmaps")
         for fn in (plain, kp, hm):
             run(fn)
@@ -910,7 +910,8 @@ def collective_overhead(dev, cname="hrt_192_p4_b4", rounds=5, steps=20):
             ms["heatmaps"].append(run(hm))
         med = {k: sorted(v)[len(v) // 2] for k, v in ms.items()}
         return {"workload": wl["label"], "what": "ms per step at N = 1, %d alternating rounds of %d steps in one process: plain forward | forward + device decode + "
-                                                 "async RCCL all-gather of the key points (one-rank group) | forward + all-gather of the heat maps" % (rounds, steps),
+                                                 "async RCCL all-gather of the key points (one-rank group) | forward + all-gather of the heat maps; decode and "
+                                                 "gather run on a side stream under the next forward (dist.PostStep)" % (rounds, steps),
                 "ms_per_step": {k: [round(t, 4) for t in v] for k, v in ms.items()}, "median_ms": {k: round(v, 4) for k, v in med.items()},
                 "overhead_keypoints": round(med["keypoints"] / med["plain"] - 1.0, 4), "overhead_heatmaps": round(med["heatmaps"] / med["plain"] - 1.0, 4)}
     finally:
@@ -1078,12 +1079,9 @@ def main(argv=None):
                     ys.append(yb["multi"] if isinstance(yb, dict) else yb)
                 # (strong scaling: a rank's forwards of one step are gathered together -- ranks run different numbers of forwards)
                 y = ys[0] if len(ys) == 1 else (torch.cat(ys, 0) if ys else torch.zeros(0, J, H_ // 4, W_ // 4, device=dev))
-                if coll:
-                    if gather == "keypoints":  # decode on the device, gather [S, J, 3] (168 B/crop) instead of 172 KB/crop
-                        preds, maxv = caller.decode(y, None, None, cfg.TEST.BLUR_KERNEL, transform_back=False)
-                        h = i2r_dist.gather_keypoints(preds, maxv, counts, async_op=True)
-                    else:
-                        h = i2r_dist.gather_heatmaps_async(y, counts)
+                if coll:  # decode (key points: [S, J, 3], 168 B/crop instead of 172 KB/crop) + all-gather on a side stream, under the next forward
+                    post[gather](y)
+                    return y
             if coll:
                 if pending[0] is not None:
                     pending[0].wait()
@@ -1091,10 +1089,17 @@ def main(argv=None):
             return y
         return step
 
+    post = {}
+    if coll and not stub:
+        post = {"keypoints": i2r_dist.PostStep(dev, counts, decode=lambda t: caller.decode(t, None, None, cfg.TEST.BLUR_KERNEL, transform_back=False)),
+                "heatmaps": i2r_dist.PostStep(dev, counts)}
+
     def drain():
         if pending[0] is not None:
             pending[0].wait()
             pending[0] = None
+        for ps in post.values():
+            ps.result()
 
     def sync():
         if not stub:
@@ -1148,7 +1153,7 @@ def main(argv=None):
                                   "run in batches of <= 16 images" % sum(STRONG_LENGTH) if strong else ""),
                    "images_per_gpu": len(length), "persons_per_image": length if len(set(length)) > 1 else (length[0] if length else 0),
                    "crops_per_gpu_step": sum(length),
-                   "parallelism": "dp%d (images sharded, one RCCL all-gather of the %s per step, waited for one step later)" % (world, payload)
+                   "parallelism": "dp%d (images sharded, one RCCL all-gather of the %s per step, issued on a side stream under the next forward)" % (world, payload)
                                   if coll else "single GPU",
                    "gflop_per_step_per_gpu": round(gflop_per_step / world, 2),
                    "programs_per_forward": (len(net.engine().last_programs) if (net is not None and getattr(net.engine(), "last_programs", None)) else 1)},

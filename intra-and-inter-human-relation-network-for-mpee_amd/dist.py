@@ -99,3 +99,51 @@ def gather_keypoints(preds, maxvals, counts, group=None, async_op=False):
     if async_op:
         return gather_heatmaps_async(kp, counts, group)
     return gather_heatmaps(kp, counts, group)
+
+
+class PostStep:
+    """What follows the forward inside a data-parallel step -- device decode + the all-gather -- issued on a side stream so that it runs
+    under the NEXT forward instead of between two forwards: the caller's stream only records one event; the side stream waits for it,
+    decodes (`decode(y) -> (preds, maxvals)`, or None for the heat-map payload), starts the asynchronous all-gather and, one step later,
+    waits for it.  `result()` joins the caller's stream with the last gather and returns its tensor (the host-visible end of a run).
+    The forward's output stays alive for the side stream through record_stream."""
+
+    _streams = {}  # device -> the side stream, shared by every PostStep of the process
+
+    def __init__(self, device, counts, decode=None, group=None):
+        import torch as _t
+        key = str(device)
+        if key not in PostStep._streams:
+            # default priority: a HIGH-priority side stream was measured (config 4, one-rank RCCL group, fresh processes) at 0.55 of the plain
+            # line -- an active stream of another priority class wrecks the overlap of the engine's lanes (as stream priorities for the
+            # lanes themselves did in round 3); and so did GPU_MAX_HW_QUEUES=8 (0.66)
+            PostStep._streams[key] = _t.cuda.Stream(device=device)
+        self.stream = PostStep._streams[key]
+        self.counts, self.decode, self.group = list(counts), decode, group
+        self.pending = None
+        self.ready = _t.cuda.Event()
+
+    def __call__(self, y):
+        cur = torch.cuda.current_stream(y.device)
+        self.ready.record(cur)
+        y.record_stream(self.stream)
+        with torch.cuda.stream(self.stream):
+            self.stream.wait_event(self.ready)
+            if self.decode is not None:
+                preds, maxv = self.decode(y)
+                h = gather_keypoints(preds, maxv, self.counts, self.group, async_op=True)
+            else:
+                h = gather_heatmaps_async(y, self.counts, self.group)
+            if self.pending is not None:
+                self.pending.wait()     # (the gather of the step before: the SIDE stream waits, not the forward's)
+            self.pending = h
+        return h
+
+    def result(self):
+        if self.pending is None:
+            return None
+        with torch.cuda.stream(self.stream):
+            out = self.pending.wait()
+        torch.cuda.current_stream(out.device).wait_stream(self.stream)
+        self.pending = None
+        return out

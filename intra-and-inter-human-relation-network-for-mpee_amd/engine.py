@@ -2014,7 +2014,11 @@ def lanes_independent(device, streams, caller=None):
 def lane_report(device):
     """what lane_streams found on this device, for the bench line"""
     key = str(torch.device(device)) if not isinstance(device, str) else device
-    return {"lanes": [hex(s.cuda_stream) for s in _LANE_STREAMS.get(key, [])], "candidates": list(_LANE_PROBE.get(key, []))}
+    lst = _LANE_STREAMS.get(key, [])
+    return {"lanes": [hex(s.cuda_stream) for s in lst], "candidates": list(_LANE_PROBE.get(key, [])),
+            # fork / join / record / wait of the multi-lane programs as device-side signal / wait kernels (csrc/i2r_api.hip): only with
+            # independent hardware queues under every lane, and only for forwards issued from the stream the lanes were probed against
+            "device_side_sync": bool(DEVICE_SYNC and len(lst) >= 3 and lanes_independent(key, lst[:3]))}
 
 
 class Engine:

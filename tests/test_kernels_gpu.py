@@ -1363,3 +1363,56 @@ def test_run_program_timed_same_results_and_positive_durations():
         for i, (kind, lane, st) in enumerate(Pm.ops):
             if kind not in cabi.SYNC_OPS:
                 assert t0[i].elapsed_time(t1[i]) > 0.0
+
+
+@pytest.mark.parametrize("device_sync", [False, True])
+def test_record_wait_ops_order_two_lanes(device_sync):
+    """I2R_OP_RECORD / I2R_OP_WAIT (+ FORK / JOIN) through i2r_run_program, in the event form and in the device-side form behind an
+    I2R_OP_LANE_FLAGS op (one-wave signal / wait kernels): lane 1 computes a conv, lane 0 waits for lane 1's record and consumes it, lane 1
+    waits for lane 0's; 20 replays give the single-stream result bit for bit and no device-side wait times out."""
+    from i2r_amd import cabi
+    dev = torch.device(DEV)
+    sd = {"a.weight": _rand((96, 48, 3, 3), "rwa", (6.0 / (48 * 9)) ** 0.5), "b.weight": _rand((48, 96, 1, 1), "rwb", (6.0 / 96) ** 0.5)}
+    x = _rand((4, 48, 32, 24), "rwx")
+
+    def build(lanes):
+        P = engine.Program(dev)
+        pk = engine.Packer(sd, dev)
+        xa = to_act(P, x)
+        if lanes:
+            P.fork(2)
+            P.lane_ctx = 1
+        y = P.conv(xa, pk.conv("a", None), relu=True, lane=1 if lanes else 0)
+        if lanes:
+            slots = P.records([0, 1])
+            P.wait(0, slots[1])
+            P.lane_ctx = 0
+        z = P.conv(y, pk.conv("b", None), relu=False, lane=0)
+        if lanes:
+            P.wait(1, slots[0])
+            P.all_waited()
+            P.join(2)
+        P.finalize()
+        return P, z
+
+    P0, z0 = build(False)
+    P0.run()
+    torch.cuda.synchronize()
+    ref = from_act(z0).clone()
+    side = engine.lane_streams(dev, 3)
+    saved = engine.DEVICE_SYNC
+    engine.DEVICE_SYNC = device_sync
+    try:
+        P1, z1 = build(True)
+        kinds = [k for k, _, _ in P1.ops]
+        assert kinds.count(cabi.OP_RECORD) == 2 and kinds.count(cabi.OP_WAIT) == 2 and kinds.count(cabi.OP_LANE_FLAGS) == 1
+        for _ in range(20):
+            z1.t.zero_()
+            P1.run(side)
+            torch.cuda.synchronize()
+            assert torch.equal(from_act(z1), ref)
+        # the device-side form is used exactly when it was asked for and the lanes were probed to be independent hardware queues
+        assert P1.device_sync == (device_sync and engine.lanes_independent(dev, side, torch.cuda.current_stream(dev).cuda_stream))
+        assert not P1.sync_timed_out()
+    finally:
+        engine.DEVICE_SYNC = saved

@@ -706,3 +706,32 @@ def test_tools_test_py_flow_dataparallel_and_checkpoint(tmp_path):
     assert np.abs(output.cpu().numpy() - g["out_multi"]).max() < TOL
     out2 = (output + output) * 0.5                                                            # consumers do arithmetic on it (:162)
     assert torch.equal(out2, output)
+
+
+def test_hrformer_device_side_lane_sync_equals_event_sync():
+    """The four-lane HRFormer-B forward with its fork / join / record / wait ops as device-side signal / wait kernels (the default when the
+    lane streams were probed to be independent hardware queues) against the same forward with HIP events: bit-identical heat maps over
+    repeated forwards, the golden still holds, no wait timed out."""
+    from i2r_amd import engine
+    cfg, sd, x, m, length, g = setup("hrt_l21")
+    outs = {}
+    for dsync in (True, False):
+        saved = engine.DEVICE_SYNC
+        engine.DEVICE_SYNC = dsync
+        try:
+            net = eval("models." + cfg.MODEL.NAME + ".get_pose_net")(cfg, is_train=False)
+            net.load_state_dict(sd, strict=True)
+            net = net.cuda().set_precision("bf16")
+            ys = [net(x.cuda(), m.cuda(), length)["multi"].clone() for _ in range(6)]
+            torch.cuda.synchronize()
+            progs = [P for P, _ in net.engine().programs.values()]
+        finally:
+            engine.DEVICE_SYNC = saved
+        assert all(torch.equal(ys[0], y) for y in ys[1:])
+        assert any(getattr(P, "device_sync", False) for P in progs) == (dsync and engine.lanes_independent(
+            net.engine().device, net.engine().side_streams, torch.cuda.current_stream().cuda_stream))
+        assert not any(P.sync_timed_out() for P in progs)
+        outs[dsync] = ys[0].cpu()
+    assert torch.equal(outs[True], outs[False])
+    ref = torch.from_numpy(g["out_multi"])
+    assert (outs[True] - ref).abs().max().item() <= LP_TOL["bf16"][0] * ref.abs().max().item()
