@@ -56,6 +56,32 @@ def test_rccl_gather_after_real_forward(nccl_world1):
     assert t.item() == 1.0
 
 
+def test_post_step_on_side_stream_equals_direct_gather(nccl_world1):
+    """dist.PostStep (bench.py's data-parallel step): decode + asynchronous all-gather issued on a side stream under the NEXT forward --
+    three consecutive steps give what the direct calls on the caller's stream give, in order, for both payloads."""
+    cfg, sd, x, m, length, g = setup("w48_l213")
+    net = models.interformer_pureMulti.get_pose_net(cfg, is_train=False)
+    net.load_state_dict(sd, strict=True)
+    net = net.cuda()
+    counts = [sum(length)]
+    dec = lambda t: caller.decode(t, None, None, cfg.TEST.BLUR_KERNEL, transform_back=False)
+    kp_step = i2r_dist.PostStep(torch.device("cuda", 0), counts, decode=dec)
+    hm_step = i2r_dist.PostStep(torch.device("cuda", 0), counts)
+    xs = [x.cuda() * s for s in (1.0, 0.5, 0.25)]
+    hs = []
+    for xi in xs:  # (the handle of step k is only waited for by the side stream while step k + 1 is issued)
+        y = net(xi, m.cuda(), length)
+        hs.append((kp_step(y), hm_step(y)))
+    last_kp, last_hm = kp_step.result(), hm_step.result()
+    torch.cuda.synchronize()
+    for i, xi in enumerate(xs):
+        y = net(xi, m.cuda(), length)
+        preds, maxv = dec(y)
+        kp = torch.cat([preds, maxv], 2)
+        got_kp, got_hm = (last_kp, last_hm) if i == len(xs) - 1 else (hs[i][0].out, hs[i][1].out)
+        assert torch.equal(got_kp.view_as(kp), kp) and torch.equal(got_hm.view_as(y), y)
+
+
 def _bench(*args, timeout=900):
     """bench.py as the driver runs it (a process of its own), -> its one JSON line"""
     import json
