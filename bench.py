@@ -445,7 +445,7 @@ def hbm_traffic(cname, kernel):
     being the launch-weighted mean over all instantiations that ran (what `algorithmic_bytes` -- the launch-weighted mean of bench's
     own byte model over the same launches -- compares with); older files hold one instantiation.  -> (bytes, source, what) or Nones."""
     base = _kbase(kernel)
-    for rnd in ("round5", "round4", "round3", "round2", "round1"):
+    for rnd in ("round6", "round5", "round4", "round3", "round2", "round1"):
         path = os.path.join(ROOT, "profiles", "%s_hbm_traffic%s.json" % (rnd, "" if cname == "w48_pure_en6" else "_" + cname))
         try:
             with open(path) as f:

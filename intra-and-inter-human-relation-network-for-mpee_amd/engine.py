@@ -136,7 +136,11 @@ _PAIR_MT = int(_tune("I2R_PAIR_MT", "0"))  # 16-pixel tiles per wave of that ker
 WINOGRAD = _tune("I2R_WINOGRAD", "1") != "0"  # fp32 3x3 stride-1 convs on the Winograd F(2x2, 3x3) kernels
 _S2_MT = int(_tune("I2R_S2_MT", "1"))  # pixel fragments per wave of the stride-2 convs of the direct kernels (A/B: 0 = cost model's choice)
 _FUSE_PRE = int(_tune("I2R_FUSE_PRE", "1"))  # A/B: 0 = the fuse layers' down paths run entirely on the output's lane, after the xsync
-DEVICE_SYNC = _tune("I2R_DEVICE_SYNC", "1") != "0"  # fork / join / record / wait as device-side signal / wait kernels (csrc/i2r_api.hip) when the lanes are independent queues
+# fork / join / record / wait as device-side signal / wait kernels (csrc/i2r_api.hip) when the lanes are independent queues.  A wait kernel
+# spins until ANOTHER kernel signals it: under a tool that lets one kernel run at a time (rocprofv3 counter collection serialises dispatches)
+# it could only time out, so the event form is used whenever a profiler library is attached to the process.
+PROFILER_ATTACHED = bool(os.environ.get("ROCP_TOOL_LIBRARIES") or os.environ.get("ROCPROFILER_LIBRARY_CTOR"))
+DEVICE_SYNC = _tune("I2R_DEVICE_SYNC", "1") != "0" and (not PROFILER_ATTACHED or _tune("I2R_DEVICE_SYNC_UNDER_PROFILER", "0") == "1")
 _FUSE_P2P = int(_tune("I2R_FUSE_P2P", "1"))  # A/B: 0 = one all-to-all xsync between a module's blocks and its fuse layers (rounds 3-5)
 _LANE_CAP = int(_tune("I2R_LANE_CAP", "4"))  # HRFormer-B: branches i >= cap - 1 share stream lane cap - 1 (A/B: fewer, longer lanes)
 
@@ -2018,7 +2022,8 @@ def lane_report(device):
     return {"lanes": [hex(s.cuda_stream) for s in lst], "candidates": list(_LANE_PROBE.get(key, [])),
             # fork / join / record / wait of the multi-lane programs as device-side signal / wait kernels (csrc/i2r_api.hip): only with
             # independent hardware queues under every lane, and only for forwards issued from the stream the lanes were probed against
-            "device_side_sync": bool(DEVICE_SYNC and len(lst) >= 3 and lanes_independent(key, lst[:3]))}
+            "device_side_sync": bool(DEVICE_SYNC and len(lst) >= 3 and lanes_independent(key, lst[:3])),
+            "profiler_attached": PROFILER_ATTACHED}
 
 
 class Engine:
