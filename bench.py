@@ -517,7 +517,37 @@ def _kernel_view(name, s, reps, total_ms, precision, alone=None):
     return out
 
 
-def roofline_report(fwd, prog, precision, cname):
+def concurrent_phase(fwd, eng, precision, reps=10):
+    """The part-batch programs of a forward (Engine._split_bounds: towers / whole programs of independent image groups side by side on
+    their own streams) as ONE unit: the span from the fork to the join between two timing events on the caller's stream -- two markers
+    per forward, so the forward runs at its product speed -- against the executed FLOPs of all their launches.  This is the chip-level
+    rate of that phase with everything overlapping as it does in the product; the per-kernel in-situ figures (one marker per launch,
+    timed forward 15-25 % slower) are lower bounds beside it.  -> dict or None when the forward does not split."""
+    progs = list(eng.last_concurrent)
+    if len(progs) < 2:
+        return None
+    ev = [torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)]
+    eng.phase_events = ev
+    try:
+        fwd()
+        torch.cuda.synchronize()
+        span = []
+        for _ in range(reps):
+            for _ in range(3):  # (back to back: the events hold the LAST forward's span, issued with the host running ahead as in the timed loop)
+                fwd()
+            torch.cuda.synchronize()
+            span.append(ev[0].elapsed_time(ev[1]))
+    finally:
+        eng.phase_events = None
+    flop = sum(f / (WINO_CUT if name.startswith("conv_wino") else 1.0) for P in progs for _, name, f, _, _ in _op_models(P, precision))
+    ms = sorted(span)[len(span) // 2]
+    tf = flop / (ms * 1e-3) / 1e12
+    return {"programs": len(progs), "launches": sum(len(_op_models(P, precision)) for P in progs), "span_ms": round(ms, 3),
+            "executed_gflop": round(flop / 1e9, 2), "tflops_executed": round(tf, 2), "frac_of_mfma_peak": round(tf / MFMA_PEAK_TFLOPS[precision], 4),
+            "what": "fork -> join of the concurrent part-batch programs, two timing events per forward (median of %d forwards, each the last of three issued back to back)" % reps}
+
+
+def roofline_report(fwd, prog, precision, cname, eng=None):
     """fwd: the forward whose programs `prog` are (the callable of the timed region); see in_situ_timing"""
     stats, reps, wall_ms = in_situ_timing(fwd, precision)
     alone = standalone_timing(prog, precision)
@@ -530,6 +560,10 @@ def roofline_report(fwd, prog, precision, cname):
                    "standalone = the same launches alone on one stream (what a rocprofv3 kernel trace shows for part-batch programs: its "
                    "interception serialises them)" % reps)
     r["forward_ms_with_timing_events"] = round(wall_ms, 3)
+    if eng is not None:
+        cp = concurrent_phase(fwd, eng, precision)
+        if cp is not None:
+            r["concurrent_programs"] = cp
     # `traffic` (PMC, per launch) next to `algorithmic_bytes` (bench's byte model, per launch, same launch-weighted mean over the kernel's
     # launches): their ratio is computable from the line
     traffic, traffic_src, traffic_what = hbm_traffic(cname, r["kernel"])
@@ -794,7 +828,7 @@ def quick_workload(cname, dev, steps=30, warmup=5):
     dt, y = _time_steps(fwd, steps, warmup)
     assert torch.isfinite(y).all()
     eng = net.engine()
-    r = roofline_report(fwd, eng.last_programs, precision, cname)  # (the forward just timed and its program(s))
+    r = roofline_report(fwd, eng.last_programs, precision, cname, eng)  # (the forward just timed and its program(s))
     gflop = sum(n * wl["gflop"](n) for n in length)
     out = {"workload": wl["label"], "dtype": DTYPE_NAME[precision], "crops_per_step": sum(length), "steps": steps, "warmup": warmup,
            "value": round(sum(length) * steps / dt, 1), "unit": "images/sec", "ms_per_step": round(dt / steps * 1e3, 3),
@@ -805,6 +839,8 @@ def quick_workload(cname, dev, steps=30, warmup=5):
            "kernel_time_sum_ms_per_step": r["kernel_time_sum_ms_per_step"],
            "kernel_time_overlap": round(r["kernel_time_sum_ms_per_step"] / (dt / steps * 1e3), 3),
            "per_kernel_avg_launch_us": r["per_kernel_avg_launch_us"], "forward_ms_with_timing_events": r["forward_ms_with_timing_events"]}
+    if "concurrent_programs" in r:
+        out["concurrent_programs"] = r["concurrent_programs"]
     if any(getattr(P, "uses_lanes", False) for P in eng.last_programs):
         out["device_side_lane_sync"] = any(getattr(P, "device_sync", False) for P in eng.last_programs)
     if "attention_blocks" in r:
@@ -1180,7 +1216,7 @@ def main(argv=None):
                     return pipe()
                 for xb, mb, ln in batches:
                     net(xb, mb, ln)
-            out["roofline"] = roofline_report(fwd1, eng.last_programs, precision, args.config)  # (the forward(s) of the timed step and the last one's program(s))
+            out["roofline"] = roofline_report(fwd1, eng.last_programs, precision, args.config, eng)  # (the forward(s) of the timed step and the last one's program(s))
             if not strong and not args.pipeline:  # executed matrix-pipe + element-wise FLOPs of one forward over the step's wall time
                 out["roofline"]["model_tflops_executed"] = round(out["roofline"].pop("_executed_gflop_per_step") * args.steps / dt / 1e3, 2)
             out["roofline"].pop("_executed_gflop_per_step", None)

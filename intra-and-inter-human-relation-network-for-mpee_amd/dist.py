@@ -112,12 +112,17 @@ class PostStep:
 
     def __init__(self, device, counts, decode=None, group=None):
         import torch as _t
-        key = str(device)
+        from . import engine as _engine
+        key = str(_t.device(device))
         if key not in PostStep._streams:
-            # default priority: a HIGH-priority side stream was measured (config 4, one-rank RCCL group, fresh processes) at 0.55 of the plain
-            # line -- an active stream of another priority class wrecks the overlap of the engine's lanes (as stream priorities for the
-            # lanes themselves did in round 3); and so did GPU_MAX_HW_QUEUES=8 (0.66)
-            PostStep._streams[key] = _t.cuda.Stream(device=device)
+            # The LAST engine lane's stream, not a stream of its own: a process has four hardware queues (the caller's stream + three
+            # lanes), a fifth stream shares one of them, and which one is the runtime's choice.  Measured in fresh processes with a
+            # one-rank RCCL group (config 4, collective line / plain line, 8 pairs each on one box): a stream of its own 0.89-0.986
+            # (median 0.97), lane 3's stream 0.980-1.004 (median 0.99).  Lane 3 only works in the last stage of a four-lane forward (and
+            # not at all in the part-batch forwards): it is idle while the next forward starts, which is when the decode + gather run.
+            # Default priority: a HIGH-priority side stream was measured at 0.55 -- an active stream of another priority class wrecks the
+            # overlap of the lanes (as stream priorities for the lanes themselves did in round 3); so did GPU_MAX_HW_QUEUES=8 (0.66).
+            PostStep._streams[key] = _engine.lane_streams(_t.device(device), 3)[2]
         self.stream = PostStep._streams[key]
         self.counts, self.decode, self.group = list(counts), decode, group
         self.pending = None

@@ -2538,6 +2538,7 @@ class Engine:
             self._part_events = [torch.cuda.Event() for _ in range(parts)]
         e_fork = self._part_events[0]
         e_fork.record(cur)  # (the inputs are ready on the caller's stream)
+        self._phase_mark(cur, 0)
         ys, progs = [None] * parts, []
         for i in range(1, parts):
             st = self._part_streams[i - 1]
@@ -2557,9 +2558,19 @@ class Engine:
             cur.wait_event(self._part_events[i])
             for t in (ys[i].values() if isinstance(ys[i], dict) else (ys[i],)):
                 t.record_stream(cur)  # (allocated on the side stream, consumed on the caller's)
+        self._phase_mark(cur, 1)
         if isinstance(ys[0], dict):
             return {key: torch.cat([y[key] for y in ys], 0) for key in ys[0]}
         return torch.cat(ys, 0)
+
+    # bench.py: the span of the CONCURRENT part-batch programs of a forward (fork -> join) between two timing events on the caller's
+    # stream -- two markers per forward instead of one per launch, so the forward runs at its product speed (phase_events = [e0, e1]
+    # armed by the caller; None = off)
+    phase_events = None
+
+    def _phase_mark(self, cur, which):
+        if self.phase_events is not None:
+            self.phase_events[which].record(cur)
 
     def program_bytes(self):
         """arena + workspace bytes held by the cached programs (bench.py --ragged-stream reports it)"""
@@ -2595,6 +2606,7 @@ class Engine:
         feat = patch["feat"].view()  # [cap (x 2 with the flip test), h, w, cs]
         e_fork = self._part_events[0]
         e_fork.record(cur)  # (the inputs are ready, and the tail of the previous forward has read the feature buffer)
+        self._phase_mark(cur, 0)
         progs = []
         for i in range(parts - 1, -1, -1):  # (the caller's stream takes part 0 last: its launches queue behind the side streams')
             sp = offs[i + 1] - offs[i]
@@ -2619,6 +2631,7 @@ class Engine:
             progs.append(Pw)
         for i in range(1, parts):
             cur.wait_event(self._part_events[i])
+        self._phase_mark(cur, 1)
         # ---- the tail, as _forward_part runs a whole program ----
         glen = list(length) + [1] * (cap - S)
         if flip:

@@ -143,9 +143,10 @@ if __name__ == "__main__":
         for k, v in j.items():
             if any(k.startswith(p_) for p_ in ("hrt_attn_head_k", "hrt_mlp_wide_k", "hrt_mlp_block_k", "enc_layer", "conv_wino_f32", "conv_igemm_lp<3, 3, 8, 1>")) and "SQ_INSTS_MFMA" in v:
                 e = {n: v[n] for n in v if n.startswith("SQ_") or n in ("dispatches", "grid", "wg", "lds", "vgpr", "agpr", "GRBM_GUI_ACTIVE")}
-                if v.get("SQ_BUSY_CYCLES"):
-                    # SQ_VALU_MFMA_BUSY_CYCLES counts per SIMD... the ratio below is (matrix-pipe busy cycles) / (4 SIMDs x SQ busy cycles summed over the SEs' SQs)
-                    e["mfma_busy_over_sq_busy"] = round(v.get("SQ_VALU_MFMA_BUSY_CYCLES", 0.0) / (4.0 * v["SQ_BUSY_CYCLES"]), 4)
+                if v.get("GRBM_GUI_ACTIVE"):
+                    # matrix-pipe busy cycles per SIMD (the counter sums the chip's 1024 SIMDs) over the launch's cycles (GRBM_GUI_ACTIVE sums
+                    # the 8 XCDs); a launch with fewer workgroups than CUs leaves the idle CUs in the denominator
+                    e["mfma_busy_frac_of_launch_cycles"] = round(v.get("SQ_VALU_MFMA_BUSY_CYCLES", 0.0) / 1024.0 / (v["GRBM_GUI_ACTIVE"] / 8.0), 4)
                 mf.setdefault(c, {})[k] = e
     json.dump({"what": "rocprofv3 --pmc SQ pass of a 2-step bench run per workload (event-form lane sync under the profiler): per-dispatch means", "by_workload": mf},
               open(os.path.join(P, tag + "_pmc_mfma_counters.json"), "w"), indent=1)
