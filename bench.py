@@ -324,6 +324,8 @@ def in_situ_timing(fwd, precision, reps=5):
                             ready[l] = m
                     continue
                 sk = lane_streams[lane]
+                if t1[i] is None:  # (not timed in this pass)
+                    continue
                 end = e0.elapsed_time(t1[i])
                 start = e0.elapsed_time(t0[i]) if t0[i] is not None else ready.get(sk)
                 if start is None or start > end:
@@ -556,14 +558,13 @@ def roofline_report(fwd, prog, precision, cname, eng=None):
     dom = order[0]  # the kernel with the largest share of the step's kernel time, whatever it is
     r = _kernel_view(dom, stats[dom], reps, total_ms, precision, alone.get(dom))
     r["timing"] = ("in situ: a HIP stop event bound to every dispatch + a start marker in front of it, on the launch's own stream inside the product "
-                   "forward (i2r_run_program_timed), %d forwards; avg_launch_us = mean kernel duration with lanes / sibling programs in flight; "
-                   "standalone = the same launches alone on one stream (what a rocprofv3 kernel trace shows for part-batch programs: its "
-                   "interception serialises them)" % reps)
+                   "forward (i2r_run_program_timed), %d forwards; avg_launch_us = mean kernel duration with lanes / sibling programs in flight; the markers "
+                   "slow the forward (forward_ms_with_timing_events beside ms_per_step), so busy times are upper bounds and frac a lower bound -- "
+                   "concurrent_programs (two events per forward) is the unperturbed figure of the part-batch phase as a whole; standalone = the same "
+                   "launches alone on one stream (what a rocprofv3 kernel trace shows for the part-batch programs: under it the host is the bottleneck "
+                   "and they run one after the other).  Measured and dropped: events on the dominant kernel's launches only -- mixing "
+                   "hipExtLaunchKernelGGL and plain launches in one stream cost MORE (w48 forward 6.3 ms, no overlap left)" % reps)
     r["forward_ms_with_timing_events"] = round(wall_ms, 3)
-    if eng is not None:
-        cp = concurrent_phase(fwd, eng, precision)
-        if cp is not None:
-            r["concurrent_programs"] = cp
     # `traffic` (PMC, per launch) next to `algorithmic_bytes` (bench's byte model, per launch, same launch-weighted mean over the kernel's
     # launches): their ratio is computable from the line
     traffic, traffic_src, traffic_what = hbm_traffic(cname, r["kernel"])

@@ -1445,8 +1445,8 @@ class Program:
 
     def _run_timed(self, L, streams, evs):
         n = len(self.ops)
-        key = tuple(streams)
-        if getattr(self, "_tev", (None,))[0] != key:  # events are created once per program (and lane layout)
+        key = (tuple(streams), Program.timing_markers)
+        if getattr(self, "_tev", (None,))[0] != key:  # events are created once per program (lane layout, marker mode)
             t0, t1, seen = [None] * n, [None] * n, set()
             for i, (kind, lane, st) in enumerate(self.ops):
                 if kind in cabi.SYNC_OPS:
@@ -1462,7 +1462,7 @@ class Program:
                          (C.c_void_p * n)(*[e.cuda_event if e is not None else None for e in t1]))
         _, t0, t1, a0, a1 = self._tev
         cabi.check(L.i2r_run_program_timed(self._c_ops, n, streams, evs, a0, a1), "i2r_run_program_timed")
-        Program.timing_log.append((self, t0, t1, key))
+        Program.timing_log.append((self, t0, t1, key[0]))
 
     def _lane_flags(self):
         if not hasattr(self, "_flags"):
