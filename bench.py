@@ -844,6 +844,8 @@ def quick_workload(cname, dev, steps=30, warmup=5):
         out["concurrent_programs"] = r["concurrent_programs"]
     if any(getattr(P, "uses_lanes", False) for P in eng.last_programs):
         out["device_side_lane_sync"] = any(getattr(P, "device_sync", False) for P in eng.last_programs)
+        out["device_side_waits_timed_out"] = any(P.sync_timed_out() for P in eng.last_programs)
+        assert not out["device_side_waits_timed_out"], "a device-side lane wait timed out: the forward's results are not ordered"
     if "attention_blocks" in r:
         out["attention_blocks"] = {k: r["attention_blocks"][k] for k in ("kernels", "ms_per_step", "achieved", "peak", "frac", "standalone") if k in r["attention_blocks"]}
     out["parity"] = oracle_parity(cfg, sd, x, m, length, fwd(), precision)
@@ -1241,6 +1243,9 @@ def main(argv=None):
             out["other_workloads"]["wall_s"] = round(time.perf_counter() - t_other, 1)
         from i2r_amd import engine as _engine
         out["lanes"] = _engine.lane_report(dev)
+        # a device-side wait that saw nothing for 50 ms gives up and raises a flag instead of hanging the GPU: none may have (the step's results
+        # would not be ordered); checked here, behind the timed region's synchronize
+        out["lanes"]["device_side_waits_timed_out"] = any(P.sync_timed_out() for v in eng.programs.values() for P in v[:1])
         if default_line and not args.no_other_workloads and not coll:
             out["collective_overhead"] = collective_overhead(dev)
         if not args.no_cpu_baseline and world == 1:
