@@ -14,21 +14,30 @@ coco_hrt_288_p2_b4 fp16 (one image of 12 persons at 384x288).
 N > 1: one process per GPU.  Under torch.distributed.run (WORLD_SIZE set) this process is one rank; called plainly as
 `python bench.py --gpus N` it launches the N ranks itself (self_launch: re-executes under torch.distributed.run on 127.0.0.1).
 Every rank runs its own batch of the workload's shape (weak scaling, images are the independent unit) and the per-crop results are
-all-gathered over RCCL each step: the predicted HEAT MAPS (the collective BASELINE.json's north_star names; --gather keypoints
-gathers the decoded [S, J, 3] key points instead).  The line's `value` is timed with the --gather payload; `gather_alt` is the
-same K steps re-timed with the other payload.
+all-gathered over RCCL each step: the key points decoded on the device, [S, J, 3] (168 B per crop: what validate() keeps of a batch;
+--gather heatmaps gathers the predicted heat maps, the payload BASELINE.json's north_star names, 172 KB per crop).  Decode and gather
+are issued on a side stream under the next forward (dist.PostStep).  The line's `value` is timed with the --gather payload;
+`gather_alt` is the same K steps re-timed with the other payload.
 
 --scaling strong (default weak): the total job is FIXED -- 64 images with 1-6 persons -- and cut into contiguous image shards balanced by
 crop count (dist.shard_bounds); the ranks' crop counts differ, the line carries them and the imbalance (`shards`).
 
 One JSON line is printed by rank 0:
   value        crops/s of the whole job (all ranks), from the max-over-ranks wall time of exactly K steps
-  roofline     the kernel with the LARGEST share of the step (over all kernels): EXECUTED FLOPs / algorithmic HBM bytes per launch
+  roofline     the kernel with the LARGEST share of the step (over all kernels), measured IN SITU: the forward of the timed region is re-run
+               with a HIP stop event bound to every dispatch and a start marker in front of it, on the launch's own stream
+               (i2r_run_program_timed) -- avg_launch_us = mean kernel duration with lanes / sibling programs in flight, busy_ms_per_step =
+               time with at least one launch of the kernel in flight, frac = EXECUTED FLOPs / algorithmic HBM bytes of all its launches
                (op_model; for the Winograd kernel the executed multiply-adds = the direct convolution's / 2.25, so frac <= 1 -- the
-               direct-convolution FLOPs it delivers are filed under direct_equivalent) over its average launch duration, both from a
-               per-launch HIP-event timing pass inside this script, against the roof its arithmetic intensity selects
-               (MI355X_MICROARCH.md: fp32 MFMA 157.3 TFLOP/s, bf16/fp16 2500 TFLOP/s, HBM 8 TB/s);
+               direct-convolution FLOPs it delivers are filed under direct_equivalent) over that busy time against the roof its
+               arithmetic intensity selects (MI355X_MICROARCH.md: fp32 MFMA 157.3 TFLOP/s, bf16/fp16 2500 TFLOP/s, HBM 8 TB/s); the
+               markers slow the forward (forward_ms_with_timing_events), so frac is a LOWER bound; `standalone` = the same launches alone
+               on one stream; `concurrent_programs` = the part-batch programs fork -> join between two events (unperturbed);
                `kernels` = the same figures for the five largest kernels; attention_blocks = the encoder kernels
+  lanes        what the engine's stream probe found (candidate streams, alone / together spin times, roles), whether the device-side
+               lane synchronisation is in use and that none of its waits timed out
+  collective_overhead  (default line) BASELINE configs[3] timed alternately as the plain step and as the data-parallel step (device decode +
+               RCCL all-gather through a one-rank group, on a side stream under the next forward) in this process
   other_workloads  (default single-GPU line only) BASELINE configs[2..4] at their own batch shapes and dtypes, the ragged stream and the
                pipeline, 10-30 steps each, measured in this process after the headline's timed region: value, ms_per_step, dominant kernel
                with its roofline fraction, parity against the CPU oracle

@@ -33,6 +33,8 @@ def decode(heatmaps, center=None, scale=None, blur_kernel=11, transform_back=Tru
     dev = hm.device
     preds = torch.empty(S, J, 2, dtype=torch.float32, device=dev)
     maxvals = torch.empty(S, J, 1, dtype=torch.float32, device=dev)
+    if S == 0:  # (a data-parallel rank without images: nothing to decode)
+        return preds, maxvals
     c = s = None
     if transform_back:
         c = torch.as_tensor(center, dtype=torch.float32).to(dev).contiguous()
