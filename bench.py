@@ -574,6 +574,10 @@ def roofline_report(fwd, prog, precision, cname, eng=None):
                    "and they run one after the other).  Measured and dropped: events on the dominant kernel's launches only -- mixing "
                    "hipExtLaunchKernelGGL and plain launches in one stream cost MORE (w48 forward 6.3 ms, no overlap left)" % reps)
     r["forward_ms_with_timing_events"] = round(wall_ms, 3)
+    if eng is not None:
+        cp = concurrent_phase(fwd, eng, precision)
+        if cp is not None:
+            r["concurrent_programs"] = cp
     # `traffic` (PMC, per launch) next to `algorithmic_bytes` (bench's byte model, per launch, same launch-weighted mean over the kernel's
     # launches): their ratio is computable from the line
     traffic, traffic_src, traffic_what = hbm_traffic(cname, r["kernel"])

@@ -139,7 +139,8 @@ _FUSE_PRE = int(_tune("I2R_FUSE_PRE", "1"))  # A/B: 0 = the fuse layers' down pa
 # fork / join / record / wait as device-side signal / wait kernels (csrc/i2r_api.hip) when the lanes are independent queues.  A wait kernel
 # spins until ANOTHER kernel signals it: under a tool that lets one kernel run at a time (rocprofv3 counter collection serialises dispatches)
 # it could only time out, so the event form is used whenever a profiler library is attached to the process.
-PROFILER_ATTACHED = bool(os.environ.get("ROCP_TOOL_LIBRARIES") or os.environ.get("ROCPROFILER_LIBRARY_CTOR"))
+PROFILER_ATTACHED = bool(os.environ.get("ROCP_TOOL_LIBRARIES") or os.environ.get("ROCPROFILER_LIBRARY_CTOR") or os.environ.get("HSA_TOOLS_LIB")
+                         or any(t in os.environ.get("LD_PRELOAD", "") for t in ("rocprof", "roctracer", "rocprofiler")))  # rocprofv3 / rocprofv2 / rocprof / preloaded tools
 DEVICE_SYNC = _tune("I2R_DEVICE_SYNC", "1") != "0" and (not PROFILER_ATTACHED or _tune("I2R_DEVICE_SYNC_UNDER_PROFILER", "0") == "1")
 _FUSE_P2P = int(_tune("I2R_FUSE_P2P", "1"))  # A/B: 0 = one all-to-all xsync between a module's blocks and its fuse layers (rounds 3-5)
 _LANE_CAP = int(_tune("I2R_LANE_CAP", "4"))  # HRFormer-B: branches i >= cap - 1 share stream lane cap - 1 (A/B: fewer, longer lanes)
