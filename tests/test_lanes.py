@@ -158,3 +158,65 @@ def test_checker_catches_a_missing_sync():
     P.ops = [op for op in P.ops if op[0] != cabi.OP_WAIT]
     with pytest.raises(AssertionError, match="races"):
         check_program(P)
+
+
+def test_records_hand_buffers_over_only_behind_all_waits():
+    """Program.records / wait / all_waited (round 6): a buffer one lane released BEFORE the records may be re-used by another lane only
+    behind the point where every lane has waited for every record (all_waited); what a lane releases AFTER its record stays its own until
+    the next round; join flushes everything."""
+    P = engine.Program(torch.device("cpu"))
+    P.fork(6)
+    P.lane_ctx = 1
+    a = P.alloc(1, 4, 4, 16)          # lane 1's buffer ...
+    P.release(a)                      # ... released ahead of the records
+    slots = P.records([0, 1, 2])
+    assert sorted(slots) == [0, 1, 2] and len(set(slots.values())) == 3
+    P.lane_ctx = 2
+    b = P.alloc(1, 4, 4, 16)
+    assert b.t.data_ptr() != a.t.data_ptr(), "lane 2 must not get lane 1's buffer before the waits"
+    P.lane_ctx = 1
+    c = P.alloc(1, 4, 4, 16)          # (lane 1 itself does not get it back either: it went into the round's snapshot)
+    assert c.t.data_ptr() != a.t.data_ptr()
+    P.release(c)                      # released AFTER the record: lane 1's own again at once, nobody else's until the next round
+    for ln in (0, 1, 2):
+        for lj in (0, 1, 2):
+            if ln != lj:
+                P.wait(ln, slots[lj])
+    P.all_waited()
+    P.lane_ctx = 0
+    d = P.alloc(1, 4, 4, 16)
+    assert d.t.data_ptr() == a.t.data_ptr(), "behind all_waited the pre-record release is everybody's"
+    e = P.alloc(1, 4, 4, 16)
+    assert e.t.data_ptr() != c.t.data_ptr(), "lane 1's post-record release is still lane 1's"
+    P.lane_ctx = 1
+    f = P.alloc(1, 4, 4, 16)
+    assert f.t.data_ptr() == c.t.data_ptr()
+    P.join(6)
+    kinds = [k for k, _, _ in P.ops]
+    assert kinds.count(cabi.OP_RECORD) == 3 and kinds.count(cabi.OP_WAIT) == 6 and kinds[0] == cabi.OP_LANE_FLAGS and kinds[-1] == cabi.OP_JOIN
+    # RECORD carries lane | slot << 8 | consumer lanes << 16
+    recs = [lane for k, lane, _ in P.ops if k == cabi.OP_RECORD]
+    assert all((r >> 16) & 15 == 7 for r in recs) and sorted(r & 3 for r in recs) == [0, 1, 2]
+
+
+def test_lanes_independent_needs_probed_overlap_for_every_pair(monkeypatch):
+    """engine.lanes_independent: the device-side lane synchronisation is only allowed on streams the probe saw running beside the caller's
+    stream and beside every lane chosen before them, and only for the caller stream the probe used"""
+    class S:
+        def __init__(self, h):
+            self.cuda_stream = h
+    ok = {"alone_ms": 0.06, "together_ms": 0.08, "overlap": True}
+    bad = {"alone_ms": 0.06, "together_ms": 0.12, "overlap": False}
+    probe = [{"stream": hex(0x10), "candidate": 1, "vs_caller": ok, "role": "lane1"},
+             {"stream": hex(0x20), "candidate": 2, "vs_caller": bad, "role": "spare (shares a hardware queue)"},
+             {"stream": hex(0x30), "candidate": 3, "vs_caller": ok, "vs_lane1": ok, "role": "lane2"},
+             {"stream": hex(0x40), "role": "lane3 (no independent queue left: shares)"},
+             {"stream": hex(0x50), "candidate": 5, "probe": "off", "role": "lane3"}]
+    monkeypatch.setitem(engine._LANE_PROBE, "cuda:7", probe)
+    monkeypatch.setitem(engine._LANE_CALLER, "cuda:7", 0)
+    assert engine.lanes_independent("cuda:7", [S(0x10), S(0x30)], 0)
+    assert not engine.lanes_independent("cuda:7", [S(0x10), S(0x30)], 0x99)      # another caller stream: nothing is known about it
+    assert not engine.lanes_independent("cuda:7", [S(0x10), S(0x20)], 0)         # shares a queue with the caller
+    assert not engine.lanes_independent("cuda:7", [S(0x10), S(0x30), S(0x40)], 0)  # took a shared queue
+    assert not engine.lanes_independent("cuda:7", [S(0x10), S(0x30), S(0x50)], 0)  # never probed
+    assert not engine.lanes_independent("cuda:3", [S(0x10)], 0)                  # no probe record for the device
