@@ -578,6 +578,16 @@ def roofline_report(fwd, prog, precision, cname, eng=None):
         cp = concurrent_phase(fwd, eng, precision)
         if cp is not None:
             r["concurrent_programs"] = cp
+    # the three fractions of the dominant kernel's roof side by side (all measured in this run)
+    r["fractions"] = {"in_situ": r["frac"], "in_situ_per_launch": r["frac_per_launch_in_situ"],
+                      "standalone": r.get("standalone", {}).get("frac"),
+                      "what": "in_situ: all launches of the kernel / the time with >= 1 of them in flight, inside a forward slowed by one event marker per "
+                              "launch (lower bound); in_situ_per_launch: one launch / its own duration while it shares the chip; standalone: the kernel with "
+                              "the chip to itself"}
+    if "concurrent_programs" in r and r["bound"] == "mfma":
+        r["fractions"]["concurrent_programs_all_kernels"] = r["concurrent_programs"]["frac_of_mfma_peak"]
+        r["fractions"]["what"] += ("; concurrent_programs_all_kernels: EVERY kernel of the part-batch programs together, fork -> join between two events "
+                                   "in an unperturbed forward -- the dominant kernel, more efficient than the glue around it, runs above this average")
     # `traffic` (PMC, per launch) next to `algorithmic_bytes` (bench's byte model, per launch, same launch-weighted mean over the kernel's
     # launches): their ratio is computable from the line
     traffic, traffic_src, traffic_what = hbm_traffic(cname, r["kernel"])
