@@ -1270,7 +1270,10 @@ def main(argv=None):
         # would not be ordered); checked here, behind the timed region's synchronize
         out["lanes"]["device_side_waits_timed_out"] = any(P.sync_timed_out() for v in eng.programs.values() for P in v[:1])
         if default_line and not args.no_other_workloads and not coll:
-            out["collective_overhead"] = collective_overhead(dev)
+            try:
+                out["collective_overhead"] = collective_overhead(dev)
+            except Exception as e:  # (an RCCL group that cannot be created here must not cost the driver its bench line)
+                out["collective_overhead"] = {"error": "%s: %s" % (type(e).__name__, str(e)[:300])}
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(cfg, sd, H_, W_, first)
     if rank == 0:
